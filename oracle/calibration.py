@@ -1,0 +1,97 @@
+"""CPU restatement of the mask-calibration side of the hot path (TEST INFRASTRUCTURE ONLY).
+
+Reference files:
+  ATT = /root/reference/AOC-Net/complete_project/AOCNet/networks/layers/attention.py
+  CL  = /root/reference/AOC-Net/conditioning_layer.py  (== CLB:6-48)
+  CLB = /root/reference/AOC-Net/complete_project/AOCNet/networks/aoc/conditioning_layer.py
+
+Functions take explicit weight tensors (no nn.Module state) so that tests can feed the same
+weights to the HIP path.
+
+PARITY STATUS
+* ``ia_gate``, ``attention_head_for_eval_p_m``, ``conditioning_layer`` (4-D input): pinned by
+  golden vectors generated from the reference (tests/golden/make_golden.py).
+* ``conditioning_block``: **parity unpinned**.  CLB:66-86 cannot execute as shipped
+  (``CL_1``/``mlp_layer`` without ``self.``; ``CL_2``/``CL_3`` receive 2-D tensors that Conv2d
+  rejects; with [N,D,1,1] inputs ``k = int(beta*1*1) = 0`` and CLB:36 raises IndexError).
+  The repairs applied here (documented in DESIGN.md) are: ``self.`` prefixes; a 2-D input v is
+  treated as the H=W=1 limit of Eq.7 with the gate identically 1, i.e. ``CL(v) = mlp(v)``;
+  ``CL_3`` is sized by ``proxy_dim``.
+"""
+import torch
+
+
+# -------------------------------------------------------------------------- a10
+def attention_head_for_eval_p_m(ref_embeddings, ref_labels, prev_embedding, prev_label, epsilon=1e-5):
+    """ATT:155-189.  ref_embeddings: list of [1 or O, C, h, w]; ref_labels: list of [O,1,h,w];
+    prev_embedding [O,C,h,w]; prev_label [O,1,h,w].  Returns (total_head [O,4C], ref_pos, ref_neg,
+    prev_pos, prev_neg) each [O, C]."""
+    tot_pos = tot_neg = tot_pos_n = tot_neg_n = 0.
+    for emb, lab in zip(ref_embeddings, ref_labels):
+        head = emb * lab                                                   # ATT:164
+        pos = torch.sum(head, dim=(2, 3))
+        neg = torch.sum(emb, dim=(2, 3)) - pos                             # ATT:166
+        tot_pos = tot_pos + pos
+        tot_neg = tot_neg + neg
+        tot_pos_n = tot_pos_n + torch.sum(lab, dim=(2, 3))
+        tot_neg_n = tot_neg_n + torch.sum(1. - lab, dim=(2, 3))
+    ref_pos = tot_pos / (tot_pos_n + epsilon)                              # ATT:173-174
+    ref_neg = tot_neg / (tot_neg_n + epsilon)
+    head = prev_embedding * prev_label
+    p_pos = torch.sum(head, dim=(2, 3))
+    p_neg = torch.sum(prev_embedding, dim=(2, 3)) - p_pos
+    p_pos = p_pos / (torch.sum(prev_label, dim=(2, 3)) + epsilon)
+    p_neg = p_neg / (torch.sum(1. - prev_label, dim=(2, 3)) + epsilon)
+    total = torch.cat([ref_pos, ref_neg, p_pos, p_neg], dim=1)            # ATT:188
+    return total, ref_pos, ref_neg, p_pos, p_neg
+
+
+# -------------------------------------------------------------------------- a11
+def film_gain(head, weight, bias):
+    """ATT:13-14:  a = 1 + tanh(Linear(head))      head [O,D], weight [c,D], bias [c] -> [O,c]"""
+    return 1. + torch.tanh(torch.nn.functional.linear(head, weight, bias))
+
+
+def ia_gate(x, head, weight, bias):
+    """ATT:12-17 (IA_gate.forward): x * (1 + tanh(W head + b))[:, :, None, None]"""
+    return film_gain(head, weight, bias).unsqueeze(-1).unsqueeze(-1) * x
+
+
+# -------------------------------------------------------------------------- a12
+def conditioning_gate_stats(z, phi_w, phi_b, beta_percentage=0.3):
+    """CL:23-43.  z [N,C,H,W]; phi_w [C] (the 1x1 conv C->1), phi_b scalar.
+    Returns (scores [N,HW], threshold [N], mask [N,HW] bool, gap [N,C])."""
+    n, c, hgt, wid = z.shape
+    zf = z.reshape(n, c, -1)
+    s = (zf * phi_w.reshape(1, c, 1)).sum(1) + phi_b                      # CL:27  phi(z)
+    k = int(beta_percentage * wid * hgt)                                   # CL:32
+    top, _ = torch.topk(s, k=k, dim=-1, sorted=True)                      # CL:33
+    thr = top[..., -1]
+    mask = s > thr.unsqueeze(-1)                                           # CL:36  strict > : k-1 pixels
+    gap = (zf * mask.unsqueeze(1)).mean(dim=-1)                            # CL:39-43 mean over ALL HW
+    return s, thr, mask, gap
+
+
+def conditioning_layer(z, phi_w, phi_b, mlp_w, mlp_b, beta_percentage=0.3):
+    """CL:22-45 (paper Eq.7) with the missing ``self.`` on mlp_layer repaired.
+    4-D z -> Linear(GAP(z * (phi(z) > kth_largest(phi(z)))));  2-D z (vector input, the
+    conditioning_block repair) -> Linear(z)."""
+    if z.dim() == 2:
+        return torch.nn.functional.linear(z, mlp_w, mlp_b)
+    _, _, _, gap = conditioning_gate_stats(z, phi_w, phi_b, beta_percentage)
+    return torch.nn.functional.linear(gap, mlp_w, mlp_b)
+
+
+# -------------------------------------------------------------------------- a13
+def conditioning_block(x, proxy_ia_head, p, beta_percentage=0.3):
+    """CLB:66-86 (paper Eq.5), repaired as described in the module docstring.
+    ``p`` is a dict of weights: CL_1.{phi_w,phi_b,mlp_w,mlp_b}, CL_2.{mlp_w,mlp_b},
+    CL_3.{mlp_w,mlp_b}, mlp_w [C, 2C+P], mlp_b [C]."""
+    px1 = x.mean(dim=(2, 3))                                               # CLB:68 avg_pool2d over HxW
+    x_delta = px1.sum(dim=0, keepdim=True) - px1                           # CLB:69
+    c1 = conditioning_layer(x, p["CL_1.phi_w"], p["CL_1.phi_b"], p["CL_1.mlp_w"], p["CL_1.mlp_b"], beta_percentage)
+    c2 = conditioning_layer(x_delta, None, None, p["CL_2.mlp_w"], p["CL_2.mlp_b"])
+    c3 = conditioning_layer(proxy_ia_head, None, None, p["CL_3.mlp_w"], p["CL_3.mlp_b"])
+    a = torch.nn.functional.linear(torch.cat([c1, c2, c3], dim=1), p["mlp_w"], p["mlp_b"])   # CLB:81
+    a = 1. + torch.tanh(a)                                                 # CLB:82
+    return a.unsqueeze(-1).unsqueeze(-1) * x                               # CLB:83-84

@@ -1,0 +1,10 @@
+"""MI355X-native AOC-Net matching / calibration hot path.
+
+Python mirror of the reference's operator surface (networks/layers/matching.py,
+networks/layers/attention.py, networks/aoc/conditioning_layer.py) over a C-ABI HIP library
+(``csrc/libaoc_hip.so``, declared in ``include/aoc_hip.h``).  There is no CPU fallback: every
+operator raises if the HIP library is missing or no GPU is present.
+"""
+from . import synthetic  # noqa: F401
+
+__all__ = ["synthetic"]

@@ -1,0 +1,171 @@
+"""Pins the CPU oracle (oracle/) against golden vectors produced by the reference itself
+(tests/golden/make_golden.py).  The reference ships no tests of its own."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import calibration as ocal
+from oracle import matching as om
+
+T = torch.from_numpy
+# float32 reassociation between the reference's chunked matmuls / unfold and the de-chunked
+# oracle: features live in (-1, 1); observed differences are ~1e-6.
+TOL = dict(rtol=0, atol=2e-6)
+
+
+def _refs(g):
+    return [T(e) for e in g["in_ref"]], [T(l.copy()) for l in g["lab_onehot"]]
+
+
+def _ori(g):
+    o = tuple(int(v) for v in g["ori_size"])
+    return o if o[0] > 0 else None
+
+
+CLUSTER_CASES = ["cluster_basic_R1_O3", "cluster_basic_R1_O3_mt", "cluster_R3_O4_bias", "cluster_orisize",
+                 "cluster_sticky_empty_obj0", "cluster_small_first_obj", "cluster_small_mid_obj",
+                 "cluster_duplicates_empty", "cluster_uncertain125", "cluster_all_unlabelled"]
+
+
+@pytest.mark.parametrize("name", CLUSTER_CASES)
+def test_cluster_path(golden, name):
+    g = golden(name)
+    refs, labs = _refs(g)
+    np.random.seed(int(g["seed"]))           # the oracle draws init rows exactly as scipy does
+    out, proxies = om.global_matching_for_eval_cluster(refs, T(g["in_query"]), labs, 4, T(g["in_bias"]),
+                                                       _ori(g), return_proxies=True)
+    assert tuple(out.shape) == g["out"].shape
+    np.testing.assert_allclose(out.numpy(), g["out"], **TOL)
+    # every kmeans2 call the reference made: same rows drawn, same labels, same code book (bit-exact)
+    live = [p for p in (proxies or []) if p is not None]
+    assert len(live) == int(g["km_calls"])
+    for i, p in enumerate(live):
+        assert p["k"] == int(g[f"km{i}_k"]) and len(p["labels"]) == int(g[f"km{i}_n"])
+        assert np.array_equal(p["init_rows"], g[f"km{i}_rows"])
+        assert np.array_equal(p["labels"], g[f"km{i}_labels"])
+        assert np.array_equal(p["centroid"].numpy(), g[f"km{i}_centroid"])
+
+
+def test_cluster_kmeans_iteration_trace(golden):
+    """Labels after iterations 1, 2 and 20 of every recorded kmeans2 call."""
+    from oracle import kmeans as okm
+    g = golden("cluster_R3_O4_bias")
+    ref = T(g["in_ref"]).reshape(-1, 100)
+    lab = T(g["lab_onehot"]).reshape(-1, 4)
+    keep = lab.sum(1) > 0.9
+    ref, lab = ref[keep].numpy(), lab[keep].numpy()
+    for i in range(int(g["km_calls"])):
+        x = ref[lab[:, i] > 0.9]
+        _, _, _, tr = okm.kmeans2_matrix(x, x[g[f"km{i}_rows"]], 20, trace=True)
+        assert np.array_equal(tr[0], g[f"km{i}_labels_it1"])
+        assert np.array_equal(tr[1], g[f"km{i}_labels_it2"])
+        assert np.array_equal(tr[19], g[f"km{i}_labels"])
+
+
+def test_cluster_special_values(golden):
+    g = golden("cluster_sticky_empty_obj0")
+    assert np.all(g["out"] == 1.0)                      # sticky K = 0 (AEM:268)
+    g = golden("cluster_all_unlabelled")
+    assert g["out"].shape[-1] == 1 and np.all(g["out"] == 1.0)   # early-out has last dim 1 (AEM:588-589)
+    g = golden("cluster_small_first_obj")
+    assert [int(g[f"km{i}_k"]) for i in range(int(g["km_calls"]))] == [3, 3, 3]
+
+
+@pytest.mark.parametrize("name", ["dense_R1_O3", "dense_R2_O4_bias_unc", "dense_orisize", "dense_all_unlabelled"])
+def test_dense_path(golden, name):
+    g = golden(name)
+    refs, labs = _refs(g)
+    out = om.global_matching_for_eval(refs, T(g["in_query"]), labs, 4, T(g["in_bias"]), _ori(g))
+    assert tuple(out.shape) == g["out"].shape
+    np.testing.assert_allclose(out.numpy(), g["out"], **TOL)
+
+
+def test_dense_train_twin(golden):
+    g = golden("dense_train_twin")
+    out = om.global_matching(T(g["in_ref"][0]), T(g["in_query"]), T(g["lab_onehot"][0].copy()), 3, T(g["in_bias"]))
+    np.testing.assert_allclose(out.numpy(), g["out"], **TOL)
+
+
+@pytest.mark.parametrize("name,fn", [("proxy_eval_O3", "global_matching_for_eval_proxy"), ("proxy_train_O3", "global_matching_proxy")])
+def test_proxy_path(golden, name, fn):
+    g = golden(name)
+    labs = T(g["lab_onehot"][0].copy())
+    if fn == "global_matching_proxy":
+        out = om.global_matching_proxy(T(g["in_proxies"]), T(g["in_query"]), labs, 3, T(g["in_bias"]))
+    else:
+        out = om.global_matching_for_eval_proxy(T(g["in_proxies"]), T(g["in_query"]), [labs], 4, T(g["in_bias"]))
+    np.testing.assert_allclose(out.numpy(), g["out"], **TOL)
+
+
+@pytest.mark.parametrize("name", ["local_down_O3", "local_down_O4_bias", "local_nodown_O3",
+                                  "local_down_odd_C36", "local_proxy_down_O3"])
+def test_local_path(golden, name):
+    g = golden(name)
+    out = om.local_matching(T(g["in_prev"]), T(g["in_query"]), T(g["lab_onehot"].copy()), T(g["in_bias"]),
+                            [int(v) for v in g["mld"]], None, 1, False, bool(g["down"]))
+    assert tuple(out.shape) == g["out"].shape
+    np.testing.assert_allclose(out.numpy(), g["out"], **TOL)
+
+
+@pytest.mark.parametrize("name,n", [("fg2bg_O4", 4), ("fg2bg_O1", 1)])
+def test_fg2bg(golden, name, n):
+    g = golden(name)
+    assert np.array_equal(om.foreground2background(T(g["in_dis"]), n).numpy(), g["out"])
+
+
+def _onehot(lab, n):
+    return (T(lab.astype(np.int64)).unsqueeze(0) == torch.arange(n).view(-1, 1, 1)).float().unsqueeze(1)
+
+
+def test_attention_head(golden):
+    g = golden("attention_head_eval_p_m")
+    n = int(g["n_obj"])
+    ref_e = [T(e).permute(2, 0, 1).unsqueeze(0) for e in g["in_ref"]]
+    ref_l = [_onehot(l, n) for l in g["lab_ref"]]
+    prev_e = T(g["in_prev"]).permute(2, 0, 1).unsqueeze(0).expand(n, -1, -1, -1)
+    outs = ocal.attention_head_for_eval_p_m(ref_e, ref_l, prev_e, _onehot(g["lab_prev"], n))
+    for o, key in zip(outs, ["total", "ref_pos", "ref_neg", "prev_pos", "prev_neg"]):
+        np.testing.assert_allclose(o.numpy(), g[key], rtol=1e-6, atol=1e-7)
+    # the training twin (ATT:134-153) with one reference frame gives the same head
+    g2 = golden("attention_head_train_p_m")
+    o2 = ocal.attention_head_for_eval_p_m([T(g2["in_ref"][0]).permute(2, 0, 1).unsqueeze(0)], [_onehot(g2["lab_ref"][0], n)],
+                                          T(g2["in_prev"]).permute(2, 0, 1).unsqueeze(0).expand(n, -1, -1, -1),
+                                          _onehot(g2["lab_prev"], n))[0]
+    np.testing.assert_allclose(o2.numpy(), g2["total"], rtol=1e-6, atol=1e-7)
+
+
+def test_ia_gate(golden):
+    g = golden("ia_gate")
+    y = ocal.ia_gate(T(g["in_x"]), T(g["in_head"]), T(g["in_w"]), T(g["in_b"]))
+    np.testing.assert_allclose(y.numpy(), g["out"], rtol=1e-6, atol=1e-7)
+
+
+def test_conditioning_layer(golden):
+    g = golden("conditioning_layer_4d")
+    z = T(g["in_z"])
+    s, thr, mask, gap = ocal.conditioning_gate_stats(z, T(g["in_phi_w"]), T(g["in_phi_b"]), float(g["beta"]))
+    np.testing.assert_allclose(s.numpy(), g["scores"], rtol=1e-5, atol=1e-6)
+    k = int(0.3 * z.shape[2] * z.shape[3])
+    assert np.array_equal(mask.sum(1).numpy(), g["mask_count"]) and np.all(g["mask_count"] == k - 1)
+    out = ocal.conditioning_layer(z, T(g["in_phi_w"]), T(g["in_phi_b"]), T(g["in_mlp_w"]), T(g["in_mlp_b"]), float(g["beta"]))
+    np.testing.assert_allclose(out.numpy(), g["out"], rtol=1e-5, atol=1e-6)
+
+
+def test_conditioning_block_repair_is_consistent():
+    """a13 is unpinned by the reference (not executable).  Check the documented repair: the block
+    equals x * (1 + tanh(mlp([CL_1(x), mlp_2(x_delta), mlp_3(head)]))) built from pinned pieces."""
+    rng = np.random.RandomState(0)
+    n, c, p = 3, 8, 6
+    x = T(rng.randn(n, c, 5, 7).astype(np.float32))
+    head = T(rng.randn(n, p).astype(np.float32))
+    w = {k: T(rng.randn(*s).astype(np.float32) * 0.2) for k, s in {
+        "CL_1.phi_w": (c,), "CL_1.phi_b": (1,), "CL_1.mlp_w": (c, c), "CL_1.mlp_b": (c,),
+        "CL_2.mlp_w": (c, c), "CL_2.mlp_b": (c,), "CL_3.mlp_w": (p, p), "CL_3.mlp_b": (p,),
+        "mlp_w": (c, 2 * c + p), "mlp_b": (c,)}.items()}
+    y = ocal.conditioning_block(x, head, w)
+    px = x.mean(dim=(2, 3))
+    delta = px.sum(0, keepdim=True) - px
+    c1 = ocal.conditioning_layer(x, w["CL_1.phi_w"], w["CL_1.phi_b"], w["CL_1.mlp_w"], w["CL_1.mlp_b"])
+    a = 1 + torch.tanh(torch.cat([c1, delta @ w["CL_2.mlp_w"].t() + w["CL_2.mlp_b"],
+                                  head @ w["CL_3.mlp_w"].t() + w["CL_3.mlp_b"]], 1) @ w["mlp_w"].t() + w["mlp_b"])
+    np.testing.assert_allclose(y.numpy(), (a[:, :, None, None] * x).numpy(), rtol=1e-6, atol=1e-6)
