@@ -1,0 +1,234 @@
+/*
+ * aoc_hip.h -- C ABI of libaoc_hip.so: the MI355X (gfx950) implementation of the AOC-Net
+ * adaptive-proxy matching + mask-calibration hot path.
+ *
+ * The reference has no FFI layer; its operator surface is the set of Python functions that
+ * aocnet.py:6-7 and decoding_module.py:4,7 import.  Each entry point below names the reference
+ * code it replaces (paths relative to /root/reference/AOC-Net; AEM =
+ * adaptive_embedding_for_matching.py == complete_project/AOCNet/networks/layers/matching.py,
+ * ATT = complete_project/AOCNet/networks/layers/attention.py, CL = conditioning_layer.py).
+ * INTEGRATION.md shows the ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *  - plain C types only; every pointer is a DEVICE pointer unless the name ends in _host;
+ *  - all buffers (outputs and workspaces included) are caller-owned; nothing is allocated;
+ *  - work is enqueued on `stream` (a hipStream_t passed as void*) and NOT synchronised;
+ *  - return value: 0 = enqueued, < 0 = aoc_status error (nothing enqueued); never throws;
+ *  - fp32 data, row-major; "rows" are pixels of stride-4 feature maps; C = embedding width.
+ */
+#ifndef AOC_HIP_H
+#define AOC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *aoc_stream_t; /* hipStream_t */
+
+enum aoc_status {
+    AOC_OK = 0,
+    AOC_ERR_INVALID_ARG = -1,   /* null pointer, negative size, unsupported width ... */
+    AOC_ERR_WORKSPACE = -2,     /* workspace smaller than aoc_*_workspace_bytes()       */
+    AOC_ERR_LAUNCH = -3,        /* hipGetLastError() != hipSuccess after a launch        */
+    AOC_ERR_UNSUPPORTED = -4    /* e.g. more than AOC_MAX_OBJECTS objects                */
+};
+
+#define AOC_MAX_OBJECTS 30          /* label bits live in a uint32 (bit 31 = "row kept")      */
+#define AOC_MAX_CHANNELS 256        /* embedding width handled by the matching kernels         */
+#define AOC_MAX_CLUSTERS 64         /* proxies per object per level (cfg4)                     */
+#define AOC_PAD_DISTANCE 5.0e4f     /* WRONG_LABEL_PADDING_DISTANCE, AEM:25                    */
+#define AOC_ROW_KEPT_BIT 0x80000000u
+
+/* Library / build identification (string is static). */
+const char *aoc_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Label preparation.  Replaces the masked_select / nonzero / index_select plumbing of
+ * AEM:197-198 (wrong-label mask, label < 0.1), AEM:252,263-264 (per-object rows, label > 0.9)
+ * and AEM:585-591 (keep rows whose label sum > 0.9).  Nothing is copied: the reference pool
+ * stays in place and later kernels gather rows through the index lists produced here.
+ *
+ *  labels      [n, n_obj] float            (the concatenated [h,w,O] label maps of the pool)
+ *  right_bits  [n] out: bit o = label[j,o] > 0.9 ; bit 31 = row kept (sum_o label[j,o] > 0.9)
+ *  wrong_bits  [n] out: bit o = label[j,o] < 0.1
+ *  fg_rows     [n] out: pool row of every kept row, ascending (first counts[n_obj] valid)
+ *  obj_rows    [n_obj * n] out: for object o, at obj_offsets[o], the pool rows that are kept
+ *              AND right for o, ascending  (the reference's reference_embeddings_flat_cur)
+ *  counts      [n_obj + 1] out: rows per object; counts[n_obj] = kept rows
+ *  obj_offsets [n_obj + 1] out: exclusive prefix sum of counts[0..n_obj)
+ */
+size_t aoc_label_prep_workspace_bytes(int64_t n, int n_obj);
+int aoc_label_prep(const float *labels, int64_t n, int n_obj,
+                   uint32_t *right_bits, uint32_t *wrong_bits,
+                   int32_t *fg_rows, int32_t *obj_rows,
+                   int32_t *counts, int32_t *obj_offsets,
+                   void *workspace, size_t workspace_bytes, aoc_stream_t stream);
+
+/* Bit masks only (same definition as above; wrong_bits may be NULL).  Used by local matching
+ * (AEM:1023-1028: label > 0.9 of the previous frame). */
+int aoc_label_bits(const float *labels, int64_t n, int n_obj, uint32_t *right_bits,
+                   uint32_t *wrong_bits, aoc_stream_t stream);
+
+/* Sticky cluster count of AEM:268 (the loop variable is overwritten): k[o] = min(k[o-1], counts[o]),
+ * k[-1] = cluster_num.  Device-side so that a pipeline needs no host round trip. */
+int aoc_kmeans_plan(const int32_t *counts, int n_seg, int cluster_num, int32_t *seg_k,
+                    aoc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Segmented Lloyd k-means, bit-identical to scipy.cluster.vq.kmeans2(X, K, minit='matrix',
+ * iter=iters) as called at AEM:276 (one "segment" = one object's rows; all segments advance in
+ * the same launches).  Arithmetic order is scipy's (see oracle/csrc/aoc_oracle.c): sequential
+ * mul-then-add row norms, one k-ordered fma chain per dot product, (M + |x|^2) + |c|^2, strict <
+ * (ties -> lowest index), per-cluster sums in row order, division by (float)count, empty cluster
+ * keeps its centroid.
+ *
+ *  pool         [*, C]        embeddings the row ids refer to
+ *  rows         packed row ids (aoc_label_prep's obj_rows); segment s = rows[seg_offsets[s] .. seg_offsets[s+1])
+ *  seg_offsets  [n_seg + 1]   device
+ *  seg_k        [n_seg]       device; 0 = segment skipped (reference: centroid None, AEM:271-273)
+ *  init_rows    [n_seg, kmax] device; segment-local indices of the initial centroids
+ *                             (scipy minit='points': permutation(n_i)[:K_i])
+ *  rows_capacity              host-known upper bound of seg_offsets[n_seg] (sizes the grids)
+ *  centroids    [n_seg, kmax, C] out   final code book
+ *  labels       [rows_capacity]  out   segment-local cluster id of every packed row (last assignment)
+ *  cluster_counts [n_seg, kmax]  out   members per cluster in the last update
+ */
+size_t aoc_kmeans_workspace_bytes(int64_t rows_capacity, int n_seg, int kmax, int C);
+int aoc_kmeans_segmented(const float *pool, int C,
+                         const int32_t *rows, const int32_t *seg_offsets, const int32_t *seg_k,
+                         const int32_t *init_rows, int n_seg, int kmax, int iters,
+                         int64_t rows_capacity,
+                         float *centroids, int32_t *labels, int32_t *cluster_counts,
+                         void *workspace, size_t workspace_bytes, aoc_stream_t stream);
+
+/* The reference's second proxy set, AEM:280: for every non-empty cluster j of segment s the mean of
+ * the rows  fg[p], p in {segment-local indices with label == j}  of the GLOBAL kept-row array (the
+ * reference indexes the wrong array; reproduced as is).  Also emits the squared norms of both
+ * proxy sets (AEM:282); an empty / absent proxy gets norm = +inf so that a min skips it.
+ *
+ *  proxies      [n_seg, 2, kmax, C] out : [:,0] = centroids (copied), [:,1] = centroid_avg
+ *  proxy_sqnorm [n_seg, 2, kmax]   out
+ */
+int aoc_build_proxies(const float *pool, int C, const int32_t *fg_rows,
+                      const int32_t *seg_offsets, const int32_t *seg_k, const int32_t *labels,
+                      const float *centroids, int n_seg, int kmax,
+                      float *proxies, float *proxy_sqnorm, aoc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Pixel-to-proxy correlation ("the correlation kernel"): AEM:92-110 + 316-319 (min over an
+ * object's adaptive proxies), AEM:112-128 (k = 1 proxies, no min), fused with the proto-mask
+ * transform (sigmoid(d + bias) - 0.5) * 2 of AEM:393/602/864.
+ *
+ *  query        [m, C]
+ *  proxies      [n_proxy, C], proxy_sqnorm [n_proxy] (+inf = ignore; NULL = computed in-kernel)
+ *  set_offsets_host  [n_set + 1] HOST array: set s = proxies[set_offsets[s] .. set_offsets[s+1]);
+ *               out value = min over the set; an empty or all-ignored set yields AOC_PAD_DISTANCE
+ *               (reference: absent object, AEM:310-313).  Runs of single-proxy sets are the k = 1
+ *               proxies (no min).  The set structure is static (kmax slots per object; unused
+ *               slots carry norm = +inf), so it is known to the host without a device round trip.
+ *  set_bias     [n_set] device (dis_bias of the set's object); may be NULL (= 0)
+ *  out element (pixel i, set s) is written at out[i * out_pixel_stride + s * out_set_stride]
+ *  transform    1 = apply the proto-mask transform, 0 = raw squared distance
+ */
+int aoc_proxy_corr_min(const float *query, int64_t m, int C,
+                       const float *proxies, const float *proxy_sqnorm, int n_proxy,
+                       const int32_t *set_offsets_host, const float *set_bias, int n_set,
+                       float *out, int64_t out_pixel_stride, int64_t out_set_stride,
+                       int transform, aoc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Dense pixel-level matching: AEM:178-227 + 61-89 without materialising [m, O, n]:
+ *   out[i,o] = min_j ( (|q_i|^2 + |r_j|^2) - 2 q_i.r_j + 5e4 * wrong[j,o] ),  j over kept rows,
+ * fused with the proto-mask transform (AEM:808).  fp32 MFMA (v_mfma_f32_16x16x4_f32).
+ *
+ *  pool [*, C]; fg_rows [n_fg_capacity] kept rows; n_fg device scalar (counts[n_obj] of label prep);
+ *  wrong_bits [pool rows]; out element (i,o) at out[i*out_pixel_stride + o*out_obj_stride].
+ *  n_fg == 0 yields 1.0 everywhere when transform != 0 (AEM:796-797), +inf otherwise.
+ */
+size_t aoc_dense_match_workspace_bytes(int64_t m, int64_t n_fg_capacity, int n_obj);
+int aoc_dense_match_min(const float *query, int64_t m, int C,
+                        const float *pool, const int32_t *fg_rows, const int32_t *n_fg,
+                        int64_t n_fg_capacity, const uint32_t *wrong_bits,
+                        const float *obj_bias, int n_obj,
+                        float *out, int64_t out_pixel_stride, int64_t out_obj_stride,
+                        int transform, void *workspace, size_t workspace_bytes, aoc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Local (windowed) matching: AEM:921-963 + 968-1060 (and the identical local_matching_proxy,
+ * AEM:1064-1156) without the F.unfold materialisation.  Works on maps already at matching
+ * resolution (the bilinear down / up-sampling of AEM:938-941,1054-1056 are aoc_resize_*).
+ *
+ *  query, prev   [H, W, C]       right_bits [H*W] (bit o = prev label > 0.9 at that pixel)
+ *  window radii  radii_host[n_radii] ascending, radii_host[n_radii-1] = max_distance (atrous 1)
+ *  out           [n_obj, n_radii, H, W]; channel order [max, r_0, r_1, ...] (AEM:1034-1046);
+ *                value = transform(min over the window of masked distances; 5e4 if none)
+ */
+int aoc_local_window_match(const float *query, const float *prev, const uint32_t *right_bits,
+                           int H, int W, int C, const int32_t *radii_host, int n_radii,
+                           const float *obj_bias, int n_obj, float *out, int transform,
+                           aoc_stream_t stream);
+
+/* Bilinear (align_corners=True) resize of a channel-last map [h,w,C] -> [H,W,C]  (AEM:938-941). */
+int aoc_resize_bilinear_hwc(const float *in, int h, int w, int C, float *out, int H, int W,
+                            aoc_stream_t stream);
+/* Bilinear (align_corners=True) resize of planes [P,h,w] -> element (p,y,x) written at
+ * out[p*out_plane_stride + (y*W + x)*out_pixel_stride]           (AEM:604-607, 1054-1058). */
+int aoc_resize_bilinear_planes(const float *in, int P, int h, int w, float *out, int H, int W,
+                               int64_t out_plane_stride, int64_t out_pixel_stride,
+                               aoc_stream_t stream);
+/* torch 'nearest' resize of per-pixel label bits [h,w] -> [H,W]  (AEM:1017-1018). */
+int aoc_resize_nearest_bits(const uint32_t *in, int h, int w, uint32_t *out, int H, int W,
+                            aoc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * foreground2background, AEM:9-23: out[o] = min over o' != o of dis[o'] (elementwise).
+ *  dis, out  [n_obj, inner]   (inner = c*h*w).  n_obj == 1 copies. */
+int aoc_fg2bg_min(const float *dis, int n_obj, int64_t inner, float *out, aoc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * k = 1 proxies / IA head: ATT:134-189 (calculate_attention_head[_for_eval]_p_m).
+ *  Accumulates over n_frames maps  emb [n_frames, hw, C] (channel-last) with float label maps
+ *  labels [n_frames, n_obj, hw] (the reference's one-hot [O,1,h,w] tensors; any float works):
+ *    pos[o] = sum_p emb[p] * label[o,p] / (sum_p label[o,p] + eps)
+ *    neg[o] = (sum_p emb[p] - pos_sum[o]) / (sum_p (1 - label[o,p]) + eps)
+ *  out_pos, out_neg [n_obj, C].
+ */
+size_t aoc_masked_mean_pool_workspace_bytes(int n_frames, int64_t hw, int n_obj, int C);
+int aoc_masked_mean_pool(const float *emb, const float *labels, int n_frames, int64_t hw, int C,
+                         int n_obj, float epsilon, float *out_pos, float *out_neg,
+                         void *workspace, size_t workspace_bytes, aoc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * FiLM gate: ATT:12-17 (IA_gate.forward) and CLB:81-84:
+ *   gain[o,c] = 1 + tanh( sum_d head[o,d] * weight[c,d] + bias[c] );  y[o,c,:] = gain[o,c] * x[o,c,:]
+ *  aoc_film_gain writes gain [n_obj, channels]; aoc_channel_scale streams x (in place allowed). */
+int aoc_film_gain(const float *head, const float *weight, const float *bias, int n_obj,
+                  int head_dim, int channels, float *gain, aoc_stream_t stream);
+int aoc_channel_scale(const float *x, const float *gain, int64_t planes, int64_t hw, float *y,
+                      aoc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * conditioning_layer gate + pool: CL:23-43 (paper Eq. 7):
+ *   s = phi(z) (1x1 conv C->1), t = k-th largest of s per sample (k = int(beta*H*W), exact radix
+ *   select), mask = s > t (strict), gap[n,c] = mean over ALL HW of z[n,c,:] * mask.
+ *  z [N, C, HW]; phi_w [C]; phi_b [1]; gap [N, C] out; scores [N, HW] / threshold [N] optional outs
+ *  (may be NULL, then they live in the workspace).
+ */
+size_t aoc_cond_gate_pool_workspace_bytes(int N, int C, int64_t hw);
+int aoc_cond_gate_pool(const float *z, int N, int C, int64_t hw, const float *phi_w,
+                       const float *phi_b, int k_rank, float *gap, float *scores, float *threshold,
+                       void *workspace, size_t workspace_bytes, aoc_stream_t stream);
+
+/* Small dense layer used by the conditioning MLPs (CL:46, CLB:81): y[n,:] = x[n,:] W^T + b. */
+int aoc_linear(const float *x, const float *weight, const float *bias, int N, int in_dim,
+               int out_dim, float *y, aoc_stream_t stream);
+/* Global average pool of planes [planes, hw] -> [planes]  (CLB:68). */
+int aoc_plane_mean(const float *x, int64_t planes, int64_t hw, float *out, aoc_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AOC_HIP_H */

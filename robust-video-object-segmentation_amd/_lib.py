@@ -1,0 +1,79 @@
+"""ctypes binding of csrc/libaoc_hip.so (the C ABI declared in include/aoc_hip.h).
+
+There is deliberately no fallback: if the shared library is missing the import of an operator
+fails with a clear error instead of silently running something else.
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+SO_PATH = os.path.join(CSRC, "libaoc_hip.so")
+
+_vp, _i, _i64, _sz, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_size_t, ctypes.c_float
+
+# name -> (restype, argtypes); mirrors include/aoc_hip.h one to one
+SIGNATURES = {
+    "aoc_version": (ctypes.c_char_p, []),
+    "aoc_label_prep_workspace_bytes": (_sz, [_i64, _i]),
+    "aoc_label_prep": (_i, [_vp, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "aoc_label_bits": (_i, [_vp, _i64, _i, _vp, _vp, _vp]),
+    "aoc_kmeans_plan": (_i, [_vp, _i, _i, _vp, _vp]),
+    "aoc_kmeans_workspace_bytes": (_sz, [_i64, _i, _i, _i]),
+    "aoc_kmeans_segmented": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "aoc_build_proxies": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
+    "aoc_proxy_corr_min": (_i, [_vp, _i64, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _i64, _i64, _i, _vp]),
+    "aoc_dense_match_workspace_bytes": (_sz, [_i64, _i64, _i]),
+    "aoc_dense_match_min": (_i, [_vp, _i64, _i, _vp, _vp, _vp, _i64, _vp, _vp, _i, _vp, _i64, _i64, _i, _vp, _sz, _vp]),
+    "aoc_local_window_match": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp]),
+    "aoc_resize_bilinear_hwc": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _vp]),
+    "aoc_resize_bilinear_planes": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i64, _i64, _vp]),
+    "aoc_resize_nearest_bits": (_i, [_vp, _i, _i, _vp, _i, _i, _vp]),
+    "aoc_fg2bg_min": (_i, [_vp, _i, _i64, _vp, _vp]),
+    "aoc_masked_mean_pool_workspace_bytes": (_sz, [_i, _i64, _i, _i]),
+    "aoc_masked_mean_pool": (_i, [_vp, _vp, _i, _i64, _i, _i, _f, _vp, _vp, _vp, _sz, _vp]),
+    "aoc_film_gain": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "aoc_channel_scale": (_i, [_vp, _vp, _i64, _i64, _vp, _vp]),
+    "aoc_cond_gate_pool_workspace_bytes": (_sz, [_i, _i, _i64]),
+    "aoc_cond_gate_pool": (_i, [_vp, _i, _i, _i64, _vp, _vp, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "aoc_linear": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "aoc_plane_mean": (_i, [_vp, _i64, _i64, _vp, _vp]),
+}
+
+STATUS = {0: "AOC_OK", -1: "AOC_ERR_INVALID_ARG", -2: "AOC_ERR_WORKSPACE", -3: "AOC_ERR_LAUNCH", -4: "AOC_ERR_UNSUPPORTED"}
+
+_lib = None
+
+
+class AocHipError(RuntimeError):
+    pass
+
+
+def build(force=False):
+    """hipcc --offload-arch=gfx950 build of csrc/*.hip -> csrc/libaoc_hip.so (in-tree)."""
+    if force:
+        subprocess.check_call(["make", "-s", "-C", CSRC, "clean"])
+    subprocess.check_call(["make", "-s", "-j4", "-C", CSRC])
+    return SO_PATH
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise AocHipError(
+                f"{SO_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback for the aoc_amd operators.")
+        L = ctypes.CDLL(SO_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)      # AttributeError here = header / library mismatch
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise AocHipError(f"{what} failed: {STATUS.get(rc, rc)}")

@@ -1,0 +1,58 @@
+"""Drop-in mirror of AOC-Net/conditioning_layer.py ("CL", == networks/aoc/conditioning_layer.py
+"CLB":6-48) and of ``conditioning_block`` (CLB:50-86) on the HIP library.
+
+Parameter names (``phi_layer``, ``mlp_layer``, ``CL_1``, ``CL_2``, ``CL_3``) are the reference's, so a
+reference ``state_dict`` loads.  The reference code is not executable as shipped;
+the repairs are the minimal ones, spelled out in DESIGN.md:
+  * ``self.`` in front of ``mlp_layer`` / ``CL_1..3``;
+  * ``conditioning_block`` feeds ``CL_2`` / ``CL_3`` with 2-D tensors that ``Conv2d`` rejects (and, as
+    [N,D,1,1], ``k = int(beta*1*1) = 0`` raises): a vector input is treated as the H = W = 1 limit of
+    paper Eq. 7 with the gate identically 1, i.e. ``CL(v) = mlp_layer(v)``;
+  * ``CL_3`` is sized by ``proxy_dim`` (its input is the [O, 400] IA head).
+"""
+import torch
+from torch import nn
+
+from . import ops
+
+
+class conditioning_layer(nn.Module):
+    """Paper Eq. 7, CL:6-45."""
+
+    def __init__(self, in_dim=256, beta_percentage=0.3):
+        super(conditioning_layer, self).__init__()
+        self.beta_percentage = beta_percentage
+        kernel_size = 1
+        self.phi_layer = nn.Conv2d(in_dim, 1, kernel_size=kernel_size, stride=1, padding=int((kernel_size - 1) / 2))
+        self.mlp_layer = nn.Linear(in_dim, in_dim)
+        nn.init.kaiming_normal_(self.phi_layer.weight, mode='fan_out', nonlinearity='relu')
+
+    def forward(self, z_in):
+        if z_in.dim() == 2:                                   # vector input (conditioning_block repair)
+            return ops.linear(z_in, self.mlp_layer.weight.detach(), self.mlp_layer.bias.detach())
+        beta_rank = int(self.beta_percentage * z_in.size()[-1] * z_in.size()[-2])      # CL:32
+        if beta_rank < 1:
+            raise IndexError("conditioning_layer: beta_rank == 0 (the reference fails at beta_val[..., -1])")
+        gap = ops.cond_gate_pool(z_in, self.phi_layer.weight.detach().reshape(-1), self.phi_layer.bias.detach(), beta_rank)
+        return ops.linear(gap, self.mlp_layer.weight.detach(), self.mlp_layer.bias.detach())   # CL:46
+
+
+class conditioning_block(nn.Module):
+    """Paper Eq. 5, CLB:50-86."""
+
+    def __init__(self, in_dim=256, proxy_dim=400, beta_percentage=0.3):
+        super(conditioning_block, self).__init__()
+        self.CL_1 = conditioning_layer(in_dim, beta_percentage)
+        self.CL_2 = conditioning_layer(in_dim, beta_percentage)
+        self.CL_3 = conditioning_layer(proxy_dim, 1)
+        self.mlp_layer = nn.Linear(in_dim * 2 + proxy_dim, in_dim)
+
+    def forward(self, x, proxy_IA_head):
+        px1 = ops.plane_mean(x)                                              # CLB:68
+        x_delta = px1.sum(dim=0, keepdim=True) - px1                         # CLB:69 ([O, C] glue)
+        cl_out_1 = self.CL_1(x)                                              # CLB:72 intra-object code
+        cl_out_2 = self.CL_2(x_delta)                                        # CLB:75 inter-object code
+        cl_out_3 = self.CL_3(proxy_IA_head)                                  # CLB:78 proxy code
+        code = torch.cat([cl_out_1, cl_out_2, cl_out_3], dim=1)
+        gain = ops.film_gain(code, self.mlp_layer.weight.detach(), self.mlp_layer.bias.detach())   # CLB:81-82
+        return ops.channel_scale(x, gain)                                    # CLB:83-84

@@ -1,0 +1,47 @@
+// Shared device helpers for libaoc_hip.so (gfx950 only; wave = 64 lanes).
+// The whole library is compiled with -ffp-contract=off: nothing fuses unless the code says
+// __builtin_fmaf, because the k-means path must reproduce scipy's rounding sequence exactly.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "../../include/aoc_hip.h"
+
+#define AOC_RETURN_IF_LAUNCH_FAILED()                       \
+    do {                                                    \
+        if (hipGetLastError() != hipSuccess) return AOC_ERR_LAUNCH; \
+    } while (0)
+
+static inline hipStream_t aoc_hip_stream(aoc_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+static inline size_t aoc_align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Proto-mask transform of AEM:393/602/808/1049: (sigmoid(d + bias) - 0.5) * 2.
+__device__ __forceinline__ float aoc_proto_transform(float d, float bias) {
+    float s = 1.0f / (1.0f + expf(-(d + bias)));
+    return (s - 0.5f) * 2.0f;
+}
+
+__device__ __forceinline__ int aoc_lane() { return threadIdx.x & 63; }
+
+// min / sum across the 16 lanes that share (lane >> 4)  (one MFMA 16x16 output row group).
+__device__ __forceinline__ float aoc_min16(float v) {
+    v = fminf(v, __shfl_xor(v, 1));
+    v = fminf(v, __shfl_xor(v, 2));
+    v = fminf(v, __shfl_xor(v, 4));
+    v = fminf(v, __shfl_xor(v, 8));
+    return v;
+}
+__device__ __forceinline__ float aoc_wave_sum(float v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// LDS image of a 16-row operand tile for v_mfma_f32_16x16x4_f32, "k-permuted":
+// lane (j = lane & 15, kq = lane >> 4) consumes x[j][4t + kq], t = 0..T-1.  Row j keeps its four
+// kq-streams contiguous ([kq][t], each stream padded to TP = roundup(T,4) floats) so the lane reads
+// its stream with ds_read_b128.  Row stride = 4*TP + 4 floats (the +4 staggers rows by 16 B).
+__host__ __device__ __forceinline__ int aoc_tile_tp(int C) { return ((C / 4) + 3) / 4 * 4; }
+__host__ __device__ __forceinline__ int aoc_tile_row_stride(int C) { return 4 * aoc_tile_tp(C) + 4; }

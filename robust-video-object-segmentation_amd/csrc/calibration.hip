@@ -1,0 +1,321 @@
+// Streaming kernels of the mask-calibration side: fg->bg min (AEM:9-23), k = 1 proxy pooling
+// (ATT:134-189), FiLM gate (ATT:12-17, CLB:81-84) and the conditioning-layer gate + pool (CL:23-43).
+// All of them are HBM-bound: one coalesced pass over the big operand, reductions in LDS/registers.
+#include "aoc_common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------ fg2bg
+__global__ __launch_bounds__(256) void fg2bg_kernel(const float *__restrict__ dis, int n_obj, int64_t inner, float *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= inner) return;
+    if (n_obj == 1) { out[i] = dis[i]; return; }           // AEM:10-11
+    float m1 = INFINITY, m2 = INFINITY;
+    int arg = -1;
+    for (int o = 0; o < n_obj; ++o) {
+        const float v = dis[(size_t)o * inner + i];
+        if (v < m1) { m2 = m1; m1 = v; arg = o; }
+        else if (v < m2) { m2 = v; }
+    }
+    for (int o = 0; o < n_obj; ++o) out[(size_t)o * inner + i] = (o == arg) ? m2 : m1;   // min over the OTHER objects
+}
+
+// ------------------------------------------------------------------------------------------ pooling
+constexpr int MP_PIX = 512;      // pixels per block
+constexpr int MP_OMAX = 32;
+
+// partial[blk][o][c] = sum_{p in chunk} emb[p,c] * lab[o,p]  (o < O), partial[blk][O][c] = sum emb[p,c];
+// pcount[blk][o] = sum lab[o,p].   emb [F, hw, C] channel-last, lab [F, O, hw].
+__global__ __launch_bounds__(128) void masked_pool_partial_kernel(const float *__restrict__ emb, const float *__restrict__ lab,
+                                                                   int64_t hw, int C, int n_obj, int chunks_per_frame,
+                                                                   float *__restrict__ partial, float *__restrict__ pcount) {
+    extern __shared__ float llab[];   // [n_obj][MP_PIX]
+    const int f = blockIdx.x / chunks_per_frame, chunk = blockIdx.x - f * chunks_per_frame;
+    const int64_t p0 = (int64_t)chunk * MP_PIX;
+    const int np = (int)min((int64_t)MP_PIX, hw - p0);
+    for (int i = threadIdx.x; i < n_obj * MP_PIX; i += blockDim.x) {
+        const int o = i / MP_PIX, p = i - o * MP_PIX;
+        llab[i] = (p < np) ? lab[((size_t)f * n_obj + o) * hw + p0 + p] : 0.0f;
+    }
+    __syncthreads();
+    const float *e = emb + ((size_t)f * hw + p0) * C;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float acc[MP_OMAX + 1];
+#pragma unroll
+        for (int o = 0; o <= MP_OMAX; ++o) acc[o] = 0.0f;
+        for (int p = 0; p < np; ++p) {
+            const float v = e[(size_t)p * C + c];
+            acc[MP_OMAX] += v;
+#pragma unroll
+            for (int o = 0; o < MP_OMAX; ++o)
+                if (o < n_obj) acc[o] += v * llab[o * MP_PIX + p];
+        }
+#pragma unroll
+        for (int o = 0; o < MP_OMAX; ++o)
+            if (o < n_obj) partial[((size_t)blockIdx.x * (n_obj + 1) + o) * C + c] = acc[o];
+        partial[((size_t)blockIdx.x * (n_obj + 1) + n_obj) * C + c] = acc[MP_OMAX];
+    }
+    if (threadIdx.x < n_obj) {
+        float s = 0.0f;
+        for (int p = 0; p < np; ++p) s += llab[threadIdx.x * MP_PIX + p];
+        pcount[(size_t)blockIdx.x * n_obj + threadIdx.x] = s;
+    }
+}
+
+__global__ __launch_bounds__(128) void masked_pool_final_kernel(const float *__restrict__ partial, const float *__restrict__ pcount,
+                                                                 int n_blocks, int C, int n_obj, float total_pixels, float eps,
+                                                                 float *__restrict__ out_pos, float *__restrict__ out_neg) {
+    const int o = blockIdx.x;
+    float cnt = 0.0f;
+    for (int b = 0; b < n_blocks; ++b) cnt += pcount[(size_t)b * n_obj + o];
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float pos = 0.0f, tot = 0.0f;
+        for (int b = 0; b < n_blocks; ++b) {
+            pos += partial[((size_t)b * (n_obj + 1) + o) * C + c];
+            tot += partial[((size_t)b * (n_obj + 1) + n_obj) * C + c];
+        }
+        out_pos[(size_t)o * C + c] = pos / (cnt + eps);                             // ATT:173
+        out_neg[(size_t)o * C + c] = (tot - pos) / ((total_pixels - cnt) + eps);    // ATT:166,174
+    }
+}
+
+// ------------------------------------------------------------------------------------------ FiLM
+// one wave per output channel; all objects at once.  gain[o,c] = 1 + tanh(head[o,:].W[c,:] + b[c])
+__global__ __launch_bounds__(64) void film_gain_kernel(const float *__restrict__ head, const float *__restrict__ weight,
+                                                        const float *__restrict__ bias, int n_obj, int D, int channels,
+                                                        float *__restrict__ gain) {
+    const int c = blockIdx.x;
+    const int lane = threadIdx.x;
+    const float *w = weight + (size_t)c * D;
+    for (int o0 = 0; o0 < n_obj; o0 += 4) {
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int d = lane; d < D; d += 64) {
+            const float wv = w[d];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (o0 + q < n_obj) acc[q] += wv * head[(size_t)(o0 + q) * D + d];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float s = aoc_wave_sum(acc[q]);
+            if (lane == 0 && o0 + q < n_obj) gain[(size_t)(o0 + q) * channels + c] = 1.0f + tanhf(s + (bias ? bias[c] : 0.0f));
+        }
+    }
+}
+
+// y[p, :] = gain[p] * x[p, :]   (planes p = (object, channel)); grid.y = plane
+__global__ __launch_bounds__(256) void channel_scale_kernel(const float *__restrict__ x, const float *__restrict__ gain, int64_t hw,
+                                                             float *__restrict__ y) {
+    const int64_t plane = blockIdx.y;
+    const float g = gain[plane];
+    const float *xp = x + plane * hw;
+    float *yp = y + plane * hw;
+    // 16-byte aligned body + scalar head/tail (hw is odd for the 16k+1 input sizes)
+    const uintptr_t addr = reinterpret_cast<uintptr_t>(xp);
+    int64_t head = ((16 - (addr & 15)) & 15) / 4;
+    if (head > hw) head = hw;
+    const bool same_align = ((reinterpret_cast<uintptr_t>(yp) & 15) == (addr & 15));
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
+    if (same_align) {
+        if (tid < head) yp[tid] = g * xp[tid];
+        const int64_t body4 = (hw - head) / 4;
+        const float4 *x4 = reinterpret_cast<const float4 *>(xp + head);
+        float4 *y4 = reinterpret_cast<float4 *>(yp + head);
+        for (int64_t i = tid; i < body4; i += nthreads) {
+            float4 v = x4[i];
+            v.x *= g; v.y *= g; v.z *= g; v.w *= g;
+            y4[i] = v;
+        }
+        const int64_t tail0 = head + body4 * 4;
+        if (tid < hw - tail0) yp[tail0 + tid] = g * xp[tail0 + tid];
+    } else {
+        for (int64_t i = tid; i < hw; i += nthreads) yp[i] = g * xp[i];
+    }
+}
+
+// ------------------------------------------------------------------------------------------ conditioning layer
+// scores[n,p] = sum_c w[c] z[n,c,p] + b      (CL:27, the 1x1 conv C -> 1)
+__global__ __launch_bounds__(256) void cond_scores_kernel(const float *__restrict__ z, int C, int64_t hw, const float *__restrict__ phi_w,
+                                                           const float *__restrict__ phi_b, float *__restrict__ scores) {
+    const int n = blockIdx.y;
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= hw) return;
+    const float *zp = z + (size_t)n * C * hw + p;
+    float s = 0.0f;
+    for (int c = 0; c < C; ++c) s += phi_w[c] * zp[(size_t)c * hw];
+    scores[(size_t)n * hw + p] = s + phi_b[0];
+}
+
+__device__ __forceinline__ uint32_t float_order_key(float f) {
+    const uint32_t b = __float_as_uint(f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);    // larger float <=> larger key
+}
+__device__ __forceinline__ float key_to_float(uint32_t k) {
+    return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+
+// threshold[n] = k-th largest score of sample n  (CL:33 topk(...)[..., -1]); exact radix select.
+__global__ __launch_bounds__(1024) void cond_kth_largest_kernel(const float *__restrict__ scores, int64_t hw, int k_rank,
+                                                                 float *__restrict__ threshold) {
+    __shared__ uint32_t hist[256];
+    __shared__ uint32_t sel_prefix, sel_k;
+    const int n = blockIdx.x;
+    const float *s = scores + (size_t)n * hw;
+    if (threadIdx.x == 0) { sel_prefix = 0; sel_k = (uint32_t)k_rank; }
+    uint32_t mask = 0;
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        if (threadIdx.x < 256) hist[threadIdx.x] = 0;
+        __syncthreads();
+        const uint32_t prefix = sel_prefix;
+        for (int64_t i = threadIdx.x; i < hw; i += blockDim.x) {
+            const uint32_t key = float_order_key(s[i]);
+            if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t need = sel_k, acc = 0;
+            int b = 255;
+            for (; b > 0; --b) {
+                if (acc + hist[b] >= need) break;
+                acc += hist[b];
+            }
+            sel_k = need - acc;
+            sel_prefix = prefix | ((uint32_t)b << shift);
+        }
+        mask |= 0xffu << shift;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) threshold[n] = key_to_float(sel_prefix);
+}
+
+// gap[n,c] = (1/HW) * sum_p z[n,c,p] * (scores[n,p] > threshold[n])    (CL:36-43); one block per plane
+__global__ __launch_bounds__(256) void cond_masked_gap_kernel(const float *__restrict__ z, int C, int64_t hw, const float *__restrict__ scores,
+                                                               const float *__restrict__ threshold, float *__restrict__ gap) {
+    __shared__ float wsum[4];
+    const int c = blockIdx.x, n = blockIdx.y;
+    const float thr = threshold[n];
+    const float *zp = z + ((size_t)n * C + c) * hw;
+    const float *sp = scores + (size_t)n * hw;
+    float acc = 0.0f;
+    for (int64_t p = threadIdx.x; p < hw; p += blockDim.x) acc += (sp[p] > thr) ? zp[p] : 0.0f;
+    acc = aoc_wave_sum(acc);
+    if (aoc_lane() == 0) wsum[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) gap[(size_t)n * C + c] = (wsum[0] + wsum[1] + wsum[2] + wsum[3]) / (float)hw;
+}
+
+// y[n,o] = x[n,:] . W[o,:] + b[o]; one wave per output
+__global__ __launch_bounds__(64) void linear_kernel(const float *__restrict__ x, const float *__restrict__ weight, const float *__restrict__ bias,
+                                                     int in_dim, int out_dim, float *__restrict__ y) {
+    const int o = blockIdx.x, n = blockIdx.y;
+    const float *xr = x + (size_t)n * in_dim, *wr = weight + (size_t)o * in_dim;
+    float acc = 0.0f;
+    for (int d = threadIdx.x; d < in_dim; d += 64) acc += xr[d] * wr[d];
+    acc = aoc_wave_sum(acc);
+    if (threadIdx.x == 0) y[(size_t)n * out_dim + o] = acc + (bias ? bias[o] : 0.0f);
+}
+
+__global__ __launch_bounds__(256) void plane_mean_kernel(const float *__restrict__ x, int64_t hw, float *__restrict__ out) {
+    __shared__ float wsum[4];
+    const float *xp = x + (size_t)blockIdx.x * hw;
+    float acc = 0.0f;
+    for (int64_t p = threadIdx.x; p < hw; p += blockDim.x) acc += xp[p];
+    acc = aoc_wave_sum(acc);
+    if (aoc_lane() == 0) wsum[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) out[blockIdx.x] = (wsum[0] + wsum[1] + wsum[2] + wsum[3]) / (float)hw;
+}
+
+inline int pool_chunks(int64_t hw) { return (int)((hw + MP_PIX - 1) / MP_PIX); }
+
+}  // namespace
+
+extern "C" {
+
+int aoc_fg2bg_min(const float *dis, int n_obj, int64_t inner, float *out, aoc_stream_t stream) {
+    if (!dis || !out || n_obj < 1 || inner < 1) return AOC_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(fg2bg_kernel, dim3((unsigned)((inner + 255) / 256)), dim3(256), 0, aoc_hip_stream(stream), dis, n_obj, inner, out);
+    AOC_RETURN_IF_LAUNCH_FAILED();
+    return AOC_OK;
+}
+
+size_t aoc_masked_mean_pool_workspace_bytes(int n_frames, int64_t hw, int n_obj, int C) {
+    if (n_frames < 1 || hw < 1 || n_obj < 1 || C < 1) return 0;
+    const size_t nb = (size_t)n_frames * pool_chunks(hw);
+    return aoc_align_up(nb * (n_obj + 1) * C * sizeof(float), 256) + aoc_align_up(nb * n_obj * sizeof(float), 256);
+}
+
+int aoc_masked_mean_pool(const float *emb, const float *labels, int n_frames, int64_t hw, int C, int n_obj, float epsilon,
+                         float *out_pos, float *out_neg, void *workspace, size_t workspace_bytes, aoc_stream_t stream) {
+    if (!emb || !labels || !out_pos || !out_neg || !workspace) return AOC_ERR_INVALID_ARG;
+    if (n_frames < 1 || hw < 1 || C < 1 || n_obj < 1) return AOC_ERR_INVALID_ARG;
+    if (n_obj > MP_OMAX) return AOC_ERR_UNSUPPORTED;
+    if (workspace_bytes < aoc_masked_mean_pool_workspace_bytes(n_frames, hw, n_obj, C)) return AOC_ERR_WORKSPACE;
+    hipStream_t st = aoc_hip_stream(stream);
+    const int cpf = pool_chunks(hw);
+    const int nb = n_frames * cpf;
+    float *partial = static_cast<float *>(workspace);
+    float *pcount = reinterpret_cast<float *>(static_cast<char *>(workspace) + aoc_align_up((size_t)nb * (n_obj + 1) * C * sizeof(float), 256));
+    hipLaunchKernelGGL(masked_pool_partial_kernel, dim3(nb), dim3(128), (size_t)n_obj * MP_PIX * sizeof(float), st, emb, labels, hw, C, n_obj, cpf, partial, pcount);
+    hipLaunchKernelGGL(masked_pool_final_kernel, dim3(n_obj), dim3(128), 0, st, partial, pcount, nb, C, n_obj, (float)((double)hw * n_frames), epsilon, out_pos, out_neg);
+    AOC_RETURN_IF_LAUNCH_FAILED();
+    return AOC_OK;
+}
+
+int aoc_film_gain(const float *head, const float *weight, const float *bias, int n_obj, int head_dim, int channels, float *gain, aoc_stream_t stream) {
+    if (!head || !weight || !gain || n_obj < 1 || head_dim < 1 || channels < 1) return AOC_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(film_gain_kernel, dim3(channels), dim3(64), 0, aoc_hip_stream(stream), head, weight, bias, n_obj, head_dim, channels, gain);
+    AOC_RETURN_IF_LAUNCH_FAILED();
+    return AOC_OK;
+}
+
+int aoc_channel_scale(const float *x, const float *gain, int64_t planes, int64_t hw, float *y, aoc_stream_t stream) {
+    if (!x || !gain || !y || planes < 1 || hw < 1) return AOC_ERR_INVALID_ARG;
+    if (planes > 65535) return AOC_ERR_UNSUPPORTED;
+    int bx = (int)((hw / 4 + 255) / 256);
+    if (bx < 1) bx = 1;
+    if (bx > 8) bx = 8;
+    hipLaunchKernelGGL(channel_scale_kernel, dim3(bx, (unsigned)planes), dim3(256), 0, aoc_hip_stream(stream), x, gain, hw, y);
+    AOC_RETURN_IF_LAUNCH_FAILED();
+    return AOC_OK;
+}
+
+size_t aoc_cond_gate_pool_workspace_bytes(int N, int C, int64_t hw) {
+    (void)C;
+    if (N < 1 || hw < 1) return 0;
+    return aoc_align_up((size_t)N * hw * sizeof(float), 256) + aoc_align_up((size_t)N * sizeof(float), 256);
+}
+
+int aoc_cond_gate_pool(const float *z, int N, int C, int64_t hw, const float *phi_w, const float *phi_b, int k_rank,
+                       float *gap, float *scores, float *threshold, void *workspace, size_t workspace_bytes, aoc_stream_t stream) {
+    if (!z || !phi_w || !phi_b || !gap || !workspace) return AOC_ERR_INVALID_ARG;
+    if (N < 1 || C < 1 || hw < 1 || k_rank < 1 || k_rank > hw) return AOC_ERR_INVALID_ARG;
+    if (N > 65535 || C > 65535) return AOC_ERR_UNSUPPORTED;
+    if (workspace_bytes < aoc_cond_gate_pool_workspace_bytes(N, C, hw)) return AOC_ERR_WORKSPACE;
+    hipStream_t st = aoc_hip_stream(stream);
+    float *sc = scores ? scores : static_cast<float *>(workspace);
+    float *th = threshold ? threshold : reinterpret_cast<float *>(static_cast<char *>(workspace) + aoc_align_up((size_t)N * hw * sizeof(float), 256));
+    hipLaunchKernelGGL(cond_scores_kernel, dim3((unsigned)((hw + 255) / 256), N), dim3(256), 0, st, z, C, hw, phi_w, phi_b, sc);
+    hipLaunchKernelGGL(cond_kth_largest_kernel, dim3(N), dim3(1024), 0, st, sc, hw, k_rank, th);
+    hipLaunchKernelGGL(cond_masked_gap_kernel, dim3(C, N), dim3(256), 0, st, z, C, hw, sc, th, gap);
+    AOC_RETURN_IF_LAUNCH_FAILED();
+    return AOC_OK;
+}
+
+int aoc_linear(const float *x, const float *weight, const float *bias, int N, int in_dim, int out_dim, float *y, aoc_stream_t stream) {
+    if (!x || !weight || !y || N < 1 || in_dim < 1 || out_dim < 1) return AOC_ERR_INVALID_ARG;
+    if (N > 65535) return AOC_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(linear_kernel, dim3(out_dim, N), dim3(64), 0, aoc_hip_stream(stream), x, weight, bias, in_dim, out_dim, y);
+    AOC_RETURN_IF_LAUNCH_FAILED();
+    return AOC_OK;
+}
+
+int aoc_plane_mean(const float *x, int64_t planes, int64_t hw, float *out, aoc_stream_t stream) {
+    if (!x || !out || planes < 1 || hw < 1) return AOC_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(plane_mean_kernel, dim3((unsigned)planes), dim3(256), 0, aoc_hip_stream(stream), x, hw, out);
+    AOC_RETURN_IF_LAUNCH_FAILED();
+    return AOC_OK;
+}
+
+}  // extern "C"

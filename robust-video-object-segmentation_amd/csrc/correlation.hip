@@ -1,0 +1,414 @@
+// Pixel-to-proxy correlation (AEM:92-128, 316-319) and dense pixel-level matching (AEM:61-89,
+// 178-227) on v_mfma_f32_16x16x4_f32 (exact fp32), fused with the proto-mask transform.
+//
+// MFMA operand map (16x16x4, f32): A lane l holds A[i = l & 15][k = l >> 4]; B lane l holds
+// B[k = l >> 4][j = l & 15]; D reg r of lane l is D[row = (l >> 4) * 4 + r][col = l & 15].
+// Query pixels are the A rows, proxies / reference pixels the B columns.  Step t of the K loop
+// multiplies channel 4t + kq on both sides (kq = l >> 4), so the B image in LDS is "k-permuted"
+// (see aoc_common.h) and each lane streams its channels with ds_read_b128.
+#include "aoc_common.h"
+
+namespace {
+
+constexpr int PC_MAX_TILES = 20;
+
+struct ProxyTile {
+    int32_t proxy_begin;  // first proxy row of this 16-column tile
+    int32_t ncols;        // valid columns (0..16)
+    int32_t set;          // kind 0: set index; kind 1: set index of column 0
+    int32_t flags;        // bit0: column-wise (every column is its own set), bit1: first tile of set, bit2: last tile of set
+};
+struct ProxyTileTable {
+    ProxyTile t[PC_MAX_TILES];
+    int32_t n;
+};
+
+// Stage 16-column operand tiles into the k-permuted LDS image.  row_of(c) gives the source row
+// pointer of tile column c (nullptr = zero fill).
+template <typename RowFn>
+__device__ __forceinline__ void stage_tile_rows(float *__restrict__ lds, int n_rows, int C, int TP, int RS, RowFn row_of) {
+    const int c4 = C >> 2;
+    for (int idx = threadIdx.x; idx < n_rows * c4; idx += blockDim.x) {
+        const int rr = idx / c4, t = idx - rr * c4;
+        const float *src = row_of(rr);
+        float4 v = src ? reinterpret_cast<const float4 *>(src)[t] : make_float4(0.f, 0.f, 0.f, 0.f);
+        float *d = lds + (size_t)rr * RS + t;
+        d[0] = v.x;
+        d[TP] = v.y;
+        d[2 * TP] = v.z;
+        d[3 * TP] = v.w;
+    }
+    // zero the TP - T padding of every stream (read by the last ds_read_b128 of a stream)
+    const int T = c4, padn = TP - T;
+    if (padn > 0) {
+        for (int idx = threadIdx.x; idx < n_rows * 4 * padn; idx += blockDim.x) {
+            const int rr = idx / (4 * padn), rem = idx - rr * 4 * padn;
+            const int kq = rem / padn, u = rem - kq * padn;
+            lds[(size_t)rr * RS + kq * TP + T + u] = 0.0f;
+        }
+    }
+}
+
+// Load the A fragment (16 query rows) and the rows' squared norms.
+template <int TMAX>
+__device__ __forceinline__ void load_a_fragment(const float *__restrict__ query, int64_t m, int C, int64_t row0, float (&a)[TMAX], float &q2) {
+    const int lane = aoc_lane();
+    const int i = lane & 15, kq = lane >> 4, T = C >> 2;
+    int64_t row = row0 + i;
+    if (row > m - 1) row = m - 1;
+    const float *src = query + row * C + kq;
+    float part = 0.0f;
+#pragma unroll
+    for (int t = 0; t < TMAX; ++t) {
+        a[t] = (t < T) ? src[4 * t] : 0.0f;
+        part += a[t] * a[t];
+    }
+    part += __shfl_xor(part, 16);
+    part += __shfl_xor(part, 32);
+    q2 = part;   // |q_i|^2 on every lane with (lane & 15) == i
+}
+
+template <int TMAX>
+__device__ __forceinline__ f32x4 mfma_tile(const float (&a)[TMAX], const float *__restrict__ bstream, int TP) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < (TMAX + 3) / 4; ++u) {
+        if (4 * u >= TP) break;   // streams are TP floats long (a[t] = 0 beyond T anyway)
+        const float4 b = *reinterpret_cast<const float4 *>(bstream + 4 * u);
+        if (4 * u + 0 < TMAX) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[4 * u + 0 < TMAX ? 4 * u + 0 : 0], b.x, acc, 0, 0, 0);
+        if (4 * u + 1 < TMAX) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[4 * u + 1 < TMAX ? 4 * u + 1 : 0], b.y, acc, 0, 0, 0);
+        if (4 * u + 2 < TMAX) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[4 * u + 2 < TMAX ? 4 * u + 2 : 0], b.z, acc, 0, 0, 0);
+        if (4 * u + 3 < TMAX) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[4 * u + 3 < TMAX ? 4 * u + 3 : 0], b.w, acc, 0, 0, 0);
+    }
+    return acc;
+}
+
+// ------------------------------------------------------------------------------------------
+// proxy_corr_min: one block stages every proxy tile once; each wave walks 16-pixel row tiles.
+template <int TMAX>
+__global__ __launch_bounds__(256) void proxy_corr_min_kernel(const float *__restrict__ query, int64_t m, int C,
+                                                              const float *__restrict__ proxies, const float *__restrict__ proxy_sqnorm,
+                                                              ProxyTileTable tiles, const float *__restrict__ set_bias,
+                                                              float *__restrict__ out, int64_t pstride, int64_t sstride, int transform) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int TP = aoc_tile_tp(C), RS = aoc_tile_row_stride(C);
+    const int ncols_total = tiles.n * 16;
+    float *lp2 = lds + (size_t)ncols_total * RS;
+    stage_tile_rows(lds, ncols_total, C, TP, RS, [&](int c) -> const float * {
+        const ProxyTile &pt = tiles.t[c >> 4];
+        return ((c & 15) < pt.ncols) ? proxies + (size_t)(pt.proxy_begin + (c & 15)) * C : nullptr;
+    });
+    __syncthreads();
+    for (int c = threadIdx.x; c < ncols_total; c += blockDim.x) {
+        const ProxyTile &pt = tiles.t[c >> 4];
+        float v = INFINITY;
+        if ((c & 15) < pt.ncols) {
+            if (proxy_sqnorm) {
+                v = proxy_sqnorm[pt.proxy_begin + (c & 15)];
+            } else {   // |p|^2 from the staged image (AEM:150 .pow(2).sum(1); any order)
+                const float *r = lds + (size_t)c * RS;
+                v = 0.0f;
+                for (int kq = 0; kq < 4; ++kq)
+                    for (int t = 0; t < (C >> 2); ++t) v += r[kq * TP + t] * r[kq * TP + t];
+            }
+        }
+        lp2[c] = v;
+    }
+    __syncthreads();
+
+    const int lane = aoc_lane(), wave = threadIdx.x >> 6;
+    const int j = lane & 15, g = lane >> 4;
+    const int64_t n_row_tiles = (m + 15) / 16;
+    for (int64_t rt = (int64_t)blockIdx.x * 4 + wave; rt < n_row_tiles; rt += (int64_t)gridDim.x * 4) {
+        const int64_t row0 = rt * 16;
+        float a[TMAX], q2;
+        load_a_fragment<TMAX>(query, m, C, row0, a, q2);
+        float q2r[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) q2r[r] = __shfl(q2, g * 4 + r);
+        float setmin[4] = {INFINITY, INFINITY, INFINITY, INFINITY};
+        for (int ti = 0; ti < tiles.n; ++ti) {
+            const ProxyTile pt = tiles.t[ti];
+            const f32x4 acc = mfma_tile<TMAX>(a, lds + (size_t)(ti * 16 + j) * RS + g * TP, TP);
+            const float p2 = lp2[ti * 16 + j];
+            float d[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) d[r] = (q2r[r] + p2) - 2.0f * acc[r];   // AEM:43
+            if (pt.flags & 1) {   // column-wise: k = 1 proxies, no min (AEM:127)
+                if (j < pt.ncols) {
+                    const int s = pt.set + j;
+                    const float b = set_bias ? set_bias[s] : 0.0f;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int64_t row = row0 + g * 4 + r;
+                        if (row < m) out[row * pstride + s * sstride] = transform ? aoc_proto_transform(d[r], b) : d[r];
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) setmin[r] = (pt.flags & 2) ? d[r] : fminf(setmin[r], d[r]);
+                if (pt.flags & 4) {
+                    float v = 0.0f;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float mr = aoc_min16(setmin[r]);   // AEM:109 min over the set's proxies
+                        if (j == r) v = mr;
+                    }
+                    if (v == INFINITY) v = AOC_PAD_DISTANCE;   // absent object: AEM:310-313
+                    const int64_t row = row0 + g * 4 + j;
+                    if (j < 4 && row < m) {
+                        const float b = set_bias ? set_bias[pt.set] : 0.0f;
+                        out[row * pstride + pt.set * sstride] = transform ? aoc_proto_transform(v, b) : v;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// dense_match_min.  Block = 4 waves x NA A-tiles (16 query pixels each); reference pixels stream
+// through LDS in chunks of DM_NB 16-row tiles; the m x n distance matrix only ever exists as MFMA
+// accumulators.  Grid = (row blocks, n-splits); partial minima go to the workspace.
+constexpr int DM_NB = 8;
+
+__global__ __launch_bounds__(256) void gather_sqnorm_kernel(const float *__restrict__ pool, int C, const int32_t *__restrict__ fg_rows,
+                                                             const int32_t *__restrict__ n_fg, float *__restrict__ r2) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= *n_fg) return;
+    const float *x = pool + (size_t)fg_rows[p] * C;
+    float s = 0.0f;
+    for (int t = 0; t < C; ++t) s += x[t] * x[t];
+    r2[p] = s;
+}
+
+template <int NA, int OMAX, int TMAX>
+__global__ __launch_bounds__(256) void dense_match_partial_kernel(const float *__restrict__ query, int64_t m, int C,
+                                                                   const float *__restrict__ pool, const int32_t *__restrict__ fg_rows,
+                                                                   const int32_t *__restrict__ n_fg_ptr, const float *__restrict__ r2_all,
+                                                                   const uint32_t *__restrict__ wrong_bits, int n_obj,
+                                                                   float *__restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int TP = aoc_tile_tp(C), RS = aoc_tile_row_stride(C);
+    float *lr2 = lds + (size_t)DM_NB * 16 * RS;
+    uint32_t *lwrong = reinterpret_cast<uint32_t *>(lr2 + DM_NB * 16);
+
+    const int n_fg = *n_fg_ptr;
+    const int n_tiles = (n_fg + 15) / 16;
+    const int tiles_per_split = (n_tiles + gridDim.y - 1) / gridDim.y;
+    const int tile_beg = blockIdx.y * tiles_per_split;
+    const int tile_end = min(n_tiles, tile_beg + tiles_per_split);
+
+    const int lane = aoc_lane(), wave = threadIdx.x >> 6;
+    const int j = lane & 15, g = lane >> 4;
+    const int64_t block_row0 = (int64_t)blockIdx.x * (64 * NA);
+    const int64_t wave_row0 = block_row0 + (int64_t)wave * 16 * NA;
+
+    float a[NA][TMAX], q2r[NA][4];
+#pragma unroll
+    for (int ia = 0; ia < NA; ++ia) {
+        float q2;
+        load_a_fragment<TMAX>(query, m, C, wave_row0 + ia * 16, a[ia], q2);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) q2r[ia][r] = __shfl(q2, g * 4 + r);
+    }
+    float mn[OMAX][NA][4];
+#pragma unroll
+    for (int o = 0; o < OMAX; ++o)
+#pragma unroll
+        for (int ia = 0; ia < NA; ++ia)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mn[o][ia][r] = INFINITY;
+
+    for (int chunk = tile_beg; chunk < tile_end; chunk += DM_NB) {
+        const int nt = min(DM_NB, tile_end - chunk);
+        __syncthreads();   // previous chunk fully consumed
+        stage_tile_rows(lds, nt * 16, C, TP, RS, [&](int c) -> const float * {
+            const int p = chunk * 16 + c;
+            return (p < n_fg) ? pool + (size_t)fg_rows[p] * C : nullptr;
+        });
+        for (int c = threadIdx.x; c < nt * 16; c += blockDim.x) {
+            const int p = chunk * 16 + c;
+            lr2[c] = (p < n_fg) ? r2_all[p] : INFINITY;
+            lwrong[c] = (p < n_fg) ? wrong_bits[fg_rows[p]] : 0xffffffffu;
+        }
+        __syncthreads();
+        for (int ti = 0; ti < nt; ++ti) {
+            const float *bstream = lds + (size_t)(ti * 16 + j) * RS + g * TP;
+            f32x4 acc[NA];
+#pragma unroll
+            for (int ia = 0; ia < NA; ++ia) acc[ia] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int u = 0; u < (TMAX + 3) / 4; ++u) {
+                if (4 * u >= TP) break;
+                const float4 b = *reinterpret_cast<const float4 *>(bstream + 4 * u);
+                const float bb[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (4 * u + e < TMAX) {
+#pragma unroll
+                        for (int ia = 0; ia < NA; ++ia)
+                            acc[ia] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ia][4 * u + e < TMAX ? 4 * u + e : 0], bb[e], acc[ia], 0, 0, 0);
+                    }
+                }
+            }
+            const float r2 = lr2[ti * 16 + j];
+            const uint32_t w = lwrong[ti * 16 + j];
+#pragma unroll
+            for (int ia = 0; ia < NA; ++ia)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float d = (q2r[ia][r] + r2) - 2.0f * acc[ia][r];   // AEM:43
+#pragma unroll
+                    for (int o = 0; o < OMAX; ++o) {
+                        if (o < n_obj) {
+                            const float v = d + (((w >> o) & 1u) ? AOC_PAD_DISTANCE : 0.0f);   // AEM:84-86
+                            mn[o][ia][r] = fminf(mn[o][ia][r], v);                          // AEM:88
+                        }
+                    }
+                }
+        }
+    }
+    // reduce over the 16 columns a lane group holds and write this split's partial minima
+#pragma unroll
+    for (int o = 0; o < OMAX; ++o) {
+        if (o < n_obj) {
+#pragma unroll
+            for (int ia = 0; ia < NA; ++ia) {
+                float v = 0.0f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float mr = aoc_min16(mn[o][ia][r]);
+                    if (j == r) v = mr;
+                }
+                const int64_t row = wave_row0 + ia * 16 + g * 4 + j;
+                if (j < 4 && row < m) partial[((int64_t)blockIdx.y * m + row) * n_obj + o] = v;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void dense_match_finalize_kernel(const float *__restrict__ partial, int n_split, int64_t m, int n_obj,
+                                                                    const int32_t *__restrict__ n_fg_ptr, const float *__restrict__ obj_bias,
+                                                                    float *__restrict__ out, int64_t pstride, int64_t ostride, int transform) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= m * n_obj) return;
+    const int64_t row = idx / n_obj;
+    const int o = (int)(idx - row * n_obj);
+    float v;
+    if (*n_fg_ptr == 0) {
+        v = transform ? 1.0f : INFINITY;   // AEM:796-797: nothing labelled -> ones
+    } else {
+        v = INFINITY;
+        for (int s = 0; s < n_split; ++s) v = fminf(v, partial[((int64_t)s * m + row) * n_obj + o]);
+        if (transform) v = aoc_proto_transform(v, obj_bias ? obj_bias[o] : 0.0f);
+    }
+    out[row * pstride + o * ostride] = v;
+}
+
+inline int dense_nsplit(int64_t m, int na) {
+    const int64_t row_blocks = (m + 64 * na - 1) / (64 * na);
+    int64_t s = (1024 + row_blocks - 1) / row_blocks;
+    if (s < 1) s = 1;
+    if (s > 64) s = 64;
+    return (int)s;
+}
+inline int dense_na(int n_obj) { return n_obj <= 4 ? 2 : (n_obj <= 8 ? 2 : 1); }
+
+}  // namespace
+
+extern "C" {
+
+int aoc_proxy_corr_min(const float *query, int64_t m, int C, const float *proxies, const float *proxy_sqnorm, int n_proxy,
+                       const int32_t *set_offsets_host, const float *set_bias, int n_set,
+                       float *out, int64_t out_pixel_stride, int64_t out_set_stride, int transform, aoc_stream_t stream) {
+    if (!query || !proxies || !set_offsets_host || !out) return AOC_ERR_INVALID_ARG;
+    if (m < 1 || C < 4 || n_set < 1 || n_proxy < 0) return AOC_ERR_INVALID_ARG;
+    if ((C & 3) || C > AOC_MAX_CHANNELS) return AOC_ERR_UNSUPPORTED;
+    for (int s = 0; s < n_set; ++s)
+        if (set_offsets_host[s] > set_offsets_host[s + 1] || set_offsets_host[s] < 0 || set_offsets_host[s + 1] > n_proxy) return AOC_ERR_INVALID_ARG;
+    hipStream_t st = aoc_hip_stream(stream);
+    const int RS = aoc_tile_row_stride(C);
+    const size_t tile_bytes = (size_t)16 * RS * sizeof(float) + 16 * sizeof(float);
+    int max_tiles = (int)((size_t)150 * 1024 / tile_bytes);
+    if (max_tiles > PC_MAX_TILES) max_tiles = PC_MAX_TILES;
+    if (max_tiles < 4) return AOC_ERR_UNSUPPORTED;
+    const int64_t n_row_tiles = (m + 15) / 16;
+    int grid = (int)((n_row_tiles + 3) / 4);
+    if (grid > 1024) grid = 1024;
+
+    ProxyTileTable tab;
+    tab.n = 0;
+    auto flush = [&]() -> int {
+        if (tab.n == 0) return AOC_OK;
+        const size_t lds = (size_t)tab.n * tile_bytes;
+#define AOC_PC(TM) hipLaunchKernelGGL(proxy_corr_min_kernel<TM>, dim3(grid), dim3(256), lds, st, query, m, C, proxies, proxy_sqnorm, tab, set_bias, out, out_pixel_stride, out_set_stride, transform)
+        if (C == 100) AOC_PC(25); else if (C <= 128) AOC_PC(32); else AOC_PC(64);
+#undef AOC_PC
+        tab.n = 0;
+        return hipGetLastError() == hipSuccess ? AOC_OK : AOC_ERR_LAUNCH;
+    };
+    int s = 0;
+    while (s < n_set) {
+        const int size = set_offsets_host[s + 1] - set_offsets_host[s];
+        if (size == 1) {
+            // run of consecutive single-proxy sets with consecutive proxies -> one column-wise tile
+            int run = 1;
+            while (run < 16 && s + run < n_set && set_offsets_host[s + run + 1] - set_offsets_host[s + run] == 1) ++run;
+            if (tab.n + 1 > max_tiles) { int rc = flush(); if (rc) return rc; }
+            tab.t[tab.n++] = ProxyTile{set_offsets_host[s], run, s, 1};
+            s += run;
+        } else {
+            const int nt = size == 0 ? 1 : (size + 15) / 16;
+            if (nt > max_tiles) return AOC_ERR_UNSUPPORTED;
+            if (tab.n + nt > max_tiles) { int rc = flush(); if (rc) return rc; }
+            for (int t = 0; t < nt; ++t) {
+                const int cols = size == 0 ? 0 : ((t == nt - 1) ? size - 16 * t : 16);
+                tab.t[tab.n++] = ProxyTile{set_offsets_host[s] + 16 * t, cols, s, (t == 0 ? 2 : 0) | (t == nt - 1 ? 4 : 0)};
+            }
+            ++s;
+        }
+    }
+    return flush();
+}
+
+size_t aoc_dense_match_workspace_bytes(int64_t m, int64_t n_fg_capacity, int n_obj) {
+    if (m < 1 || n_fg_capacity < 0 || n_obj < 1) return 0;
+    const int ns = dense_nsplit(m, dense_na(n_obj));
+    return aoc_align_up((size_t)n_fg_capacity * sizeof(float) + 16, 256) + aoc_align_up((size_t)ns * m * n_obj * sizeof(float), 256);
+}
+
+int aoc_dense_match_min(const float *query, int64_t m, int C, const float *pool, const int32_t *fg_rows, const int32_t *n_fg,
+                        int64_t n_fg_capacity, const uint32_t *wrong_bits, const float *obj_bias, int n_obj,
+                        float *out, int64_t out_pixel_stride, int64_t out_obj_stride, int transform,
+                        void *workspace, size_t workspace_bytes, aoc_stream_t stream) {
+    if (!query || !pool || !fg_rows || !n_fg || !wrong_bits || !out || !workspace) return AOC_ERR_INVALID_ARG;
+    if (m < 1 || C < 4 || n_obj < 1 || n_fg_capacity < 1 || n_fg_capacity >= (1ll << 31)) return AOC_ERR_INVALID_ARG;
+    if ((C & 3) || C > 128 || n_obj > 16) return AOC_ERR_UNSUPPORTED;
+    if (workspace_bytes < aoc_dense_match_workspace_bytes(m, n_fg_capacity, n_obj)) return AOC_ERR_WORKSPACE;
+    hipStream_t st = aoc_hip_stream(stream);
+    float *r2 = static_cast<float *>(workspace);
+    float *partial = reinterpret_cast<float *>(static_cast<char *>(workspace) + aoc_align_up((size_t)n_fg_capacity * sizeof(float) + 16, 256));
+    const int na = dense_na(n_obj);
+    const int ns = dense_nsplit(m, na);
+    const int row_blocks = (int)((m + 64 * na - 1) / (64 * na));
+    const int RS = aoc_tile_row_stride(C);
+    const size_t lds = (size_t)DM_NB * 16 * RS * sizeof(float) + DM_NB * 16 * (sizeof(float) + sizeof(uint32_t));
+
+    hipLaunchKernelGGL(gather_sqnorm_kernel, dim3((unsigned)((n_fg_capacity + 255) / 256)), dim3(256), 0, st, pool, C, fg_rows, n_fg, r2);
+    const dim3 grid(row_blocks, ns);
+#define AOC_DM(NA, OM, TM) hipLaunchKernelGGL((dense_match_partial_kernel<NA, OM, TM>), grid, dim3(256), lds, st, query, m, C, pool, fg_rows, n_fg, r2, wrong_bits, n_obj, partial)
+    if (C == 100) {
+        if (n_obj <= 4) AOC_DM(2, 4, 25); else if (n_obj <= 8) AOC_DM(2, 8, 25); else AOC_DM(1, 16, 25);
+    } else {
+        if (n_obj <= 4) AOC_DM(2, 4, 32); else if (n_obj <= 8) AOC_DM(2, 8, 32); else AOC_DM(1, 16, 32);
+    }
+#undef AOC_DM
+    const int64_t total = m * n_obj;
+    hipLaunchKernelGGL(dense_match_finalize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, partial, ns, m, n_obj, n_fg,
+                       obj_bias, out, out_pixel_stride, out_obj_stride, transform);
+    AOC_RETURN_IF_LAUNCH_FAILED();
+    return AOC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,293 @@
+// Local (windowed) matching, AEM:921-963 + 968-1060, without F.unfold: the [HW, (2R+1)^2] distance
+// volume only exists as MFMA accumulators.  Also the three resize helpers of that path.
+//
+// Block = 4 waves = 4 consecutive query rows x 16 query columns.  For every candidate row cy the
+// block stages the 16 + 2R candidate pixels of the previous frame (k-permuted LDS image, see
+// aoc_common.h); each wave whose query row is within R of cy multiplies its 16 query pixels against
+// them (v_mfma_f32_16x16x4_f32) and folds the masked distances into per-(pixel, ring, object)
+// minima in LDS with ds_min_f32.  "ring" = max(|dy|,|dx|) bucketed by the nested window radii, so
+// the nested-window minima of AEM:1036-1046 are a prefix-min over rings at the end.
+#include "aoc_common.h"
+
+namespace {
+
+__device__ __forceinline__ void lds_fmin(float *p, float v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_ds_fminf((__attribute__((address_space(3))) float *)p, v, 0, 0, false);
+#endif
+}
+
+constexpr int LM_MAX_RADII = 8;
+struct LocalRadii {
+    int32_t r[LM_MAX_RADII];
+    int32_t n;
+};
+
+template <int TMAX>
+__global__ __launch_bounds__(256) void local_window_kernel(const float *__restrict__ query, const float *__restrict__ prev,
+                                                            const uint32_t *__restrict__ right_bits, int H, int W, int C,
+                                                            LocalRadii radii, const float *__restrict__ obj_bias, int n_obj,
+                                                            float *__restrict__ out, int transform) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int R = radii.r[radii.n - 1];
+    const int TP = aoc_tile_tp(C), RS = aoc_tile_row_stride(C);
+    const int NC = 16 + 2 * R;
+    const int NG = (NC + 15) / 16;
+    float *ly2 = lds + (size_t)NG * 16 * RS;                          // [NG*16] candidate |y|^2
+    uint32_t *lbits = reinterpret_cast<uint32_t *>(ly2 + NG * 16);     // [NG*16] candidate label bits
+    int32_t *lcls = reinterpret_cast<int32_t *>(lbits + NG * 16);      // [R+1] ring -> class
+    float *lacc = reinterpret_cast<float *>(lcls + 32);                // [4 waves][16][n_radii][n_obj]
+    const int nr = radii.n;
+    const int acc_per_wave = 16 * nr * n_obj;
+
+    const int lane = aoc_lane(), wave = threadIdx.x >> 6;
+    const int j = lane & 15, g = lane >> 4;
+    const int x0 = blockIdx.x * 16;
+    const int y0 = blockIdx.y * 4;
+    const int y = y0 + wave;
+
+    for (int i = threadIdx.x; i < 4 * acc_per_wave; i += blockDim.x) lacc[i] = AOC_PAD_DISTANCE;   // AEM:1032 pad
+    if (threadIdx.x <= R) {
+        int c = 0;
+        while (radii.r[c] < (int)threadIdx.x) ++c;
+        lcls[threadIdx.x] = c;
+    }
+
+    float a[TMAX], q2 = 0.0f, q2r[4];
+    {   // A fragment: 16 query pixels of row y (clamped when y >= H; such waves never accumulate)
+        const int i = lane & 15, kq = lane >> 4, T = C >> 2;
+        const int qx = min(x0 + i, W - 1), qy = min(y, H - 1);
+        const float *src = query + ((size_t)qy * W + qx) * C + kq;
+        float part = 0.0f;
+#pragma unroll
+        for (int t = 0; t < TMAX; ++t) {
+            a[t] = (t < T) ? src[4 * t] : 0.0f;
+            part += a[t] * a[t];
+        }
+        part += __shfl_xor(part, 16);
+        part += __shfl_xor(part, 32);
+        q2 = part;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) q2r[r] = __shfl(q2, g * 4 + r);
+    }
+    float *my_acc = lacc + wave * acc_per_wave;
+
+    const int cy_beg = max(0, y0 - R), cy_end = min(H - 1, y0 + 3 + R);
+    for (int cy = cy_beg; cy <= cy_end; ++cy) {
+        __syncthreads();
+        {   // stage candidate pixels (cy, x0 - R + c), c = 0..NG*16-1
+            const int c4 = C >> 2;
+            for (int idx = threadIdx.x; idx < NG * 16 * c4; idx += blockDim.x) {
+                const int c = idx / c4, t = idx - c * c4;
+                const int cx = x0 - R + c;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (c < NC && cx >= 0 && cx < W) v = reinterpret_cast<const float4 *>(prev + ((size_t)cy * W + cx) * C)[t];
+                float *d = lds + (size_t)c * RS + t;
+                d[0] = v.x; d[TP] = v.y; d[2 * TP] = v.z; d[3 * TP] = v.w;
+            }
+            const int padn = TP - c4;
+            for (int idx = threadIdx.x; idx < NG * 16 * 4 * padn; idx += blockDim.x) {
+                const int c = idx / (4 * padn), rem = idx - c * 4 * padn;
+                lds[(size_t)c * RS + (rem / padn) * TP + c4 + (rem % padn)] = 0.0f;
+            }
+            for (int c = threadIdx.x; c < NG * 16; c += blockDim.x) {
+                const int cx = x0 - R + c;
+                const bool in = c < NC && cx >= 0 && cx < W;
+                lbits[c] = in ? (right_bits[(size_t)cy * W + cx] & ~AOC_ROW_KEPT_BIT) : 0u;   // AEM:1023-1028 (pad 0)
+            }
+        }
+        __syncthreads();
+        // per-candidate |y|^2 from the staged image (any summation order: tolerance-level)
+        for (int c = threadIdx.x; c < NG * 16; c += blockDim.x) {
+            const float *r = lds + (size_t)c * RS;
+            float s = 0.0f;
+            for (int kq = 0; kq < 4; ++kq)
+                for (int t = 0; t < (C >> 2); ++t) s += r[kq * TP + t] * r[kq * TP + t];
+            ly2[c] = s;
+        }
+        __syncthreads();
+        const int dy = cy - y;
+        const int ady = dy < 0 ? -dy : dy;
+        if (y < H && ady <= R) {
+            for (int gi = 0; gi < NG; ++gi) {
+                const float *bstream = lds + (size_t)(gi * 16 + j) * RS + g * TP;
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int u = 0; u < (TMAX + 3) / 4; ++u) {
+                    if (4 * u < TP) {
+                        const float4 b = *reinterpret_cast<const float4 *>(bstream + 4 * u);
+                        const float bb[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (4 * u + e < TMAX) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[4 * u + e < TMAX ? 4 * u + e : 0], bb[e], acc, 0, 0, 0);
+                    }
+                }
+                const int c = gi * 16 + j;
+                const int cx = x0 - R + c;
+                uint32_t bits = lbits[c];
+                const float y2 = ly2[c];
+                if (bits != 0u) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int qi = g * 4 + r;
+                        const int qx = x0 + qi;
+                        int dx = cx - qx;
+                        dx = dx < 0 ? -dx : dx;
+                        if (dx <= R && qx < W) {
+                            const float d = (q2r[r] + y2) - 2.0f * acc[r];   // AEM:961
+                            const int cls = lcls[max(ady, dx)];
+                            uint32_t b = bits;
+                            while (b) {                                     // AEM:1032 where(mask, d, pad)
+                                const int o = __builtin_ctz(b);
+                                b &= b - 1;
+                                if (o < n_obj) lds_fmin(&my_acc[(qi * nr + cls) * n_obj + o], d);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // prefix-min over rings -> nested windows; channel order [max, r_0, r_1, ...] (AEM:1034-1046)
+    if (y < H) {
+        for (int idx = lane; idx < 16 * n_obj; idx += 64) {
+            const int qi = idx / n_obj, o = idx - qi * n_obj;
+            const int qx = x0 + qi;
+            if (qx >= W) continue;
+            const float bias = obj_bias ? obj_bias[o] : 0.0f;
+            float run = INFINITY;
+            for (int cls = 0; cls < nr; ++cls) {
+                run = fminf(run, my_acc[(qi * nr + cls) * n_obj + o]);
+                const int ch = (cls == nr - 1) ? 0 : cls + 1;
+                out[(((size_t)o * nr + ch) * H + y) * W + qx] = transform ? aoc_proto_transform(run, bias) : run;   // AEM:1049
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Resize helpers (torch semantics, fp32).
+__device__ __forceinline__ void bilinear_src(int dst, float scale, int in_size, int &i0, int &i1, float &l0, float &l1) {
+    const float real = scale * (float)dst;                 // align_corners=True: area_pixel_compute_source_index
+    i0 = (int)real;
+    if (i0 > in_size - 1) i0 = in_size - 1;
+    i1 = i0 + ((i0 < in_size - 1) ? 1 : 0);
+    float lam = real - (float)i0;
+    lam = fminf(fmaxf(lam, 0.0f), 1.0f);
+    l1 = lam;
+    l0 = 1.0f - lam;
+}
+
+__global__ __launch_bounds__(256) void resize_bilinear_hwc_kernel(const float *__restrict__ in, int h, int w, int C,
+                                                                   float *__restrict__ out, int H, int W, float sh, float sw) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t total = (int64_t)H * W * C;
+    if (idx >= total) return;
+    const int c = (int)(idx % C);
+    const int64_t pix = idx / C;
+    const int X = (int)(pix % W), Y = (int)(pix / W);
+    int y0, y1, x0, x1;
+    float hy0, hy1, wx0, wx1;
+    bilinear_src(Y, sh, h, y0, y1, hy0, hy1);
+    bilinear_src(X, sw, w, x0, x1, wx0, wx1);
+    const float v00 = in[((size_t)y0 * w + x0) * C + c], v01 = in[((size_t)y0 * w + x1) * C + c];
+    const float v10 = in[((size_t)y1 * w + x0) * C + c], v11 = in[((size_t)y1 * w + x1) * C + c];
+    out[idx] = hy0 * (wx0 * v00 + wx1 * v01) + hy1 * (wx0 * v10 + wx1 * v11);
+}
+
+__global__ __launch_bounds__(256) void resize_bilinear_planes_kernel(const float *__restrict__ in, int P, int h, int w,
+                                                                      float *__restrict__ out, int H, int W, float sh, float sw,
+                                                                      int64_t plane_stride, int64_t pixel_stride) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t total = (int64_t)P * H * W;
+    if (idx >= total) return;
+    const int X = (int)(idx % W);
+    const int Y = (int)((idx / W) % H);
+    const int p = (int)(idx / ((int64_t)W * H));
+    int y0, y1, x0, x1;
+    float hy0, hy1, wx0, wx1;
+    bilinear_src(Y, sh, h, y0, y1, hy0, hy1);
+    bilinear_src(X, sw, w, x0, x1, wx0, wx1);
+    const float *ip = in + (size_t)p * h * w;
+    const float v00 = ip[(size_t)y0 * w + x0], v01 = ip[(size_t)y0 * w + x1];
+    const float v10 = ip[(size_t)y1 * w + x0], v11 = ip[(size_t)y1 * w + x1];
+    out[p * plane_stride + ((int64_t)Y * W + X) * pixel_stride] = hy0 * (wx0 * v00 + wx1 * v01) + hy1 * (wx0 * v10 + wx1 * v11);
+}
+
+__global__ __launch_bounds__(256) void resize_nearest_bits_kernel(const uint32_t *__restrict__ in, int h, int w,
+                                                                   uint32_t *__restrict__ out, int H, int W, float sh, float sw) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= H * W) return;
+    const int X = idx % W, Y = idx / W;
+    const int sy = min((int)floorf((float)Y * sh), h - 1);   // torch nearest: floor(dst * in/out)
+    const int sx = min((int)floorf((float)X * sw), w - 1);
+    out[idx] = in[(size_t)sy * w + sx];
+}
+
+}  // namespace
+
+extern "C" {
+
+int aoc_local_window_match(const float *query, const float *prev, const uint32_t *right_bits, int H, int W, int C,
+                           const int32_t *radii_host, int n_radii, const float *obj_bias, int n_obj,
+                           float *out, int transform, aoc_stream_t stream) {
+    if (!query || !prev || !right_bits || !radii_host || !out) return AOC_ERR_INVALID_ARG;
+    if (H < 1 || W < 1 || C < 4 || n_radii < 1 || n_obj < 1) return AOC_ERR_INVALID_ARG;
+    if ((C & 3) || C > 128 || n_radii > LM_MAX_RADII || n_obj > AOC_MAX_OBJECTS) return AOC_ERR_UNSUPPORTED;
+    LocalRadii radii;
+    radii.n = n_radii;
+    for (int i = 0; i < n_radii; ++i) {
+        radii.r[i] = radii_host[i];
+        if (radii_host[i] < 0 || (i > 0 && radii_host[i] <= radii_host[i - 1])) return AOC_ERR_INVALID_ARG;
+    }
+    for (int i = n_radii; i < LM_MAX_RADII; ++i) radii.r[i] = radii_host[n_radii - 1];
+    const int R = radii_host[n_radii - 1];
+    if (R > 31) return AOC_ERR_UNSUPPORTED;
+    const int RS = aoc_tile_row_stride(C);
+    const int NG = (16 + 2 * R + 15) / 16;
+    const size_t lds = (size_t)NG * 16 * RS * sizeof(float) + (size_t)NG * 16 * 8 + 32 * sizeof(int32_t) +
+                       (size_t)4 * 16 * n_radii * n_obj * sizeof(float);
+    if (lds > 150 * 1024) return AOC_ERR_UNSUPPORTED;
+    const dim3 grid((W + 15) / 16, (H + 3) / 4);
+    hipStream_t st = aoc_hip_stream(stream);
+    if (C == 100)
+        hipLaunchKernelGGL(local_window_kernel<25>, grid, dim3(256), lds, st, query, prev, right_bits, H, W, C, radii, obj_bias, n_obj, out, transform);
+    else
+        hipLaunchKernelGGL(local_window_kernel<32>, grid, dim3(256), lds, st, query, prev, right_bits, H, W, C, radii, obj_bias, n_obj, out, transform);
+    AOC_RETURN_IF_LAUNCH_FAILED();
+    return AOC_OK;
+}
+
+static inline float align_corners_scale(int in_size, int out_size) {
+    return out_size > 1 ? (float)(in_size - 1) / (float)(out_size - 1) : 0.0f;
+}
+
+int aoc_resize_bilinear_hwc(const float *in, int h, int w, int C, float *out, int H, int W, aoc_stream_t stream) {
+    if (!in || !out || h < 1 || w < 1 || C < 1 || H < 1 || W < 1) return AOC_ERR_INVALID_ARG;
+    const int64_t total = (int64_t)H * W * C;
+    hipLaunchKernelGGL(resize_bilinear_hwc_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, aoc_hip_stream(stream), in, h, w, C,
+                       out, H, W, align_corners_scale(h, H), align_corners_scale(w, W));
+    AOC_RETURN_IF_LAUNCH_FAILED();
+    return AOC_OK;
+}
+
+int aoc_resize_bilinear_planes(const float *in, int P, int h, int w, float *out, int H, int W, int64_t out_plane_stride,
+                               int64_t out_pixel_stride, aoc_stream_t stream) {
+    if (!in || !out || P < 1 || h < 1 || w < 1 || H < 1 || W < 1) return AOC_ERR_INVALID_ARG;
+    const int64_t total = (int64_t)P * H * W;
+    hipLaunchKernelGGL(resize_bilinear_planes_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, aoc_hip_stream(stream), in, P, h, w,
+                       out, H, W, align_corners_scale(h, H), align_corners_scale(w, W), out_plane_stride, out_pixel_stride);
+    AOC_RETURN_IF_LAUNCH_FAILED();
+    return AOC_OK;
+}
+
+int aoc_resize_nearest_bits(const uint32_t *in, int h, int w, uint32_t *out, int H, int W, aoc_stream_t stream) {
+    if (!in || !out || h < 1 || w < 1 || H < 1 || W < 1) return AOC_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(resize_nearest_bits_kernel, dim3((unsigned)((H * W + 255) / 256)), dim3(256), 0, aoc_hip_stream(stream), in, h, w, out, H, W,
+                       (float)h / (float)H, (float)w / (float)W);
+    AOC_RETURN_IF_LAUNCH_FAILED();
+    return AOC_OK;
+}
+
+}  // extern "C"

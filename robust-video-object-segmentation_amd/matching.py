@@ -1,0 +1,276 @@
+"""Drop-in mirror of the reference matching library (networks/layers/matching.py ==
+AOC-Net/adaptive_embedding_for_matching.py, "AEM") on the HIP library.
+
+Same function names, positional order, defaults, output shapes and special cases as the
+reference (cited per function); every computation runs in csrc/libaoc_hip.so.  ``n_chunks`` and
+``allow_parallel`` are accepted and ignored: the fused kernels never materialise the
+[m, O, n] / unfold tensors those flags exist to bound.
+
+Divergences, all documented in DESIGN.md:
+* ``use_float16=True`` -- the cluster path returns the constant the reference degrades to
+  (scipy's kmeans2 rejects float16 -> bare ``except`` -> 5e4 padding, AEM:275-286 -> feature 1.0);
+  the other paths raise NotImplementedError (the model runs with MODEL_FLOAT16_MATCHING=False).
+* atrous_rate > 1 for *local* matching is not implemented (all shipped configs use 1).
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import ops
+
+WRONG_LABEL_PADDING_DISTANCE = 5e4   # AEM:25
+DEFAULT_CLUSTER_NUM = 16             # AEM:232
+KMEANS_ITERS = 20                    # AEM:276
+
+
+# ------------------------------------------------------------------------------------------ helpers
+def _bias_vec(dis_bias, obj_nums, device):
+    """dis_bias arrives as an nn.Parameter slice shaped [O,1,1,1] (aocnet.py:144) or a float."""
+    if torch.is_tensor(dis_bias):
+        b = dis_bias.detach().to(device=device, dtype=torch.float32).reshape(-1)
+        if b.numel() == 1 and obj_nums > 1:
+            b = b.expand(obj_nums)
+        return b.contiguous()
+    return torch.full((obj_nums,), float(dis_bias), dtype=torch.float32, device=device)
+
+
+def _flatten_pool(all_ref_emb, all_ref_labels, h, w, atrous_rate, atrous_obj_pixel_num):
+    """AEM:507-579 / 715-787: concatenate the reference frames (+ optional atrous subsampling).
+    Pure view / concat plumbing; unlike the reference it never writes into the caller's labels."""
+    embedding_dim = all_ref_emb[0].size(2)
+    obj_nums = all_ref_labels[0].size(2)
+    embs, labs = [], []
+    if atrous_obj_pixel_num > 0:
+        sel = None
+        if atrous_rate > 1:
+            h_pad = (atrous_rate - h % atrous_rate) % atrous_rate
+            w_pad = (atrous_rate - w % atrous_rate) % atrous_rate
+            sel = torch.zeros(h + h_pad, w + w_pad, device=all_ref_emb[0].device)
+            sel = sel.view((h + h_pad) // atrous_rate, atrous_rate, (w + w_pad) // atrous_rate, atrous_rate)
+            sel[:, 0, :, 0] = 1.
+            sel = sel.reshape(h + h_pad, w + w_pad, 1)[:h, :w]
+        for e, l in zip(all_ref_emb, all_ref_labels):
+            if atrous_rate > 1:
+                l = l.clone()
+                big = l.sum(dim=(0, 1)) > (atrous_obj_pixel_num * atrous_rate ** 2)
+                l[:, :, big] = l[:, :, big] * sel
+            embs.append(e.reshape(-1, embedding_dim))
+            labs.append(l.reshape(-1, obj_nums))
+    else:
+        for e, l in zip(all_ref_emb, all_ref_labels):
+            if atrous_rate > 1:
+                h_pad = (atrous_rate - h % atrous_rate) % atrous_rate
+                w_pad = (atrous_rate - w % atrous_rate) % atrous_rate
+                if h_pad > 0 or w_pad > 0:
+                    e = F.pad(e, (0, 0, 0, w_pad, 0, h_pad))
+                    l = F.pad(l, (0, 0, 0, w_pad, 0, h_pad))
+                e = e.reshape((h + h_pad) // atrous_rate, atrous_rate, (w + w_pad) // atrous_rate, atrous_rate, -1)[:, 0, :, 0, :]
+                l = l.reshape((h + h_pad) // atrous_rate, atrous_rate, (w + w_pad) // atrous_rate, atrous_rate, -1)[:, 0, :, 0, :]
+            embs.append(e.reshape(-1, embedding_dim))
+            labs.append(l.reshape(-1, obj_nums))
+    pool = embs[0] if len(embs) == 1 else torch.cat(embs, 0)
+    labels = labs[0] if len(labs) == 1 else torch.cat(labs, 0)
+    return pool.float().contiguous(), labels.float().contiguous()
+
+
+def _emit(feature_planes, h, w, n_planes_per_obj, obj_nums, ori_size):
+    """feature_planes [O * F, h, w] -> [1, H, W, O, F]; bilinear(align_corners) when ori_size differs
+    (AEM:604-607).  An identity-size resize is an exact copy, so it doubles as the layout change."""
+    H, W = (h, w) if ori_size is None else (int(ori_size[0]), int(ori_size[1]))
+    out = torch.empty(1, H, W, obj_nums, n_planes_per_obj, dtype=torch.float32, device=feature_planes.device)
+    ops.resize_bilinear_planes(feature_planes, H, W, out, 1, obj_nums * n_planes_per_obj)
+    return out
+
+
+# ------------------------------------------------------------------------------------------ cluster path (a2-a5)
+def cluster_proxies(pool, labels_flat, cluster_num=DEFAULT_CLUSTER_NUM, init_rows=None, rng=None, iters=KMEANS_ITERS):
+    """Adaptive-proxy construction, AEM:252-286, on the device.
+
+    Returns None when no row is labelled (AEM:588-589) or a dict with
+      prep, seg_k (host list), init_rows (host list), centroids [O,K,C], labels (packed, per object
+      segment), cluster_counts [O,K], proxies [O,2,K,C], proxy_sqnorm [O,2,K], counts (host).
+    The only host round trip is the read-back of the O+1 row counts, which the reference's control
+    flow needs anyway: sticky ``K_i = min(K_{i-1}, n_i)`` (AEM:268) and the rows scipy's
+    ``minit='points'`` draws from numpy's global RandomState (``permutation(n_i)[:K_i]``).
+    """
+    prep = ops.label_prep(labels_flat)
+    n_obj = prep.n_obj
+    counts = prep.counts.cpu().numpy()
+    if int(counts[n_obj]) == 0:
+        return None
+    rng = np.random if rng is None else rng
+    seg_k, rows_host, k = [], np.zeros((n_obj, cluster_num), np.int32), cluster_num
+    drawn = []
+    for i in range(n_obj):
+        k = min(k, int(counts[i]))                       # AEM:268 (sticky)
+        seg_k.append(k)
+        if k == 0:
+            drawn.append(None)
+            continue
+        if init_rows is not None and init_rows[i] is not None:
+            r = np.asarray(init_rows[i], np.int64)[:k]
+        else:
+            r = np.asarray(rng.permutation(int(counts[i]))[:k], np.int64)   # scipy vq.py:519 on RandomState
+        rows_host[i, :k] = r
+        drawn.append(r)
+    dev = pool.device
+    seg_k_dev = torch.tensor(seg_k, dtype=torch.int32, device=dev)
+    init_dev = torch.from_numpy(rows_host).to(dev)
+    centroids, labels, ccounts = ops.kmeans_segmented(pool, prep.obj_rows, prep.obj_offsets, seg_k_dev, init_dev,
+                                                      cluster_num, iters, rows_capacity=prep.obj_rows.numel())
+    proxies, sqnorm = ops.build_proxies(pool, prep.fg_rows, prep.obj_offsets, seg_k_dev, labels, centroids)
+    return dict(prep=prep, seg_k=seg_k, init_rows=drawn, centroids=centroids, labels=labels, cluster_counts=ccounts,
+                proxies=proxies, proxy_sqnorm=sqnorm, counts=counts)
+
+
+def global_matching_for_eval_cluster(all_reference_embeddings, query_embeddings, all_reference_labels,
+                                     n_chunks=20, dis_bias=0., ori_size=None, atrous_rate=1, use_float16=True,
+                                     atrous_obj_pixel_num=0, init_rows=None):
+    """AEM:480-613.  -> [1, H, W, O, 2]; [1, h, w, O, 1] of ones when no reference pixel is labelled."""
+    h, w, embedding_dim = query_embeddings.size()
+    obj_nums = all_reference_labels[0].size(2)
+    dev = query_embeddings.device
+    pool, labels_flat = _flatten_pool(all_reference_embeddings, all_reference_labels, h, w, atrous_rate, atrous_obj_pixel_num)
+    if use_float16:
+        # kmeans2 raises TypeError on float16 -> except -> constant 5e4 -> (sigmoid(5e4+b)-.5)*2 == 1
+        right, _ = ops.label_bits(labels_flat, want_wrong=False)
+        if not bool((right < 0).any()):                                   # bit 31 set <=> row kept
+            return torch.ones(1, h, w, obj_nums, 1, device=dev)
+        H, W = (h, w) if ori_size is None else ori_size
+        return torch.ones(1, H, W, obj_nums, 2, device=dev)
+    cp = cluster_proxies(pool, labels_flat, DEFAULT_CLUSTER_NUM, init_rows)
+    if cp is None:
+        return torch.ones(1, h, w, obj_nums, 1, device=dev)               # AEM:588-589
+    kmax = cp["proxies"].shape[2]
+    query_flat = query_embeddings.reshape(-1, embedding_dim)
+    bias = _bias_vec(dis_bias, obj_nums, dev)
+    planes = torch.empty(obj_nums * 2, h, w, dtype=torch.float32, device=dev)
+    ops.proxy_corr_min(query_flat, cp["proxies"].reshape(-1, embedding_dim), cp["proxy_sqnorm"].reshape(-1),
+                       [s * kmax for s in range(2 * obj_nums + 1)], bias.repeat_interleave(2), planes, 1, h * w, True)
+    return _emit(planes, h, w, 2, obj_nums, ori_size)
+
+
+def global_matching_cluster(reference_embeddings, query_embeddings, reference_labels,
+                            n_chunks=100, dis_bias=0., ori_size=None, atrous_rate=1, use_float16=True, atrous_obj_pixel_num=0):
+    """AEM:405-478 / matching.py:506-640 (training twin; single reference frame)."""
+    return global_matching_for_eval_cluster([reference_embeddings], query_embeddings, [reference_labels], n_chunks,
+                                            dis_bias, ori_size, atrous_rate, use_float16, 0)
+
+
+global_matching_cluster2 = global_matching_cluster   # name imported by aocnet.py:6
+
+
+# ------------------------------------------------------------------------------------------ dense path (a6)
+def global_matching_for_eval(all_reference_embeddings, query_embeddings, all_reference_labels,
+                             n_chunks=20, dis_bias=0., ori_size=None, atrous_rate=1, use_float16=True, atrous_obj_pixel_num=0):
+    """AEM:688-817.  -> [1, H, W, O, 1]; ones when nothing is labelled (AEM:796-797).  No host sync."""
+    if use_float16:
+        raise NotImplementedError("aoc_amd: float16 matching is not implemented (MODEL_FLOAT16_MATCHING=False in all configs)")
+    h, w, embedding_dim = query_embeddings.size()
+    obj_nums = all_reference_labels[0].size(2)
+    dev = query_embeddings.device
+    pool, labels_flat = _flatten_pool(all_reference_embeddings, all_reference_labels, h, w, atrous_rate, atrous_obj_pixel_num)
+    prep = ops.label_prep(labels_flat)
+    planes = torch.empty(obj_nums, h, w, dtype=torch.float32, device=dev)
+    ops.dense_match_min(query_embeddings.reshape(-1, embedding_dim), pool, prep, _bias_vec(dis_bias, obj_nums, dev),
+                        planes, 1, h * w, True)
+    if ori_size is not None:
+        # the all-unlabelled early-out of the reference keeps the map at (h, w) even with ori_size
+        if int(prep.counts[obj_nums]) == 0:
+            return torch.ones(1, h, w, obj_nums, 1, device=dev)
+    return _emit(planes, h, w, 1, obj_nums, ori_size)
+
+
+def global_matching(reference_embeddings, query_embeddings, reference_labels,
+                    n_chunks=100, dis_bias=0., ori_size=None, atrous_rate=1, use_float16=True, atrous_obj_pixel_num=0):
+    """AEM:616-685 (training twin)."""
+    assert reference_embeddings.size()[:2] == reference_labels.size()[:2]     # AEM:641
+    if atrous_rate > 1:
+        h, w, _ = query_embeddings.size()
+        h_pad = (atrous_rate - h % atrous_rate) % atrous_rate
+        w_pad = (atrous_rate - w % atrous_rate) % atrous_rate
+        sel = torch.zeros(h + h_pad, w + w_pad, device=query_embeddings.device)
+        sel = sel.view((h + h_pad) // atrous_rate, atrous_rate, (w + w_pad) // atrous_rate, atrous_rate)
+        sel[:, 0, :, 0] = 1.
+        sel = sel.reshape(h + h_pad, w + w_pad, 1)[:h, :w]
+        reference_labels = reference_labels.clone()
+        big = reference_labels.sum(dim=(0, 1)) > (atrous_obj_pixel_num * atrous_rate ** 2)      # AEM:656-657
+        reference_labels[:, :, big] = reference_labels[:, :, big] * sel
+    return global_matching_for_eval([reference_embeddings], query_embeddings, [reference_labels], n_chunks,
+                                    dis_bias, ori_size, 1, use_float16, 0)
+
+
+# ------------------------------------------------------------------------------------------ k = 1 proxy path (a7)
+def global_matching_for_eval_proxy(all_reference_embeddings, query_embeddings, all_reference_labels,
+                                   n_chunks=20, dis_bias=0., ori_size=None, atrous_rate=1, use_float16=True, atrous_obj_pixel_num=0):
+    """matching.py:2518-2662 (the AEM:819-873 copy references undefined names).  ``all_reference_embeddings``
+    is the [O, C] tensor of mean-pooled proxies (aocnet.py:314-315); out[i,o] = d(q_i, proxy_o).  -> [1,H,W,O,1]"""
+    if use_float16:
+        raise NotImplementedError("aoc_amd: float16 matching is not implemented")
+    h, w, embedding_dim = query_embeddings.size()
+    obj_nums = all_reference_labels[0].size(2)
+    dev = query_embeddings.device
+    if len(all_reference_labels) == 0:
+        return torch.ones(1, h, w, obj_nums, 1, device=dev)
+    proxies = all_reference_embeddings.float().contiguous()
+    planes = torch.empty(obj_nums, h, w, dtype=torch.float32, device=dev)
+    ops.proxy_corr_min(query_embeddings.reshape(-1, embedding_dim), proxies, None, list(range(obj_nums + 1)),
+                       _bias_vec(dis_bias, obj_nums, dev), planes, 1, h * w, True)
+    return _emit(planes, h, w, 1, obj_nums, ori_size)
+
+
+def global_matching_proxy(reference_embeddings, query_embeddings, reference_labels,
+                          n_chunks=100, dis_bias=0., ori_size=None, atrous_rate=1, use_float16=True, atrous_obj_pixel_num=0):
+    """AEM:336-402 (training twin): ones when no reference pixel is labelled (AEM:382-386)."""
+    h, w, _ = query_embeddings.size()
+    obj_nums = reference_labels.size(2)
+    right, _ = ops.label_bits(reference_labels.reshape(-1, obj_nums), want_wrong=False)
+    if not bool((right < 0).any()):
+        return torch.ones(1, h, w, obj_nums, 1, device=query_embeddings.device)
+    return global_matching_for_eval_proxy(reference_embeddings, query_embeddings, [reference_labels], n_chunks,
+                                          dis_bias, ori_size, 1, use_float16, 0)
+
+
+# ------------------------------------------------------------------------------------------ local path (a8)
+def local_matching(prev_frame_embedding, query_embedding, prev_frame_labels, dis_bias=0., multi_local_distance=[15],
+                   ori_size=None, atrous_rate=1, use_float16=True, allow_downsample=True, allow_parallel=True):
+    """AEM:968-1060.  -> [1, H, W, O, len(multi_local_distance)], channel order [max, d_0, d_1, ...]."""
+    if use_float16:
+        raise NotImplementedError("aoc_amd: float16 matching is not implemented")
+    if atrous_rate != 1:
+        raise NotImplementedError("aoc_amd: local matching supports atrous_rate == 1 (TEST/TRAIN_LOCAL_ATROUS_RATE)")
+    h, w, _ = prev_frame_embedding.size()
+    if ori_size is None:
+        ori_size = (h, w)
+    obj_num = prev_frame_labels.size(2)
+    dev = query_embedding.device
+    radii = [int(r) for r in multi_local_distance]
+    right, _ = ops.label_bits(prev_frame_labels.reshape(-1, obj_num), want_wrong=False)
+    if allow_downsample:
+        H, W = int(h / 2) + 1, int(w / 2) + 1                              # AEM:939
+        q = ops.resize_bilinear_hwc(query_embedding, H, W)
+        p = ops.resize_bilinear_hwc(prev_frame_embedding, H, W)
+    else:
+        H, W = h, w
+        q, p = query_embedding, prev_frame_embedding
+    if (H, W) != tuple(ori_size):
+        # AEM:1017-1018: labels go to the matching resolution by 'nearest' FROM THEIR OWN size (h, w)
+        right = ops.resize_nearest_bits(right, h, w, H, W)
+    elif (H, W) != (h, w):
+        raise ValueError("local_matching: label map and distance map sizes differ")   # reference would fail in unfold too
+    feats = ops.local_window_match(q, p, right, radii, _bias_vec(dis_bias, obj_num, dev), obj_num, True)   # [O, nr, H, W]
+    nr = len(radii)
+    out = torch.empty(1, ori_size[0], ori_size[1], obj_num, nr, dtype=torch.float32, device=dev)
+    ops.resize_bilinear_planes(feats.reshape(obj_num * nr, H, W), int(ori_size[0]), int(ori_size[1]), out, 1, obj_num * nr)
+    return out
+
+
+local_matching_proxy = local_matching   # AEM:1064-1156 is a verbatim copy of AEM:968-1060
+
+
+# ------------------------------------------------------------------------------------------ fg -> bg (a9)
+def foreground2background(dis, obj_num):
+    """AEM:9-23: per object the elementwise min over all other objects.  dis [O, c, h, w]."""
+    if obj_num == 1:
+        return dis
+    return ops.fg2bg_min(dis, obj_num)

@@ -1,0 +1,283 @@
+"""Tensor-level front-end of the C ABI: allocates outputs / workspaces as torch device tensors
+and passes raw pointers + the current HIP stream to libaoc_hip.so.  PyTorch is plumbing here
+(device memory and streams); every computation happens in the HIP library.
+
+All functions require CUDA(HIP) tensors and raise otherwise -- there is no CPU path.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+
+PAD_DISTANCE = 5e4
+MAX_OBJECTS = 30
+
+
+def _need_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise _lib.AocHipError("aoc_amd operators run only on an MI355X device tensor (no CPU fallback); "
+                                   f"got a tensor on {t.device}")
+
+
+def _p(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _f32c(t):
+    """float32 + contiguous (the reference hands over permuted views, aocnet.py:149,153,188)."""
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def _ws(nbytes, device):
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+
+
+# ------------------------------------------------------------------------------------------ labels
+def label_bits(labels_flat, want_wrong=True):
+    """labels [n, O] float -> (right_bits, wrong_bits) uint32-as-int32 tensors [n]."""
+    labels_flat = _f32c(labels_flat)
+    _need_gpu(labels_flat)
+    n, n_obj = labels_flat.shape
+    right = torch.empty(n, dtype=torch.int32, device=labels_flat.device)
+    wrong = torch.empty(n, dtype=torch.int32, device=labels_flat.device) if want_wrong else None
+    _lib.check(_lib.lib().aoc_label_bits(_p(labels_flat), n, n_obj, _p(right), _p(wrong), _stream()), "aoc_label_bits")
+    return right, wrong
+
+
+class LabelPrep:
+    """Result of aoc_label_prep (all device tensors)."""
+    __slots__ = ("n", "n_obj", "right_bits", "wrong_bits", "fg_rows", "obj_rows", "counts", "obj_offsets")
+
+
+def label_prep(labels_flat):
+    labels_flat = _f32c(labels_flat)
+    _need_gpu(labels_flat)
+    n, n_obj = labels_flat.shape
+    dev = labels_flat.device
+    L = _lib.lib()
+    r = LabelPrep()
+    r.n, r.n_obj = n, n_obj
+    r.right_bits = torch.empty(n, dtype=torch.int32, device=dev)
+    r.wrong_bits = torch.empty(n, dtype=torch.int32, device=dev)
+    r.fg_rows = torch.empty(n, dtype=torch.int32, device=dev)
+    r.obj_rows = torch.empty(n * n_obj, dtype=torch.int32, device=dev)
+    r.counts = torch.empty(n_obj + 1, dtype=torch.int32, device=dev)
+    r.obj_offsets = torch.empty(n_obj + 1, dtype=torch.int32, device=dev)
+    ws = _ws(L.aoc_label_prep_workspace_bytes(n, n_obj), dev)
+    _lib.check(L.aoc_label_prep(_p(labels_flat), n, n_obj, _p(r.right_bits), _p(r.wrong_bits), _p(r.fg_rows), _p(r.obj_rows),
+                                _p(r.counts), _p(r.obj_offsets), _p(ws), ws.numel(), _stream()), "aoc_label_prep")
+    return r
+
+
+def kmeans_plan(counts, n_seg, cluster_num):
+    _need_gpu(counts)
+    seg_k = torch.empty(n_seg, dtype=torch.int32, device=counts.device)
+    _lib.check(_lib.lib().aoc_kmeans_plan(_p(counts), n_seg, int(cluster_num), _p(seg_k), _stream()), "aoc_kmeans_plan")
+    return seg_k
+
+
+# ------------------------------------------------------------------------------------------ k-means
+def kmeans_segmented(pool, rows, seg_offsets, seg_k, init_rows, kmax, iters=20, rows_capacity=None):
+    """Segmented k-means, bit-identical to scipy kmeans2 (see include/aoc_hip.h).
+    Returns (centroids [S,kmax,C], labels [rows_capacity], cluster_counts [S,kmax])."""
+    pool = _f32c(pool)
+    _need_gpu(pool, rows, seg_offsets, seg_k, init_rows)
+    n_seg = seg_k.numel()
+    C = pool.shape[1]
+    cap = int(rows.numel() if rows_capacity is None else rows_capacity)
+    dev = pool.device
+    L = _lib.lib()
+    centroids = torch.empty(n_seg, kmax, C, dtype=torch.float32, device=dev)
+    labels = torch.empty(cap, dtype=torch.int32, device=dev)
+    ccounts = torch.empty(n_seg, kmax, dtype=torch.int32, device=dev)
+    ws = _ws(L.aoc_kmeans_workspace_bytes(cap, n_seg, kmax, C), dev)
+    init_rows = init_rows.to(torch.int32).contiguous()
+    _lib.check(L.aoc_kmeans_segmented(_p(pool), C, _p(rows), _p(seg_offsets), _p(seg_k), _p(init_rows), n_seg, kmax, int(iters), cap,
+                                      _p(centroids), _p(labels), _p(ccounts), _p(ws), ws.numel(), _stream()), "aoc_kmeans_segmented")
+    return centroids, labels, ccounts
+
+
+def build_proxies(pool, fg_rows, seg_offsets, seg_k, labels, centroids):
+    """AEM:280-282 -> (proxies [S,2,kmax,C], proxy_sqnorm [S,2,kmax]); +inf norm = absent proxy."""
+    pool = _f32c(pool)
+    _need_gpu(pool, fg_rows, seg_offsets, seg_k, labels, centroids)
+    n_seg, kmax, C = centroids.shape
+    proxies = torch.empty(n_seg, 2, kmax, C, dtype=torch.float32, device=pool.device)
+    sqnorm = torch.empty(n_seg, 2, kmax, dtype=torch.float32, device=pool.device)
+    _lib.check(_lib.lib().aoc_build_proxies(_p(pool), C, _p(fg_rows), _p(seg_offsets), _p(seg_k), _p(labels), _p(centroids), n_seg, kmax,
+                                            _p(proxies), _p(sqnorm), _stream()), "aoc_build_proxies")
+    return proxies, sqnorm
+
+
+# ------------------------------------------------------------------------------------------ correlation
+def proxy_corr_min(query_flat, proxies, proxy_sqnorm, set_offsets, set_bias, out, out_pixel_stride, out_set_stride, transform=True):
+    """Writes, for every pixel i and set s, f(min over the set's proxies of d(q_i, p)) at
+    out.data_ptr()[i*out_pixel_stride + s*out_set_stride]."""
+    query_flat = _f32c(query_flat)
+    proxies = _f32c(proxies)
+    proxy_sqnorm = _f32c(proxy_sqnorm) if proxy_sqnorm is not None else None
+    _need_gpu(query_flat, proxies, proxy_sqnorm, out, set_bias)
+    m, C = query_flat.shape
+    so = np.ascontiguousarray(np.asarray(set_offsets, dtype=np.int32))
+    n_set = so.size - 1
+    if set_bias is not None:
+        set_bias = _f32c(set_bias)
+        assert set_bias.numel() == n_set
+    _lib.check(_lib.lib().aoc_proxy_corr_min(_p(query_flat), m, C, _p(proxies), _p(proxy_sqnorm), proxies.shape[0],
+                                             so.ctypes.data_as(ctypes.c_void_p), _p(set_bias), n_set, _p(out),
+                                             int(out_pixel_stride), int(out_set_stride), int(bool(transform)), _stream()),
+               "aoc_proxy_corr_min")
+    return out
+
+
+def dense_match_min(query_flat, pool, prep, obj_bias, out, out_pixel_stride, out_obj_stride, transform=True):
+    query_flat = _f32c(query_flat)
+    pool = _f32c(pool)
+    _need_gpu(query_flat, pool, out)
+    m, C = query_flat.shape
+    n_obj = prep.n_obj
+    L = _lib.lib()
+    ws = _ws(L.aoc_dense_match_workspace_bytes(m, prep.n, n_obj), pool.device)
+    if obj_bias is not None:
+        obj_bias = _f32c(obj_bias)
+    n_fg = prep.counts[n_obj:n_obj + 1]
+    _lib.check(L.aoc_dense_match_min(_p(query_flat), m, C, _p(pool), _p(prep.fg_rows), _p(n_fg), prep.n, _p(prep.wrong_bits),
+                                     _p(obj_bias), n_obj, _p(out), int(out_pixel_stride), int(out_obj_stride), int(bool(transform)),
+                                     _p(ws), ws.numel(), _stream()), "aoc_dense_match_min")
+    return out
+
+
+# ------------------------------------------------------------------------------------------ local matching + resize
+def resize_bilinear_hwc(x, H, W):
+    x = _f32c(x)
+    _need_gpu(x)
+    h, w, C = x.shape
+    out = torch.empty(H, W, C, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().aoc_resize_bilinear_hwc(_p(x), h, w, C, _p(out), H, W, _stream()), "aoc_resize_bilinear_hwc")
+    return out
+
+
+def resize_bilinear_planes(x, H, W, out, out_plane_stride, out_pixel_stride):
+    x = _f32c(x)
+    _need_gpu(x, out)
+    P, h, w = x.shape
+    _lib.check(_lib.lib().aoc_resize_bilinear_planes(_p(x), P, h, w, _p(out), H, W, int(out_plane_stride), int(out_pixel_stride), _stream()),
+               "aoc_resize_bilinear_planes")
+    return out
+
+
+def resize_nearest_bits(bits, h, w, H, W):
+    _need_gpu(bits)
+    out = torch.empty(H * W, dtype=torch.int32, device=bits.device)
+    _lib.check(_lib.lib().aoc_resize_nearest_bits(_p(bits), h, w, _p(out), H, W, _stream()), "aoc_resize_nearest_bits")
+    return out
+
+
+def local_window_match(query, prev, right_bits, radii, obj_bias, n_obj, transform=True):
+    """query, prev [H,W,C] -> [n_obj, len(radii), H, W] (channel order [max, r_0, ...])."""
+    query, prev = _f32c(query), _f32c(prev)
+    _need_gpu(query, prev, right_bits)
+    H, W, C = query.shape
+    radii = np.ascontiguousarray(np.asarray(radii, dtype=np.int32))
+    out = torch.empty(n_obj, radii.size, H, W, dtype=torch.float32, device=query.device)
+    if obj_bias is not None:
+        obj_bias = _f32c(obj_bias)
+    _lib.check(_lib.lib().aoc_local_window_match(_p(query), _p(prev), _p(right_bits), H, W, C, radii.ctypes.data_as(ctypes.c_void_p),
+                                                 int(radii.size), _p(obj_bias), n_obj, _p(out), int(bool(transform)), _stream()),
+               "aoc_local_window_match")
+    return out
+
+
+# ------------------------------------------------------------------------------------------ calibration side
+def fg2bg_min(dis, n_obj):
+    dis = _f32c(dis)
+    _need_gpu(dis)
+    out = torch.empty_like(dis)
+    inner = dis.numel() // n_obj
+    _lib.check(_lib.lib().aoc_fg2bg_min(_p(dis), n_obj, inner, _p(out), _stream()), "aoc_fg2bg_min")
+    return out
+
+
+def masked_mean_pool(emb, labels, epsilon):
+    """emb [F, hw, C], labels [F, O, hw] -> (pos [O,C], neg [O,C])   (ATT:155-189)."""
+    emb, labels = _f32c(emb), _f32c(labels)
+    _need_gpu(emb, labels)
+    F_, hw, C = emb.shape
+    n_obj = labels.shape[1]
+    L = _lib.lib()
+    pos = torch.empty(n_obj, C, dtype=torch.float32, device=emb.device)
+    neg = torch.empty(n_obj, C, dtype=torch.float32, device=emb.device)
+    ws = _ws(L.aoc_masked_mean_pool_workspace_bytes(F_, hw, n_obj, C), emb.device)
+    _lib.check(L.aoc_masked_mean_pool(_p(emb), _p(labels), F_, hw, C, n_obj, float(epsilon), _p(pos), _p(neg), _p(ws), ws.numel(), _stream()),
+               "aoc_masked_mean_pool")
+    return pos, neg
+
+
+def film_gain(head, weight, bias):
+    head, weight = _f32c(head), _f32c(weight)
+    bias = _f32c(bias) if bias is not None else None
+    _need_gpu(head, weight, bias)
+    n_obj, D = head.shape
+    channels = weight.shape[0]
+    gain = torch.empty(n_obj, channels, dtype=torch.float32, device=head.device)
+    _lib.check(_lib.lib().aoc_film_gain(_p(head), _p(weight), _p(bias), n_obj, D, channels, _p(gain), _stream()), "aoc_film_gain")
+    return gain
+
+
+def channel_scale(x, gain, out=None):
+    """y[n,c,:,:] = gain[n,c] * x[n,c,:,:]."""
+    x, gain = _f32c(x), _f32c(gain)
+    _need_gpu(x, gain)
+    planes = x.shape[0] * x.shape[1]
+    hw = x.numel() // planes
+    assert gain.numel() == planes
+    y = torch.empty_like(x) if out is None else out
+    _lib.check(_lib.lib().aoc_channel_scale(_p(x), _p(gain), planes, hw, _p(y), _stream()), "aoc_channel_scale")
+    return y
+
+
+def cond_gate_pool(z, phi_w, phi_b, k_rank, want_debug=False):
+    """CL:23-43 -> gap [N, C] (optionally also scores [N,HW] and threshold [N])."""
+    z, phi_w, phi_b = _f32c(z), _f32c(phi_w).reshape(-1), _f32c(phi_b).reshape(-1)
+    _need_gpu(z, phi_w, phi_b)
+    N, C = z.shape[0], z.shape[1]
+    hw = z.numel() // (N * C)
+    L = _lib.lib()
+    gap = torch.empty(N, C, dtype=torch.float32, device=z.device)
+    scores = torch.empty(N, hw, dtype=torch.float32, device=z.device) if want_debug else None
+    thr = torch.empty(N, dtype=torch.float32, device=z.device) if want_debug else None
+    ws = _ws(L.aoc_cond_gate_pool_workspace_bytes(N, C, hw), z.device)
+    _lib.check(L.aoc_cond_gate_pool(_p(z), N, C, hw, _p(phi_w), _p(phi_b), int(k_rank), _p(gap), _p(scores), _p(thr), _p(ws), ws.numel(),
+                                    _stream()), "aoc_cond_gate_pool")
+    return (gap, scores, thr) if want_debug else gap
+
+
+def linear(x, weight, bias):
+    x, weight = _f32c(x), _f32c(weight)
+    bias = _f32c(bias) if bias is not None else None
+    _need_gpu(x, weight, bias)
+    N, in_dim = x.shape
+    out_dim = weight.shape[0]
+    y = torch.empty(N, out_dim, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().aoc_linear(_p(x), _p(weight), _p(bias), N, in_dim, out_dim, _p(y), _stream()), "aoc_linear")
+    return y
+
+
+def plane_mean(x):
+    """[N, C, H, W] -> [N, C] (CLB:68 avg_pool2d over the whole map)."""
+    x = _f32c(x)
+    _need_gpu(x)
+    planes = x.shape[0] * x.shape[1]
+    hw = x.numel() // planes
+    out = torch.empty(x.shape[0], x.shape[1], dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().aoc_plane_mean(_p(x), planes, hw, _p(out), _stream()), "aoc_plane_mean")
+    return out

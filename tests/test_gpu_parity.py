@@ -1,0 +1,278 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the golden vectors recorded from
+the reference and against the CPU oracle, on the same seeded inputs.
+
+Tolerances: k-means labels / code books are compared BIT-EXACT (north_star: "bit-exact for argmin
+cluster assignments").  Proto-mask features live in (-1, 1); they are fp32 sums of ~100 products
+followed by expf, so they are compared with atol = 5e-6 (the 1e-3 mask-IoU budget is 200x looser).
+"""
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ATOL = 5e-6
+
+
+@pytest.fixture(scope="module")
+def aoc():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    import aoc_amd
+    aoc_amd._lib.lib()      # raises if the HIP library is missing: no silent fallback
+    return aoc_amd
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _refs(g):
+    return [dev(e) for e in g["in_ref"]], [dev(l) for l in g["lab_onehot"]]
+
+
+def _ori(g):
+    o = tuple(int(v) for v in g["ori_size"])
+    return o if o[0] > 0 else None
+
+
+# ------------------------------------------------------------------------------------------ k-means
+@pytest.mark.parametrize("sizes,k,c", [([3000, 700, 41], 16, 100), ([5000], 64, 100), ([900, 900], 8, 100),
+                                        ([40, 12, 300], 16, 100), ([1200, 60], 16, 36), ([500], 16, 130)])
+def test_kmeans_bit_exact_vs_oracle_and_scipy(aoc, sizes, k, c):
+    """aoc_kmeans_segmented == oracle C restatement == scipy.cluster.vq.kmeans2, bit for bit."""
+    from scipy.cluster.vq import kmeans2
+    from oracle import kmeans as okm
+    rng = np.random.RandomState(sum(sizes) + k)
+    n = sum(sizes)
+    pool = (np.maximum(rng.randn(n + 50, c), 0) * 0.3).astype(np.float32)
+    if sizes[0] == 40:
+        pool[5:30] = pool[3]                                     # duplicates -> empty clusters
+    perm = rng.permutation(n + 50)[:n]                           # rows scattered through the pool
+    rows, offs, seg_k, init = [], [0], [], np.zeros((len(sizes), k), np.int32)
+    start = 0
+    for s, ns in enumerate(sizes):
+        r = np.sort(perm[start:start + ns])
+        start += ns
+        rows.append(r)
+        offs.append(offs[-1] + ns)
+        ks = min(k, ns)
+        seg_k.append(ks)
+        init[s, :ks] = rng.permutation(ns)[:ks]
+    rows_all = np.concatenate(rows).astype(np.int32)
+    cen, lab, cnt = aoc.ops.kmeans_segmented(dev(pool), dev(rows_all), dev(np.array(offs, np.int32)), dev(np.array(seg_k, np.int32)),
+                                              dev(init), k, 20)
+    cen, lab, cnt = cen.cpu().numpy(), lab.cpu().numpy(), cnt.cpu().numpy()
+    for s, ns in enumerate(sizes):
+        x = pool[rows[s]]
+        ks = seg_k[s]
+        cb_o, lab_o, cnt_o = okm.kmeans2_matrix(x, x[init[s, :ks]], 20)
+        assert np.array_equal(lab[offs[s]:offs[s + 1]], lab_o), f"segment {s}: labels differ from the oracle"
+        assert np.array_equal(cen[s, :ks], cb_o), f"segment {s}: code book differs from the oracle"
+        assert np.array_equal(cnt[s, :ks], cnt_o)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            cb_s, lab_s = kmeans2(x, x[init[s, :ks]].copy(), minit='matrix', iter=20)
+        assert np.array_equal(lab[offs[s]:offs[s + 1]], lab_s) and np.array_equal(cen[s, :ks], cb_s), "differs from scipy"
+
+
+CLUSTER_CASES = ["cluster_basic_R1_O3", "cluster_R3_O4_bias", "cluster_orisize", "cluster_sticky_empty_obj0",
+                 "cluster_small_first_obj", "cluster_small_mid_obj", "cluster_duplicates_empty", "cluster_uncertain125",
+                 "cluster_all_unlabelled"]
+
+
+@pytest.mark.parametrize("name", CLUSTER_CASES)
+def test_cluster_path_golden(aoc, golden, name):
+    g = golden(name)
+    refs, labs = _refs(g)
+    np.random.seed(int(g["seed"]))           # same global RandomState stream as the reference run
+    out = aoc.matching.global_matching_for_eval_cluster(refs, dev(g["in_query"]), labs, 4, dev(g["in_bias"]).view(-1, 1, 1, 1),
+                                                        _ori(g), 1, False, 0)
+    assert tuple(out.shape) == g["out"].shape
+    np.testing.assert_allclose(out.cpu().numpy(), g["out"], rtol=0, atol=ATOL)
+
+
+@pytest.mark.parametrize("name", ["cluster_basic_R1_O3", "cluster_R3_O4_bias", "cluster_small_first_obj",
+                                  "cluster_duplicates_empty", "cluster_uncertain125"])
+def test_cluster_kmeans_calls_bit_exact(aoc, golden, name):
+    """Every kmeans2 call the reference made: same rows drawn, labels and code book bit-identical."""
+    g = golden(name)
+    c = g["in_ref"].shape[-1]
+    o = g["lab_onehot"].shape[-1]
+    pool = dev(g["in_ref"].reshape(-1, c))
+    labels = dev(g["lab_onehot"].reshape(-1, o))
+    np.random.seed(int(g["seed"]))
+    cp = aoc.matching.cluster_proxies(pool, labels)
+    offs = cp["prep"].obj_offsets.cpu().numpy()
+    lab = cp["labels"].cpu().numpy()
+    cen = cp["centroids"].cpu().numpy()
+    call = 0
+    for i in range(o):
+        if cp["seg_k"][i] == 0:
+            continue
+        k = cp["seg_k"][i]
+        assert k == int(g[f"km{call}_k"]) and offs[i + 1] - offs[i] == int(g[f"km{call}_n"])
+        assert np.array_equal(cp["init_rows"][i], g[f"km{call}_rows"])
+        assert np.array_equal(lab[offs[i]:offs[i + 1]], g[f"km{call}_labels"])
+        assert np.array_equal(cen[i, :k], g[f"km{call}_centroid"])
+        call += 1
+    assert call == int(g["km_calls"])
+
+
+def test_cluster_vs_oracle_proxies(aoc, golden):
+    """Proxy tables (centroid + the bug-compatible centroid_avg) against the oracle."""
+    from oracle import matching as om
+    g = golden("cluster_R3_O4_bias")
+    ref = torch.from_numpy(g["in_ref"].reshape(-1, 100))
+    lab = torch.from_numpy(g["lab_onehot"].reshape(-1, 4))
+    keep = lab.sum(1) > 0.9
+    np.random.seed(5)
+    prox = om.build_adaptive_proxies(ref[keep], lab[keep])
+    np.random.seed(5)
+    cp = aoc.matching.cluster_proxies(ref.cuda(), lab.cuda())
+    P, N = cp["proxies"].cpu().numpy(), cp["proxy_sqnorm"].cpu().numpy()
+    for i, p in enumerate(prox):
+        k = p["k"]
+        assert np.array_equal(P[i, 0, :k], p["centroid"].numpy())
+        live = np.nonzero(p["counts"] > 0)[0]
+        np.testing.assert_allclose(P[i, 1, live], p["centroid_avg"].numpy(), rtol=2e-6, atol=1e-7)
+        assert np.all(np.isinf(N[i, 1, np.nonzero(p["counts"] == 0)[0]])) and np.all(np.isinf(N[i, :, k:]))
+
+
+def test_cluster_float16_mode_constant(aoc, golden):
+    """use_float16=True: scipy rejects float16, the reference's bare except pads with 5e4 -> exactly 1.0."""
+    g = golden("cluster_basic_R1_O3")
+    refs, labs = _refs(g)
+    out = aoc.matching.global_matching_for_eval_cluster(refs, dev(g["in_query"]), labs, 4, dev(g["in_bias"]).view(-1, 1, 1, 1))
+    assert tuple(out.shape) == (1, 24, 40, 3, 2) and bool((out == 1).all())
+
+
+# ------------------------------------------------------------------------------------------ dense / proxy / local
+@pytest.mark.parametrize("name", ["dense_R1_O3", "dense_R2_O4_bias_unc", "dense_orisize", "dense_all_unlabelled"])
+def test_dense_path_golden(aoc, golden, name):
+    g = golden(name)
+    refs, labs = _refs(g)
+    out = aoc.matching.global_matching_for_eval(refs, dev(g["in_query"]), labs, 4, dev(g["in_bias"]).view(-1, 1, 1, 1), _ori(g), 1, False, 0)
+    assert tuple(out.shape) == g["out"].shape
+    np.testing.assert_allclose(out.cpu().numpy(), g["out"], rtol=0, atol=ATOL)
+
+
+def test_dense_train_twin_golden(aoc, golden):
+    g = golden("dense_train_twin")
+    out = aoc.matching.global_matching(dev(g["in_ref"][0]), dev(g["in_query"]), dev(g["lab_onehot"][0]), 3,
+                                       dev(g["in_bias"]).view(-1, 1, 1, 1), None, 1, False, 0)
+    np.testing.assert_allclose(out.cpu().numpy(), g["out"], rtol=0, atol=ATOL)
+
+
+def test_dense_general_float_labels_vs_oracle(aoc):
+    """Non one-hot labels (two objects right on the same pixel, soft values between the thresholds)."""
+    from oracle import matching as om
+    rng = np.random.RandomState(3)
+    h, w, c, o = 17, 23, 100, 5
+    ref = (np.maximum(rng.randn(2, h, w, c), 0) * 0.3).astype(np.float32)
+    q = (np.maximum(rng.randn(h, w, c), 0) * 0.3).astype(np.float32)
+    lab = rng.choice([0.0, 0.05, 0.5, 0.95, 1.0], size=(2, h, w, o)).astype(np.float32)
+    bias = (rng.rand(o).astype(np.float32) - 0.5)
+    want = om.global_matching_for_eval([torch.from_numpy(r) for r in ref], torch.from_numpy(q), [torch.from_numpy(l) for l in lab],
+                                       4, torch.from_numpy(bias))
+    got = aoc.matching.global_matching_for_eval([dev(r) for r in ref], dev(q), [dev(l) for l in lab], 4, dev(bias), None, 1, False, 0)
+    np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), rtol=0, atol=ATOL)
+
+
+@pytest.mark.parametrize("name,train", [("proxy_eval_O3", False), ("proxy_train_O3", True)])
+def test_proxy_path_golden(aoc, golden, name, train):
+    g = golden(name)
+    lab = dev(g["lab_onehot"][0])
+    b = dev(g["in_bias"]).view(-1, 1, 1, 1)
+    if train:
+        out = aoc.matching.global_matching_proxy(dev(g["in_proxies"]), dev(g["in_query"]), lab, 3, b, None, 1, False, 0)
+    else:
+        out = aoc.matching.global_matching_for_eval_proxy(dev(g["in_proxies"]), dev(g["in_query"]), [lab], 4, b, None, 1, False, 0)
+    np.testing.assert_allclose(out.cpu().numpy(), g["out"], rtol=0, atol=ATOL)
+
+
+@pytest.mark.parametrize("name", ["local_down_O3", "local_down_O4_bias", "local_nodown_O3", "local_down_odd_C36", "local_proxy_down_O3"])
+def test_local_path_golden(aoc, golden, name):
+    g = golden(name)
+    fn = aoc.matching.local_matching_proxy if "proxy" in name else aoc.matching.local_matching
+    out = fn(dev(g["in_prev"]), dev(g["in_query"]), dev(g["lab_onehot"]), dev(g["in_bias"]).view(-1, 1, 1, 1),
+             [int(v) for v in g["mld"]], None, 1, False, bool(g["down"]), True)
+    assert tuple(out.shape) == g["out"].shape
+    np.testing.assert_allclose(out.cpu().numpy(), g["out"], rtol=0, atol=ATOL)
+
+
+@pytest.mark.parametrize("name,n", [("fg2bg_O4", 4), ("fg2bg_O1", 1)])
+def test_fg2bg_golden(aoc, golden, name, n):
+    g = golden(name)
+    assert np.array_equal(aoc.matching.foreground2background(dev(g["in_dis"]), n).cpu().numpy(), g["out"])
+
+
+# ------------------------------------------------------------------------------------------ calibration side
+def _onehot(lab, n):
+    return (torch.from_numpy(lab.astype(np.int64)).unsqueeze(0) == torch.arange(n).view(-1, 1, 1)).float().unsqueeze(1).cuda()
+
+
+def test_attention_head_golden(aoc, golden):
+    g = golden("attention_head_eval_p_m")
+    n = int(g["n_obj"])
+    ref_e = [dev(e).permute(2, 0, 1).unsqueeze(0) for e in g["in_ref"]]
+    ref_l = [_onehot(l, n) for l in g["lab_ref"]]
+    prev_e = dev(g["in_prev"]).permute(2, 0, 1).unsqueeze(0).expand(n, -1, -1, -1)
+    outs = aoc.attention.calculate_attention_head_for_eval_p_m(ref_e, ref_l, prev_e, _onehot(g["lab_prev"], n), 1e-5)
+    for o, key in zip(outs, ["total", "ref_pos", "ref_neg", "prev_pos", "prev_neg"]):
+        np.testing.assert_allclose(o.cpu().numpy(), g[key], rtol=5e-6, atol=1e-7)
+
+
+def test_ia_gate_golden(aoc, golden):
+    g = golden("ia_gate")
+    gate = aoc.attention.IA_gate(40, 12).cuda()
+    with torch.no_grad():
+        gate.IA.weight.copy_(dev(g["in_w"]))
+        gate.IA.bias.copy_(dev(g["in_b"]))
+        y = gate(dev(g["in_x"]), dev(g["in_head"]))
+    np.testing.assert_allclose(y.cpu().numpy(), g["out"], rtol=2e-6, atol=1e-6)
+
+
+def test_conditioning_layer_golden(aoc, golden):
+    g = golden("conditioning_layer_4d")
+    layer = aoc.conditioning_layer.conditioning_layer(24, float(g["beta"])).cuda()
+    with torch.no_grad():
+        layer.phi_layer.weight.copy_(dev(g["in_phi_w"]).view(1, 24, 1, 1))
+        layer.phi_layer.bias.copy_(dev(g["in_phi_b"]))
+        layer.mlp_layer.weight.copy_(dev(g["in_mlp_w"]))
+        layer.mlp_layer.bias.copy_(dev(g["in_mlp_b"]))
+        out = layer(dev(g["in_z"]))
+        k = int(0.3 * 13 * 17)
+        gap, scores, thr = aoc.ops.cond_gate_pool(dev(g["in_z"]), dev(g["in_phi_w"]), dev(g["in_phi_b"]), k, want_debug=True)
+    np.testing.assert_allclose(scores.cpu().numpy(), g["scores"], rtol=1e-5, atol=2e-6)
+    # the threshold is an element of the score vector: exact selection of the k-th largest
+    s = scores.cpu().numpy()
+    assert np.array_equal(thr.cpu().numpy(), np.sort(s, axis=1)[:, ::-1][:, k - 1])
+    assert np.array_equal((s > thr.cpu().numpy()[:, None]).sum(1), g["mask_count"])
+    np.testing.assert_allclose(out.cpu().numpy(), g["out"], rtol=1e-5, atol=2e-6)
+
+
+def test_conditioning_block_vs_oracle(aoc):
+    from oracle import calibration as ocal
+    torch.manual_seed(0)
+    n, c, p = 3, 16, 10
+    blk = aoc.conditioning_layer.conditioning_block(c, p, 0.3).cuda()
+    x = torch.randn(n, c, 11, 13)
+    head = torch.randn(n, p)
+    sd = {k: v.detach().cpu() for k, v in blk.state_dict().items()}
+    w = {"CL_1.phi_w": sd["CL_1.phi_layer.weight"].reshape(-1), "CL_1.phi_b": sd["CL_1.phi_layer.bias"],
+         "CL_1.mlp_w": sd["CL_1.mlp_layer.weight"], "CL_1.mlp_b": sd["CL_1.mlp_layer.bias"],
+         "CL_2.mlp_w": sd["CL_2.mlp_layer.weight"], "CL_2.mlp_b": sd["CL_2.mlp_layer.bias"],
+         "CL_3.mlp_w": sd["CL_3.mlp_layer.weight"], "CL_3.mlp_b": sd["CL_3.mlp_layer.bias"],
+         "mlp_w": sd["mlp_layer.weight"], "mlp_b": sd["mlp_layer.bias"]}
+    want = ocal.conditioning_block(x, head, w, 0.3)
+    with torch.no_grad():
+        got = blk(x.cuda(), head.cuda())
+    np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), rtol=1e-5, atol=1e-5)
+
+
+def test_no_cpu_fallback(aoc):
+    with pytest.raises(aoc._lib.AocHipError):
+        aoc.ops.fg2bg_min(torch.zeros(2, 8), 2)
