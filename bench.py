@@ -1,0 +1,329 @@
+#!/usr/bin/env python3
+"""Benchmark of the AOC-Net matching + calibration hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one frame of one synthetic video sequence per stream (--streams, default 1) through the
+whole hot path: label prep, scipy-exact k-means proxies, proxy / dense / local matching, fg->bg,
+the 24-channel proto-mask tensor, then the ten IA gates and four conditioning blocks at the
+decoder's activation shapes.  Workload = BASELINE.json configs[1] (cfg2): 480p -> 121x213 stride-4
+maps, 3 objects + background, K = 16 proxies, 60-frame clips whose reference pool grows by one frame
+every MEM_EVERY = 5 frames (R = 1..12), exactly as the reference's eval loop does
+(eval_manager_mm.py:309-361).  Inputs (feature maps, label maps, k-means initial rows, decoder
+activations) are synthetic, seeded and resident in HBM before the timed region.
+
+Prints ONE JSON line on rank 0 (contract in the task statement): whole-job frames/s, the roofline of
+the dominant kernel measured with HIP events inside the timed region, and a CPU baseline (the oracle
+timed on the host cores, rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import aoc_amd  # noqa: E402
+from aoc_amd import hotpath, ops, sharding  # noqa: E402
+from aoc_amd import synthetic as syn  # noqa: E402
+
+PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
+PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
+
+
+class OpTimer:
+    """HIP-event timing of every call of selected aoc_amd.ops functions on the stream they are
+    launched on (torch's current stream), inside the timed region."""
+
+    def __init__(self, names):
+        self.names = names
+        self.records = {n: [] for n in names}
+        self.meta = {n: [] for n in names}
+        self.enabled = False
+        self._orig = {}
+
+    def install(self, meta_fns):
+        for n in self.names:
+            fn = getattr(ops, n)
+            self._orig[n] = fn
+
+            def wrapped(*a, _fn=fn, _n=n, **k):
+                if not self.enabled:
+                    return _fn(*a, **k)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                out = _fn(*a, **k)
+                e1.record()
+                self.records[_n].append((e0, e1))
+                self.meta[_n].append(meta_fns[_n](*a, **k) if _n in meta_fns else None)
+                return out
+
+            setattr(ops, n, wrapped)
+
+    def summary(self):
+        out = {}
+        for n in self.names:
+            ms = [a.elapsed_time(b) for a, b in self.records[n]]
+            if ms:
+                out[n] = dict(calls=len(ms), total_ms=float(np.sum(ms)), avg_ms=float(np.mean(ms)), meta=self.meta[n])
+        return out
+
+
+class ClipWorkload:
+    """One synthetic sequence of a config, resident on the GPU, stepped with the reference's memory policy."""
+
+    def __init__(self, cfg, seed, device, mc):
+        self.cfg, self.mc, self.dev = cfg, mc, device
+        clip = syn.make_clip(cfg, seed)
+        O = cfg.n_obj
+        self.emb = torch.from_numpy(clip["emb"]).to(device)                                   # [T,h,w,C]
+        self.lab_ids = clip["lab"]
+        self.lab = torch.from_numpy(np.stack([syn.one_hot(l, O) for l in clip["lab"]])).to(device)   # [T,h,w,O]
+        self.T = cfg.frames
+        self.bias = torch.zeros(O, device=device)
+        rmax = 1 + (self.T - 1) // mc.MEM_EVERY + 1
+        self.pool_emb = torch.empty(rmax, cfg.h, cfg.w, cfg.c, device=device)
+        self.pool_lab = torch.empty(rmax, cfg.h, cfg.w, O, device=device)
+        # per-frame k-means initial rows (inputs): permutation(n_i)[:K_i] with the sticky K rule
+        self.init_rows = {}
+        ref_idx = [0]
+        for t in range(1, self.T):
+            counts = [int(sum((self.lab_ids[i] == o).sum() for i in ref_idx)) for o in range(O)]
+            rows = syn.kmeans_init_rows(seed * 100003 + t, counts, mc.CLUSTER_NUM)
+            init = np.zeros((O, mc.CLUSTER_NUM), np.int32)
+            for o, r in enumerate(rows):
+                if r is not None:
+                    init[o, :len(r)] = r
+            self.init_rows[t] = (torch.from_numpy(init).to(device), rows)
+            if t % mc.MEM_EVERY == 0:
+                ref_idx.append(t)
+        self.reset()
+
+    def reset(self):
+        self.t, self.R = 1, 1
+        self.pool_emb[0].copy_(self.emb[0])
+        self.pool_lab[0].copy_(self.lab[0])
+
+    def refs(self):
+        return self.pool_emb[:self.R], self.pool_lab[:self.R]
+
+    def advance(self):
+        """eval_manager_mm.py:309-312,356-361: append the frame to the pool every MEM_EVERY frames."""
+        if self.t % self.mc.MEM_EVERY == 0:
+            self.pool_emb[self.R].copy_(self.emb[self.t])
+            self.pool_lab[self.R].copy_(self.lab[self.t])
+            self.R += 1
+        self.t += 1
+        if self.t >= self.T:
+            self.reset()
+
+
+def make_activations(gates, O, h, w, device, seed):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return [torch.randn(O, c, hh, ww, generator=g).to(device) for (_, c, hh, ww, _) in gates.plan(h, w)]
+
+
+def frame_step(wl, gates, acts):
+    ref_emb, ref_lab = wl.refs()
+    t = wl.t
+    feat, head, _ = hotpath.proto_mask_features(wl.mc, ref_emb, ref_lab, wl.emb[t - 1], wl.lab[t - 1], wl.emb[t], wl.bias,
+                                                cluster_state=dict(init_rows=wl.init_rows[t][0]))
+    outs = gates(acts, head)
+    wl.advance()
+    return feat, outs
+
+
+def cpu_baseline(cfg, mc, seed, gates, acts_cpu):
+    """The oracle (a port of the reference path, proved equal to it on the golden vectors) timed on
+    the host cores for ONE frame of the same workload at R = 1 (the cheapest frame of the clip)."""
+    from oracle import calibration as ocal
+    from oracle import hotpath as ohot
+    torch.set_num_threads(os.cpu_count() or 1)
+    clip = syn.make_clip(cfg, seed, frames=2)
+    O = cfg.n_obj
+    emb = torch.from_numpy(clip["emb"])
+    lab = torch.from_numpy(np.stack([syn.one_hot(l, O) for l in clip["lab"]]))
+    counts = [int((clip["lab"][0] == o).sum()) for o in range(O)]
+    rows = syn.kmeans_init_rows(seed * 100003 + 1, counts, mc.CLUSTER_NUM)
+    t0 = time.perf_counter()
+    feat, head = ohot.proto_mask_features(emb[:1], lab[:1], emb[0], lab[0], emb[1], torch.zeros(O), init_rows=rows)
+    t_match = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    for (name, c, hh, ww, extra), x in zip(gates.plan(cfg.h, cfg.w), acts_cpu):
+        mod = getattr(gates, name)
+        sd = {k: v.detach().cpu() for k, v in mod.state_dict().items()}
+        if name.startswith("CLB"):
+            wts = {"CL_1.phi_w": sd["CL_1.phi_layer.weight"].reshape(-1), "CL_1.phi_b": sd["CL_1.phi_layer.bias"],
+                   "CL_1.mlp_w": sd["CL_1.mlp_layer.weight"], "CL_1.mlp_b": sd["CL_1.mlp_layer.bias"],
+                   "CL_2.mlp_w": sd["CL_2.mlp_layer.weight"], "CL_2.mlp_b": sd["CL_2.mlp_layer.bias"],
+                   "CL_3.mlp_w": sd["CL_3.mlp_layer.weight"], "CL_3.mlp_b": sd["CL_3.mlp_layer.bias"],
+                   "mlp_w": sd["mlp_layer.weight"], "mlp_b": sd["mlp_layer.bias"]}
+            ocal.conditioning_block(x, head, wts, mc.BETA_PERCENTAGE)
+        else:
+            hd = head
+            if extra:
+                px = x.mean(dim=(2, 3))
+                hd = torch.cat([head, px.sum(0, keepdim=True) - px], 1)
+            ocal.ia_gate(x, hd, sd["IA.weight"], sd["IA.bias"])
+    t_cal = time.perf_counter() - t0
+    return feat, head, rows, t_match, t_cal
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=59)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="cfg2", choices=list(syn.CONFIGS))
+    ap.add_argument("--streams", type=int, default=1, help="independent sequences stepped concurrently on separate HIP streams")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # RCCL over xGMI
+    aoc_amd._lib.lib()
+
+    cfg = syn.CONFIGS[args.config]
+    mc = hotpath.MatchingConfig(CLUSTER_NUM=cfg.k)
+    torch.manual_seed(0)
+    gates = hotpath.CalibrationGates(mc).to(dev)
+    n_streams = max(1, args.streams)
+    # sequences are sharded over ranks: rank r owns sequences r*n_streams .. (+n_streams)
+    workloads = [ClipWorkload(cfg, seed=1 + rank * n_streams + s, device=dev, mc=mc) for s in range(n_streams)]
+    acts = make_activations(gates, cfg.n_obj, cfg.h, cfg.w, dev, seed=7)
+    streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)] if n_streams > 1 else [torch.cuda.current_stream()]
+
+    hw, C, O = cfg.h * cfg.w, cfg.c, cfg.n_obj
+
+    def meta_dense(query_flat, pool, prep, *a, **k):
+        m, n = query_flat.shape[0], pool.shape[0]      # synthetic labels: every pool pixel is kept
+        return dict(flops=2.0 * m * n * C, bytes=(m + n) * C * 4 + n * 4 + m * O * 4)
+
+    def meta_proxy(query_flat, proxies, *a, **k):
+        m, npx = query_flat.shape[0], proxies.shape[0]
+        return dict(flops=2.0 * m * npx * C, bytes=m * C * 4 + npx * C * 4 + m * (3 * O) * 4)
+
+    def meta_kmeans(pool, rows, seg_offsets, seg_k, init_rows, kmax, iters=20, rows_capacity=None):
+        n = pool.shape[0]
+        return dict(flops=2.0 * iters * n * kmax * C, bytes=float(iters) * n * C * 4 * 2 + n * 4)
+
+    timer = OpTimer(["dense_match_min", "proxy_corr_min", "kmeans_segmented", "build_proxies", "label_prep", "local_window_match",
+                     "masked_mean_pool", "cond_gate_pool", "channel_scale", "fg2bg_min", "resize_bilinear_hwc", "resize_bilinear_planes",
+                     "plane_mean", "film_gain", "linear", "label_mix", "label_bits", "resize_nearest_bits", "kmeans_plan"])
+    timer.install(dict(dense_match_min=meta_dense, proxy_corr_min=meta_proxy, kmeans_segmented=meta_kmeans))
+
+    def run_steps(n):
+        for _ in range(n):
+            for wl, st in zip(workloads, streams):
+                if n_streams > 1:
+                    with torch.cuda.stream(st):
+                        frame_step(wl, gates, acts)
+                else:
+                    frame_step(wl, gates, acts)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+
+    with torch.no_grad():
+        run_steps(args.warmup)
+        barrier()
+        timer.enabled = (n_streams == 1)     # per-op events are only meaningful on a single stream
+        t0 = time.perf_counter()
+        run_steps(args.steps)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        timer.enabled = False
+
+    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        torch.distributed.all_reduce(el, op=torch.distributed.ReduceOp.MAX)
+    elapsed_max = float(el.item())
+    frames_local = args.steps * n_streams
+    metrics = sharding.allreduce_metrics(dict(frames=frames_local, objects=frames_local * (O - 1), gpu_seconds=elapsed), device=dev)
+
+    if rank == 0:
+        summ = timer.summary()
+        kernels = {}
+        for name, s in summ.items():
+            k = dict(calls=s["calls"], avg_ms=round(s["avg_ms"], 4), total_ms=round(s["total_ms"], 3))
+            metas = [m for m in s["meta"] if m]
+            if metas:
+                fl = float(np.mean([m["flops"] for m in metas]))
+                by = float(np.mean([m["bytes"] for m in metas]))
+                k.update(avg_flops=fl, avg_bytes=by, tflops=round(fl / (s["avg_ms"] * 1e-3) / 1e12, 3),
+                         gbs=round(by / (s["avg_ms"] * 1e-3) / 1e9, 2))
+            kernels[name] = k
+        roofline = None
+        if kernels:
+            dom = max(kernels, key=lambda n: kernels[n]["total_ms"])
+            k = kernels[dom]
+            if dom == "dense_match_min":
+                roofline = dict(kernel="dense_match_partial_kernel (aoc_dense_match_min)", bound="mfma", achieved=k["tflops"],
+                                peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s", frac=round(k["tflops"] / PEAK_FP32_MFMA_TFLOPS, 4), traffic=None,
+                                avg_launch_ms=k["avg_ms"], algorithmic_flops_per_launch=k["avg_flops"])
+            elif "gbs" in k:
+                roofline = dict(kernel=dom, bound="hbm", achieved=k["gbs"], peak=PEAK_HBM_GBS, unit="GB/s",
+                                frac=round(k["gbs"] / PEAK_HBM_GBS, 4), traffic=None, avg_launch_ms=k["avg_ms"],
+                                algorithmic_bytes_per_launch=k["avg_bytes"])
+            else:
+                roofline = dict(kernel=dom, bound="hbm", achieved=None, peak=PEAK_HBM_GBS, unit="GB/s", frac=None, traffic=None,
+                                avg_launch_ms=k["avg_ms"])
+        corr = kernels.get("proxy_corr_min")
+        corr_roof = None
+        if corr and "gbs" in corr:
+            corr_roof = dict(kernel="proxy_corr_min_kernel", bound="hbm", achieved=corr["gbs"], peak=PEAK_HBM_GBS, unit="GB/s",
+                             frac=round(corr["gbs"] / PEAK_HBM_GBS, 4), avg_launch_ms=corr["avg_ms"], algorithmic_bytes_per_launch=corr["avg_bytes"])
+
+        cpu = None
+        parity = None
+        if world == 1 and not args.no_cpu_baseline:
+            acts_cpu = [a.cpu() for a in acts]
+            feat_cpu, head_cpu, rows, t_match, t_cal = cpu_baseline(cfg, mc, 1, gates, acts_cpu)
+            cpu = dict(value=round(1.0 / (t_match + t_cal), 5), unit="frames/s", cores=os.cpu_count(), kind="port",
+                       sample=f"1 frame of {cfg.name} at R=1 (cheapest frame of the clip; the GPU figure averages R=1..12): "
+                              f"matching {t_match:.2f} s + calibration gates {t_cal:.2f} s, torch CPU fp32 + C k-means oracle")
+            # parity of the same frame on the GPU (features + a surrogate mask = argmin_o of the dense global distance channel)
+            wl = workloads[0]
+            with torch.no_grad():
+                feat_gpu, head_gpu, _ = hotpath.proto_mask_features(mc, wl.emb[:1], wl.lab[:1], wl.emb[0], wl.lab[0], wl.emb[1], wl.bias, init_rows=rows)
+            diff = float((feat_gpu.cpu() - feat_cpu).abs().max())
+            pg, pc = feat_gpu[:, 0].argmin(0).cpu(), feat_cpu[:, 0].argmin(0)
+            iou_sum, iou_n = sharding.mask_iou_sums(pg, pc, O)
+            parity = dict(max_abs_feature_diff=diff, surrogate_mask_mean_iou=iou_sum / iou_n)
+
+        value = metrics["frames"] / elapsed_max
+        line = {
+            "metric": "frames/sec, AOC-Net matching + calibration hot path (480p, 3 objects)",
+            "value": round(value, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed_max / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{cfg.name}: {cfg.h}x{cfg.w} stride-4 maps (480p), O={O} (3 objects + background), K={cfg.k} proxies, "
+                                   f"C={C}, {cfg.frames}-frame clips, MEM_EVERY={mc.MEM_EVERY} (R=1..{1 + (cfg.frames - 2) // mc.MEM_EVERY}), "
+                                   "20 Lloyd iterations, local windows [2..12]",
+                       "sequences_per_gpu": n_streams, "frames_per_step": n_streams, "sharding": "sequences over ranks, no data-path collective"},
+            "roofline": roofline, "roofline_correlation_kernel": corr_roof, "cpu_baseline": cpu, "parity": parity, "kernels": kernels,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

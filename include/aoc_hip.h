@@ -124,20 +124,21 @@ int aoc_build_proxies(const float *pool, int C, const int32_t *fg_rows,
  *
  *  query        [m, C]
  *  proxies      [n_proxy, C], proxy_sqnorm [n_proxy] (+inf = ignore; NULL = computed in-kernel)
- *  set_offsets_host  [n_set + 1] HOST array: set s = proxies[set_offsets[s] .. set_offsets[s+1]);
- *               out value = min over the set; an empty or all-ignored set yields AOC_PAD_DISTANCE
- *               (reference: absent object, AEM:310-313).  Runs of single-proxy sets are the k = 1
- *               proxies (no min).  The set structure is static (kmax slots per object; unused
- *               slots carry norm = +inf), so it is known to the host without a device round trip.
+ *  sets         HOST arrays of length n_set: set s = proxies[set_begin[s] .. set_begin[s] + set_size[s]);
+ *               value = min over the set; an empty or all-ignored set yields AOC_PAD_DISTANCE
+ *               (reference: absent object, AEM:310-313).  Single-proxy sets are the k = 1 proxies
+ *               (no min).  The set structure is static (kmax slots per object; unused slots carry
+ *               norm = +inf), so the host knows it without a device round trip.
  *  set_bias     [n_set] device (dis_bias of the set's object); may be NULL (= 0)
- *  out element (pixel i, set s) is written at out[i * out_pixel_stride + s * out_set_stride]
+ *  out element (pixel i, set s) is written at out[i * out_pixel_stride + set_out_offset[s]], so a set
+ *               can land in its channel of the [O, 24, h, w] proto-mask buffer or in [1,h,w,O,F].
  *  transform    1 = apply the proto-mask transform, 0 = raw squared distance
  */
 int aoc_proxy_corr_min(const float *query, int64_t m, int C,
                        const float *proxies, const float *proxy_sqnorm, int n_proxy,
-                       const int32_t *set_offsets_host, const float *set_bias, int n_set,
-                       float *out, int64_t out_pixel_stride, int64_t out_set_stride,
-                       int transform, aoc_stream_t stream);
+                       int n_set, const int32_t *set_begin_host, const int32_t *set_size_host,
+                       const int64_t *set_out_offset_host, const float *set_bias,
+                       float *out, int64_t out_pixel_stride, int transform, aoc_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Dense pixel-level matching: AEM:178-227 + 61-89 without materialising [m, O, n]:
@@ -174,32 +175,41 @@ int aoc_local_window_match(const float *query, const float *prev, const uint32_t
 /* Bilinear (align_corners=True) resize of a channel-last map [h,w,C] -> [H,W,C]  (AEM:938-941). */
 int aoc_resize_bilinear_hwc(const float *in, int h, int w, int C, float *out, int H, int W,
                             aoc_stream_t stream);
-/* Bilinear (align_corners=True) resize of planes [P,h,w] -> element (p,y,x) written at
- * out[p*out_plane_stride + (y*W + x)*out_pixel_stride]           (AEM:604-607, 1054-1058). */
+/* Bilinear (align_corners=True) resize of planes [P,h,w]; plane p = (po, pi) = (p / inner_count,
+ * p % inner_count); element (p,y,x) is written at
+ *   out[po*out_outer_stride + pi*out_plane_stride + (y*W + x)*out_pixel_stride]
+ * so one call can drop [O, F, h, w] results into their channel slice of the [O, 24, H, W] proto-mask
+ * buffer or into the reference's [1, H, W, O, F] layout (AEM:604-607, 1054-1058).  An identity-size
+ * resize is an exact copy. */
 int aoc_resize_bilinear_planes(const float *in, int P, int h, int w, float *out, int H, int W,
-                               int64_t out_plane_stride, int64_t out_pixel_stride,
-                               aoc_stream_t stream);
+                               int inner_count, int64_t out_outer_stride, int64_t out_plane_stride,
+                               int64_t out_pixel_stride, aoc_stream_t stream);
 /* torch 'nearest' resize of per-pixel label bits [h,w] -> [H,W]  (AEM:1017-1018). */
 int aoc_resize_nearest_bits(const uint32_t *in, int h, int w, uint32_t *out, int H, int W,
                             aoc_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
- * foreground2background, AEM:9-23: out[o] = min over o' != o of dis[o'] (elementwise).
- *  dis, out  [n_obj, inner]   (inner = c*h*w).  n_obj == 1 copies. */
-int aoc_fg2bg_min(const float *dis, int n_obj, int64_t inner, float *out, aoc_stream_t stream);
+ * foreground2background, AEM:9-23: the reference concatenates the OTHER objects' maps along dim 1
+ * and reduces that dim, so  out[o, 0, x] = min over o' != o and over channels c of dis[o', c, x].
+ *  dis: object o at dis + o*dis_obj_stride holds [n_ch, inner]; out: object o at out + o*out_obj_stride
+ *  holds [inner]; n_obj >= 2 (n_obj == 1 returns the input, AEM:10-11). */
+int aoc_fg2bg_min(const float *dis, int n_obj, int n_ch, int64_t inner, int64_t dis_obj_stride,
+                  float *out, int64_t out_obj_stride, aoc_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * k = 1 proxies / IA head: ATT:134-189 (calculate_attention_head[_for_eval]_p_m).
  *  Accumulates over n_frames maps  emb [n_frames, hw, C] (channel-last) with float label maps
- *  labels [n_frames, n_obj, hw] (the reference's one-hot [O,1,h,w] tensors; any float works):
+ *  labels [n_frames, n_obj, hw] (the reference's one-hot [O,1,h,w] tensors; any float works), or
+ *  [n_frames, hw, n_obj] when labels_pixel_major != 0 (the layout the matching functions take):
  *    pos[o] = sum_p emb[p] * label[o,p] / (sum_p label[o,p] + eps)
  *    neg[o] = (sum_p emb[p] - pos_sum[o]) / (sum_p (1 - label[o,p]) + eps)
- *  out_pos, out_neg [n_obj, C].
+ *  out_pos, out_neg [n_obj, C]; out_pos_sqnorm [n_obj] = |pos[o]|^2 (optional, may be NULL): the k = 1
+ *  proxies go straight into aoc_proxy_corr_min's proxy table.
  */
 size_t aoc_masked_mean_pool_workspace_bytes(int n_frames, int64_t hw, int n_obj, int C);
 int aoc_masked_mean_pool(const float *emb, const float *labels, int n_frames, int64_t hw, int C,
-                         int n_obj, float epsilon, float *out_pos, float *out_neg,
-                         void *workspace, size_t workspace_bytes, aoc_stream_t stream);
+                         int n_obj, int labels_pixel_major, float epsilon, float *out_pos, float *out_neg,
+                         float *out_pos_sqnorm, void *workspace, size_t workspace_bytes, aoc_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * FiLM gate: ATT:12-17 (IA_gate.forward) and CLB:81-84:
@@ -225,6 +235,10 @@ int aoc_cond_gate_pool(const float *z, int N, int C, int64_t hw, const float *ph
 /* Small dense layer used by the conditioning MLPs (CL:46, CLB:81): y[n,:] = x[n,:] W^T + b. */
 int aoc_linear(const float *x, const float *weight, const float *bias, int N, int in_dim,
                int out_dim, float *y, aoc_stream_t stream);
+/* out[p,:] = sum_o labels[p,o] * rows[o,:]: the per-pixel proxy map fed to local_matching_proxy
+ * (aocnet.py:325).  labels [n, n_obj], rows [n_obj, C], out [n, C]. */
+int aoc_label_mix(const float *labels, const float *rows, int64_t n, int n_obj, int C, float *out,
+                  aoc_stream_t stream);
 /* Global average pool of planes [planes, hw] -> [planes]  (CLB:68). */
 int aoc_plane_mean(const float *x, int64_t planes, int64_t hw, float *out, aoc_stream_t stream);
 

@@ -1,0 +1,47 @@
+"""CPU restatement of the matching half of ``AOCNet.before_seghead_process`` (TEST INFRASTRUCTURE ONLY).
+
+Reference: /root/reference/AOC-Net/complete_project/AOCNet/networks/aoc/aocnet.py:141-358 (eval branch,
+batch size 1).  The module itself cannot be imported (missing ``networks.p2t``), so the
+call order and the channel order are restated from the source and every callee is the oracle function
+that IS pinned by golden vectors.  Parity of this orchestration is therefore pinned through its parts.
+"""
+import torch
+
+from . import calibration as ocal
+from . import matching as om
+
+
+def proto_mask_features(ref_emb, ref_labels, prev_emb, prev_labels, cur_emb, dis_bias, multi_local_distance=(2, 4, 6, 8, 10, 12),
+                        epsilon=1e-5, matching_background=True, init_rows=None):
+    """ref_emb [R,h,w,C], ref_labels [R,h,w,O] one-hot float, prev_emb/cur_emb [h,w,C], prev_labels [h,w,O].
+    Returns (features [O, 24, h, w], attention_head [O, 4C])."""
+    R, h, w, C = ref_emb.shape
+    O = ref_labels.shape[-1]
+    refs = [ref_emb[i] for i in range(R)]
+    labs = [ref_labels[i] for i in range(R)]
+    bias = dis_bias.reshape(-1)
+    g_fg = om.global_matching_for_eval(refs, cur_emb, labs, 4, bias)                               # aocnet.py:196
+    g_cl = om.global_matching_for_eval_cluster(refs, cur_emb, labs, 4, bias, init_rows=init_rows)  # aocnet.py:242
+    l_fg = om.local_matching(prev_emb, cur_emb, prev_labels, bias, list(multi_local_distance))     # aocnet.py:255
+    ref_e = [e.permute(2, 0, 1).unsqueeze(0) for e in refs]
+    ref_l = [l.permute(2, 0, 1).unsqueeze(1) for l in labs]
+    prev_l = prev_labels.permute(2, 0, 1).unsqueeze(1)                                              # to_cat_previous_frame
+    head, ref_pos, _, prev_pos, _ = ocal.attention_head_for_eval_p_m(                               # aocnet.py:297
+        ref_e, ref_l, prev_emb.permute(2, 0, 1).unsqueeze(0).expand(O, -1, -1, -1), prev_l, epsilon)
+    g_px = om.global_matching_for_eval_proxy(ref_pos, cur_emb, labs, 4, bias)                       # aocnet.py:314
+    proxy_map = torch.matmul(prev_labels, prev_pos)                                                 # aocnet.py:325
+    l_px = om.local_matching(proxy_map, cur_emb, prev_labels, bias, list(multi_local_distance))     # aocnet.py:328
+    if g_cl.shape[-1] == 1:      # all-unlabelled early-out returns one channel (AEM:588-589); cannot be concatenated
+        raise ValueError("reference pool has no labelled pixel")
+    to_g_px = g_px.squeeze(0).permute(2, 3, 0, 1)                                                   # aocnet.py:341-345
+    to_g_cl = g_cl.squeeze(0).permute(2, 3, 0, 1)
+    to_g_fg = g_fg.squeeze(0).permute(2, 3, 0, 1)
+    to_l_px = l_px.squeeze(0).permute(2, 3, 0, 1)
+    to_l_fg = l_fg.squeeze(0).permute(2, 3, 0, 1)
+    pre = torch.cat((to_g_fg, to_g_cl, to_g_px, to_l_fg, to_l_px, prev_l), 1)                       # aocnet.py:355
+    if matching_background:
+        g_bg = om.foreground2background(to_g_fg, O)                                                 # aocnet.py:350
+        resh = to_l_fg.permute(0, 2, 3, 1).unsqueeze(1)
+        l_bg = om.foreground2background(resh, O).permute(0, 4, 2, 3, 1).squeeze(-1)                 # aocnet.py:351-353
+        pre = torch.cat([pre, l_bg, g_bg], 1)                                                       # aocnet.py:358
+    return pre, head

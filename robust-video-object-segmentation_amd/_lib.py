@@ -23,21 +23,22 @@ SIGNATURES = {
     "aoc_kmeans_workspace_bytes": (_sz, [_i64, _i, _i, _i]),
     "aoc_kmeans_segmented": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
     "aoc_build_proxies": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
-    "aoc_proxy_corr_min": (_i, [_vp, _i64, _i, _vp, _vp, _i, _vp, _vp, _i, _vp, _i64, _i64, _i, _vp]),
+    "aoc_proxy_corr_min": (_i, [_vp, _i64, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i64, _i, _vp]),
     "aoc_dense_match_workspace_bytes": (_sz, [_i64, _i64, _i]),
     "aoc_dense_match_min": (_i, [_vp, _i64, _i, _vp, _vp, _vp, _i64, _vp, _vp, _i, _vp, _i64, _i64, _i, _vp, _sz, _vp]),
     "aoc_local_window_match": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp]),
     "aoc_resize_bilinear_hwc": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _vp]),
-    "aoc_resize_bilinear_planes": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i64, _i64, _vp]),
+    "aoc_resize_bilinear_planes": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _i64, _i64, _i64, _vp]),
     "aoc_resize_nearest_bits": (_i, [_vp, _i, _i, _vp, _i, _i, _vp]),
-    "aoc_fg2bg_min": (_i, [_vp, _i, _i64, _vp, _vp]),
+    "aoc_fg2bg_min": (_i, [_vp, _i, _i, _i64, _i64, _vp, _i64, _vp]),
     "aoc_masked_mean_pool_workspace_bytes": (_sz, [_i, _i64, _i, _i]),
-    "aoc_masked_mean_pool": (_i, [_vp, _vp, _i, _i64, _i, _i, _f, _vp, _vp, _vp, _sz, _vp]),
+    "aoc_masked_mean_pool": (_i, [_vp, _vp, _i, _i64, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _sz, _vp]),
     "aoc_film_gain": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "aoc_channel_scale": (_i, [_vp, _vp, _i64, _i64, _vp, _vp]),
     "aoc_cond_gate_pool_workspace_bytes": (_sz, [_i, _i, _i64]),
     "aoc_cond_gate_pool": (_i, [_vp, _i, _i, _i64, _vp, _vp, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "aoc_linear": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "aoc_label_mix": (_i, [_vp, _vp, _i64, _i, _i, _vp, _vp]),
     "aoc_plane_mean": (_i, [_vp, _i64, _i64, _vp, _vp]),
 }
 

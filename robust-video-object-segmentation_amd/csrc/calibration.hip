@@ -6,18 +6,21 @@
 namespace {
 
 // ------------------------------------------------------------------------------------------ fg2bg
-__global__ __launch_bounds__(256) void fg2bg_kernel(const float *__restrict__ dis, int n_obj, int64_t inner, float *__restrict__ out) {
+// dis [n_obj, n_ch, inner] -> out [n_obj, 1, inner]: the reference concatenates the other objects'
+// maps along dim 1 and takes the min over that dim (AEM:18-20), i.e. over (other objects x channels).
+__global__ __launch_bounds__(256) void fg2bg_kernel(const float *__restrict__ dis, int n_obj, int n_ch, int64_t inner, int64_t dis_obj_stride,
+                                                    float *__restrict__ out, int64_t out_obj_stride) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= inner) return;
-    if (n_obj == 1) { out[i] = dis[i]; return; }           // AEM:10-11
     float m1 = INFINITY, m2 = INFINITY;
     int arg = -1;
     for (int o = 0; o < n_obj; ++o) {
-        const float v = dis[(size_t)o * inner + i];
+        float v = INFINITY;
+        for (int c = 0; c < n_ch; ++c) v = fminf(v, dis[(size_t)o * dis_obj_stride + (size_t)c * inner + i]);
         if (v < m1) { m2 = m1; m1 = v; arg = o; }
         else if (v < m2) { m2 = v; }
     }
-    for (int o = 0; o < n_obj; ++o) out[(size_t)o * inner + i] = (o == arg) ? m2 : m1;   // min over the OTHER objects
+    for (int o = 0; o < n_obj; ++o) out[(size_t)o * out_obj_stride + i] = (o == arg) ? m2 : m1;   // min over the OTHER objects
 }
 
 // ------------------------------------------------------------------------------------------ pooling
@@ -27,7 +30,7 @@ constexpr int MP_OMAX = 32;
 // partial[blk][o][c] = sum_{p in chunk} emb[p,c] * lab[o,p]  (o < O), partial[blk][O][c] = sum emb[p,c];
 // pcount[blk][o] = sum lab[o,p].   emb [F, hw, C] channel-last, lab [F, O, hw].
 __global__ __launch_bounds__(128) void masked_pool_partial_kernel(const float *__restrict__ emb, const float *__restrict__ lab,
-                                                                   int64_t hw, int C, int n_obj, int chunks_per_frame,
+                                                                   int64_t hw, int C, int n_obj, int chunks_per_frame, int pixel_major,
                                                                    float *__restrict__ partial, float *__restrict__ pcount) {
     extern __shared__ float llab[];   // [n_obj][MP_PIX]
     const int f = blockIdx.x / chunks_per_frame, chunk = blockIdx.x - f * chunks_per_frame;
@@ -35,7 +38,7 @@ __global__ __launch_bounds__(128) void masked_pool_partial_kernel(const float *_
     const int np = (int)min((int64_t)MP_PIX, hw - p0);
     for (int i = threadIdx.x; i < n_obj * MP_PIX; i += blockDim.x) {
         const int o = i / MP_PIX, p = i - o * MP_PIX;
-        llab[i] = (p < np) ? lab[((size_t)f * n_obj + o) * hw + p0 + p] : 0.0f;
+        llab[i] = (p >= np) ? 0.0f : (pixel_major ? lab[((size_t)f * hw + p0 + p) * n_obj + o] : lab[((size_t)f * n_obj + o) * hw + p0 + p]);
     }
     __syncthreads();
     const float *e = emb + ((size_t)f * hw + p0) * C;
@@ -64,19 +67,28 @@ __global__ __launch_bounds__(128) void masked_pool_partial_kernel(const float *_
 
 __global__ __launch_bounds__(128) void masked_pool_final_kernel(const float *__restrict__ partial, const float *__restrict__ pcount,
                                                                  int n_blocks, int C, int n_obj, float total_pixels, float eps,
-                                                                 float *__restrict__ out_pos, float *__restrict__ out_neg) {
+                                                                 float *__restrict__ out_pos, float *__restrict__ out_neg,
+                                                                 float *__restrict__ out_pos_sqnorm) {
+    __shared__ float wsum[2];
     const int o = blockIdx.x;
     float cnt = 0.0f;
     for (int b = 0; b < n_blocks; ++b) cnt += pcount[(size_t)b * n_obj + o];
+    float sq = 0.0f;
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
         float pos = 0.0f, tot = 0.0f;
         for (int b = 0; b < n_blocks; ++b) {
             pos += partial[((size_t)b * (n_obj + 1) + o) * C + c];
             tot += partial[((size_t)b * (n_obj + 1) + n_obj) * C + c];
         }
-        out_pos[(size_t)o * C + c] = pos / (cnt + eps);                             // ATT:173
+        const float pv = pos / (cnt + eps);                                         // ATT:173
+        out_pos[(size_t)o * C + c] = pv;
         out_neg[(size_t)o * C + c] = (tot - pos) / ((total_pixels - cnt) + eps);    // ATT:166,174
+        sq += pv * pv;
     }
+    sq = aoc_wave_sum(sq);
+    if (aoc_lane() == 0) wsum[threadIdx.x >> 6] = sq;
+    __syncthreads();
+    if (threadIdx.x == 0 && out_pos_sqnorm) out_pos_sqnorm[o] = wsum[0] + wsum[1];
 }
 
 // ------------------------------------------------------------------------------------------ FiLM
@@ -205,6 +217,18 @@ __global__ __launch_bounds__(256) void cond_masked_gap_kernel(const float *__res
     if (threadIdx.x == 0) gap[(size_t)n * C + c] = (wsum[0] + wsum[1] + wsum[2] + wsum[3]) / (float)hw;
 }
 
+// out[p, :] = sum_o lab[p, o] * rows[o, :]   (aocnet.py:325: matmul(prev label, prev_head_pos))
+__global__ __launch_bounds__(256) void label_mix_kernel(const float *__restrict__ lab, const float *__restrict__ rows, int64_t n, int n_obj, int C,
+                                                         float *__restrict__ out) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * C) return;
+    const int64_t p = idx / C;
+    const int c = (int)(idx - p * C);
+    float acc = 0.0f;
+    for (int o = 0; o < n_obj; ++o) acc += lab[p * n_obj + o] * rows[(size_t)o * C + c];
+    out[idx] = acc;
+}
+
 // y[n,o] = x[n,:] . W[o,:] + b[o]; one wave per output
 __global__ __launch_bounds__(64) void linear_kernel(const float *__restrict__ x, const float *__restrict__ weight, const float *__restrict__ bias,
                                                      int in_dim, int out_dim, float *__restrict__ y) {
@@ -233,9 +257,11 @@ inline int pool_chunks(int64_t hw) { return (int)((hw + MP_PIX - 1) / MP_PIX); }
 
 extern "C" {
 
-int aoc_fg2bg_min(const float *dis, int n_obj, int64_t inner, float *out, aoc_stream_t stream) {
-    if (!dis || !out || n_obj < 1 || inner < 1) return AOC_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(fg2bg_kernel, dim3((unsigned)((inner + 255) / 256)), dim3(256), 0, aoc_hip_stream(stream), dis, n_obj, inner, out);
+int aoc_fg2bg_min(const float *dis, int n_obj, int n_ch, int64_t inner, int64_t dis_obj_stride, float *out, int64_t out_obj_stride,
+                  aoc_stream_t stream) {
+    if (!dis || !out || n_obj < 2 || n_ch < 1 || inner < 1 || dis_obj_stride < n_ch * inner || out_obj_stride < inner) return AOC_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(fg2bg_kernel, dim3((unsigned)((inner + 255) / 256)), dim3(256), 0, aoc_hip_stream(stream), dis, n_obj, n_ch, inner,
+                       dis_obj_stride, out, out_obj_stride);
     AOC_RETURN_IF_LAUNCH_FAILED();
     return AOC_OK;
 }
@@ -246,8 +272,8 @@ size_t aoc_masked_mean_pool_workspace_bytes(int n_frames, int64_t hw, int n_obj,
     return aoc_align_up(nb * (n_obj + 1) * C * sizeof(float), 256) + aoc_align_up(nb * n_obj * sizeof(float), 256);
 }
 
-int aoc_masked_mean_pool(const float *emb, const float *labels, int n_frames, int64_t hw, int C, int n_obj, float epsilon,
-                         float *out_pos, float *out_neg, void *workspace, size_t workspace_bytes, aoc_stream_t stream) {
+int aoc_masked_mean_pool(const float *emb, const float *labels, int n_frames, int64_t hw, int C, int n_obj, int labels_pixel_major, float epsilon,
+                         float *out_pos, float *out_neg, float *out_pos_sqnorm, void *workspace, size_t workspace_bytes, aoc_stream_t stream) {
     if (!emb || !labels || !out_pos || !out_neg || !workspace) return AOC_ERR_INVALID_ARG;
     if (n_frames < 1 || hw < 1 || C < 1 || n_obj < 1) return AOC_ERR_INVALID_ARG;
     if (n_obj > MP_OMAX) return AOC_ERR_UNSUPPORTED;
@@ -257,8 +283,8 @@ int aoc_masked_mean_pool(const float *emb, const float *labels, int n_frames, in
     const int nb = n_frames * cpf;
     float *partial = static_cast<float *>(workspace);
     float *pcount = reinterpret_cast<float *>(static_cast<char *>(workspace) + aoc_align_up((size_t)nb * (n_obj + 1) * C * sizeof(float), 256));
-    hipLaunchKernelGGL(masked_pool_partial_kernel, dim3(nb), dim3(128), (size_t)n_obj * MP_PIX * sizeof(float), st, emb, labels, hw, C, n_obj, cpf, partial, pcount);
-    hipLaunchKernelGGL(masked_pool_final_kernel, dim3(n_obj), dim3(128), 0, st, partial, pcount, nb, C, n_obj, (float)((double)hw * n_frames), epsilon, out_pos, out_neg);
+    hipLaunchKernelGGL(masked_pool_partial_kernel, dim3(nb), dim3(128), (size_t)n_obj * MP_PIX * sizeof(float), st, emb, labels, hw, C, n_obj, cpf, labels_pixel_major, partial, pcount);
+    hipLaunchKernelGGL(masked_pool_final_kernel, dim3(n_obj), dim3(128), 0, st, partial, pcount, nb, C, n_obj, (float)((double)hw * n_frames), epsilon, out_pos, out_neg, out_pos_sqnorm);
     AOC_RETURN_IF_LAUNCH_FAILED();
     return AOC_OK;
 }
@@ -307,6 +333,14 @@ int aoc_linear(const float *x, const float *weight, const float *bias, int N, in
     if (!x || !weight || !y || N < 1 || in_dim < 1 || out_dim < 1) return AOC_ERR_INVALID_ARG;
     if (N > 65535) return AOC_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(linear_kernel, dim3(out_dim, N), dim3(64), 0, aoc_hip_stream(stream), x, weight, bias, in_dim, out_dim, y);
+    AOC_RETURN_IF_LAUNCH_FAILED();
+    return AOC_OK;
+}
+
+int aoc_label_mix(const float *labels, const float *rows, int64_t n, int n_obj, int C, float *out, aoc_stream_t stream) {
+    if (!labels || !rows || !out || n < 1 || n_obj < 1 || C < 1) return AOC_ERR_INVALID_ARG;
+    const int64_t total = n * C;
+    hipLaunchKernelGGL(label_mix_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, aoc_hip_stream(stream), labels, rows, n, n_obj, C, out);
     AOC_RETURN_IF_LAUNCH_FAILED();
     return AOC_OK;
 }

@@ -15,8 +15,10 @@ constexpr int PC_MAX_TILES = 20;
 struct ProxyTile {
     int32_t proxy_begin;  // first proxy row of this 16-column tile
     int32_t ncols;        // valid columns (0..16)
-    int32_t set;          // kind 0: set index; kind 1: set index of column 0
+    int32_t set;          // kind 0: set index; kind 1: set index of column 0 (indexes set_bias)
     int32_t flags;        // bit0: column-wise (every column is its own set), bit1: first tile of set, bit2: last tile of set
+    int64_t out_offset;   // element offset of the set's output plane (kind 1: of column 0)
+    int64_t col_stride;   // kind 1: output offset step between consecutive columns
 };
 struct ProxyTileTable {
     ProxyTile t[PC_MAX_TILES];
@@ -89,7 +91,7 @@ template <int TMAX>
 __global__ __launch_bounds__(256) void proxy_corr_min_kernel(const float *__restrict__ query, int64_t m, int C,
                                                               const float *__restrict__ proxies, const float *__restrict__ proxy_sqnorm,
                                                               ProxyTileTable tiles, const float *__restrict__ set_bias,
-                                                              float *__restrict__ out, int64_t pstride, int64_t sstride, int transform) {
+                                                              float *__restrict__ out, int64_t pstride, int transform) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int TP = aoc_tile_tp(C), RS = aoc_tile_row_stride(C);
     const int ncols_total = tiles.n * 16;
@@ -141,7 +143,7 @@ __global__ __launch_bounds__(256) void proxy_corr_min_kernel(const float *__rest
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int64_t row = row0 + g * 4 + r;
-                        if (row < m) out[row * pstride + s * sstride] = transform ? aoc_proto_transform(d[r], b) : d[r];
+                        if (row < m) out[row * pstride + pt.out_offset + j * pt.col_stride] = transform ? aoc_proto_transform(d[r], b) : d[r];
                     }
                 }
             } else {
@@ -158,7 +160,7 @@ __global__ __launch_bounds__(256) void proxy_corr_min_kernel(const float *__rest
                     const int64_t row = row0 + g * 4 + j;
                     if (j < 4 && row < m) {
                         const float b = set_bias ? set_bias[pt.set] : 0.0f;
-                        out[row * pstride + pt.set * sstride] = transform ? aoc_proto_transform(v, b) : v;
+                        out[row * pstride + pt.out_offset] = transform ? aoc_proto_transform(v, b) : v;
                     }
                 }
             }
@@ -320,13 +322,13 @@ inline int dense_na(int n_obj) { return n_obj <= 4 ? 2 : (n_obj <= 8 ? 2 : 1); }
 extern "C" {
 
 int aoc_proxy_corr_min(const float *query, int64_t m, int C, const float *proxies, const float *proxy_sqnorm, int n_proxy,
-                       const int32_t *set_offsets_host, const float *set_bias, int n_set,
-                       float *out, int64_t out_pixel_stride, int64_t out_set_stride, int transform, aoc_stream_t stream) {
-    if (!query || !proxies || !set_offsets_host || !out) return AOC_ERR_INVALID_ARG;
+                       int n_set, const int32_t *set_begin_host, const int32_t *set_size_host, const int64_t *set_out_offset_host,
+                       const float *set_bias, float *out, int64_t out_pixel_stride, int transform, aoc_stream_t stream) {
+    if (!query || !proxies || !set_begin_host || !set_size_host || !set_out_offset_host || !out) return AOC_ERR_INVALID_ARG;
     if (m < 1 || C < 4 || n_set < 1 || n_proxy < 0) return AOC_ERR_INVALID_ARG;
     if ((C & 3) || C > AOC_MAX_CHANNELS) return AOC_ERR_UNSUPPORTED;
     for (int s = 0; s < n_set; ++s)
-        if (set_offsets_host[s] > set_offsets_host[s + 1] || set_offsets_host[s] < 0 || set_offsets_host[s + 1] > n_proxy) return AOC_ERR_INVALID_ARG;
+        if (set_size_host[s] < 0 || set_begin_host[s] < 0 || set_begin_host[s] + set_size_host[s] > n_proxy) return AOC_ERR_INVALID_ARG;
     hipStream_t st = aoc_hip_stream(stream);
     const int RS = aoc_tile_row_stride(C);
     const size_t tile_bytes = (size_t)16 * RS * sizeof(float) + 16 * sizeof(float);
@@ -342,7 +344,7 @@ int aoc_proxy_corr_min(const float *query, int64_t m, int C, const float *proxie
     auto flush = [&]() -> int {
         if (tab.n == 0) return AOC_OK;
         const size_t lds = (size_t)tab.n * tile_bytes;
-#define AOC_PC(TM) hipLaunchKernelGGL(proxy_corr_min_kernel<TM>, dim3(grid), dim3(256), lds, st, query, m, C, proxies, proxy_sqnorm, tab, set_bias, out, out_pixel_stride, out_set_stride, transform)
+#define AOC_PC(TM) hipLaunchKernelGGL(proxy_corr_min_kernel<TM>, dim3(grid), dim3(256), lds, st, query, m, C, proxies, proxy_sqnorm, tab, set_bias, out, out_pixel_stride, transform)
         if (C == 100) AOC_PC(25); else if (C <= 128) AOC_PC(32); else AOC_PC(64);
 #undef AOC_PC
         tab.n = 0;
@@ -350,13 +352,16 @@ int aoc_proxy_corr_min(const float *query, int64_t m, int C, const float *proxie
     };
     int s = 0;
     while (s < n_set) {
-        const int size = set_offsets_host[s + 1] - set_offsets_host[s];
+        const int size = set_size_host[s];
         if (size == 1) {
-            // run of consecutive single-proxy sets with consecutive proxies -> one column-wise tile
+            // run of single-proxy sets over consecutive proxies with a constant output step -> one column-wise tile
             int run = 1;
-            while (run < 16 && s + run < n_set && set_offsets_host[s + run + 1] - set_offsets_host[s + run] == 1) ++run;
+            const int64_t step = (s + 1 < n_set) ? set_out_offset_host[s + 1] - set_out_offset_host[s] : 0;
+            while (run < 16 && s + run < n_set && set_size_host[s + run] == 1 && set_begin_host[s + run] == set_begin_host[s] + run &&
+                   set_out_offset_host[s + run] - set_out_offset_host[s + run - 1] == step)
+                ++run;
             if (tab.n + 1 > max_tiles) { int rc = flush(); if (rc) return rc; }
-            tab.t[tab.n++] = ProxyTile{set_offsets_host[s], run, s, 1};
+            tab.t[tab.n++] = ProxyTile{set_begin_host[s], run, s, 1, set_out_offset_host[s], step};
             s += run;
         } else {
             const int nt = size == 0 ? 1 : (size + 15) / 16;
@@ -364,7 +369,7 @@ int aoc_proxy_corr_min(const float *query, int64_t m, int C, const float *proxie
             if (tab.n + nt > max_tiles) { int rc = flush(); if (rc) return rc; }
             for (int t = 0; t < nt; ++t) {
                 const int cols = size == 0 ? 0 : ((t == nt - 1) ? size - 16 * t : 16);
-                tab.t[tab.n++] = ProxyTile{set_offsets_host[s] + 16 * t, cols, s, (t == 0 ? 2 : 0) | (t == nt - 1 ? 4 : 0)};
+                tab.t[tab.n++] = ProxyTile{set_begin_host[s] + 16 * t, cols, s, (t == 0 ? 2 : 0) | (t == nt - 1 ? 4 : 0), set_out_offset_host[s], 0};
             }
             ++s;
         }

@@ -198,7 +198,8 @@ __global__ __launch_bounds__(256) void resize_bilinear_hwc_kernel(const float *_
 
 __global__ __launch_bounds__(256) void resize_bilinear_planes_kernel(const float *__restrict__ in, int P, int h, int w,
                                                                       float *__restrict__ out, int H, int W, float sh, float sw,
-                                                                      int64_t plane_stride, int64_t pixel_stride) {
+                                                                      int inner_count, int64_t outer_stride, int64_t plane_stride,
+                                                                      int64_t pixel_stride) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t total = (int64_t)P * H * W;
     if (idx >= total) return;
@@ -212,7 +213,7 @@ __global__ __launch_bounds__(256) void resize_bilinear_planes_kernel(const float
     const float *ip = in + (size_t)p * h * w;
     const float v00 = ip[(size_t)y0 * w + x0], v01 = ip[(size_t)y0 * w + x1];
     const float v10 = ip[(size_t)y1 * w + x0], v11 = ip[(size_t)y1 * w + x1];
-    out[p * plane_stride + ((int64_t)Y * W + X) * pixel_stride] = hy0 * (wx0 * v00 + wx1 * v01) + hy1 * (wx0 * v10 + wx1 * v11);
+    out[(p / inner_count) * outer_stride + (p % inner_count) * plane_stride + ((int64_t)Y * W + X) * pixel_stride] = hy0 * (wx0 * v00 + wx1 * v01) + hy1 * (wx0 * v10 + wx1 * v11);
 }
 
 __global__ __launch_bounds__(256) void resize_nearest_bits_kernel(const uint32_t *__restrict__ in, int h, int w,
@@ -272,12 +273,12 @@ int aoc_resize_bilinear_hwc(const float *in, int h, int w, int C, float *out, in
     return AOC_OK;
 }
 
-int aoc_resize_bilinear_planes(const float *in, int P, int h, int w, float *out, int H, int W, int64_t out_plane_stride,
-                               int64_t out_pixel_stride, aoc_stream_t stream) {
-    if (!in || !out || P < 1 || h < 1 || w < 1 || H < 1 || W < 1) return AOC_ERR_INVALID_ARG;
+int aoc_resize_bilinear_planes(const float *in, int P, int h, int w, float *out, int H, int W, int inner_count,
+                               int64_t out_outer_stride, int64_t out_plane_stride, int64_t out_pixel_stride, aoc_stream_t stream) {
+    if (!in || !out || P < 1 || h < 1 || w < 1 || H < 1 || W < 1 || inner_count < 1) return AOC_ERR_INVALID_ARG;
     const int64_t total = (int64_t)P * H * W;
     hipLaunchKernelGGL(resize_bilinear_planes_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, aoc_hip_stream(stream), in, P, h, w,
-                       out, H, W, align_corners_scale(h, H), align_corners_scale(w, W), out_plane_stride, out_pixel_stride);
+                       out, H, W, align_corners_scale(h, H), align_corners_scale(w, W), inner_count, out_outer_stride, out_plane_stride, out_pixel_stride);
     AOC_RETURN_IF_LAUNCH_FAILED();
     return AOC_OK;
 }

@@ -1,0 +1,213 @@
+"""Per-frame hot path: the counterpart of ``AOCNet.before_seghead_process`` (aocnet.py:114-372)
+up to the 24-channel proto-mask tensor, plus the FiLM / conditioning gates that
+``CalibrationDecoding.forward`` (decoding_module.py:96-149) applies.  The conv / GroupNorm bodies
+between the gates are out of scope (they stay ordinary PyTorch-ROCm modules in a full model).
+
+Everything is channel-last and resident in HBM: the reference pool is one [R, h*w, C] tensor that
+is never copied or compacted (kernels gather rows through index lists), and every matching
+kernel writes straight into its channel slice of the [O, 24, h, w] buffer (aocnet.py:341-358
+permutes and concatenates five tensors instead).
+"""
+from dataclasses import dataclass, field
+from typing import List
+
+import torch
+from torch import nn
+
+from . import ops
+from .attention import IA_gate
+from .conditioning_layer import conditioning_block
+from .matching import DEFAULT_CLUSTER_NUM, KMEANS_ITERS, _bias_vec, cluster_proxies
+
+
+@dataclass
+class MatchingConfig:
+    """Hot-path constants, named as in configs/resnet101_aocnet.py."""
+    MODEL_SEMANTIC_EMBEDDING_DIM: int = 100                      # :65
+    MODEL_HEAD_EMBEDDING_DIM: int = 256                          # :66
+    MODEL_PRE_HEAD_EMBEDDING_DIM: int = 64                       # :67
+    MODEL_REFINE_CHANNELS: int = 64
+    MODEL_MULTI_LOCAL_DISTANCE: List[int] = field(default_factory=lambda: [2, 4, 6, 8, 10, 12])   # :70
+    MODEL_LOCAL_DOWNSAMPLE: bool = True                          # :71
+    MODEL_EPSILON: float = 1e-5                                  # :75
+    MODEL_MATCHING_BACKGROUND: bool = True                       # :76
+    MODEL_FLOAT16_MATCHING: bool = False                         # :78
+    MEM_EVERY: int = 5                                           # :17
+    CLUSTER_NUM: int = DEFAULT_CLUSTER_NUM                       # AEM:232
+    BETA_PERCENTAGE: float = 0.3
+
+    @property
+    def proto_channels(self):
+        """in_dim of DynamicPreHead, aocnet.py:43-46."""
+        n_local = len(self.MODEL_MULTI_LOCAL_DISTANCE)
+        c = 2 * (2 + n_local) - 1 + 2
+        return c + (1 + n_local if self.MODEL_MATCHING_BACKGROUND else 0)
+
+
+# channel layout of the proto-mask tensor (aocnet.py:355-358)
+def channel_slices(cfg):
+    n = len(cfg.MODEL_MULTI_LOCAL_DISTANCE)
+    s = dict(global_fg=0, cluster=1, proxy=3, local=4, local_proxy=4 + n, prev_mask=4 + 2 * n)
+    if cfg.MODEL_MATCHING_BACKGROUND:
+        s.update(local_bg=5 + 2 * n, global_bg=5 + 3 * n)
+    return s
+
+
+def proto_mask_features(cfg, ref_emb, ref_labels, prev_emb, prev_labels, cur_emb, dis_bias, init_rows=None,
+                        cluster_state=None):
+    """All matching branches of one frame -> (features [O, 24, h, w], attention_head [O, 4C], aux).
+
+    ref_emb     [R, h, w, C]  reference pool (channel-last)          ref_labels [R, h, w, O] float one-hot
+    prev_emb    [h, w, C]     previous frame embedding               prev_labels [h, w, O]
+    cur_emb     [h, w, C]     current (query) frame embedding        dis_bias   [O] or [O,1,1,1]
+    init_rows   optional explicit k-means initial rows per object (else drawn like scipy from np.random)
+    cluster_state  optional dict with device tensors (seg_k, init_rows) for the host-sync-free pipeline
+    """
+    R, h, w, C = ref_emb.shape
+    O = ref_labels.shape[-1]
+    hw = h * w
+    dev = cur_emb.device
+    nl = len(cfg.MODEL_MULTI_LOCAL_DISTANCE)
+    ch = channel_slices(cfg)
+    n_ch = cfg.proto_channels
+    bias = _bias_vec(dis_bias, O, dev)
+    feat = torch.empty(O, n_ch, h, w, dtype=torch.float32, device=dev)
+    base = feat.view(-1)
+    obj_stride = n_ch * hw
+    pool = ref_emb.reshape(R * hw, C)
+    labels_flat = ref_labels.reshape(R * hw, O)
+    query_flat = cur_emb.reshape(hw, C)
+    kmax = cfg.CLUSTER_NUM
+
+    # ---- adaptive proxies (k-means, AEM:252-286) + k = 1 proxies (ATT:155-189) in ONE proxy table
+    table = torch.empty(O * 2 * kmax + O, C, dtype=torch.float32, device=dev)
+    sqn = torch.empty(O * 2 * kmax + O, dtype=torch.float32, device=dev)
+    if cluster_state is None:
+        cp = cluster_proxies(pool, labels_flat, kmax, init_rows)
+        prep = cp["prep"] if cp is not None else ops.label_prep(labels_flat)
+        if cp is not None:
+            table[:O * 2 * kmax].copy_(cp["proxies"].reshape(-1, C))
+            sqn[:O * 2 * kmax].copy_(cp["proxy_sqnorm"].reshape(-1))
+        else:
+            sqn[:O * 2 * kmax].fill_(float("inf"))       # nothing labelled -> every cluster feature is 1
+    else:
+        # host-sync-free variant: sticky K on the device, explicit init rows, proxies written in place
+        prep = ops.label_prep(labels_flat)
+        seg_k = ops.kmeans_plan(prep.counts, O, kmax)
+        cen, lab, _ = ops.kmeans_segmented(pool, prep.obj_rows, prep.obj_offsets, seg_k, cluster_state["init_rows"], kmax,
+                                           KMEANS_ITERS, rows_capacity=prep.obj_rows.numel())
+        proxies, psq = ops.build_proxies(pool, prep.fg_rows, prep.obj_offsets, seg_k, lab, cen)
+        table[:O * 2 * kmax].copy_(proxies.reshape(-1, C))
+        sqn[:O * 2 * kmax].copy_(psq.reshape(-1))
+        cp = dict(prep=prep, centroids=cen, labels=lab, proxies=proxies, proxy_sqnorm=psq)
+
+    ref_pos, ref_neg = ops.masked_mean_pool(ref_emb.reshape(R, hw, C), ref_labels.reshape(R, hw, O), cfg.MODEL_EPSILON, pixel_major=True,
+                                            out_pos=table[O * 2 * kmax:], out_pos_sqnorm=sqn[O * 2 * kmax:])
+    prev_pos, prev_neg = ops.masked_mean_pool(prev_emb.reshape(1, hw, C), prev_labels.reshape(1, hw, O), cfg.MODEL_EPSILON, pixel_major=True)
+    attention_head = torch.cat([ref_pos, ref_neg, prev_pos, prev_neg], dim=1)          # ATT:188, [O, 4C]
+
+    # ---- one correlation launch: cluster (2 sets / object) + k = 1 proxy (1 set / object), AEM:316-319 + matching.py:2653
+    set_begin, set_size, set_off, set_bias = [], [], [], []
+    for o in range(O):
+        for f in range(2):
+            set_begin.append((o * 2 + f) * kmax)
+            set_size.append(kmax)
+            set_off.append(o * obj_stride + (ch["cluster"] + f) * hw)
+    for o in range(O):
+        set_begin.append(O * 2 * kmax + o)
+        set_size.append(1)
+        set_off.append(o * obj_stride + ch["proxy"] * hw)
+    set_bias = torch.cat([bias.repeat_interleave(2), bias])
+    ops.proxy_corr_min(query_flat, table, sqn, set_begin, set_size, set_off, set_bias, feat, 1, True)
+
+    # ---- dense pixel-level matching, AEM:688-817 -> channel 0
+    ops.dense_match_min(query_flat, pool, prep, bias, feat, 1, obj_stride, True)
+
+    # ---- local matching against the previous frame and against its per-pixel proxy map (aocnet.py:255,325-337)
+    radii = list(cfg.MODEL_MULTI_LOCAL_DISTANCE)
+    prev_flat_labels = prev_labels.reshape(hw, O)
+    right_prev, _ = ops.label_bits(prev_flat_labels, want_wrong=False)
+    proxy_map = ops.label_mix(prev_flat_labels, prev_pos).view(h, w, C)                # aocnet.py:325
+    if cfg.MODEL_LOCAL_DOWNSAMPLE:
+        H2, W2 = int(h / 2) + 1, int(w / 2) + 1
+        q2 = ops.resize_bilinear_hwc(cur_emb, H2, W2)
+        p2 = ops.resize_bilinear_hwc(prev_emb, H2, W2)
+        pm2 = ops.resize_bilinear_hwc(proxy_map, H2, W2)
+        bits2 = ops.resize_nearest_bits(right_prev, h, w, H2, W2)
+    else:
+        H2, W2, q2, p2, pm2, bits2 = h, w, cur_emb, prev_emb, proxy_map, right_prev
+    for key, prev_map in (("local", p2), ("local_proxy", pm2)):
+        lf = ops.local_window_match(q2, prev_map, bits2, radii, bias, O, True)        # [O, nl, H2, W2]
+        ops.resize_bilinear_planes(lf.view(O * nl, H2, W2), h, w, base[ch[key] * hw:], hw, 1, inner_count=nl, out_outer_stride=obj_stride)
+
+    # ---- previous-frame mask channel (aocnet.py:356 to_cat_previous_frame)
+    feat[:, ch["prev_mask"]].copy_(prev_labels.permute(2, 0, 1))
+
+    # ---- background maps, AEM:9-23 (aocnet.py:349-353)
+    if cfg.MODEL_MATCHING_BACKGROUND and O > 1:
+        ops.fg2bg_min(base[ch["local"] * hw:], O, out=base[ch["local_bg"] * hw:], dis_obj_stride=obj_stride, out_obj_stride=obj_stride,
+                      n_ch=1, inner=nl * hw)
+        ops.fg2bg_min(base[ch["global_fg"] * hw:], O, out=base[ch["global_bg"] * hw:], dis_obj_stride=obj_stride, out_obj_stride=obj_stride,
+                      n_ch=1, inner=hw)
+    elif cfg.MODEL_MATCHING_BACKGROUND:
+        feat[:, ch["local_bg"]:ch["local_bg"] + nl].copy_(feat[:, ch["local"]:ch["local"] + nl])     # AEM:10-11
+        feat[:, ch["global_bg"]].copy_(feat[:, ch["global_fg"]])
+    return feat, attention_head, dict(cluster=cp, prev_pos=prev_pos, ref_pos=ref_pos)
+
+
+class CalibrationGates(nn.Module):
+    """The ten IA gates and four conditioning blocks of CalibrationDecoding (decoding_module.py:22-84),
+    with the reference's attribute names.  ``shapes(h, w)`` lists the activation each one modulates."""
+
+    def __init__(self, cfg=None):
+        super().__init__()
+        cfg = cfg or MatchingConfig()
+        att = cfg.MODEL_SEMANTIC_EMBEDDING_DIM * 4
+        in_dim = cfg.MODEL_SEMANTIC_EMBEDDING_DIM + cfg.MODEL_PRE_HEAD_EMBEDDING_DIM
+        e, r = cfg.MODEL_HEAD_EMBEDDING_DIM, cfg.MODEL_REFINE_CHANNELS
+        b = cfg.BETA_PERCENTAGE
+        self.IA1 = IA_gate(att, in_dim)                                   # :22
+        self.CLB2 = conditioning_block(e, att, b)                         # :27
+        self.CLB3 = conditioning_block(e, att, b)                         # :34
+        self.CLB4 = conditioning_block(e * 2, att, b)                     # :41
+        self.CLB5 = conditioning_block(e * 2, att, b)                     # :47
+        self.IA9 = IA_gate(att + e * 2, e * 2)                            # :52
+        self.M1_Reweight_Layer_1 = IA_gate(att, e * 2)                    # :55
+        self.M1_Reweight_Layer_2 = IA_gate(att, e * 2)
+        self.M1_Reweight_Layer_3 = IA_gate(att, e)
+        self.M2_Reweight_Layer_1 = IA_gate(att, e * 2)
+        self.M2_Reweight_Layer_2 = IA_gate(att, e * 2)
+        self.M2_Reweight_Layer_3 = IA_gate(att, e)
+        self.IA10 = IA_gate(att + e + r, e + r)                           # :79
+        self.IA11 = IA_gate(att + int(e / 2), int(e / 2))                 # :84
+        self.cfg = cfg
+
+    def plan(self, h, w):
+        """(module name, channels, map height, map width, extra head width) in call order
+        (decoding_module.py:99-148, 162-210).  layer3 has stride 2, so CLB4..M2 see half-size maps."""
+        e, r = self.cfg.MODEL_HEAD_EMBEDDING_DIM, self.cfg.MODEL_REFINE_CHANNELS
+        in_dim = self.cfg.MODEL_SEMANTIC_EMBEDDING_DIM + self.cfg.MODEL_PRE_HEAD_EMBEDDING_DIM
+        h2, w2 = (h + 1) // 2, (w + 1) // 2
+        return [("IA1", in_dim, h, w, 0), ("CLB2", e, h, w, 0), ("CLB3", e, h, w, 0), ("CLB4", 2 * e, h2, w2, 0),
+                ("CLB5", 2 * e, h2, w2, 0), ("IA9", 2 * e, h2, w2, 2 * e),
+                ("M1_Reweight_Layer_1", 2 * e, h2, w2, 0), ("M1_Reweight_Layer_2", 2 * e, h2, w2, 0), ("M1_Reweight_Layer_3", e, h2, w2, 0),
+                ("M2_Reweight_Layer_1", 2 * e, h2, w2, 0), ("M2_Reweight_Layer_2", 2 * e, h2, w2, 0), ("M2_Reweight_Layer_3", e, h2, w2, 0),
+                ("IA10", e + r, h, w, e + r), ("IA11", int(e / 2), h, w, int(e / 2))]
+
+    @torch.no_grad()
+    def forward(self, activations, attention_head):
+        """Applies every gate to its activation (list ordered as ``plan``); returns the modulated list.
+        Gates whose head is extended with the inter-object code (IA9/IA10/IA11, decoding_module.py:126-130)
+        compute ``px1_delta`` from their own input."""
+        out = []
+        for (name, c, hh, ww, extra), x in zip(self.plan(0, 0), activations):
+            mod = getattr(self, name)
+            if isinstance(mod, conditioning_block):
+                out.append(mod(x, attention_head))
+            else:
+                head = attention_head
+                if extra:
+                    px1 = ops.plane_mean(x)
+                    head = torch.cat([attention_head, px1.sum(dim=0, keepdim=True) - px1], dim=1)
+                out.append(mod(x, head))
+        return out

@@ -145,8 +145,10 @@ def global_matching_for_eval_cluster(all_reference_embeddings, query_embeddings,
     query_flat = query_embeddings.reshape(-1, embedding_dim)
     bias = _bias_vec(dis_bias, obj_nums, dev)
     planes = torch.empty(obj_nums * 2, h, w, dtype=torch.float32, device=dev)
+    n_set = 2 * obj_nums                                                   # set s = (object, centroid | centroid_avg)
     ops.proxy_corr_min(query_flat, cp["proxies"].reshape(-1, embedding_dim), cp["proxy_sqnorm"].reshape(-1),
-                       [s * kmax for s in range(2 * obj_nums + 1)], bias.repeat_interleave(2), planes, 1, h * w, True)
+                       [s * kmax for s in range(n_set)], [kmax] * n_set, [s * h * w for s in range(n_set)],
+                       bias.repeat_interleave(2), planes, 1, True)
     return _emit(planes, h, w, 2, obj_nums, ori_size)
 
 
@@ -214,8 +216,8 @@ def global_matching_for_eval_proxy(all_reference_embeddings, query_embeddings, a
         return torch.ones(1, h, w, obj_nums, 1, device=dev)
     proxies = all_reference_embeddings.float().contiguous()
     planes = torch.empty(obj_nums, h, w, dtype=torch.float32, device=dev)
-    ops.proxy_corr_min(query_embeddings.reshape(-1, embedding_dim), proxies, None, list(range(obj_nums + 1)),
-                       _bias_vec(dis_bias, obj_nums, dev), planes, 1, h * w, True)
+    ops.proxy_corr_min(query_embeddings.reshape(-1, embedding_dim), proxies, None, list(range(obj_nums)), [1] * obj_nums,
+                       [o * h * w for o in range(obj_nums)], _bias_vec(dis_bias, obj_nums, dev), planes, 1, True)
     return _emit(planes, h, w, 1, obj_nums, ori_size)
 
 
@@ -270,7 +272,8 @@ local_matching_proxy = local_matching   # AEM:1064-1156 is a verbatim copy of AE
 
 # ------------------------------------------------------------------------------------------ fg -> bg (a9)
 def foreground2background(dis, obj_num):
-    """AEM:9-23: per object the elementwise min over all other objects.  dis [O, c, h, w]."""
+    """AEM:9-23: per object the min over all other objects (and over dim 1, which the reference
+    concatenates on).  dis [O, c, ...] -> [O, 1, ...]."""
     if obj_num == 1:
         return dis
     return ops.fg2bg_min(dis, obj_num)

@@ -119,23 +119,27 @@ def build_proxies(pool, fg_rows, seg_offsets, seg_k, labels, centroids):
 
 
 # ------------------------------------------------------------------------------------------ correlation
-def proxy_corr_min(query_flat, proxies, proxy_sqnorm, set_offsets, set_bias, out, out_pixel_stride, out_set_stride, transform=True):
-    """Writes, for every pixel i and set s, f(min over the set's proxies of d(q_i, p)) at
-    out.data_ptr()[i*out_pixel_stride + s*out_set_stride]."""
+def proxy_corr_min(query_flat, proxies, proxy_sqnorm, set_begin, set_size, set_out_offset, set_bias, out, out_pixel_stride,
+                   transform=True):
+    """For every pixel i and set s writes f(min over proxies[set_begin[s] : +set_size[s]] of d(q_i, p)) at
+    out.data_ptr()[i*out_pixel_stride + set_out_offset[s]]  (see include/aoc_hip.h)."""
     query_flat = _f32c(query_flat)
     proxies = _f32c(proxies)
     proxy_sqnorm = _f32c(proxy_sqnorm) if proxy_sqnorm is not None else None
     _need_gpu(query_flat, proxies, proxy_sqnorm, out, set_bias)
     m, C = query_flat.shape
-    so = np.ascontiguousarray(np.asarray(set_offsets, dtype=np.int32))
-    n_set = so.size - 1
+    sb = np.ascontiguousarray(np.asarray(set_begin, dtype=np.int32))
+    ss = np.ascontiguousarray(np.asarray(set_size, dtype=np.int32))
+    so = np.ascontiguousarray(np.asarray(set_out_offset, dtype=np.int64))
+    n_set = sb.size
+    assert ss.size == n_set and so.size == n_set
     if set_bias is not None:
         set_bias = _f32c(set_bias)
         assert set_bias.numel() == n_set
-    _lib.check(_lib.lib().aoc_proxy_corr_min(_p(query_flat), m, C, _p(proxies), _p(proxy_sqnorm), proxies.shape[0],
-                                             so.ctypes.data_as(ctypes.c_void_p), _p(set_bias), n_set, _p(out),
-                                             int(out_pixel_stride), int(out_set_stride), int(bool(transform)), _stream()),
-               "aoc_proxy_corr_min")
+    vp = ctypes.c_void_p
+    _lib.check(_lib.lib().aoc_proxy_corr_min(_p(query_flat), m, C, _p(proxies), _p(proxy_sqnorm), proxies.shape[0], n_set,
+                                             sb.ctypes.data_as(vp), ss.ctypes.data_as(vp), so.ctypes.data_as(vp), _p(set_bias), _p(out),
+                                             int(out_pixel_stride), int(bool(transform)), _stream()), "aoc_proxy_corr_min")
     return out
 
 
@@ -166,12 +170,14 @@ def resize_bilinear_hwc(x, H, W):
     return out
 
 
-def resize_bilinear_planes(x, H, W, out, out_plane_stride, out_pixel_stride):
+def resize_bilinear_planes(x, H, W, out, out_plane_stride, out_pixel_stride, inner_count=None, out_outer_stride=0):
+    """x [P,h,w] -> strided destination (see include/aoc_hip.h); ``out`` may be a view: its data_ptr is the base."""
     x = _f32c(x)
     _need_gpu(x, out)
     P, h, w = x.shape
-    _lib.check(_lib.lib().aoc_resize_bilinear_planes(_p(x), P, h, w, _p(out), H, W, int(out_plane_stride), int(out_pixel_stride), _stream()),
-               "aoc_resize_bilinear_planes")
+    inner = P if inner_count is None else int(inner_count)
+    _lib.check(_lib.lib().aoc_resize_bilinear_planes(_p(x), P, h, w, _p(out), H, W, inner, int(out_outer_stride), int(out_plane_stride),
+                                                     int(out_pixel_stride), _stream()), "aoc_resize_bilinear_planes")
     return out
 
 
@@ -198,27 +204,44 @@ def local_window_match(query, prev, right_bits, radii, obj_bias, n_obj, transfor
 
 
 # ------------------------------------------------------------------------------------------ calibration side
-def fg2bg_min(dis, n_obj):
-    dis = _f32c(dis)
+def fg2bg_min(dis, n_obj, out=None, dis_obj_stride=None, out_obj_stride=None, n_ch=None, inner=None):
+    """dis [O, c, ...] -> [O, 1, ...]: min over the other objects and over dim 1 (AEM:18-20).
+    With explicit strides / sizes it reads and writes channel slices of a larger buffer in place."""
     _need_gpu(dis)
-    out = torch.empty_like(dis)
-    inner = dis.numel() // n_obj
-    _lib.check(_lib.lib().aoc_fg2bg_min(_p(dis), n_obj, inner, _p(out), _stream()), "aoc_fg2bg_min")
+    if out is None:
+        dis = _f32c(dis)
+        n_ch = dis.shape[1]
+        inner = dis.numel() // (n_obj * n_ch)
+        out = torch.empty((n_obj, 1) + tuple(dis.shape[2:]), dtype=torch.float32, device=dis.device)
+        dis_obj_stride, out_obj_stride = n_ch * inner, inner
+    _lib.check(_lib.lib().aoc_fg2bg_min(_p(dis), n_obj, int(n_ch), int(inner), int(dis_obj_stride), _p(out), int(out_obj_stride), _stream()),
+               "aoc_fg2bg_min")
     return out
 
 
-def masked_mean_pool(emb, labels, epsilon):
-    """emb [F, hw, C], labels [F, O, hw] -> (pos [O,C], neg [O,C])   (ATT:155-189)."""
+def label_mix(labels_flat, rows):
+    """out[p,:] = sum_o labels[p,o] * rows[o,:]   (aocnet.py:325)."""
+    labels_flat, rows = _f32c(labels_flat), _f32c(rows)
+    _need_gpu(labels_flat, rows)
+    n, n_obj = labels_flat.shape
+    C = rows.shape[1]
+    out = torch.empty(n, C, dtype=torch.float32, device=rows.device)
+    _lib.check(_lib.lib().aoc_label_mix(_p(labels_flat), _p(rows), n, n_obj, C, _p(out), _stream()), "aoc_label_mix")
+    return out
+
+
+def masked_mean_pool(emb, labels, epsilon, pixel_major=False, out_pos=None, out_neg=None, out_pos_sqnorm=None):
+    """emb [F, hw, C]; labels [F, O, hw] (or [F, hw, O] with pixel_major) -> (pos [O,C], neg [O,C])   (ATT:155-189)."""
     emb, labels = _f32c(emb), _f32c(labels)
     _need_gpu(emb, labels)
     F_, hw, C = emb.shape
-    n_obj = labels.shape[1]
+    n_obj = labels.shape[2] if pixel_major else labels.shape[1]
     L = _lib.lib()
-    pos = torch.empty(n_obj, C, dtype=torch.float32, device=emb.device)
-    neg = torch.empty(n_obj, C, dtype=torch.float32, device=emb.device)
+    pos = torch.empty(n_obj, C, dtype=torch.float32, device=emb.device) if out_pos is None else out_pos
+    neg = torch.empty(n_obj, C, dtype=torch.float32, device=emb.device) if out_neg is None else out_neg
     ws = _ws(L.aoc_masked_mean_pool_workspace_bytes(F_, hw, n_obj, C), emb.device)
-    _lib.check(L.aoc_masked_mean_pool(_p(emb), _p(labels), F_, hw, C, n_obj, float(epsilon), _p(pos), _p(neg), _p(ws), ws.numel(), _stream()),
-               "aoc_masked_mean_pool")
+    _lib.check(L.aoc_masked_mean_pool(_p(emb), _p(labels), F_, hw, C, n_obj, int(bool(pixel_major)), float(epsilon), _p(pos), _p(neg),
+                                      _p(out_pos_sqnorm), _p(ws), ws.numel(), _stream()), "aoc_masked_mean_pool")
     return pos, neg
 
 

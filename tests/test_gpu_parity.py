@@ -276,3 +276,76 @@ def test_conditioning_block_vs_oracle(aoc):
 def test_no_cpu_fallback(aoc):
     with pytest.raises(aoc._lib.AocHipError):
         aoc.ops.fg2bg_min(torch.zeros(2, 8), 2)
+
+
+# ------------------------------------------------------------------------------------------ whole frame
+def test_proto_mask_tensor_vs_oracle(aoc):
+    """The 24-channel proto-mask tensor (aocnet.py:341-358 order) + IA head of one frame, R = 2 references."""
+    from aoc_amd import hotpath, synthetic as syn
+    from oracle import hotpath as ohot
+    cfg = syn.CONFIGS["tiny"]
+    clip = syn.make_clip(cfg, seed=5, frames=5)
+    O = cfg.n_obj
+    emb = torch.from_numpy(clip["emb"])
+    lab = torch.from_numpy(np.stack([syn.one_hot(l, O) for l in clip["lab"]]))
+    bias = torch.tensor([0.2, -0.1, 0.05])
+    np.random.seed(42)
+    want, want_head = ohot.proto_mask_features(emb[[0, 2]], lab[[0, 2]], emb[3], lab[3], emb[4], bias)
+    np.random.seed(42)
+    got, head, _ = hotpath.proto_mask_features(hotpath.MatchingConfig(), emb[[0, 2]].cuda(), lab[[0, 2]].cuda(), emb[3].cuda(), lab[3].cuda(),
+                                               emb[4].cuda(), bias.cuda())
+    assert tuple(got.shape) == (O, 24, cfg.h, cfg.w) == tuple(want.shape)
+    np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), rtol=0, atol=ATOL)
+    np.testing.assert_allclose(head.cpu().numpy(), want_head.numpy(), rtol=5e-6, atol=1e-7)
+
+
+def test_proto_mask_tensor_syncfree_pipeline(aoc):
+    """Explicit init rows + device-side sticky K (no host round trip) gives the same tensor."""
+    from aoc_amd import hotpath, synthetic as syn
+    cfg = syn.CONFIGS["tiny"]
+    clip = syn.make_clip(cfg, seed=6, frames=4)
+    O = cfg.n_obj
+    emb = torch.from_numpy(clip["emb"]).cuda()
+    lab = torch.from_numpy(np.stack([syn.one_hot(l, O) for l in clip["lab"]])).cuda()
+    bias = torch.zeros(O).cuda()
+    counts = [int((clip["lab"][0] == o).sum()) for o in range(O)]
+    rows = syn.kmeans_init_rows(9, counts, 16)
+    mc = hotpath.MatchingConfig()
+    a, ha, _ = hotpath.proto_mask_features(mc, emb[:1], lab[:1], emb[2], lab[2], emb[3], bias, init_rows=rows)
+    init = np.zeros((O, 16), np.int32)
+    for o, r in enumerate(rows):
+        if r is not None:
+            init[o, :len(r)] = r
+    b, hb, _ = hotpath.proto_mask_features(mc, emb[:1], lab[:1], emb[2], lab[2], emb[3], bias, cluster_state=dict(init_rows=dev(init)))
+    assert torch.equal(a, b) and torch.equal(ha, hb)
+
+
+def test_calibration_gates_vs_oracle(aoc):
+    """Ten IA gates + four conditioning blocks at (reduced) decoder shapes against the oracle."""
+    from aoc_amd import hotpath
+    from oracle import calibration as ocal
+    torch.manual_seed(1)
+    mc = hotpath.MatchingConfig(MODEL_SEMANTIC_EMBEDDING_DIM=8, MODEL_HEAD_EMBEDDING_DIM=16, MODEL_PRE_HEAD_EMBEDDING_DIM=4, MODEL_REFINE_CHANNELS=4)
+    gates = hotpath.CalibrationGates(mc).cuda()
+    O, h, w = 3, 13, 17
+    plan = gates.plan(h, w)
+    xs = [torch.randn(O, c, hh, ww) for (_, c, hh, ww, _) in plan]
+    head = torch.randn(O, 32)
+    got = gates([x.cuda() for x in xs], head.cuda())
+    for (name, c, hh, ww, extra), x, y in zip(plan, xs, got):
+        mod = getattr(gates, name)
+        sd = {k: v.detach().cpu() for k, v in mod.state_dict().items()}
+        if name.startswith("CLB"):
+            wts = {"CL_1.phi_w": sd["CL_1.phi_layer.weight"].reshape(-1), "CL_1.phi_b": sd["CL_1.phi_layer.bias"],
+                   "CL_1.mlp_w": sd["CL_1.mlp_layer.weight"], "CL_1.mlp_b": sd["CL_1.mlp_layer.bias"],
+                   "CL_2.mlp_w": sd["CL_2.mlp_layer.weight"], "CL_2.mlp_b": sd["CL_2.mlp_layer.bias"],
+                   "CL_3.mlp_w": sd["CL_3.mlp_layer.weight"], "CL_3.mlp_b": sd["CL_3.mlp_layer.bias"],
+                   "mlp_w": sd["mlp_layer.weight"], "mlp_b": sd["mlp_layer.bias"]}
+            want = ocal.conditioning_block(x, head, wts, 0.3)
+        else:
+            hd = head
+            if extra:
+                px = x.mean(dim=(2, 3))
+                hd = torch.cat([head, px.sum(0, keepdim=True) - px], 1)       # decoding_module.py:126-130
+            want = ocal.ia_gate(x, hd, sd["IA.weight"], sd["IA.bias"])
+        np.testing.assert_allclose(y.cpu().numpy(), want.numpy(), rtol=2e-5, atol=2e-5, err_msg=name)
