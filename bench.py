@@ -140,40 +140,74 @@ def frame_step(wl, gates, acts):
     return feat, outs
 
 
+def _block_weights(mod):
+    sd = {k: v.detach().cpu() for k, v in mod.state_dict().items()}
+    return {"CL_1.phi_w": sd["CL_1.phi_layer.weight"].reshape(-1), "CL_1.phi_b": sd["CL_1.phi_layer.bias"],
+            "CL_1.mlp_w": sd["CL_1.mlp_layer.weight"], "CL_1.mlp_b": sd["CL_1.mlp_layer.bias"],
+            "CL_2.mlp_w": sd["CL_2.mlp_layer.weight"], "CL_2.mlp_b": sd["CL_2.mlp_layer.bias"],
+            "CL_3.mlp_w": sd["CL_3.mlp_layer.weight"], "CL_3.mlp_b": sd["CL_3.mlp_layer.bias"],
+            "mlp_w": sd["mlp_layer.weight"], "mlp_b": sd["mlp_layer.bias"]}
+
+
+DENSE_SUBSAMPLE = 16
+
+
 def cpu_baseline(cfg, mc, seed, gates, acts_cpu):
-    """The oracle (a port of the reference path, proved equal to it on the golden vectors) timed on
-    the host cores for ONE frame of the same workload at R = 1 (the cheapest frame of the clip)."""
+    """The oracle (a port of the reference path, proved equal to it on the golden vectors) timed on the
+    host cores for ONE frame of the same workload at R = 1 (the cheapest frame of the clip), bounded to
+    a few tens of seconds: the dense branch (linear in query pixels) runs on every 16th query pixel and
+    is scaled by 16; each distinct calibration gate shape is timed once and multiplied by its count.
+    Returns the per-branch features (for a parity spot check) and the timings."""
     from oracle import calibration as ocal
-    from oracle import hotpath as ohot
-    torch.set_num_threads(os.cpu_count() or 1)
+    from oracle import matching as om
+    threads = min(32, os.cpu_count() or 1)
+    torch.set_num_threads(threads)
     clip = syn.make_clip(cfg, seed, frames=2)
     O = cfg.n_obj
     emb = torch.from_numpy(clip["emb"])
     lab = torch.from_numpy(np.stack([syn.one_hot(l, O) for l in clip["lab"]]))
     counts = [int((clip["lab"][0] == o).sum()) for o in range(O)]
     rows = syn.kmeans_init_rows(seed * 100003 + 1, counts, mc.CLUSTER_NUM)
-    t0 = time.perf_counter()
-    feat, head = ohot.proto_mask_features(emb[:1], lab[:1], emb[0], lab[0], emb[1], torch.zeros(O), init_rows=rows)
-    t_match = time.perf_counter() - t0
-    t0 = time.perf_counter()
+    bias = torch.zeros(O)
+    mld = list(mc.MODEL_MULTI_LOCAL_DISTANCE)
+    tm, feats = {}, {}
+
+    def timed(key, fn):
+        t0 = time.perf_counter()
+        out = fn()
+        tm[key] = time.perf_counter() - t0
+        return out
+
+    ref_flat, lab_flat = emb[0].reshape(-1, cfg.c), lab[0].reshape(-1, O)
+    q_sub = emb[1].reshape(-1, cfg.c)[::DENSE_SUBSAMPLE]
+    feats["dense_sub"] = timed("dense", lambda: om.proto_transform(om.nearest_neighbor_features_per_object(ref_flat, q_sub, lab_flat).squeeze(-1), bias.view(1, -1)))
+    tm["dense"] *= DENSE_SUBSAMPLE
+    feats["cluster"] = timed("cluster", lambda: om.global_matching_for_eval_cluster([emb[0]], emb[1], [lab[0]], 4, bias, init_rows=rows))
+    feats["local"] = timed("local", lambda: om.local_matching(emb[0], emb[1], lab[0], bias, mld))
+    ref_e, ref_l = [emb[0].permute(2, 0, 1).unsqueeze(0)], [lab[0].permute(2, 0, 1).unsqueeze(1)]
+    head, ref_pos, _, prev_pos, _ = timed("pool", lambda: ocal.attention_head_for_eval_p_m(
+        ref_e, ref_l, emb[0].permute(2, 0, 1).unsqueeze(0).expand(O, -1, -1, -1), ref_l[0], mc.MODEL_EPSILON))
+    feats["proxy"] = timed("proxy", lambda: om.global_matching_for_eval_proxy(ref_pos, emb[1], [lab[0]], 4, bias))
+    feats["local_proxy"] = timed("local_proxy", lambda: om.local_matching(torch.matmul(lab[0], prev_pos), emb[1], lab[0], bias, mld))
+    t_match = sum(tm.values())
+    t_cal, seen = 0.0, {}
     for (name, c, hh, ww, extra), x in zip(gates.plan(cfg.h, cfg.w), acts_cpu):
         mod = getattr(gates, name)
-        sd = {k: v.detach().cpu() for k, v in mod.state_dict().items()}
-        if name.startswith("CLB"):
-            wts = {"CL_1.phi_w": sd["CL_1.phi_layer.weight"].reshape(-1), "CL_1.phi_b": sd["CL_1.phi_layer.bias"],
-                   "CL_1.mlp_w": sd["CL_1.mlp_layer.weight"], "CL_1.mlp_b": sd["CL_1.mlp_layer.bias"],
-                   "CL_2.mlp_w": sd["CL_2.mlp_layer.weight"], "CL_2.mlp_b": sd["CL_2.mlp_layer.bias"],
-                   "CL_3.mlp_w": sd["CL_3.mlp_layer.weight"], "CL_3.mlp_b": sd["CL_3.mlp_layer.bias"],
-                   "mlp_w": sd["mlp_layer.weight"], "mlp_b": sd["mlp_layer.bias"]}
-            ocal.conditioning_block(x, head, wts, mc.BETA_PERCENTAGE)
-        else:
-            hd = head
-            if extra:
-                px = x.mean(dim=(2, 3))
-                hd = torch.cat([head, px.sum(0, keepdim=True) - px], 1)
-            ocal.ia_gate(x, hd, sd["IA.weight"], sd["IA.bias"])
-    t_cal = time.perf_counter() - t0
-    return feat, head, rows, t_match, t_cal
+        key = (name.startswith("CLB"), c, hh, ww, extra)
+        if key not in seen:
+            t0 = time.perf_counter()
+            if name.startswith("CLB"):
+                ocal.conditioning_block(x, head, _block_weights(mod), mc.BETA_PERCENTAGE)
+            else:
+                hd = head
+                if extra:
+                    px = x.mean(dim=(2, 3))
+                    hd = torch.cat([head, px.sum(0, keepdim=True) - px], 1)
+                sd = {k: v.detach().cpu() for k, v in mod.state_dict().items()}
+                ocal.ia_gate(x, hd, sd["IA.weight"], sd["IA.bias"])
+            seen[key] = time.perf_counter() - t0
+        t_cal += seen[key]
+    return feats, rows, tm, t_match, t_cal, threads
 
 
 def main():
@@ -295,18 +329,31 @@ def main():
         parity = None
         if world == 1 and not args.no_cpu_baseline:
             acts_cpu = [a.cpu() for a in acts]
-            feat_cpu, head_cpu, rows, t_match, t_cal = cpu_baseline(cfg, mc, 1, gates, acts_cpu)
-            cpu = dict(value=round(1.0 / (t_match + t_cal), 5), unit="frames/s", cores=os.cpu_count(), kind="port",
-                       sample=f"1 frame of {cfg.name} at R=1 (cheapest frame of the clip; the GPU figure averages R=1..12): "
-                              f"matching {t_match:.2f} s + calibration gates {t_cal:.2f} s, torch CPU fp32 + C k-means oracle")
-            # parity of the same frame on the GPU (features + a surrogate mask = argmin_o of the dense global distance channel)
+            feats, rows, tm, t_match, t_cal, threads = cpu_baseline(cfg, mc, 1, gates, acts_cpu)
+            br = ", ".join(f"{k} {v:.2f}" for k, v in tm.items())
+            cpu = dict(value=round(1.0 / (t_match + t_cal), 5), unit="frames/s", cores=threads, kind="port",
+                       sample=f"1 frame of {cfg.name} at R=1 (the cheapest frame; the GPU figure averages R=1..12): matching {t_match:.2f} s "
+                              f"[{br}; dense timed on every {DENSE_SUBSAMPLE}th query pixel and scaled x{DENSE_SUBSAMPLE}] + calibration gates "
+                              f"{t_cal:.2f} s (each distinct gate shape timed once x its count); torch CPU fp32 + C k-means oracle, {threads} threads")
+            # parity spot check of the same frame on the GPU: every branch against the oracle, and a surrogate
+            # mask (argmin over objects of the dense-matching channel) on the sub-sampled pixels
             wl = workloads[0]
             with torch.no_grad():
-                feat_gpu, head_gpu, _ = hotpath.proto_mask_features(mc, wl.emb[:1], wl.lab[:1], wl.emb[0], wl.lab[0], wl.emb[1], wl.bias, init_rows=rows)
-            diff = float((feat_gpu.cpu() - feat_cpu).abs().max())
-            pg, pc = feat_gpu[:, 0].argmin(0).cpu(), feat_cpu[:, 0].argmin(0)
+                fg, _, _ = hotpath.proto_mask_features(mc, wl.emb[:1], wl.lab[:1], wl.emb[0], wl.lab[0], wl.emb[1], wl.bias, init_rows=rows)
+            fg = fg.cpu()
+            chs = hotpath.channel_slices(mc)
+            nl = len(mc.MODEL_MULTI_LOCAL_DISTANCE)
+            diffs = {
+                "dense": float((fg[:, 0].reshape(O, -1)[:, ::DENSE_SUBSAMPLE].t() - feats["dense_sub"]).abs().max()),
+                "cluster": float((fg[:, chs["cluster"]:chs["cluster"] + 2] - feats["cluster"][0].permute(2, 3, 0, 1)).abs().max()),
+                "proxy": float((fg[:, chs["proxy"]:chs["proxy"] + 1] - feats["proxy"][0].permute(2, 3, 0, 1)).abs().max()),
+                "local": float((fg[:, chs["local"]:chs["local"] + nl] - feats["local"][0].permute(2, 3, 0, 1)).abs().max()),
+                "local_proxy": float((fg[:, chs["local_proxy"]:chs["local_proxy"] + nl] - feats["local_proxy"][0].permute(2, 3, 0, 1)).abs().max()),
+            }
+            pg = fg[:, 0].reshape(O, -1)[:, ::DENSE_SUBSAMPLE].argmin(0)
+            pc = feats["dense_sub"].argmin(1)
             iou_sum, iou_n = sharding.mask_iou_sums(pg, pc, O)
-            parity = dict(max_abs_feature_diff=diff, surrogate_mask_mean_iou=iou_sum / iou_n)
+            parity = dict(max_abs_feature_diff=max(diffs.values()), per_branch=diffs, surrogate_mask_mean_iou=iou_sum / iou_n)
 
         value = metrics["frames"] / elapsed_max
         line = {

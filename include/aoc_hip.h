@@ -97,6 +97,15 @@ int aoc_kmeans_plan(const int32_t *counts, int n_seg, int cluster_num, int32_t *
  *  cluster_counts [n_seg, kmax]  out   members per cluster in the last update
  */
 size_t aoc_kmeans_workspace_bytes(int64_t rows_capacity, int n_seg, int kmax, int C);
+/* Same, with the number of rows of `pool` stated (pool_rows > 0): enables the pipelined ordered
+ * accumulation, which addresses rows through a bounds-checked buffer descriptor.  pool_rows = 0
+ * (or aoc_kmeans_segmented) selects the generic path.  Results are bit-identical either way. */
+int aoc_kmeans_segmented_ex(const float *pool, int64_t pool_rows, int C,
+                            const int32_t *rows, const int32_t *seg_offsets, const int32_t *seg_k,
+                            const int32_t *init_rows, int n_seg, int kmax, int iters,
+                            int64_t rows_capacity,
+                            float *centroids, int32_t *labels, int32_t *cluster_counts,
+                            void *workspace, size_t workspace_bytes, aoc_stream_t stream);
 int aoc_kmeans_segmented(const float *pool, int C,
                          const int32_t *rows, const int32_t *seg_offsets, const int32_t *seg_k,
                          const int32_t *init_rows, int n_seg, int kmax, int iters,
@@ -112,10 +121,12 @@ int aoc_kmeans_segmented(const float *pool, int C,
  *  proxies      [n_seg, 2, kmax, C] out : [:,0] = centroids (copied), [:,1] = centroid_avg
  *  proxy_sqnorm [n_seg, 2, kmax]   out
  */
-int aoc_build_proxies(const float *pool, int C, const int32_t *fg_rows,
+size_t aoc_build_proxies_workspace_bytes(int64_t rows_capacity, int n_seg, int kmax);
+int aoc_build_proxies(const float *pool, int64_t pool_rows, int C, const int32_t *fg_rows,
                       const int32_t *seg_offsets, const int32_t *seg_k, const int32_t *labels,
-                      const float *centroids, int n_seg, int kmax,
-                      float *proxies, float *proxy_sqnorm, aoc_stream_t stream);
+                      const float *centroids, int n_seg, int kmax, int64_t rows_capacity,
+                      float *proxies, float *proxy_sqnorm,
+                      void *workspace, size_t workspace_bytes, aoc_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Pixel-to-proxy correlation ("the correlation kernel"): AEM:92-110 + 316-319 (min over an

@@ -404,6 +404,464 @@ __global__ __launch_bounds__(64) void km_accumulate_kernel(const float *__restri
     }
 }
 
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+constexpr uint32_t KU_INVALID_OFF = 0xFFFFFF00u;   // beyond the buffer descriptor's range: raw buffer loads return 0
+
+// ==========================================================================================
+// Fast exact k-means update ("scan-sum" pipeline).
+//
+// scipy's update step adds the member rows of a cluster one after another in float32.  For the
+// non-negative embeddings of this model (ReLU outputs and their bilinear blends) that sequential sum has
+// structure: while the running sum s stays inside one binade [2^E, 2^(E+1)), every addition
+// fl(s + x) = u * RNE(n + x/u)  (u = ulp(s) = 2^(E-23), n = s/u an integer in [2^23, 2^24)) adds the
+// INTEGER rne(x/u) -- exact integer arithmetic, hence associative -- except for exact ties
+// (frac(x/u) == 1/2), which round to even and therefore only need the running PARITY of n, and after a tie
+// the parity is even whatever it was.  So 64 members are folded per step with lanes = members:
+//   r_l = floor(y_l) + [frac(y_l) > 1/2],  y_l = x_l / u      (exact: power-of-two scaling)
+//   ties fixed up from ballots (rare), n += sum_l r_l         (exact), accepted iff n stays < 2^24.
+// Anything else -- binade crossing, s == 0 / tiny, negative or non-finite x -- falls back to the literal
+// serial float additions for that 64-member block, so the result is bit-identical to the sequential sum
+// in every case (tests compare with scipy bit for bit).
+//
+// Per Lloyd iteration: km_assign_rank (labels + stable rank of every row inside its 256-row block per
+// cluster + block histogram) -> km_blockscan (block offsets, cluster sizes and bases) -> km_scatter
+// (ordered member lists, as byte offsets) -> km_sum_scan (one wave per (cluster, 4 features)).
+#ifdef AOC_KS_STATS
+__device__ unsigned long long aoc_ks_stats[8];   // attempts, folded feature-attempts, redo feature-attempts, careful ok, serial blocks, ties
+#define KS_STAT(i, n) do { if (threadIdx.x == 0) atomicAdd(&aoc_ks_stats[i], (unsigned long long)(n)); } while (0)
+#else
+#define KS_STAT(i, n) do { } while (0)
+#endif
+constexpr int KS_T = 8;          // blocks (of 64 members) folded between two cross-lane reductions
+
+// wave-wide integer sum, uniform result: 4 DPP row_shr adds (lane 15 of each 16-lane row ends up with the
+// row total) + 4 readlanes + scalar adds -- no LDS crossbar round trips on the serial chain.
+__device__ __forceinline__ int ks_wave_sum(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);   // row_shr:1, out-of-row lanes read 0
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);   // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);   // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);   // row_shr:8
+    return __builtin_amdgcn_readlane(v, 15) + __builtin_amdgcn_readlane(v, 31) + __builtin_amdgcn_readlane(v, 47) +
+           __builtin_amdgcn_readlane(v, 63);
+}
+
+// One block of 64 members of one feature, folded in the integer domain of the current binade.
+__device__ __forceinline__ void ks_fold_block(float x, float inv_u, int lane, int &accr, int &par, int &bad) {
+    const float y = x * inv_u;
+    const float fl = floorf(y);
+    const float fr = y - fl;
+    int r = (int)fl + ((fr > 0.5f) ? 1 : 0);
+    bad |= (!(x >= 0.0f) || !(y < 16777216.0f)) ? 1 : 0;
+    const unsigned long long odd = __ballot((r & 1) != 0);
+    const unsigned long long ties = __ballot(fr == 0.5f);
+    if (ties) {                                       // rare: resolve round-half-even from the running parity
+        int base_par = par, from = 0;
+        unsigned long long tm = ties;
+        while (tm) {
+            const int t = __builtin_ctzll(tm);
+            tm &= tm - 1;
+            const unsigned long long below_t = (t == 0) ? 0ull : (~0ull >> (64 - t));
+            const unsigned long long below_from = (from == 0) ? 0ull : (~0ull >> (64 - from));
+            const int pb = base_par ^ (__popcll(odd & below_t & ~below_from) & 1);   // parity of n before lane t
+            const int bump = pb ^ (int)((odd >> t) & 1ull);                           // n + floor(y) odd -> round up
+            if (lane == t) r += bump;
+            base_par = 0;                                                              // a tie always leaves n even
+            from = t + 1;
+        }
+        const unsigned long long rest = (from >= 64) ? 0ull : (~0ull << from);
+        par = base_par ^ (__popcll(odd & rest) & 1);
+    } else {
+        par ^= __popcll(odd) & 1;
+    }
+    accr += r;
+}
+
+struct KsBinade {
+    float u, inv_u;
+    int n_in;
+    bool ok;
+};
+__device__ __forceinline__ KsBinade ks_binade(float s) {
+    KsBinade b;
+    const uint32_t bits = __float_as_uint(s);
+    const int e = (int)((bits >> 23) & 0xff) - 127;
+    b.ok = (s > 0.0f) && e >= -100 && e <= 100;
+    const int ee = b.ok ? e : 0;
+    b.u = __uint_as_float((uint32_t)(ee - 23 + 127) << 23);
+    b.inv_u = __uint_as_float((uint32_t)(23 - ee + 127) << 23);
+    b.n_in = (int)(s * b.inv_u);
+    return b;
+}
+
+// literal serial additions of one 64-member block (x of absent members is +0, which is exact)
+__device__ __forceinline__ float ks_serial_block(float s, float x) {
+    if (__ballot(x != 0.0f) == 0ull) return s;   // all zeros: s + 0.0f == s (s is never -0)
+#pragma unroll 8
+    for (int kk = 0; kk < 64; ++kk) s = s + __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(x), kk));
+    return s;
+}
+
+template <int C4MAX>
+__global__ __launch_bounds__(256) void km_assign_rank_kernel(const float *__restrict__ pool, int C, const int32_t *__restrict__ rows,
+                                                              const int32_t *__restrict__ seg_off, const int32_t *__restrict__ seg_k,
+                                                              const float *__restrict__ centroids, int kmax, int32_t *__restrict__ labels,
+                                                              uint16_t *__restrict__ rank16, int32_t *__restrict__ hist, int nb_max,
+                                                              float *__restrict__ rownorm, int first_iter) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int s = blockIdx.y;
+    const int k = seg_k[s];
+    if (k <= 0) return;
+    const int beg = seg_off[s];
+    const int len = seg_off[s + 1] - beg;
+    if ((int)(blockIdx.x * 256) >= len) return;
+    const int c4 = C >> 2;
+    float *lc = lds;                                    // [k][C]
+    float *lcn = lds + (size_t)k * C;                   // [k]
+    int32_t *wcnt = reinterpret_cast<int32_t *>(lcn + kmax);   // [4][kmax]
+    const float *csrc = centroids + (size_t)s * kmax * C;
+    for (int i = threadIdx.x; i < k * C; i += 256) lc[i] = csrc[i];
+    __syncthreads();
+    if ((int)threadIdx.x < k) lcn[threadIdx.x] = sqnorm_seq(lc + (size_t)threadIdx.x * C, C);   // scipy code_sqr, sequential
+    __syncthreads();
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    const bool valid = p < len;
+    int best = -1;
+    if (valid) {
+        const float4 *xr = reinterpret_cast<const float4 *>(pool + (size_t)rows[beg + p] * C);
+        float4 x[C4MAX];
+#pragma unroll
+        for (int t = 0; t < C4MAX; ++t) x[t] = (t < c4) ? xr[t] : make_float4(0.f, 0.f, 0.f, 0.f);
+        float xs;
+        if (first_iter) {
+            xs = 0.0f;
+#pragma unroll
+            for (int t = 0; t < C4MAX; ++t) {
+                if (t < c4) {
+                    float p0 = x[t].x * x[t].x; xs = xs + p0;
+                    float p1 = x[t].y * x[t].y; xs = xs + p1;
+                    float p2 = x[t].z * x[t].z; xs = xs + p2;
+                    float p3 = x[t].w * x[t].w; xs = xs + p3;
+                }
+            }
+            rownorm[beg + p] = xs;
+        } else {
+            xs = rownorm[beg + p];
+        }
+        float low = INFINITY;
+        best = 0;
+        for (int j = 0; j < k; ++j) {
+            const float4 *cj = reinterpret_cast<const float4 *>(lc + (size_t)j * C);
+            float acc = 0.0f;
+#pragma unroll
+            for (int t = 0; t < C4MAX; ++t) {
+                if (t < c4) {
+                    float4 c = cj[t];
+                    acc = __builtin_fmaf(x[t].x, c.x, acc);
+                    acc = __builtin_fmaf(x[t].y, c.y, acc);
+                    acc = __builtin_fmaf(x[t].z, c.z, acc);
+                    acc = __builtin_fmaf(x[t].w, c.w, acc);
+                }
+            }
+            float m = -2.0f * acc;
+            float dist = (m + xs) + lcn[j];
+            if (dist < low) { low = dist; best = j; }
+        }
+        labels[beg + p] = best;
+    }
+    // stable rank of the row among the rows of its block that share its label
+    const int lane = aoc_lane(), wave = threadIdx.x >> 6;
+    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    int rank = 0;
+    for (int kk = 0; kk < k; ++kk) {
+        const unsigned long long m = __ballot(best == kk);
+        if (best == kk) rank = __popcll(m & lt);
+        if (lane == 0) wcnt[wave * kmax + kk] = __popcll(m);
+    }
+    __syncthreads();
+    if (valid) {
+        int woff = 0;
+        for (int w = 0; w < wave; ++w) woff += wcnt[w * kmax + best];
+        rank16[beg + p] = (uint16_t)(woff + rank);
+    }
+    if ((int)threadIdx.x < k)
+        hist[((size_t)s * nb_max + blockIdx.x) * kmax + threadIdx.x] =
+            wcnt[threadIdx.x] + wcnt[kmax + threadIdx.x] + wcnt[2 * kmax + threadIdx.x] + wcnt[3 * kmax + threadIdx.x];
+}
+
+// rank + histogram from EXISTING labels (proxy construction after the last iteration)
+__global__ __launch_bounds__(256) void km_rank_only_kernel(const int32_t *__restrict__ seg_off, const int32_t *__restrict__ seg_k,
+                                                            const int32_t *__restrict__ labels, int kmax, uint16_t *__restrict__ rank16,
+                                                            int32_t *__restrict__ hist, int nb_max) {
+    __shared__ int32_t wcnt[4 * AOC_MAX_CLUSTERS];
+    const int s = blockIdx.y;
+    const int k = seg_k[s];
+    if (k <= 0) return;
+    const int beg = seg_off[s];
+    const int len = seg_off[s + 1] - beg;
+    if ((int)(blockIdx.x * 256) >= len) return;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    const bool valid = p < len;
+    const int best = valid ? labels[beg + p] : -1;
+    const int lane = aoc_lane(), wave = threadIdx.x >> 6;
+    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    int rank = 0;
+    for (int kk = 0; kk < k; ++kk) {
+        const unsigned long long m = __ballot(best == kk);
+        if (best == kk) rank = __popcll(m & lt);
+        if (lane == 0) wcnt[wave * kmax + kk] = __popcll(m);
+    }
+    __syncthreads();
+    if (valid) {
+        int woff = 0;
+        for (int w = 0; w < wave; ++w) woff += wcnt[w * kmax + best];
+        rank16[beg + p] = (uint16_t)(woff + rank);
+    }
+    if ((int)threadIdx.x < k)
+        hist[((size_t)s * nb_max + blockIdx.x) * kmax + threadIdx.x] =
+            wcnt[threadIdx.x] + wcnt[kmax + threadIdx.x] + wcnt[2 * kmax + threadIdx.x] + wcnt[3 * kmax + threadIdx.x];
+}
+
+// one block per segment: exclusive scan of the block histograms per cluster, cluster sizes and bases
+__global__ __launch_bounds__(1024) void km_blockscan_kernel(const int32_t *__restrict__ seg_off, const int32_t *__restrict__ seg_k,
+                                                             const int32_t *__restrict__ hist, int32_t *__restrict__ blockoff, int nb_max,
+                                                             int kmax, int32_t *__restrict__ counts, int32_t *__restrict__ cbase) {
+    __shared__ int32_t ltot[AOC_MAX_CLUSTERS];
+    const int s = blockIdx.x;
+    const int k = seg_k[s];
+    const int len = seg_off[s + 1] - seg_off[s];
+    const int nb = (len + 255) / 256;
+    const int lane = aoc_lane(), wave = threadIdx.x >> 6;
+    for (int kk = wave; kk < kmax; kk += 16) {
+        int carry = 0;
+        if (kk < k) {
+            for (int base = 0; base < nb; base += 64) {
+                const int b = base + lane;
+                const int v = (b < nb) ? hist[((size_t)s * nb_max + b) * kmax + kk] : 0;
+                int incl = v;
+                for (int o = 1; o < 64; o <<= 1) {
+                    int t = __shfl_up(incl, o);
+                    if (lane >= o) incl += t;
+                }
+                if (b < nb) blockoff[((size_t)s * nb_max + b) * kmax + kk] = carry + incl - v;
+                carry += __shfl(incl, 63);
+            }
+        }
+        if (lane == 0) { counts[s * kmax + kk] = carry; ltot[kk] = carry; }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int off = 0;
+        for (int kk = 0; kk < kmax; ++kk) { cbase[s * kmax + kk] = off; off += ltot[kk]; }
+    }
+}
+
+// ordered member lists: moff[seg_beg + cbase[label] + blockoff + rank] = byte offset of the member's pool row.
+// rows_local != nullptr: proxy construction, AEM:280 -- the GLOBAL kept-row array at the LOCAL index p.
+__global__ __launch_bounds__(256) void km_scatter_kernel(const int32_t *__restrict__ rows, const int32_t *__restrict__ rows_local,
+                                                          const int32_t *__restrict__ seg_off, const int32_t *__restrict__ seg_k,
+                                                          const int32_t *__restrict__ labels, const uint16_t *__restrict__ rank16,
+                                                          const int32_t *__restrict__ blockoff, const int32_t *__restrict__ cbase, int nb_max,
+                                                          int kmax, uint32_t row_bytes, uint32_t *__restrict__ moff) {
+    const int s = blockIdx.y;
+    if (seg_k[s] <= 0) return;
+    const int beg = seg_off[s];
+    const int len = seg_off[s + 1] - beg;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= len) return;
+    const int lab = labels[beg + p];
+    const int pos = beg + cbase[s * kmax + lab] + blockoff[((size_t)s * nb_max + blockIdx.x) * kmax + lab] + (int)rank16[beg + p];
+    const int row = rows_local ? rows_local[p] : rows[beg + p];
+    moff[pos] = (uint32_t)row * row_bytes;
+}
+
+// MODE 0: centroids[s,j,4q..4q+3] = ordered sum / count (empty cluster untouched, vq.py:820-823)
+// MODE 1: proxies[s,1,j,4q..] = mean of the listed rows (AEM:280), zeros when empty
+// The member rows stream through registers in chunks of KS_T blocks with a 3-stage software pipeline
+// (offsets of chunk c+2, rows of chunk c+1, arithmetic on chunk c): addresses never depend on the
+// running sums, so memory latency stays off the serial chain and a redo never reloads anything.
+struct KsChunk {
+    u32x4 x[KS_T];
+};
+
+template <int MODE>
+__global__ __launch_bounds__(64) void km_sum_scan_kernel(const float *__restrict__ pool, uint32_t pool_bytes, int C,
+                                                          const int32_t *__restrict__ seg_off, const int32_t *__restrict__ seg_k,
+                                                          const int32_t *__restrict__ counts, const int32_t *__restrict__ cbase,
+                                                          const uint32_t *__restrict__ moff, int kmax, float *__restrict__ dst) {
+    const int s = blockIdx.z, j = blockIdx.y, q = blockIdx.x;
+    if (j >= seg_k[s]) return;
+    const int cnt = counts[s * kmax + j];
+    const int lane = threadIdx.x;
+    float *out = (MODE == 0) ? dst + ((size_t)s * kmax + j) * C + 4 * q : dst + (((size_t)s * 2 + 1) * kmax + j) * C + 4 * q;
+    if (cnt == 0) {
+        if (MODE == 1 && lane == 0) *reinterpret_cast<float4 *>(out) = make_float4(0.f, 0.f, 0.f, 0.f);
+        return;
+    }
+    const uint32_t *list = moff + seg_off[s] + cbase[s * kmax + j];
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(pool), 0, pool_bytes, 0x00020000);
+    const uint32_t qoff = (uint32_t)q * 16u;
+    const int n_chunks = (cnt + 64 * KS_T - 1) / (64 * KS_T);
+
+    auto load_offsets = [&](int c, uint32_t (&o)[KS_T]) {
+#pragma unroll
+        for (int b = 0; b < KS_T; ++b) {
+            const int m = (c * KS_T + b) * 64 + lane;
+            o[b] = (c < n_chunks && m < cnt) ? list[m] + qoff : KU_INVALID_OFF;
+        }
+    };
+    auto load_rows = [&](const uint32_t (&o)[KS_T], KsChunk &ch) {
+#pragma unroll
+        for (int b = 0; b < KS_T; ++b) ch.x[b] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o[b], 0, 0);
+    };
+
+    uint32_t off_a[KS_T], off_b[KS_T];
+    KsChunk cur, nxt;
+    load_offsets(0, off_a);
+    load_offsets(1, off_b);
+    load_rows(off_a, cur);
+
+    float st[4] = {0.f, 0.f, 0.f, 0.f};
+    int t_cur = 1;                       // blocks folded per attempt: doubles after a success, back to 1 after a miss
+    for (int c = 0; c < n_chunks; ++c) {
+        load_rows(off_b, nxt);           // rows of chunk c+1 (their offsets were loaded one iteration ago)
+        load_offsets(c + 2, off_a);      // offsets of chunk c+2
+        const int blocks_here = min(KS_T, (cnt - c * KS_T * 64 + 63) / 64);
+        for (int b0 = 0; b0 < blocks_here;) {
+            const int nblk = min(t_cur, blocks_here - b0);
+            // ---- optimistic pass: fold blocks [b0, b0 + nblk) in the integer domain of each feature's binade
+            KsBinade bin[4];
+            int accr[4] = {0, 0, 0, 0}, par[4], bad[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int f = 0; f < 4; ++f) { bin[f] = ks_binade(st[f]); par[f] = bin[f].n_in & 1; }
+#pragma unroll
+            for (int b = 0; b < KS_T; ++b) {
+                if (b >= b0 && b < b0 + nblk) {
+                    const float xv[4] = {__uint_as_float(cur.x[b].x), __uint_as_float(cur.x[b].y), __uint_as_float(cur.x[b].z), __uint_as_float(cur.x[b].w)};
+#pragma unroll
+                    for (int f = 0; f < 4; ++f)
+                        if (bin[f].ok) ks_fold_block(xv[f], bin[f].inv_u, lane, accr[f], par[f], bad[f]);
+                }
+            }
+            bool redo[4];
+#pragma unroll
+            for (int f = 0; f < 4; ++f) {
+                redo[f] = true;
+                if (bin[f].ok) {
+                    const int total = ks_wave_sum(accr[f]);
+                    const bool anybad = __ballot(bad[f] != 0) != 0ull;
+                    const long long n_out = (long long)bin[f].n_in + total;
+                    if (!anybad && n_out <= 0xFFFFFF) {
+                        st[f] = (float)(int)n_out * bin[f].u;      // exact: integer < 2^24 times a power of two
+                        redo[f] = false;
+                    }
+                }
+                KS_STAT(redo[f] ? 2 : 1, nblk);
+            }
+            KS_STAT(0, 1);
+            // ---- careful pass for the features that could not be folded: block by block, serial where needed
+            if (redo[0] || redo[1] || redo[2] || redo[3]) {
+#pragma unroll
+                for (int b = 0; b < KS_T; ++b) {
+                    if (b >= b0 && b < b0 + nblk) {
+                        const float xv[4] = {__uint_as_float(cur.x[b].x), __uint_as_float(cur.x[b].y), __uint_as_float(cur.x[b].z), __uint_as_float(cur.x[b].w)};
+#pragma unroll
+                        for (int f = 0; f < 4; ++f) {
+                            if (!redo[f]) continue;
+                            const KsBinade bb = ks_binade(st[f]);
+                            bool done = false;
+                            if (bb.ok) {
+                                int a = 0, pr = bb.n_in & 1, bd = 0;
+                                ks_fold_block(xv[f], bb.inv_u, lane, a, pr, bd);
+                                const int total = ks_wave_sum(a);
+                                const long long n_out = (long long)bb.n_in + total;
+                                if (__ballot(bd != 0) == 0ull && n_out <= 0xFFFFFF) {
+                                    st[f] = (float)(int)n_out * bb.u;
+                                    done = true;
+                                }
+                            }
+                            KS_STAT(done ? 3 : 4, 1);
+                            if (!done) st[f] = ks_serial_block(st[f], xv[f]);
+                        }
+                    }
+                }
+                t_cur = 1;
+            } else {
+                t_cur = min(KS_T, t_cur * 2);
+            }
+            b0 += nblk;
+        }
+        // rotate the pipeline registers
+        cur = nxt;
+#pragma unroll
+        for (int b = 0; b < KS_T; ++b) { const uint32_t t = off_a[b]; off_a[b] = off_b[b]; off_b[b] = t; }
+        // after the swap: off_b holds chunk c+2's offsets (needed next iteration), off_a is free
+    }
+    if (lane == 0) {
+        const float fc = (float)cnt;
+        *reinterpret_cast<float4 *>(out) = make_float4(st[0] / fc, st[1] / fc, st[2] / fc, st[3] / fc);
+    }
+}
+
+// proxy set 0 = centroids (copied) and the squared norms of both sets; one wave per (slot j, segment s)
+__global__ __launch_bounds__(64) void km_proxy_finish_kernel(const float *__restrict__ centroids, const int32_t *__restrict__ seg_k,
+                                                              const int32_t *__restrict__ counts, int kmax, int C,
+                                                              float *__restrict__ proxies, float *__restrict__ proxy_sqnorm) {
+    const int s = blockIdx.y, j = blockIdx.x, lane = threadIdx.x;
+    const int k = seg_k[s];
+    float *p0 = proxies + (((size_t)s * 2 + 0) * kmax + j) * C;
+    float *p1 = proxies + (((size_t)s * 2 + 1) * kmax + j) * C;
+    if (j >= k) {
+        for (int t = lane; t < C; t += 64) { p0[t] = 0.0f; p1[t] = 0.0f; }
+        if (lane == 0) {
+            proxy_sqnorm[((size_t)s * 2 + 0) * kmax + j] = INFINITY;
+            proxy_sqnorm[((size_t)s * 2 + 1) * kmax + j] = INFINITY;
+        }
+        return;
+    }
+    const float *c = centroids + ((size_t)s * kmax + j) * C;
+    float n0 = 0.0f, n1 = 0.0f;
+    for (int t = lane; t < C; t += 64) {
+        const float cv = c[t];
+        p0[t] = cv;
+        n0 += cv * cv;
+        const float av = p1[t];
+        n1 += av * av;
+    }
+    n0 = aoc_wave_sum(n0);
+    n1 = aoc_wave_sum(n1);
+    if (lane == 0) {
+        proxy_sqnorm[((size_t)s * 2 + 0) * kmax + j] = n0;
+        proxy_sqnorm[((size_t)s * 2 + 1) * kmax + j] = (counts[s * kmax + j] > 0) ? n1 : INFINITY;   // np.unique drops empty clusters
+    }
+}
+
+struct KsWorkspace {
+    float *rownorm;
+    uint16_t *rank16;
+    int32_t *hist, *blockoff, *counts, *cbase;
+    uint32_t *moff;
+    int nb_max;
+};
+inline size_t ks_workspace_bytes(int64_t cap, int n_seg, int kmax) {
+    const size_t nb = (size_t)(cap + 255) / 256 + 1;
+    return aoc_align_up((size_t)cap * 4, 256) + aoc_align_up((size_t)cap * 2, 256) + 2 * aoc_align_up((size_t)n_seg * nb * kmax * 4, 256) +
+           2 * aoc_align_up((size_t)n_seg * kmax * 4, 256) + aoc_align_up(((size_t)cap + 64) * 4, 256);
+}
+inline KsWorkspace ks_carve(void *workspace, int64_t cap, int n_seg, int kmax) {
+    KsWorkspace w;
+    char *p = static_cast<char *>(workspace);
+    const size_t nb = (size_t)(cap + 255) / 256 + 1;
+    w.nb_max = (int)nb;
+    w.rownorm = reinterpret_cast<float *>(p); p += aoc_align_up((size_t)cap * 4, 256);
+    w.rank16 = reinterpret_cast<uint16_t *>(p); p += aoc_align_up((size_t)cap * 2, 256);
+    w.hist = reinterpret_cast<int32_t *>(p); p += aoc_align_up((size_t)n_seg * nb * kmax * 4, 256);
+    w.blockoff = reinterpret_cast<int32_t *>(p); p += aoc_align_up((size_t)n_seg * nb * kmax * 4, 256);
+    w.counts = reinterpret_cast<int32_t *>(p); p += aoc_align_up((size_t)n_seg * kmax * 4, 256);
+    w.cbase = reinterpret_cast<int32_t *>(p); p += aoc_align_up((size_t)n_seg * kmax * 4, 256);
+    w.moff = reinterpret_cast<uint32_t *>(p);
+    return w;
+}
+
 inline int label_blocks(int64_t n) { return (int)((n + LP_BLOCK - 1) / LP_BLOCK); }
 
 }  // namespace
@@ -454,13 +912,21 @@ int aoc_kmeans_plan(const int32_t *counts, int n_seg, int cluster_num, int32_t *
 size_t aoc_kmeans_workspace_bytes(int64_t rows_capacity, int n_seg, int kmax, int C) {
     (void)C;
     if (rows_capacity < 0 || n_seg < 1 || kmax < 1) return 0;
-    return aoc_align_up((size_t)n_seg * kmax * sizeof(float), 256) + aoc_align_up((size_t)rows_capacity * sizeof(float), 256);
+    return aoc_align_up((size_t)n_seg * kmax * sizeof(float), 256) + ks_workspace_bytes(rows_capacity, n_seg, kmax);
 }
 
 int aoc_kmeans_segmented(const float *pool, int C, const int32_t *rows, const int32_t *seg_offsets, const int32_t *seg_k,
                          const int32_t *init_rows, int n_seg, int kmax, int iters, int64_t rows_capacity,
                          float *centroids, int32_t *labels, int32_t *cluster_counts,
                          void *workspace, size_t workspace_bytes, aoc_stream_t stream) {
+    return aoc_kmeans_segmented_ex(pool, 0, C, rows, seg_offsets, seg_k, init_rows, n_seg, kmax, iters, rows_capacity, centroids, labels,
+                                   cluster_counts, workspace, workspace_bytes, stream);
+}
+
+int aoc_kmeans_segmented_ex(const float *pool, int64_t pool_rows, int C, const int32_t *rows, const int32_t *seg_offsets, const int32_t *seg_k,
+                            const int32_t *init_rows, int n_seg, int kmax, int iters, int64_t rows_capacity,
+                            float *centroids, int32_t *labels, int32_t *cluster_counts,
+                            void *workspace, size_t workspace_bytes, aoc_stream_t stream) {
     if (!pool || !rows || !seg_offsets || !seg_k || !init_rows || !centroids || !labels || !cluster_counts || !workspace)
         return AOC_ERR_INVALID_ARG;
     if (C < 1 || n_seg < 1 || kmax < 1 || iters < 1 || rows_capacity < 1 || rows_capacity >= (1ll << 31)) return AOC_ERR_INVALID_ARG;
@@ -468,15 +934,35 @@ int aoc_kmeans_segmented(const float *pool, int C, const int32_t *rows, const in
     if (workspace_bytes < aoc_kmeans_workspace_bytes(rows_capacity, n_seg, kmax, C)) return AOC_ERR_WORKSPACE;
     hipStream_t st = aoc_hip_stream(stream);
     float *cnorm = static_cast<float *>(workspace);
-    float *rownorm = reinterpret_cast<float *>(static_cast<char *>(workspace) + aoc_align_up((size_t)n_seg * kmax * sizeof(float), 256));
+    KsWorkspace ws = ks_carve(static_cast<char *>(workspace) + aoc_align_up((size_t)n_seg * kmax * sizeof(float), 256), rows_capacity, n_seg, kmax);
+    float *rownorm = ws.rownorm;
+    // scan-sum pipeline: rows addressed by 32-bit byte offsets through a bounds-checked buffer descriptor
+    const bool fast = (C % 4) == 0 && C <= 128 && pool_rows > 0 && (uint64_t)pool_rows * C * 4 < 0xFFFFFF00ull;
+    const uint32_t pool_bytes = fast ? (uint32_t)((uint64_t)pool_rows * C * 4) : 0u;
 
     hipLaunchKernelGGL(km_init_kernel, dim3(kmax, n_seg), dim3(64), 0, st, pool, C, rows, seg_offsets, seg_k, init_rows, kmax,
                        centroids, cnorm, cluster_counts);
     const dim3 agrid((unsigned)((rows_capacity + 255) / 256), (unsigned)n_seg);
     const size_t lds = ((size_t)kmax * C + kmax) * sizeof(float);
+    const size_t lds_fast = lds + (size_t)4 * kmax * sizeof(int32_t);
     const int nf = (C + 63) / 64;
     for (int it = 0; it < iters; ++it) {
         const int first = (it == 0);
+        if (fast) {
+            if (C <= 100)
+                hipLaunchKernelGGL(km_assign_rank_kernel<25>, agrid, dim3(256), lds_fast, st, pool, C, rows, seg_offsets, seg_k, centroids, kmax, labels,
+                                   ws.rank16, ws.hist, ws.nb_max, rownorm, first);
+            else
+                hipLaunchKernelGGL(km_assign_rank_kernel<32>, agrid, dim3(256), lds_fast, st, pool, C, rows, seg_offsets, seg_k, centroids, kmax, labels,
+                                   ws.rank16, ws.hist, ws.nb_max, rownorm, first);
+            hipLaunchKernelGGL(km_blockscan_kernel, dim3(n_seg), dim3(1024), 0, st, seg_offsets, seg_k, ws.hist, ws.blockoff, ws.nb_max, kmax,
+                               cluster_counts, ws.cbase);
+            hipLaunchKernelGGL(km_scatter_kernel, agrid, dim3(256), 0, st, rows, (const int32_t *)nullptr, seg_offsets, seg_k, labels, ws.rank16,
+                               ws.blockoff, ws.cbase, ws.nb_max, kmax, (uint32_t)C * 4u, ws.moff);
+            hipLaunchKernelGGL(km_sum_scan_kernel<0>, dim3(C / 4, kmax, n_seg), dim3(64), 0, st, pool, pool_bytes, C, seg_offsets, seg_k,
+                               cluster_counts, ws.cbase, ws.moff, kmax, centroids);
+            continue;
+        }
         if ((C % 4) == 0 && C <= 100)
             hipLaunchKernelGGL(km_assign_kernel<25>, agrid, dim3(256), lds, st, pool, C, rows, seg_offsets, seg_k, centroids, cnorm, kmax, labels, rownorm, first);
         else if ((C % 4) == 0 && C <= 128)
@@ -492,20 +978,51 @@ int aoc_kmeans_segmented(const float *pool, int C, const int32_t *rows, const in
     return AOC_OK;
 }
 
-int aoc_build_proxies(const float *pool, int C, const int32_t *fg_rows, const int32_t *seg_offsets, const int32_t *seg_k,
-                      const int32_t *labels, const float *centroids, int n_seg, int kmax,
-                      float *proxies, float *proxy_sqnorm, aoc_stream_t stream) {
+size_t aoc_build_proxies_workspace_bytes(int64_t rows_capacity, int n_seg, int kmax) {
+    if (rows_capacity < 0 || n_seg < 1 || kmax < 1) return 0;
+    return ks_workspace_bytes(rows_capacity, n_seg, kmax);
+}
+
+int aoc_build_proxies(const float *pool, int64_t pool_rows, int C, const int32_t *fg_rows, const int32_t *seg_offsets, const int32_t *seg_k,
+                      const int32_t *labels, const float *centroids, int n_seg, int kmax, int64_t rows_capacity,
+                      float *proxies, float *proxy_sqnorm, void *workspace, size_t workspace_bytes, aoc_stream_t stream) {
     if (!pool || !fg_rows || !seg_offsets || !seg_k || !labels || !centroids || !proxies || !proxy_sqnorm) return AOC_ERR_INVALID_ARG;
     if (C < 1 || n_seg < 1 || kmax < 1) return AOC_ERR_INVALID_ARG;
     if (C > AOC_MAX_CHANNELS || kmax > AOC_MAX_CLUSTERS || n_seg > 65535) return AOC_ERR_UNSUPPORTED;
     hipStream_t st = aoc_hip_stream(stream);
     const dim3 grid(kmax, n_seg);
     const int nf = (C + 63) / 64;
+    const bool fast = (C % 4) == 0 && pool_rows > 0 && rows_capacity > 0 && (uint64_t)pool_rows * C * 4 < 0xFFFFFF00ull && workspace &&
+                      workspace_bytes >= aoc_build_proxies_workspace_bytes(rows_capacity, n_seg, kmax);
+    if (fast) {
+        KsWorkspace ws = ks_carve(workspace, rows_capacity, n_seg, kmax);
+        const dim3 agrid((unsigned)((rows_capacity + 255) / 256), (unsigned)n_seg);
+        hipLaunchKernelGGL(km_rank_only_kernel, agrid, dim3(256), 0, st, seg_offsets, seg_k, labels, kmax, ws.rank16, ws.hist, ws.nb_max);
+        hipLaunchKernelGGL(km_blockscan_kernel, dim3(n_seg), dim3(1024), 0, st, seg_offsets, seg_k, ws.hist, ws.blockoff, ws.nb_max, kmax, ws.counts, ws.cbase);
+        hipLaunchKernelGGL(km_scatter_kernel, agrid, dim3(256), 0, st, (const int32_t *)nullptr, fg_rows, seg_offsets, seg_k, labels, ws.rank16,
+                           ws.blockoff, ws.cbase, ws.nb_max, kmax, (uint32_t)C * 4u, ws.moff);
+        hipLaunchKernelGGL(km_sum_scan_kernel<1>, dim3(C / 4, kmax, n_seg), dim3(64), 0, st, pool, (uint32_t)((uint64_t)pool_rows * C * 4), C, seg_offsets,
+                           seg_k, ws.counts, ws.cbase, ws.moff, kmax, proxies);
+        hipLaunchKernelGGL(km_proxy_finish_kernel, grid, dim3(64), 0, st, centroids, seg_k, ws.counts, kmax, C, proxies, proxy_sqnorm);
+        AOC_RETURN_IF_LAUNCH_FAILED();
+        return AOC_OK;
+    }
 #define AOC_KP(NF) hipLaunchKernelGGL((km_accumulate_kernel<NF, 1>), grid, dim3(64), 0, st, pool, C, fg_rows, seg_offsets, seg_k, labels, kmax, const_cast<float *>(centroids), (float *)nullptr, (int32_t *)nullptr, proxies, proxy_sqnorm)
     if (nf == 1) AOC_KP(1); else if (nf == 2) AOC_KP(2); else if (nf == 3) AOC_KP(3); else AOC_KP(4);
 #undef AOC_KP
     AOC_RETURN_IF_LAUNCH_FAILED();
     return AOC_OK;
 }
+
+#ifdef AOC_KS_STATS
+int aoc_debug_ks_stats(unsigned long long *out8_host, int reset) {
+    if (hipMemcpyFromSymbol(out8_host, HIP_SYMBOL(aoc_ks_stats), 8 * sizeof(unsigned long long)) != hipSuccess) return AOC_ERR_LAUNCH;
+    if (reset) {
+        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(aoc_ks_stats), z, sizeof(z)) != hipSuccess) return AOC_ERR_LAUNCH;
+    }
+    return AOC_OK;
+}
+#endif
 
 }  // extern "C"

@@ -101,8 +101,9 @@ def kmeans_segmented(pool, rows, seg_offsets, seg_k, init_rows, kmax, iters=20, 
     ccounts = torch.empty(n_seg, kmax, dtype=torch.int32, device=dev)
     ws = _ws(L.aoc_kmeans_workspace_bytes(cap, n_seg, kmax, C), dev)
     init_rows = init_rows.to(torch.int32).contiguous()
-    _lib.check(L.aoc_kmeans_segmented(_p(pool), C, _p(rows), _p(seg_offsets), _p(seg_k), _p(init_rows), n_seg, kmax, int(iters), cap,
-                                      _p(centroids), _p(labels), _p(ccounts), _p(ws), ws.numel(), _stream()), "aoc_kmeans_segmented")
+    _lib.check(L.aoc_kmeans_segmented_ex(_p(pool), pool.shape[0], C, _p(rows), _p(seg_offsets), _p(seg_k), _p(init_rows), n_seg, kmax,
+                                         int(iters), cap, _p(centroids), _p(labels), _p(ccounts), _p(ws), ws.numel(), _stream()),
+               "aoc_kmeans_segmented_ex")
     return centroids, labels, ccounts
 
 
@@ -111,10 +112,13 @@ def build_proxies(pool, fg_rows, seg_offsets, seg_k, labels, centroids):
     pool = _f32c(pool)
     _need_gpu(pool, fg_rows, seg_offsets, seg_k, labels, centroids)
     n_seg, kmax, C = centroids.shape
+    L = _lib.lib()
     proxies = torch.empty(n_seg, 2, kmax, C, dtype=torch.float32, device=pool.device)
     sqnorm = torch.empty(n_seg, 2, kmax, dtype=torch.float32, device=pool.device)
-    _lib.check(_lib.lib().aoc_build_proxies(_p(pool), C, _p(fg_rows), _p(seg_offsets), _p(seg_k), _p(labels), _p(centroids), n_seg, kmax,
-                                            _p(proxies), _p(sqnorm), _stream()), "aoc_build_proxies")
+    cap = int(labels.numel())
+    ws = _ws(L.aoc_build_proxies_workspace_bytes(cap, n_seg, kmax), pool.device)
+    _lib.check(L.aoc_build_proxies(_p(pool), pool.shape[0], C, _p(fg_rows), _p(seg_offsets), _p(seg_k), _p(labels), _p(centroids), n_seg, kmax,
+                                   cap, _p(proxies), _p(sqnorm), _p(ws), ws.numel(), _stream()), "aoc_build_proxies")
     return proxies, sqnorm
 
 
