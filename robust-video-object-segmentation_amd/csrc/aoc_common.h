@@ -24,6 +24,13 @@ __device__ __forceinline__ float aoc_proto_transform(float d, float bias) {
     return (s - 0.5f) * 2.0f;
 }
 
+// single v_min_f32 (fminf would add a canonicalising v_max per operand); operands are never NaN here
+__device__ __forceinline__ float aoc_fmin_raw(float a, float b) {
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 __device__ __forceinline__ int aoc_lane() { return threadIdx.x & 63; }
 
 // min / sum across the 16 lanes that share (lane >> 4)  (one MFMA 16x16 output row group).

@@ -184,16 +184,28 @@ __global__ __launch_bounds__(256) void gather_sqnorm_kernel(const float *__restr
     r2[p] = s;
 }
 
-template <int NA, int OMAX, int TMAX>
-__global__ __launch_bounds__(256) void dense_match_partial_kernel(const float *__restrict__ query, int64_t m, int C,
+// One B tile (16 reference pixels) held in registers: the lane's k-stream as TP/4 float4, plus the
+// column's |r|^2 and wrong-label bits.
+template <int NB4>
+struct DenseBTile {
+    float4 b[NB4];
+    float r2;
+    uint32_t wrong;
+};
+
+template <int NA, int OMAX, int TMAX, bool EXACT>
+__global__ __launch_bounds__(256, 2) void dense_match_partial_kernel(const float *__restrict__ query, int64_t m, int C,
                                                                    const float *__restrict__ pool, const int32_t *__restrict__ fg_rows,
                                                                    const int32_t *__restrict__ n_fg_ptr, const float *__restrict__ r2_all,
                                                                    const uint32_t *__restrict__ wrong_bits, int n_obj,
                                                                    float *__restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int TP = aoc_tile_tp(C), RS = aoc_tile_row_stride(C);
+    constexpr int NB4 = (TMAX + 3) / 4;
+    const int TP = EXACT ? NB4 * 4 : aoc_tile_tp(C);
+    const int RS = EXACT ? (4 * NB4 * 4 + 4) : aoc_tile_row_stride(C);
     float *lr2 = lds + (size_t)DM_NB * 16 * RS;
     uint32_t *lwrong = reinterpret_cast<uint32_t *>(lr2 + DM_NB * 16);
+    int32_t *lrow = reinterpret_cast<int32_t *>(lwrong + DM_NB * 16);
 
     const int n_fg = *n_fg_ptr;
     const int n_tiles = (n_fg + 15) / 16;
@@ -222,53 +234,96 @@ __global__ __launch_bounds__(256) void dense_match_partial_kernel(const float *_
 #pragma unroll
             for (int r = 0; r < 4; ++r) mn[o][ia][r] = INFINITY;
 
+    auto load_tile = [&](int ti, DenseBTile<NB4> &t) {
+        const float *bstream = lds + (size_t)(ti * 16 + j) * RS + g * TP;
+#pragma unroll
+        for (int u = 0; u < NB4; ++u)
+            t.b[u] = (EXACT || 4 * u < TP) ? *reinterpret_cast<const float4 *>(bstream + 4 * u) : make_float4(0.f, 0.f, 0.f, 0.f);
+        t.r2 = lr2[ti * 16 + j];
+        t.wrong = lwrong[ti * 16 + j];
+    };
+    auto epilogue = [&](const f32x4 (&acc)[NA], float r2, uint32_t wrong) {
+        float padv[OMAX];   // per-column padding of every object (AEM:84-86); objects >= n_obj are never written
+#pragma unroll
+        for (int o = 0; o < OMAX; ++o) padv[o] = ((wrong >> o) & 1u) ? AOC_PAD_DISTANCE : 0.0f;
+#pragma unroll
+        for (int ia = 0; ia < NA; ++ia)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float d = (q2r[ia][r] + r2) - 2.0f * acc[ia][r];   // AEM:43
+#pragma unroll
+                for (int o = 0; o < OMAX; ++o) mn[o][ia][r] = aoc_fmin_raw(mn[o][ia][r], d + padv[o]);   // AEM:88
+            }
+    };
+    auto step = [&](const DenseBTile<NB4> &t) {
+        f32x4 acc[NA];
+#pragma unroll
+        for (int ia = 0; ia < NA; ++ia) acc[ia] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < NB4; ++u) {
+            const float bb[4] = {t.b[u].x, t.b[u].y, t.b[u].z, t.b[u].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (4 * u + e < TMAX) {
+#pragma unroll
+                    for (int ia = 0; ia < NA; ++ia)
+                        acc[ia] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ia][4 * u + e < TMAX ? 4 * u + e : 0], bb[e], acc[ia], 0, 0, 0);
+                }
+            }
+        }
+        epilogue(acc, t.r2, t.wrong);
+    };
+
     for (int chunk = tile_beg; chunk < tile_end; chunk += DM_NB) {
         const int nt = min(DM_NB, tile_end - chunk);
         __syncthreads();   // previous chunk fully consumed
-        stage_tile_rows(lds, nt * 16, C, TP, RS, [&](int c) -> const float * {
+        // ---- staging with full memory-level parallelism: (1) the chunk's row ids, (2) every row load of the
+        // thread issued back to back, (3) the LDS writes.  (A naive loop serialises id -> row -> write per element.)
+        for (int c = threadIdx.x; c < DM_NB * 16; c += blockDim.x) {
             const int p = chunk * 16 + c;
-            return (p < n_fg) ? pool + (size_t)fg_rows[p] * C : nullptr;
-        });
-        for (int c = threadIdx.x; c < nt * 16; c += blockDim.x) {
-            const int p = chunk * 16 + c;
-            lr2[c] = (p < n_fg) ? r2_all[p] : INFINITY;
-            lwrong[c] = (p < n_fg) ? wrong_bits[fg_rows[p]] : 0xffffffffu;
+            const bool in = c < nt * 16 && p < n_fg;
+            const int row = in ? fg_rows[p] : -1;
+            lrow[c] = row;
+            lr2[c] = in ? r2_all[p] : INFINITY;
+            lwrong[c] = in ? wrong_bits[row] : 0xffffffffu;
         }
         __syncthreads();
-        for (int ti = 0; ti < nt; ++ti) {
-            const float *bstream = lds + (size_t)(ti * 16 + j) * RS + g * TP;
-            f32x4 acc[NA];
+        {
+            const int c4 = C >> 2;
+            const int total = nt * 16 * c4;
+            constexpr int DM_STAGE_ITERS = (DM_NB * 16 * TMAX + 255) / 256;   // float4 loads per thread per chunk
+            float4 v[DM_STAGE_ITERS];
+            int dst[DM_STAGE_ITERS];
 #pragma unroll
-            for (int ia = 0; ia < NA; ++ia) acc[ia] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int it = 0; it < DM_STAGE_ITERS; ++it) {
+                const int idx = it * 256 + threadIdx.x;
+                const int rr = idx / c4, t = idx - rr * c4;
+                const int row = (idx < total) ? lrow[rr] : -1;
+                v[it] = (row >= 0) ? reinterpret_cast<const float4 *>(pool + (size_t)row * C)[t] : make_float4(0.f, 0.f, 0.f, 0.f);
+                dst[it] = (idx < total) ? rr * RS + t : -1;
+            }
 #pragma unroll
-            for (int u = 0; u < (TMAX + 3) / 4; ++u) {
-                if (4 * u >= TP) break;
-                const float4 b = *reinterpret_cast<const float4 *>(bstream + 4 * u);
-                const float bb[4] = {b.x, b.y, b.z, b.w};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    if (4 * u + e < TMAX) {
-#pragma unroll
-                        for (int ia = 0; ia < NA; ++ia)
-                            acc[ia] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ia][4 * u + e < TMAX ? 4 * u + e : 0], bb[e], acc[ia], 0, 0, 0);
-                    }
+            for (int it = 0; it < DM_STAGE_ITERS; ++it) {
+                if (dst[it] >= 0) {
+                    float *d = lds + dst[it];
+                    d[0] = v[it].x; d[TP] = v[it].y; d[2 * TP] = v[it].z; d[3 * TP] = v[it].w;
                 }
             }
-            const float r2 = lr2[ti * 16 + j];
-            const uint32_t w = lwrong[ti * 16 + j];
-#pragma unroll
-            for (int ia = 0; ia < NA; ++ia)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float d = (q2r[ia][r] + r2) - 2.0f * acc[ia][r];   // AEM:43
-#pragma unroll
-                    for (int o = 0; o < OMAX; ++o) {
-                        if (o < n_obj) {
-                            const float v = d + (((w >> o) & 1u) ? AOC_PAD_DISTANCE : 0.0f);   // AEM:84-86
-                            mn[o][ia][r] = fminf(mn[o][ia][r], v);                          // AEM:88
-                        }
-                    }
-                }
+            const int padn = TP - c4;   // zero the stream padding read by the last ds_read_b128 of a stream
+            for (int idx = threadIdx.x; idx < nt * 16 * 4 * padn; idx += blockDim.x) {
+                const int rr = idx / (4 * padn), rem = idx - rr * 4 * padn;
+                lds[(size_t)rr * RS + (rem / padn) * TP + c4 + (rem % padn)] = 0.0f;
+            }
+        }
+        __syncthreads();
+        // two register tiles ping-pong so the LDS reads of tile t+1 are in flight under tile t's MFMAs
+        DenseBTile<NB4> t0, t1;
+        load_tile(0, t0);
+        for (int ti = 0; ti < nt; ti += 2) {
+            if (ti + 1 < nt) load_tile(ti + 1, t1);
+            step(t0);
+            if (ti + 2 < nt) load_tile(ti + 2, t0);
+            if (ti + 1 < nt) step(t1);
         }
     }
     // reduce over the 16 columns a lane group holds and write this split's partial minima
@@ -315,7 +370,7 @@ inline int dense_nsplit(int64_t m, int na) {
     if (s > 64) s = 64;
     return (int)s;
 }
-inline int dense_na(int n_obj) { return n_obj <= 4 ? 2 : (n_obj <= 8 ? 2 : 1); }
+inline int dense_na(int n_obj) { return n_obj <= 4 ? 2 : 1; }
 
 }  // namespace
 
@@ -398,15 +453,15 @@ int aoc_dense_match_min(const float *query, int64_t m, int C, const float *pool,
     const int ns = dense_nsplit(m, na);
     const int row_blocks = (int)((m + 64 * na - 1) / (64 * na));
     const int RS = aoc_tile_row_stride(C);
-    const size_t lds = (size_t)DM_NB * 16 * RS * sizeof(float) + DM_NB * 16 * (sizeof(float) + sizeof(uint32_t));
+    const size_t lds = (size_t)DM_NB * 16 * RS * sizeof(float) + DM_NB * 16 * (sizeof(float) + sizeof(uint32_t) + sizeof(int32_t));
 
     hipLaunchKernelGGL(gather_sqnorm_kernel, dim3((unsigned)((n_fg_capacity + 255) / 256)), dim3(256), 0, st, pool, C, fg_rows, n_fg, r2);
     const dim3 grid(row_blocks, ns);
-#define AOC_DM(NA, OM, TM) hipLaunchKernelGGL((dense_match_partial_kernel<NA, OM, TM>), grid, dim3(256), lds, st, query, m, C, pool, fg_rows, n_fg, r2, wrong_bits, n_obj, partial)
+#define AOC_DM(NA, OM, TM, EX) hipLaunchKernelGGL((dense_match_partial_kernel<NA, OM, TM, EX>), grid, dim3(256), lds, st, query, m, C, pool, fg_rows, n_fg, r2, wrong_bits, n_obj, partial)
     if (C == 100) {
-        if (n_obj <= 4) AOC_DM(2, 4, 25); else if (n_obj <= 8) AOC_DM(2, 8, 25); else AOC_DM(1, 16, 25);
+        if (n_obj <= 4) AOC_DM(2, 4, 25, true); else if (n_obj <= 8) AOC_DM(1, 8, 25, true); else AOC_DM(1, 16, 25, true);
     } else {
-        if (n_obj <= 4) AOC_DM(2, 4, 32); else if (n_obj <= 8) AOC_DM(2, 8, 32); else AOC_DM(1, 16, 32);
+        if (n_obj <= 4) AOC_DM(2, 4, 32, false); else if (n_obj <= 8) AOC_DM(1, 8, 32, false); else AOC_DM(1, 16, 32, false);
     }
 #undef AOC_DM
     const int64_t total = m * n_obj;
