@@ -79,8 +79,11 @@ class OpTimer:
 class ClipWorkload:
     """One synthetic sequence of a config, resident on the GPU, stepped with the reference's memory policy."""
 
-    def __init__(self, cfg, seed, device, mc):
+    def __init__(self, cfg, seed, device, mc, overlap=True):
         self.cfg, self.mc, self.dev = cfg, mc, device
+        # the k-means branch (a long chain of small launches) runs on a high-priority side stream,
+        # concurrently with the MFMA-bound dense matching on the main stream
+        self.side = torch.cuda.Stream(device=device, priority=-1) if overlap else None
         clip = syn.make_clip(cfg, seed)
         O = cfg.n_obj
         self.emb = torch.from_numpy(clip["emb"]).to(device)                                   # [T,h,w,C]
@@ -134,7 +137,7 @@ def frame_step(wl, gates, acts):
     ref_emb, ref_lab = wl.refs()
     t = wl.t
     feat, head, _ = hotpath.proto_mask_features(wl.mc, ref_emb, ref_lab, wl.emb[t - 1], wl.lab[t - 1], wl.emb[t], wl.bias,
-                                                cluster_state=dict(init_rows=wl.init_rows[t][0]))
+                                                cluster_state=dict(init_rows=wl.init_rows[t][0]), side_stream=wl.side)
     outs = gates(acts, head)
     wl.advance()
     return feat, outs
@@ -218,6 +221,7 @@ def main():
     ap.add_argument("--config", default="cfg2", choices=list(syn.CONFIGS))
     ap.add_argument("--streams", type=int, default=1, help="independent sequences stepped concurrently on separate HIP streams")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true", help="run the k-means branch on the main stream (no intra-frame stream overlap)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -238,7 +242,7 @@ def main():
     gates = hotpath.CalibrationGates(mc).to(dev)
     n_streams = max(1, args.streams)
     # sequences are sharded over ranks: rank r owns sequences r*n_streams .. (+n_streams)
-    workloads = [ClipWorkload(cfg, seed=1 + rank * n_streams + s, device=dev, mc=mc) for s in range(n_streams)]
+    workloads = [ClipWorkload(cfg, seed=1 + rank * n_streams + s, device=dev, mc=mc, overlap=not args.no_overlap) for s in range(n_streams)]
     acts = make_activations(gates, cfg.n_obj, cfg.h, cfg.w, dev, seed=7)
     streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)] if n_streams > 1 else [torch.cuda.current_stream()]
 
@@ -364,7 +368,8 @@ def main():
             "config": {"workload": f"{cfg.name}: {cfg.h}x{cfg.w} stride-4 maps (480p), O={O} (3 objects + background), K={cfg.k} proxies, "
                                    f"C={C}, {cfg.frames}-frame clips, MEM_EVERY={mc.MEM_EVERY} (R=1..{1 + (cfg.frames - 2) // mc.MEM_EVERY}), "
                                    "20 Lloyd iterations, local windows [2..12]",
-                       "sequences_per_gpu": n_streams, "frames_per_step": n_streams, "sharding": "sequences over ranks, no data-path collective"},
+                       "sequences_per_gpu": n_streams, "frames_per_step": n_streams, "sharding": "sequences over ranks, no data-path collective",
+                       "intra_frame_overlap": "k-means branch on a side HIP stream" if not args.no_overlap else "none"},
             "roofline": roofline, "roofline_correlation_kernel": corr_roof, "cpu_baseline": cpu, "parity": parity, "kernels": kernels,
         }
         print(json.dumps(line))

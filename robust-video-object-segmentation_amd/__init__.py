@@ -11,5 +11,7 @@ from . import ops  # noqa: F401
 from . import matching  # noqa: F401
 from . import attention  # noqa: F401
 from . import conditioning_layer  # noqa: F401
+from . import hotpath  # noqa: F401
+from . import sharding  # noqa: F401
 
-__all__ = ["synthetic", "ops", "matching", "attention", "conditioning_layer"]
+__all__ = ["synthetic", "ops", "matching", "attention", "conditioning_layer", "hotpath", "sharding"]

@@ -446,15 +446,19 @@ __device__ __forceinline__ int ks_wave_sum(int v) {
 }
 
 // One block of 64 members of one feature, folded in the integer domain of the current binade.
-__device__ __forceinline__ void ks_fold_block(float x, float inv_u, int lane, int &accr, int &par, int &bad) {
+//   y = x / u (exact), r = RNE(y) as an integer; a tie (|RNE(y) - y| == 1/2) is re-rounded from the running
+//   parity; `badmask` collects lanes whose value is not a plain non-negative number below 2^24 ulps
+//   (negative, NaN/inf, x >> s): the caller then redoes the block with literal float additions.
+__device__ __forceinline__ void ks_fold_block(float x, float inv_u, int lane, int &accr, int &par, unsigned long long &badmask) {
     const float y = x * inv_u;
-    const float fl = floorf(y);
-    const float fr = y - fl;
-    int r = (int)fl + ((fr > 0.5f) ? 1 : 0);
-    bad |= (!(x >= 0.0f) || !(y < 16777216.0f)) ? 1 : 0;
-    const unsigned long long odd = __ballot((r & 1) != 0);
-    const unsigned long long ties = __ballot(fr == 0.5f);
+    const float rn = rintf(y);                       // v_rndne_f32
+    int r = (int)rn;
+    badmask |= __ballot(!(__float_as_uint(y) < 0x4B800000u));   // y in [+0, 2^24) <=> bits(y) < bits(2^24)
+    const unsigned long long ties = __ballot(fabsf(rn - y) == 0.5f);
     if (ties) {                                       // rare: resolve round-half-even from the running parity
+        const int fl = (int)floorf(y);
+        if ((ties >> lane) & 1ull) r = fl;            // start from floor(y); the bump below re-rounds
+        const unsigned long long odd = __ballot((r & 1) != 0);
         int base_par = par, from = 0;
         unsigned long long tm = ties;
         while (tm) {
@@ -471,7 +475,7 @@ __device__ __forceinline__ void ks_fold_block(float x, float inv_u, int lane, in
         const unsigned long long rest = (from >= 64) ? 0ull : (~0ull << from);
         par = base_par ^ (__popcll(odd & rest) & 1);
     } else {
-        par ^= __popcll(odd) & 1;
+        par ^= __popcll(__ballot((r & 1) != 0)) & 1;
     }
     accr += r;
 }
@@ -730,7 +734,8 @@ __global__ __launch_bounds__(64) void km_sum_scan_kernel(const float *__restrict
             const int nblk = min(t_cur, blocks_here - b0);
             // ---- optimistic pass: fold blocks [b0, b0 + nblk) in the integer domain of each feature's binade
             KsBinade bin[4];
-            int accr[4] = {0, 0, 0, 0}, par[4], bad[4] = {0, 0, 0, 0};
+            int accr[4] = {0, 0, 0, 0}, par[4];
+            unsigned long long bad[4] = {0ull, 0ull, 0ull, 0ull};
 #pragma unroll
             for (int f = 0; f < 4; ++f) { bin[f] = ks_binade(st[f]); par[f] = bin[f].n_in & 1; }
 #pragma unroll
@@ -739,7 +744,11 @@ __global__ __launch_bounds__(64) void km_sum_scan_kernel(const float *__restrict
                     const float xv[4] = {__uint_as_float(cur.x[b].x), __uint_as_float(cur.x[b].y), __uint_as_float(cur.x[b].z), __uint_as_float(cur.x[b].w)};
 #pragma unroll
                     for (int f = 0; f < 4; ++f)
+#if defined(AOC_KS_EXP) && AOC_KS_EXP >= 2
+                        accr[f] += (int)xv[f];   // EXPERIMENT: no fold arithmetic
+#else
                         if (bin[f].ok) ks_fold_block(xv[f], bin[f].inv_u, lane, accr[f], par[f], bad[f]);
+#endif
                 }
             }
             bool redo[4];
@@ -748,13 +757,16 @@ __global__ __launch_bounds__(64) void km_sum_scan_kernel(const float *__restrict
                 redo[f] = true;
                 if (bin[f].ok) {
                     const int total = ks_wave_sum(accr[f]);
-                    const bool anybad = __ballot(bad[f] != 0) != 0ull;
+                    const bool anybad = bad[f] != 0ull;
                     const long long n_out = (long long)bin[f].n_in + total;
                     if (!anybad && n_out <= 0xFFFFFF) {
                         st[f] = (float)(int)n_out * bin[f].u;      // exact: integer < 2^24 times a power of two
                         redo[f] = false;
                     }
                 }
+#if defined(AOC_KS_EXP) && AOC_KS_EXP >= 1
+                if (redo[f]) { st[f] = st[f] + 1.0f; redo[f] = false; }   // EXPERIMENT: never take the careful path (wrong results)
+#endif
                 KS_STAT(redo[f] ? 2 : 1, nblk);
             }
             KS_STAT(0, 1);
@@ -770,11 +782,12 @@ __global__ __launch_bounds__(64) void km_sum_scan_kernel(const float *__restrict
                             const KsBinade bb = ks_binade(st[f]);
                             bool done = false;
                             if (bb.ok) {
-                                int a = 0, pr = bb.n_in & 1, bd = 0;
+                                int a = 0, pr = bb.n_in & 1;
+                                unsigned long long bd = 0ull;
                                 ks_fold_block(xv[f], bb.inv_u, lane, a, pr, bd);
                                 const int total = ks_wave_sum(a);
                                 const long long n_out = (long long)bb.n_in + total;
-                                if (__ballot(bd != 0) == 0ull && n_out <= 0xFFFFFF) {
+                                if (bd == 0ull && n_out <= 0xFFFFFF) {
                                     st[f] = (float)(int)n_out * bb.u;
                                     done = true;
                                 }

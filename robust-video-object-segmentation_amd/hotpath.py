@@ -54,7 +54,7 @@ def channel_slices(cfg):
 
 
 def proto_mask_features(cfg, ref_emb, ref_labels, prev_emb, prev_labels, cur_emb, dis_bias, init_rows=None,
-                        cluster_state=None):
+                        cluster_state=None, side_stream=None):
     """All matching branches of one frame -> (features [O, 24, h, w], attention_head [O, 4C], aux).
 
     ref_emb     [R, h, w, C]  reference pool (channel-last)          ref_labels [R, h, w, O] float one-hot
@@ -62,6 +62,9 @@ def proto_mask_features(cfg, ref_emb, ref_labels, prev_emb, prev_labels, cur_emb
     cur_emb     [h, w, C]     current (query) frame embedding        dis_bias   [O] or [O,1,1,1]
     init_rows   optional explicit k-means initial rows per object (else drawn like scipy from np.random)
     cluster_state  optional dict with device tensors (seg_k, init_rows) for the host-sync-free pipeline
+    side_stream  optional torch.cuda.Stream: the adaptive-proxy branch (k-means: a long chain of small,
+                 latency-bound launches) runs there, concurrently with the MFMA-bound dense matching on the
+                 current stream; the two join in front of the correlation launch.  Only with cluster_state.
     """
     R, h, w, C = ref_emb.shape
     O = ref_labels.shape[-1]
@@ -93,32 +96,26 @@ def proto_mask_features(cfg, ref_emb, ref_labels, prev_emb, prev_labels, cur_emb
     else:
         # host-sync-free variant: sticky K on the device, explicit init rows, proxies written in place
         prep = ops.label_prep(labels_flat)
-        seg_k = ops.kmeans_plan(prep.counts, O, kmax)
-        cen, lab, _ = ops.kmeans_segmented(pool, prep.obj_rows, prep.obj_offsets, seg_k, cluster_state["init_rows"], kmax,
-                                           KMEANS_ITERS, rows_capacity=prep.obj_rows.numel())
-        proxies, psq = ops.build_proxies(pool, prep.fg_rows, prep.obj_offsets, seg_k, lab, cen)
-        table[:O * 2 * kmax].copy_(proxies.reshape(-1, C))
-        sqn[:O * 2 * kmax].copy_(psq.reshape(-1))
+        main = torch.cuda.current_stream()
+        fork = side_stream is not None
+        if fork:
+            side_stream.wait_stream(main)
+        with torch.cuda.stream(side_stream if fork else main):
+            seg_k = ops.kmeans_plan(prep.counts, O, kmax)
+            cen, lab, _ = ops.kmeans_segmented(pool, prep.obj_rows, prep.obj_offsets, seg_k, cluster_state["init_rows"], kmax,
+                                               KMEANS_ITERS, rows_capacity=prep.obj_rows.numel())
+            proxies, psq = ops.build_proxies(pool, prep.fg_rows, prep.obj_offsets, seg_k, lab, cen)
+            table[:O * 2 * kmax].copy_(proxies.reshape(-1, C))
+            sqn[:O * 2 * kmax].copy_(psq.reshape(-1))
+        if fork:
+            for t in (seg_k, cen, lab, proxies, psq):
+                t.record_stream(main)
         cp = dict(prep=prep, centroids=cen, labels=lab, proxies=proxies, proxy_sqnorm=psq)
 
     ref_pos, ref_neg = ops.masked_mean_pool(ref_emb.reshape(R, hw, C), ref_labels.reshape(R, hw, O), cfg.MODEL_EPSILON, pixel_major=True,
                                             out_pos=table[O * 2 * kmax:], out_pos_sqnorm=sqn[O * 2 * kmax:])
     prev_pos, prev_neg = ops.masked_mean_pool(prev_emb.reshape(1, hw, C), prev_labels.reshape(1, hw, O), cfg.MODEL_EPSILON, pixel_major=True)
     attention_head = torch.cat([ref_pos, ref_neg, prev_pos, prev_neg], dim=1)          # ATT:188, [O, 4C]
-
-    # ---- one correlation launch: cluster (2 sets / object) + k = 1 proxy (1 set / object), AEM:316-319 + matching.py:2653
-    set_begin, set_size, set_off, set_bias = [], [], [], []
-    for o in range(O):
-        for f in range(2):
-            set_begin.append((o * 2 + f) * kmax)
-            set_size.append(kmax)
-            set_off.append(o * obj_stride + (ch["cluster"] + f) * hw)
-    for o in range(O):
-        set_begin.append(O * 2 * kmax + o)
-        set_size.append(1)
-        set_off.append(o * obj_stride + ch["proxy"] * hw)
-    set_bias = torch.cat([bias.repeat_interleave(2), bias])
-    ops.proxy_corr_min(query_flat, table, sqn, set_begin, set_size, set_off, set_bias, feat, 1, True)
 
     # ---- dense pixel-level matching, AEM:688-817 -> channel 0
     ops.dense_match_min(query_flat, pool, prep, bias, feat, 1, obj_stride, True)
@@ -139,6 +136,22 @@ def proto_mask_features(cfg, ref_emb, ref_labels, prev_emb, prev_labels, cur_emb
     for key, prev_map in (("local", p2), ("local_proxy", pm2)):
         lf = ops.local_window_match(q2, prev_map, bits2, radii, bias, O, True)        # [O, nl, H2, W2]
         ops.resize_bilinear_planes(lf.view(O * nl, H2, W2), h, w, base[ch[key] * hw:], hw, 1, inner_count=nl, out_outer_stride=obj_stride)
+
+    # ---- one correlation launch: cluster (2 sets / object) + k = 1 proxy (1 set / object), AEM:316-319 + matching.py:2653
+    set_begin, set_size, set_off, set_bias = [], [], [], []
+    for o in range(O):
+        for f in range(2):
+            set_begin.append((o * 2 + f) * kmax)
+            set_size.append(kmax)
+            set_off.append(o * obj_stride + (ch["cluster"] + f) * hw)
+    for o in range(O):
+        set_begin.append(O * 2 * kmax + o)
+        set_size.append(1)
+        set_off.append(o * obj_stride + ch["proxy"] * hw)
+    set_bias = torch.cat([bias.repeat_interleave(2), bias])
+    if cluster_state is not None and side_stream is not None:
+        torch.cuda.current_stream().wait_stream(side_stream)        # join: the proxy table is complete
+    ops.proxy_corr_min(query_flat, table, sqn, set_begin, set_size, set_off, set_bias, feat, 1, True)
 
     # ---- previous-frame mask channel (aocnet.py:356 to_cat_previous_frame)
     feat[:, ch["prev_mask"]].copy_(prev_labels.permute(2, 0, 1))
