@@ -497,12 +497,51 @@ __device__ __forceinline__ KsBinade ks_binade(float s) {
     return b;
 }
 
-// literal serial additions of one 64-member block (x of absent members is +0, which is exact)
-__device__ __forceinline__ float ks_serial_block(float s, float x) {
+// literal serial additions of one 64-member block, members [from, 64) (x of absent members is +0, which is exact)
+__device__ __forceinline__ float ks_serial_block(float s, float x, int from = 0) {
     if (__ballot(x != 0.0f) == 0ull) return s;   // all zeros: s + 0.0f == s (s is never -0)
-#pragma unroll 8
-    for (int kk = 0; kk < 64; ++kk) s = s + __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(x), kk));
+    for (int kk = from; kk < 64; ++kk) s = s + __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(x), kk));
     return s;
+}
+
+// wave-wide inclusive prefix sum (DPP: Hillis-Steele inside each 16-lane row, then row_bcast:15 / :31)
+__device__ __forceinline__ int ks_wave_scan(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);    // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);    // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);    // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);    // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1, 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2, 3
+    return v;
+}
+
+// One 64-member block, exactly, from running sum s.  Members are folded in the integer domain of the current
+// binade; if n would leave the binade, a prefix scan locates the member whose addition crosses, that one
+// addition is done in floating point, and the rest of the block is folded in the new binade.  Anything
+// unusual (s == 0 or tiny, negative / non-finite values, more than a few crossings) takes the serial additions.
+__device__ __forceinline__ float ks_block_exact(float s, float x, int lane) {
+    int from = 0;
+#pragma unroll 1
+    for (int round = 0; round < 4; ++round) {
+        const KsBinade bb = ks_binade(s);
+        if (!bb.ok) break;
+        int r = 0, pr = bb.n_in & 1;
+        unsigned long long bd = 0ull;
+        ks_fold_block((lane >= from) ? x : 0.0f, bb.inv_u, lane, r, pr, bd);     // r = this lane's integer (ties resolved)
+        if (bd != 0ull) break;
+        const int pre = ks_wave_scan(r);
+        const int total = __builtin_amdgcn_readlane(pre, 63);
+        if ((long long)bb.n_in + total <= 0xFFFFFF) return (float)(bb.n_in + total) * bb.u;
+        // first member whose addition takes n to 2^24 or beyond
+        const unsigned long long over = __ballot((long long)bb.n_in + pre > 0xFFFFFF);
+        const int mstar = __builtin_ctzll(over);
+        const int before = (mstar == 0) ? 0 : __builtin_amdgcn_readlane(pre, mstar - 1);
+        const float s_before = (float)(bb.n_in + before) * bb.u;                  // exact state in front of member m*
+        s = s_before + __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(x), mstar));   // the crossing addition itself
+        from = mstar + 1;
+        if (from >= 64) return s;
+    }
+    return ks_serial_block(s, x, from);
 }
 
 template <int C4MAX>
@@ -625,14 +664,25 @@ __global__ __launch_bounds__(256) void km_rank_only_kernel(const int32_t *__rest
             wcnt[threadIdx.x] + wcnt[kmax + threadIdx.x] + wcnt[2 * kmax + threadIdx.x] + wcnt[3 * kmax + threadIdx.x];
 }
 
-// one block per segment: exclusive scan of the block histograms per cluster, cluster sizes and bases
+// Chunk = KS_CHUNK consecutive members of one cluster's ordered list.  Segment s owns the chunk ids
+// [ks_seg_chunk_base(s), +ks_seg_chunk_region(s)): enough for sum_j ceil(cnt_j / KS_CHUNK) whatever the split.
+constexpr int KS_CHUNK = 64 * KS_T;
+__host__ __device__ __forceinline__ int ks_seg_chunk_base(int seg_beg, int s, int kmax) { return seg_beg / KS_CHUNK + s * (kmax + 1); }
+__host__ __device__ __forceinline__ int ks_seg_chunk_region(int len, int kmax) { return len / KS_CHUNK + kmax + 1; }
+
+// one block per segment: exclusive scan of the block histograms per cluster, cluster sizes and bases, plus the
+// chunk table of the segment (chunk base per cluster; owner cluster / local index per chunk id, -1 = unused)
 __global__ __launch_bounds__(1024) void km_blockscan_kernel(const int32_t *__restrict__ seg_off, const int32_t *__restrict__ seg_k,
                                                              const int32_t *__restrict__ hist, int32_t *__restrict__ blockoff, int nb_max,
-                                                             int kmax, int32_t *__restrict__ counts, int32_t *__restrict__ cbase) {
+                                                             int kmax, int32_t *__restrict__ counts, int32_t *__restrict__ cbase,
+                                                             int32_t *__restrict__ cchunk, int32_t *__restrict__ owner_cluster,
+                                                             int32_t *__restrict__ owner_local, int nch_cap) {
     __shared__ int32_t ltot[AOC_MAX_CLUSTERS];
+    __shared__ int32_t lchunk[AOC_MAX_CLUSTERS + 1];
     const int s = blockIdx.x;
     const int k = seg_k[s];
-    const int len = seg_off[s + 1] - seg_off[s];
+    const int beg = seg_off[s];
+    const int len = seg_off[s + 1] - beg;
     const int nb = (len + 255) / 256;
     const int lane = aoc_lane(), wave = threadIdx.x >> 6;
     for (int kk = wave; kk < kmax; kk += 16) {
@@ -653,9 +703,33 @@ __global__ __launch_bounds__(1024) void km_blockscan_kernel(const int32_t *__res
         if (lane == 0) { counts[s * kmax + kk] = carry; ltot[kk] = carry; }
     }
     __syncthreads();
+    const int cb = ks_seg_chunk_base(beg, s, kmax);
+    // this segment initialises every chunk id up to the next segment's base (the last one up to the capacity)
+    const int region = ((s + 1 < (int)gridDim.x) ? ks_seg_chunk_base(seg_off[s + 1], s + 1, kmax) : nch_cap) - cb;
     if (threadIdx.x == 0) {
-        int off = 0;
-        for (int kk = 0; kk < kmax; ++kk) { cbase[s * kmax + kk] = off; off += ltot[kk]; }
+        int off = 0, ch = 0;
+        for (int kk = 0; kk < kmax; ++kk) {
+            cbase[s * kmax + kk] = off;
+            off += ltot[kk];
+            lchunk[kk] = ch;
+            if (cchunk) cchunk[s * kmax + kk] = cb + ch;
+            ch += (ltot[kk] + KS_CHUNK - 1) / KS_CHUNK;
+        }
+        lchunk[kmax] = ch;
+    }
+    __syncthreads();
+    if (owner_cluster) {
+        for (int i = threadIdx.x; i < region; i += blockDim.x) {
+            int oc = -1, ol = 0;
+            if (i < lchunk[kmax]) {
+                int kk = 0;
+                while (kk + 1 < kmax && lchunk[kk + 1] <= i) ++kk;
+                oc = s * kmax + kk;
+                ol = i - lchunk[kk];
+            }
+            owner_cluster[cb + i] = oc;
+            owner_local[cb + i] = ol;
+        }
     }
 }
 
@@ -678,11 +752,272 @@ __global__ __launch_bounds__(256) void km_scatter_kernel(const int32_t *__restri
     moff[pos] = (uint32_t)row * row_bytes;
 }
 
+// ------------------------------------------------------------------------------------------
+// Chunk-parallel part of the exact update.  Within a binade the fold is integer addition, so a chunk's
+// contribution is a pair of integers (one per parity of the incoming n, they differ only if the chunk
+// contains ties) that can be computed by ANY workgroup once the binade is known.  The binade is PREDICTED
+// from an any-order prefix of chunk sums; the serial stitch (km_sum_scan_kernel) verifies every prediction
+// against the exact running sum (same exponent, no overflow of n) and otherwise recomputes the chunk from the
+// rows, so a wrong prediction costs time, never exactness.
+constexpr int KC_TILE_LD = AOC_MAX_CHANNELS / 2 + 1;   // 129: row stride of the 64 x C LDS tile (C <= 128), conflict-free columns
+
+// Staging of 64-member blocks (full rows, coalesced 16-byte pieces) with memory-level parallelism: the chunk's
+// offsets sit in LDS, every thread issues all of its row loads for block b+1 before block b is consumed, and
+// writes them to the tile afterwards.  KC_STAGE_MAX float4 per thread cover 64 rows x C <= 128 floats.
+constexpr int KC_STAGE_MAX = (64 * (AOC_MAX_CHANNELS / 2 / 4) + 255) / 256;   // 8
+struct KcStage {
+    float4 v[KC_STAGE_MAX];
+};
+__device__ __forceinline__ void kc_issue_block(KcStage &st, const float *__restrict__ pool, const uint32_t *__restrict__ loffs, int blk,
+                                               int members_in_chunk, int c4) {
+#pragma unroll
+    for (int it = 0; it < KC_STAGE_MAX; ++it) {
+        const int idx = it * 256 + threadIdx.x;
+        const int mloc = idx / c4, piece = idx - mloc * c4;
+        const int m = blk * 64 + mloc;
+        st.v[it] = (idx < 64 * c4 && m < members_in_chunk)
+                       ? *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(pool) + loffs[m] + piece * 16)
+                       : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+}
+__device__ __forceinline__ void kc_write_block(const KcStage &st, float *__restrict__ tile, int c4) {
+#pragma unroll
+    for (int it = 0; it < KC_STAGE_MAX; ++it) {
+        const int idx = it * 256 + threadIdx.x;
+        if (idx < 64 * c4) {
+            const int mloc = idx / c4, piece = idx - mloc * c4;
+            float *d = tile + mloc * KC_TILE_LD + piece * 4;
+            d[0] = st.v[it].x; d[1] = st.v[it].y; d[2] = st.v[it].z; d[3] = st.v[it].w;
+        }
+    }
+}
+
+// P0: csum[chunk, f] = any-order float sum of the chunk's members (only used to predict binades)
+__global__ __launch_bounds__(256) void km_chunk_sum_kernel(const float *__restrict__ pool, int C, const int32_t *__restrict__ seg_off,
+                                                            const int32_t *__restrict__ counts, const int32_t *__restrict__ cbase,
+                                                            const uint32_t *__restrict__ moff, int kmax,
+                                                            const int32_t *__restrict__ owner_cluster, const int32_t *__restrict__ owner_local,
+                                                            float *__restrict__ csum) {
+    __shared__ __attribute__((aligned(16))) float tile[64 * KC_TILE_LD];
+    const int chunk = blockIdx.x;
+    const int oc = owner_cluster[chunk];
+    if (oc < 0) return;
+    const int s = oc / kmax;
+    const int cnt = counts[oc];
+    const uint32_t *list = moff + seg_off[s] + cbase[oc];
+    const int first = owner_local[chunk] * KS_CHUNK;
+    const int lane = aoc_lane(), wave = threadIdx.x >> 6;
+    const int fpw = (C + 3) / 4;                      // features per wave (4 waves)
+    float acc[AOC_MAX_CHANNELS / 2 / 4];
+#pragma unroll
+    for (int i = 0; i < AOC_MAX_CHANNELS / 2 / 4; ++i) acc[i] = 0.0f;
+    __shared__ uint32_t loffs[KS_CHUNK];
+    const int members = min(KS_CHUNK, cnt - first);
+    for (int i = threadIdx.x; i < KS_CHUNK; i += blockDim.x) loffs[i] = (i < members) ? list[first + i] : 0u;
+    __syncthreads();
+    const int nblk = (members + 63) / 64;
+    KcStage stg;
+    kc_issue_block(stg, pool, loffs, 0, members, C >> 2);
+    for (int b = 0; b < nblk; ++b) {
+        __syncthreads();                       // tile free
+        kc_write_block(stg, tile, C >> 2);
+        if (b + 1 < nblk) kc_issue_block(stg, pool, loffs, b + 1, members, C >> 2);   // in flight under this block's arithmetic
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < AOC_MAX_CHANNELS / 2 / 4; ++i) {
+            const int f = wave * fpw + i;
+            if (i < fpw && f < C) acc[i] += tile[lane * KC_TILE_LD + f];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < AOC_MAX_CHANNELS / 2 / 4; ++i) {
+        const int f = wave * fpw + i;
+        if (i < fpw && f < C) {
+            const float t = aoc_wave_sum(acc[i]);
+            if (lane == 0) csum[(size_t)chunk * C + f] = t;
+        }
+    }
+}
+
+// P1: per cluster, thread = feature: running any-order prefix over the chunks -> predicted binade of each chunk
+// (KC_UNSAFE when the chunk may touch a binade boundary, starts at 0, or is not plainly positive)
+constexpr int KC_UNSAFE = -128;
+__global__ __launch_bounds__(128) void km_chunk_predict_kernel(const int32_t *__restrict__ seg_k, const int32_t *__restrict__ counts,
+                                                                const int32_t *__restrict__ cchunk, const float *__restrict__ csum, int kmax,
+                                                                int C, int8_t *__restrict__ cexp) {
+    const int s = blockIdx.y, j = blockIdx.x;
+    if (j >= seg_k[s]) return;
+    const int oc = s * kmax + j;
+    const int nch = (counts[oc] + KS_CHUNK - 1) / KS_CHUNK;
+    const int base = cchunk[oc];
+    for (int f = threadIdx.x; f < C; f += blockDim.x) {
+        float pre = 0.0f;
+        for (int c = 0; c < nch; ++c) {
+            const float end = pre + csum[(size_t)(base + c) * C + f];
+            int e = KC_UNSAFE;
+            if (pre > 1e-30f && end < 1e30f && end >= pre) {
+                const int e_lo = (int)((__float_as_uint(pre * 0.9995f) >> 23) & 0xff) - 127;
+                const int e_hi = (int)((__float_as_uint(end * 1.0005f) >> 23) & 0xff) - 127;
+                if (e_lo == e_hi && e_lo >= -100 && e_lo <= 100) e = e_lo;
+            }
+            cexp[(size_t)(base + c) * C + f] = (int8_t)e;
+            pre = end;
+        }
+    }
+}
+
+// Fold with both incoming parities tracked.  The two variants differ only at ties: every lane adds
+// floor-or-rne(y) to ONE accumulator and each tie contributes a 0/1 bump that depends on the running parity,
+// so the variants are two scalar bump counters plus two scalar parities.
+struct KcFold {
+    int acc;                 // per lane
+    int par0, par1;          // uniform: parity of n after the members folded so far, for incoming parity 0 / 1
+    int bump0, bump1;        // uniform: number of ties rounded up so far
+    int bad;                 // uniform
+};
+__device__ __forceinline__ void kc_fold_block2(float x, float inv_u, KcFold &k) {
+    const float y = x * inv_u;
+    const float rn = rintf(y);
+    int r = (int)rn;
+    k.bad |= (__ballot(!(__float_as_uint(y) < 0x4B800000u)) != 0ull) ? 1 : 0;
+    const unsigned long long ties = __ballot(fabsf(rn - y) == 0.5f);
+    if (ties) {
+        const int lane = aoc_lane();
+        if ((ties >> lane) & 1ull) r = (int)floorf(y);
+        const unsigned long long odd = __ballot((r & 1) != 0);
+        int pp[2] = {k.par0, k.par1}, bb[2] = {0, 0};
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+            int base_par = pp[v], from = 0;
+            unsigned long long tm = ties;
+            while (tm) {
+                const int t = __builtin_ctzll(tm);
+                tm &= tm - 1;
+                const unsigned long long below_t = (t == 0) ? 0ull : (~0ull >> (64 - t));
+                const unsigned long long below_from = (from == 0) ? 0ull : (~0ull >> (64 - from));
+                const int pb = base_par ^ (__popcll(odd & below_t & ~below_from) & 1);
+                bb[v] += pb ^ (int)((odd >> t) & 1ull);          // n + floor(y) odd -> this tie rounds up
+                base_par = 0;                                      // a tie always leaves n even
+                from = t + 1;
+            }
+            const unsigned long long rest = (from >= 64) ? 0ull : (~0ull << from);
+            pp[v] = base_par ^ (__popcll(odd & rest) & 1);
+        }
+        k.par0 = pp[0]; k.par1 = pp[1];
+        k.bump0 += bb[0]; k.bump1 += bb[1];
+    } else {
+        const int p = __popcll(__ballot((r & 1) != 0)) & 1;
+        k.par0 ^= p; k.par1 ^= p;
+    }
+    k.acc += r;
+}
+
+// P2: cinc0/cinc1[chunk, f] = integer increment of n over the chunk for incoming parity 0 / 1, in the predicted
+// binade.  grid = (chunk ids, feature groups of KC_FG); block = 4 waves x KC_FW features; only the group's
+// columns of each row are staged (KC_FG * 4 bytes per row).
+constexpr int KC_FW = 5;                 // features per wave
+constexpr int KC_FG = 4 * KC_FW;         // features per workgroup (20 = 5 float4)
+constexpr int KC_G_LD = KC_FG + 1;       // LDS row stride of the group tile
+__global__ __launch_bounds__(256) void km_chunk_fold_kernel(const float *__restrict__ pool, int C, const int32_t *__restrict__ seg_off,
+                                                             const int32_t *__restrict__ counts, const int32_t *__restrict__ cbase,
+                                                             const uint32_t *__restrict__ moff, int kmax,
+                                                             const int32_t *__restrict__ owner_cluster, const int32_t *__restrict__ owner_local,
+                                                             int8_t *__restrict__ cexp, int32_t *__restrict__ cinc0, int32_t *__restrict__ cinc1) {
+    __shared__ float tile[2][64 * KC_G_LD];
+    __shared__ uint32_t loffs[KS_CHUNK];
+    const int chunk = blockIdx.x, grp = blockIdx.y;
+    const int oc = owner_cluster[chunk];
+    if (oc < 0) return;
+    const int f0 = grp * KC_FG;
+    const int s = oc / kmax;
+    const int cnt = counts[oc];
+    const uint32_t *list = moff + seg_off[s] + cbase[oc];
+    const int first = owner_local[chunk] * KS_CHUNK;
+    const int lane = aoc_lane(), wave = threadIdx.x >> 6;
+    const int members = min(KS_CHUNK, cnt - first);
+    const int nblk = (members + 63) / 64;
+
+    KcFold k[KC_FW];
+    float inv_u[KC_FW];
+    bool live[KC_FW];
+    bool any_live = false;
+#pragma unroll
+    for (int i = 0; i < KC_FW; ++i) {
+        const int f = f0 + wave * KC_FW + i;
+        int e = KC_UNSAFE;
+        if (f < C) e = cexp[(size_t)chunk * C + f];
+        live[i] = e != KC_UNSAFE;
+        inv_u[i] = __uint_as_float((uint32_t)(23 - (live[i] ? e : 0) + 127) << 23);
+        k[i].acc = 0; k[i].par0 = 0; k[i].par1 = 1; k[i].bump0 = 0; k[i].bump1 = 0; k[i].bad = 0;
+        any_live |= live[i];
+    }
+    // does any wave of the block have a live feature?  (uniform per block: all features of the group are read by every thread)
+    bool block_live = false;
+    for (int f = f0; f < min(C, f0 + KC_FG); ++f) block_live |= (cexp[(size_t)chunk * C + f] != KC_UNSAFE);
+    if (!block_live) return;
+
+    for (int i = threadIdx.x; i < KS_CHUNK; i += blockDim.x) loffs[i] = (i < members) ? list[first + i] : 0u;
+    __syncthreads();
+    // staging: 64 rows x (KC_FG / 4) float4 = 320 pieces per block; thread t takes pieces t and t + 256
+    const int npiece = KC_FG / 4;
+    auto issue = [&](int blk, float4 (&v)[2]) {
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int idx = it * 256 + threadIdx.x;
+            const int mloc = idx / npiece, piece = idx - mloc * npiece;
+            const int m = blk * 64 + mloc;
+            const bool in = idx < 64 * npiece && m < members && f0 + piece * 4 < C;
+            v[it] = in ? *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(pool) + loffs[in ? m : 0] + (f0 + piece * 4) * 4)
+                       : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto commit = [&](int buf, const float4 (&v)[2]) {
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int idx = it * 256 + threadIdx.x;
+            if (idx < 64 * npiece) {
+                const int mloc = idx / npiece, piece = idx - mloc * npiece;
+                float *d = tile[buf] + mloc * KC_G_LD + piece * 4;
+                d[0] = v[it].x; d[1] = v[it].y; d[2] = v[it].z; d[3] = v[it].w;
+            }
+        }
+    };
+    float4 v[2];
+    issue(0, v);
+    commit(0, v);
+    for (int b = 0; b < nblk; ++b) {
+        if (b + 1 < nblk) issue(b + 1, v);            // in flight under this block's folds
+        __syncthreads();                              // tile[b & 1] complete
+        if (any_live) {
+#pragma unroll
+            for (int i = 0; i < KC_FW; ++i)
+                if (live[i]) kc_fold_block2(tile[b & 1][lane * KC_G_LD + wave * KC_FW + i], inv_u[i], k[i]);
+        }
+        if (b + 1 < nblk) commit((b + 1) & 1, v);     // the other buffer was last read two iterations ago
+    }
+#pragma unroll
+    for (int i = 0; i < KC_FW; ++i) {
+        if (live[i]) {
+            const int f = f0 + wave * KC_FW + i;
+            const int t = ks_wave_sum(k[i].acc);
+            if (lane == 0) {
+                if (k[i].bad) cexp[(size_t)chunk * C + f] = (int8_t)KC_UNSAFE;
+                cinc0[(size_t)chunk * C + f] = t + k[i].bump0;
+                cinc1[(size_t)chunk * C + f] = t + k[i].bump1;
+            }
+        }
+    }
+}
+
+// Serial stitch, one wave per (cluster, 4 features).
 // MODE 0: centroids[s,j,4q..4q+3] = ordered sum / count (empty cluster untouched, vq.py:820-823)
 // MODE 1: proxies[s,1,j,4q..] = mean of the listed rows (AEM:280), zeros when empty
-// The member rows stream through registers in chunks of KS_T blocks with a 3-stage software pipeline
-// (offsets of chunk c+2, rows of chunk c+1, arithmetic on chunk c): addresses never depend on the
-// running sums, so memory latency stays off the serial chain and a redo never reloads anything.
+// For every chunk the wave first tries the chunk's summary (predicted binade e, integer increments for both
+// parities): it applies iff the EXACT running sum is in binade e and n stays below 2^24 -- then all members
+// of the chunk were added in that binade and the summary is the exact result.  Otherwise (first chunk, binade
+// crossing, unusable summary) the chunk's rows are folded block by block, with the literal serial additions
+// where a block itself crosses.  Summaries of 64 chunks sit in registers (v_readlane), rows of the next chunk
+// that will need them are prefetched, so memory latency stays off the chain.
 struct KsChunk {
     u32x4 x[KS_T];
 };
@@ -691,7 +1026,9 @@ template <int MODE>
 __global__ __launch_bounds__(64) void km_sum_scan_kernel(const float *__restrict__ pool, uint32_t pool_bytes, int C,
                                                           const int32_t *__restrict__ seg_off, const int32_t *__restrict__ seg_k,
                                                           const int32_t *__restrict__ counts, const int32_t *__restrict__ cbase,
-                                                          const uint32_t *__restrict__ moff, int kmax, float *__restrict__ dst) {
+                                                          const uint32_t *__restrict__ moff, int kmax, float *__restrict__ dst,
+                                                          const int32_t *__restrict__ cchunk, const int8_t *__restrict__ cexp,
+                                                          const int32_t *__restrict__ cinc0, const int32_t *__restrict__ cinc1) {
     const int s = blockIdx.z, j = blockIdx.y, q = blockIdx.x;
     if (j >= seg_k[s]) return;
     const int cnt = counts[s * kmax + j];
@@ -701,113 +1038,126 @@ __global__ __launch_bounds__(64) void km_sum_scan_kernel(const float *__restrict
         if (MODE == 1 && lane == 0) *reinterpret_cast<float4 *>(out) = make_float4(0.f, 0.f, 0.f, 0.f);
         return;
     }
+    const bool have_summ = cexp != nullptr;
+    const size_t srow = have_summ ? ((size_t)cchunk[s * kmax + j] * C + 4 * q) : 0;
     const uint32_t *list = moff + seg_off[s] + cbase[s * kmax + j];
     __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(pool), 0, pool_bytes, 0x00020000);
     const uint32_t qoff = (uint32_t)q * 16u;
-    const int n_chunks = (cnt + 64 * KS_T - 1) / (64 * KS_T);
+    const int n_chunks = (cnt + KS_CHUNK - 1) / KS_CHUNK;
 
-    auto load_offsets = [&](int c, uint32_t (&o)[KS_T]) {
+    auto fetch_rows = [&](int c, KsChunk &ch) {
+        uint32_t o[KS_T];
 #pragma unroll
         for (int b = 0; b < KS_T; ++b) {
             const int m = (c * KS_T + b) * 64 + lane;
-            o[b] = (c < n_chunks && m < cnt) ? list[m] + qoff : KU_INVALID_OFF;
+            o[b] = (m < cnt) ? list[m] + qoff : KU_INVALID_OFF;
         }
-    };
-    auto load_rows = [&](const uint32_t (&o)[KS_T], KsChunk &ch) {
 #pragma unroll
         for (int b = 0; b < KS_T; ++b) ch.x[b] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o[b], 0, 0);
     };
 
-    uint32_t off_a[KS_T], off_b[KS_T];
-    KsChunk cur, nxt;
-    load_offsets(0, off_a);
-    load_offsets(1, off_b);
-    load_rows(off_a, cur);
+    // summaries of chunks [batch0, batch0 + 64) in registers (lane l = chunk batch0 + l), next batch prefetched
+    uint32_t se4 = 0x80808080u, ne4 = 0x80808080u;
+    int4 si0 = make_int4(0, 0, 0, 0), si1 = make_int4(0, 0, 0, 0), ni0 = si0, ni1 = si0;
+    int batch0 = 0;
+    unsigned long long need_cur = ~0ull, need_next = ~0ull;
+    auto unsafe4 = [](uint32_t e4) -> bool {
+        const uint32_t u = (uint32_t)(uint8_t)KC_UNSAFE;
+        return ((e4 & 0xff) == u) || (((e4 >> 8) & 0xff) == u) || (((e4 >> 16) & 0xff) == u) || ((e4 >> 24) == u);
+    };
+    auto fetch_batch = [&](int b0, uint32_t &e4, int4 &i0, int4 &i1) {
+        const int c = b0 + lane;
+        e4 = 0x80808080u;
+        if (have_summ && c < n_chunks) {
+            e4 = *reinterpret_cast<const uint32_t *>(cexp + srow + (size_t)c * C);
+            i0 = *reinterpret_cast<const int4 *>(cinc0 + srow + (size_t)c * C);
+            i1 = *reinterpret_cast<const int4 *>(cinc1 + srow + (size_t)c * C);
+        }
+    };
+    if (have_summ) {
+        fetch_batch(0, se4, si0, si1);
+        fetch_batch(64, ne4, ni0, ni1);
+        need_cur = __ballot(unsafe4(se4));
+        need_next = __ballot(unsafe4(ne4));
+    }
+    // first chunk >= from (inside the two known batches) whose rows will be needed; n_chunks if none is known
+    auto next_needed = [&](int from) -> int {
+        int d = from - batch0;
+        if (d < 64) {
+            const unsigned long long m = need_cur & (~0ull << d);
+            if (m) return min(n_chunks, batch0 + __builtin_ctzll(m));
+            d = 64;
+        }
+        if (d < 128) {
+            const unsigned long long m = need_next & (~0ull << (d - 64));
+            if (m) return min(n_chunks, batch0 + 64 + __builtin_ctzll(m));
+        }
+        return n_chunks;
+    };
 
     float st[4] = {0.f, 0.f, 0.f, 0.f};
-    int t_cur = 1;                       // blocks folded per attempt: doubles after a success, back to 1 after a miss
+    KsChunk cur, nxt;
+    int pending = next_needed(0);
+    if (pending < n_chunks) fetch_rows(pending, nxt);
+
     for (int c = 0; c < n_chunks; ++c) {
-        load_rows(off_b, nxt);           // rows of chunk c+1 (their offsets were loaded one iteration ago)
-        load_offsets(c + 2, off_a);      // offsets of chunk c+2
-        const int blocks_here = min(KS_T, (cnt - c * KS_T * 64 + 63) / 64);
-        for (int b0 = 0; b0 < blocks_here;) {
-            const int nblk = min(t_cur, blocks_here - b0);
-            // ---- optimistic pass: fold blocks [b0, b0 + nblk) in the integer domain of each feature's binade
-            KsBinade bin[4];
-            int accr[4] = {0, 0, 0, 0}, par[4];
-            unsigned long long bad[4] = {0ull, 0ull, 0ull, 0ull};
-#pragma unroll
-            for (int f = 0; f < 4; ++f) { bin[f] = ks_binade(st[f]); par[f] = bin[f].n_in & 1; }
-#pragma unroll
-            for (int b = 0; b < KS_T; ++b) {
-                if (b >= b0 && b < b0 + nblk) {
-                    const float xv[4] = {__uint_as_float(cur.x[b].x), __uint_as_float(cur.x[b].y), __uint_as_float(cur.x[b].z), __uint_as_float(cur.x[b].w)};
-#pragma unroll
-                    for (int f = 0; f < 4; ++f)
-#if defined(AOC_KS_EXP) && AOC_KS_EXP >= 2
-                        accr[f] += (int)xv[f];   // EXPERIMENT: no fold arithmetic
-#else
-                        if (bin[f].ok) ks_fold_block(xv[f], bin[f].inv_u, lane, accr[f], par[f], bad[f]);
-#endif
-                }
+        if (have_summ && c - batch0 >= 64) {                  // advance to the prefetched batch, prefetch the one after
+            batch0 += 64;
+            se4 = ne4; si0 = ni0; si1 = ni1;
+            need_cur = need_next;
+            fetch_batch(batch0 + 64, ne4, ni0, ni1);
+            need_next = __ballot(unsafe4(ne4));
+            if (pending >= n_chunks) {                        // nothing was known to be needed: look again
+                pending = next_needed(c);
+                if (pending < n_chunks) fetch_rows(pending, nxt);
             }
-            bool redo[4];
+        }
+        bool skip[4] = {false, false, false, false};
+        if (have_summ) {
+            const int l = c - batch0;
+            const uint32_t e4 = __builtin_amdgcn_readlane(se4, l);
+            const int inc0[4] = {__builtin_amdgcn_readlane(si0.x, l), __builtin_amdgcn_readlane(si0.y, l), __builtin_amdgcn_readlane(si0.z, l),
+                                 __builtin_amdgcn_readlane(si0.w, l)};
+            const int inc1[4] = {__builtin_amdgcn_readlane(si1.x, l), __builtin_amdgcn_readlane(si1.y, l), __builtin_amdgcn_readlane(si1.z, l),
+                                 __builtin_amdgcn_readlane(si1.w, l)};
 #pragma unroll
             for (int f = 0; f < 4; ++f) {
-                redo[f] = true;
-                if (bin[f].ok) {
-                    const int total = ks_wave_sum(accr[f]);
-                    const bool anybad = bad[f] != 0ull;
-                    const long long n_out = (long long)bin[f].n_in + total;
-                    if (!anybad && n_out <= 0xFFFFFF) {
-                        st[f] = (float)(int)n_out * bin[f].u;      // exact: integer < 2^24 times a power of two
-                        redo[f] = false;
+                const int e = (int)(int8_t)((e4 >> (8 * f)) & 0xff);
+                const KsBinade bb = ks_binade(st[f]);
+                const int ecur = (int)((__float_as_uint(st[f]) >> 23) & 0xff) - 127;
+                if (e != KC_UNSAFE && bb.ok && ecur == e) {           // prediction verified against the exact sum
+                    const long long n_out = (long long)bb.n_in + ((bb.n_in & 1) ? inc1[f] : inc0[f]);
+                    if (n_out <= 0xFFFFFF) {                          // n never left the binade inside the chunk
+                        st[f] = (float)(int)n_out * bb.u;
+                        skip[f] = true;
                     }
                 }
-#if defined(AOC_KS_EXP) && AOC_KS_EXP >= 1
-                if (redo[f]) { st[f] = st[f] + 1.0f; redo[f] = false; }   // EXPERIMENT: never take the careful path (wrong results)
-#endif
-                KS_STAT(redo[f] ? 2 : 1, nblk);
             }
-            KS_STAT(0, 1);
-            // ---- careful pass for the features that could not be folded: block by block, serial where needed
-            if (redo[0] || redo[1] || redo[2] || redo[3]) {
-#pragma unroll
-                for (int b = 0; b < KS_T; ++b) {
-                    if (b >= b0 && b < b0 + nblk) {
-                        const float xv[4] = {__uint_as_float(cur.x[b].x), __uint_as_float(cur.x[b].y), __uint_as_float(cur.x[b].z), __uint_as_float(cur.x[b].w)};
-#pragma unroll
-                        for (int f = 0; f < 4; ++f) {
-                            if (!redo[f]) continue;
-                            const KsBinade bb = ks_binade(st[f]);
-                            bool done = false;
-                            if (bb.ok) {
-                                int a = 0, pr = bb.n_in & 1;
-                                unsigned long long bd = 0ull;
-                                ks_fold_block(xv[f], bb.inv_u, lane, a, pr, bd);
-                                const int total = ks_wave_sum(a);
-                                const long long n_out = (long long)bb.n_in + total;
-                                if (bd == 0ull && n_out <= 0xFFFFFF) {
-                                    st[f] = (float)(int)n_out * bb.u;
-                                    done = true;
-                                }
-                            }
-                            KS_STAT(done ? 3 : 4, 1);
-                            if (!done) st[f] = ks_serial_block(st[f], xv[f]);
-                        }
-                    }
-                }
-                t_cur = 1;
-            } else {
-                t_cur = min(KS_T, t_cur * 2);
-            }
-            b0 += nblk;
+            KS_STAT(5, (skip[0] ? 1 : 0) + (skip[1] ? 1 : 0) + (skip[2] ? 1 : 0) + (skip[3] ? 1 : 0));
         }
-        // rotate the pipeline registers
-        cur = nxt;
+        if (skip[0] && skip[1] && skip[2] && skip[3]) continue;
+        // ---- this chunk needs its rows
+        if (pending == c) {
+            cur = nxt;
+        } else {
+            fetch_rows(c, cur);                                        // not prefetched (mispredicted summary): rare
+            KS_STAT(6, 1);
+        }
+        pending = next_needed(c + 1);
+        if (pending < n_chunks) fetch_rows(pending, nxt);              // in flight while this chunk is folded
+        const int blocks_here = min(KS_T, (cnt - c * KS_CHUNK + 63) / 64);
 #pragma unroll
-        for (int b = 0; b < KS_T; ++b) { const uint32_t t = off_a[b]; off_a[b] = off_b[b]; off_b[b] = t; }
-        // after the swap: off_b holds chunk c+2's offsets (needed next iteration), off_a is free
+        for (int b = 0; b < KS_T; ++b) {
+            if (b < blocks_here) {
+                const float xv[4] = {__uint_as_float(cur.x[b].x), __uint_as_float(cur.x[b].y), __uint_as_float(cur.x[b].z), __uint_as_float(cur.x[b].w)};
+#pragma unroll
+                for (int f = 0; f < 4; ++f) {
+                    if (skip[f]) continue;
+                    st[f] = ks_block_exact(st[f], xv[f], lane);
+                    KS_STAT(3, 1);
+                }
+            }
+        }
     }
     if (lane == 0) {
         const float fc = (float)cnt;
@@ -854,11 +1204,19 @@ struct KsWorkspace {
     int32_t *hist, *blockoff, *counts, *cbase;
     uint32_t *moff;
     int nb_max;
+    // chunk summaries
+    int nch_cap;
+    int32_t *cchunk, *owner_cluster, *owner_local, *cinc0, *cinc1;
+    float *csum;
+    int8_t *cexp;
 };
+inline int ks_chunk_capacity(int64_t cap, int n_seg, int kmax) { return (int)(cap / KS_CHUNK) + n_seg * (kmax + 1) + 2; }
 inline size_t ks_workspace_bytes(int64_t cap, int n_seg, int kmax) {
     const size_t nb = (size_t)(cap + 255) / 256 + 1;
+    const size_t nch = (size_t)ks_chunk_capacity(cap, n_seg, kmax);
     return aoc_align_up((size_t)cap * 4, 256) + aoc_align_up((size_t)cap * 2, 256) + 2 * aoc_align_up((size_t)n_seg * nb * kmax * 4, 256) +
-           2 * aoc_align_up((size_t)n_seg * kmax * 4, 256) + aoc_align_up(((size_t)cap + 64) * 4, 256);
+           3 * aoc_align_up((size_t)n_seg * kmax * 4, 256) + aoc_align_up(((size_t)cap + 64) * 4, 256) + 2 * aoc_align_up(nch * 4, 256) +
+           3 * aoc_align_up(nch * AOC_MAX_CHANNELS / 2 * 4, 256) + aoc_align_up(nch * AOC_MAX_CHANNELS / 2, 256);
 }
 inline KsWorkspace ks_carve(void *workspace, int64_t cap, int n_seg, int kmax) {
     KsWorkspace w;
@@ -871,7 +1229,16 @@ inline KsWorkspace ks_carve(void *workspace, int64_t cap, int n_seg, int kmax) {
     w.blockoff = reinterpret_cast<int32_t *>(p); p += aoc_align_up((size_t)n_seg * nb * kmax * 4, 256);
     w.counts = reinterpret_cast<int32_t *>(p); p += aoc_align_up((size_t)n_seg * kmax * 4, 256);
     w.cbase = reinterpret_cast<int32_t *>(p); p += aoc_align_up((size_t)n_seg * kmax * 4, 256);
-    w.moff = reinterpret_cast<uint32_t *>(p);
+    w.cchunk = reinterpret_cast<int32_t *>(p); p += aoc_align_up((size_t)n_seg * kmax * 4, 256);
+    w.moff = reinterpret_cast<uint32_t *>(p); p += aoc_align_up(((size_t)cap + 64) * 4, 256);
+    const size_t nch = (size_t)ks_chunk_capacity(cap, n_seg, kmax);
+    w.nch_cap = (int)nch;
+    w.owner_cluster = reinterpret_cast<int32_t *>(p); p += aoc_align_up(nch * 4, 256);
+    w.owner_local = reinterpret_cast<int32_t *>(p); p += aoc_align_up(nch * 4, 256);
+    w.csum = reinterpret_cast<float *>(p); p += aoc_align_up(nch * AOC_MAX_CHANNELS / 2 * 4, 256);
+    w.cinc0 = reinterpret_cast<int32_t *>(p); p += aoc_align_up(nch * AOC_MAX_CHANNELS / 2 * 4, 256);
+    w.cinc1 = reinterpret_cast<int32_t *>(p); p += aoc_align_up(nch * AOC_MAX_CHANNELS / 2 * 4, 256);
+    w.cexp = reinterpret_cast<int8_t *>(p);
     return w;
 }
 
@@ -969,11 +1336,16 @@ int aoc_kmeans_segmented_ex(const float *pool, int64_t pool_rows, int C, const i
                 hipLaunchKernelGGL(km_assign_rank_kernel<32>, agrid, dim3(256), lds_fast, st, pool, C, rows, seg_offsets, seg_k, centroids, kmax, labels,
                                    ws.rank16, ws.hist, ws.nb_max, rownorm, first);
             hipLaunchKernelGGL(km_blockscan_kernel, dim3(n_seg), dim3(1024), 0, st, seg_offsets, seg_k, ws.hist, ws.blockoff, ws.nb_max, kmax,
-                               cluster_counts, ws.cbase);
+                               cluster_counts, ws.cbase, ws.cchunk, ws.owner_cluster, ws.owner_local, ws.nch_cap);
             hipLaunchKernelGGL(km_scatter_kernel, agrid, dim3(256), 0, st, rows, (const int32_t *)nullptr, seg_offsets, seg_k, labels, ws.rank16,
                                ws.blockoff, ws.cbase, ws.nb_max, kmax, (uint32_t)C * 4u, ws.moff);
+            hipLaunchKernelGGL(km_chunk_sum_kernel, dim3(ws.nch_cap), dim3(256), 0, st, pool, C, seg_offsets, cluster_counts, ws.cbase, ws.moff, kmax,
+                               ws.owner_cluster, ws.owner_local, ws.csum);
+            hipLaunchKernelGGL(km_chunk_predict_kernel, dim3(kmax, n_seg), dim3(128), 0, st, seg_k, cluster_counts, ws.cchunk, ws.csum, kmax, C, ws.cexp);
+            hipLaunchKernelGGL(km_chunk_fold_kernel, dim3(ws.nch_cap, (C + KC_FG - 1) / KC_FG), dim3(256), 0, st, pool, C, seg_offsets, cluster_counts, ws.cbase, ws.moff, kmax,
+                               ws.owner_cluster, ws.owner_local, ws.cexp, ws.cinc0, ws.cinc1);
             hipLaunchKernelGGL(km_sum_scan_kernel<0>, dim3(C / 4, kmax, n_seg), dim3(64), 0, st, pool, pool_bytes, C, seg_offsets, seg_k,
-                               cluster_counts, ws.cbase, ws.moff, kmax, centroids);
+                               cluster_counts, ws.cbase, ws.moff, kmax, centroids, ws.cchunk, ws.cexp, ws.cinc0, ws.cinc1);
             continue;
         }
         if ((C % 4) == 0 && C <= 100)
@@ -1011,11 +1383,21 @@ int aoc_build_proxies(const float *pool, int64_t pool_rows, int C, const int32_t
         KsWorkspace ws = ks_carve(workspace, rows_capacity, n_seg, kmax);
         const dim3 agrid((unsigned)((rows_capacity + 255) / 256), (unsigned)n_seg);
         hipLaunchKernelGGL(km_rank_only_kernel, agrid, dim3(256), 0, st, seg_offsets, seg_k, labels, kmax, ws.rank16, ws.hist, ws.nb_max);
-        hipLaunchKernelGGL(km_blockscan_kernel, dim3(n_seg), dim3(1024), 0, st, seg_offsets, seg_k, ws.hist, ws.blockoff, ws.nb_max, kmax, ws.counts, ws.cbase);
+        hipLaunchKernelGGL(km_blockscan_kernel, dim3(n_seg), dim3(1024), 0, st, seg_offsets, seg_k, ws.hist, ws.blockoff, ws.nb_max, kmax, ws.counts, ws.cbase,
+                           ws.cchunk, ws.owner_cluster, ws.owner_local, ws.nch_cap);
         hipLaunchKernelGGL(km_scatter_kernel, agrid, dim3(256), 0, st, (const int32_t *)nullptr, fg_rows, seg_offsets, seg_k, labels, ws.rank16,
                            ws.blockoff, ws.cbase, ws.nb_max, kmax, (uint32_t)C * 4u, ws.moff);
+        const bool summ = C <= 128;
+        if (summ) {
+            hipLaunchKernelGGL(km_chunk_sum_kernel, dim3(ws.nch_cap), dim3(256), 0, st, pool, C, seg_offsets, ws.counts, ws.cbase, ws.moff, kmax,
+                               ws.owner_cluster, ws.owner_local, ws.csum);
+            hipLaunchKernelGGL(km_chunk_predict_kernel, dim3(kmax, n_seg), dim3(128), 0, st, seg_k, ws.counts, ws.cchunk, ws.csum, kmax, C, ws.cexp);
+            hipLaunchKernelGGL(km_chunk_fold_kernel, dim3(ws.nch_cap, (C + KC_FG - 1) / KC_FG), dim3(256), 0, st, pool, C, seg_offsets, ws.counts, ws.cbase, ws.moff, kmax,
+                               ws.owner_cluster, ws.owner_local, ws.cexp, ws.cinc0, ws.cinc1);
+        }
         hipLaunchKernelGGL(km_sum_scan_kernel<1>, dim3(C / 4, kmax, n_seg), dim3(64), 0, st, pool, (uint32_t)((uint64_t)pool_rows * C * 4), C, seg_offsets,
-                           seg_k, ws.counts, ws.cbase, ws.moff, kmax, proxies);
+                           seg_k, ws.counts, ws.cbase, ws.moff, kmax, proxies, summ ? ws.cchunk : (const int32_t *)nullptr,
+                           summ ? ws.cexp : (const int8_t *)nullptr, ws.cinc0, ws.cinc1);
         hipLaunchKernelGGL(km_proxy_finish_kernel, grid, dim3(64), 0, st, centroids, seg_k, ws.counts, kmax, C, proxies, proxy_sqnorm);
         AOC_RETURN_IF_LAUNCH_FAILED();
         return AOC_OK;

@@ -26,7 +26,7 @@ L.aoc_debug_ks_stats(buf, 1)
 cp = aoc_amd.matching.cluster_proxies(emb, lab)
 torch.cuda.synchronize()
 L.aoc_debug_ks_stats(buf, 0)
-names = ["attempts", "folded feature-blocks", "missed feature-blocks", "careful ok", "serial blocks"]
+names = ["attempts", "folded feature-blocks", "missed feature-blocks", "careful ok", "serial blocks", "chunk summaries applied (feature-chunks)", "unprefetched chunk reloads"]
 print("R =", R, "rows", emb.shape[0], "counts", cp["counts"], "max cluster", int(cp["cluster_counts"].max()))
 for n, v in zip(names, list(buf)): print(f"{n:24s} {v}")
 t0 = torch.cuda.Event(True); t1 = torch.cuda.Event(True)
