@@ -24,15 +24,19 @@ __global__ __launch_bounds__(256) void fg2bg_kernel(const float *__restrict__ di
 }
 
 // ------------------------------------------------------------------------------------------ pooling
-constexpr int MP_PIX = 512;      // pixels per block
+constexpr int MP_PIX = 128;      // pixels per block
 constexpr int MP_OMAX = 32;
+constexpr int MP_SPLIT = 4;      // pixel sub-ranges per block (threads = MP_SPLIT x 64 channel lanes)
 
 // partial[blk][o][c] = sum_{p in chunk} emb[p,c] * lab[o,p]  (o < O), partial[blk][O][c] = sum emb[p,c];
-// pcount[blk][o] = sum lab[o,p].   emb [F, hw, C] channel-last, lab [F, O, hw].
-__global__ __launch_bounds__(128) void masked_pool_partial_kernel(const float *__restrict__ emb, const float *__restrict__ lab,
+// pcount[blk][o] = sum lab[o,p].   emb [F, hw, C] channel-last, lab [F, O, hw] (or [F, hw, O] pixel-major).
+// Block = 256 threads = MP_SPLIT pixel sub-ranges x 64 channel lanes (lane handles channels c, c+64, ...);
+// loads are coalesced along channels and unrolled along pixels for memory-level parallelism.
+__global__ __launch_bounds__(256) void masked_pool_partial_kernel(const float *__restrict__ emb, const float *__restrict__ lab,
                                                                    int64_t hw, int C, int n_obj, int chunks_per_frame, int pixel_major,
                                                                    float *__restrict__ partial, float *__restrict__ pcount) {
-    extern __shared__ float llab[];   // [n_obj][MP_PIX]
+    extern __shared__ float llab[];   // [n_obj][MP_PIX] labels, then [MP_SPLIT][(n_obj+1)][64] combine buffer
+    float *lcomb = llab + n_obj * MP_PIX;
     const int f = blockIdx.x / chunks_per_frame, chunk = blockIdx.x - f * chunks_per_frame;
     const int64_t p0 = (int64_t)chunk * MP_PIX;
     const int np = (int)min((int64_t)MP_PIX, hw - p0);
@@ -41,54 +45,105 @@ __global__ __launch_bounds__(128) void masked_pool_partial_kernel(const float *_
         llab[i] = (p >= np) ? 0.0f : (pixel_major ? lab[((size_t)f * hw + p0 + p) * n_obj + o] : lab[((size_t)f * n_obj + o) * hw + p0 + p]);
     }
     __syncthreads();
+    const int lane = threadIdx.x & 63, sub = threadIdx.x >> 6;
+    const int pb = sub * (MP_PIX / MP_SPLIT), pe = min(np, pb + MP_PIX / MP_SPLIT);
     const float *e = emb + ((size_t)f * hw + p0) * C;
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    for (int c0 = 0; c0 < C; c0 += 64) {
+        const int c = c0 + lane;
         float acc[MP_OMAX + 1];
 #pragma unroll
         for (int o = 0; o <= MP_OMAX; ++o) acc[o] = 0.0f;
-        for (int p = 0; p < np; ++p) {
-            const float v = e[(size_t)p * C + c];
-            acc[MP_OMAX] += v;
+        if (c < C) {
+            for (int p = pb; p < pe; p += 8) {
+                float v[8];
 #pragma unroll
-            for (int o = 0; o < MP_OMAX; ++o)
-                if (o < n_obj) acc[o] += v * llab[o * MP_PIX + p];
+                for (int u = 0; u < 8; ++u) v[u] = (p + u < pe) ? e[(size_t)(p + u) * C + c] : 0.0f;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    acc[MP_OMAX] += v[u];
+#pragma unroll
+                    for (int o = 0; o < MP_OMAX; ++o)
+                        if (o < n_obj) acc[o] += v[u] * llab[o * MP_PIX + min(p + u, MP_PIX - 1)];
+                }
+            }
         }
+        // combine the MP_SPLIT sub-ranges in a fixed order (deterministic)
+        __syncthreads();
 #pragma unroll
         for (int o = 0; o < MP_OMAX; ++o)
-            if (o < n_obj) partial[((size_t)blockIdx.x * (n_obj + 1) + o) * C + c] = acc[o];
-        partial[((size_t)blockIdx.x * (n_obj + 1) + n_obj) * C + c] = acc[MP_OMAX];
+            if (o < n_obj) lcomb[(sub * (n_obj + 1) + o) * 64 + lane] = acc[o];
+        lcomb[(sub * (n_obj + 1) + n_obj) * 64 + lane] = acc[MP_OMAX];
+        __syncthreads();
+        if (sub == 0 && c < C) {
+            for (int o = 0; o <= n_obj; ++o) {
+                float t = 0.0f;
+                for (int q = 0; q < MP_SPLIT; ++q) t += lcomb[(q * (n_obj + 1) + o) * 64 + lane];
+                partial[((size_t)blockIdx.x * (n_obj + 1) + o) * C + c] = t;
+            }
+        }
     }
-    if (threadIdx.x < n_obj) {
+    if ((int)threadIdx.x < n_obj) {
         float s = 0.0f;
         for (int p = 0; p < np; ++p) s += llab[threadIdx.x * MP_PIX + p];
         pcount[(size_t)blockIdx.x * n_obj + threadIdx.x] = s;
     }
 }
 
-__global__ __launch_bounds__(128) void masked_pool_final_kernel(const float *__restrict__ partial, const float *__restrict__ pcount,
-                                                                 int n_blocks, int C, int n_obj, float total_pixels, float eps,
-                                                                 float *__restrict__ out_pos, float *__restrict__ out_neg,
-                                                                 float *__restrict__ out_pos_sqnorm) {
-    __shared__ float wsum[2];
+// block = object; 1024 threads = 8 slices of the partial blocks x 128 channel lanes; fixed combine order
+__global__ __launch_bounds__(1024) void masked_pool_final_kernel(const float *__restrict__ partial, const float *__restrict__ pcount,
+                                                                  int n_blocks, int C, int n_obj, float total_pixels, float eps,
+                                                                  float *__restrict__ out_pos, float *__restrict__ out_neg,
+                                                                  float *__restrict__ out_pos_sqnorm) {
+    __shared__ float lpos[8][128], ltot[8][128], lcnt[8], lsq[2];
     const int o = blockIdx.x;
-    float cnt = 0.0f;
-    for (int b = 0; b < n_blocks; ++b) cnt += pcount[(size_t)b * n_obj + o];
-    float sq = 0.0f;
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        float pos = 0.0f, tot = 0.0f;
-        for (int b = 0; b < n_blocks; ++b) {
-            pos += partial[((size_t)b * (n_obj + 1) + o) * C + c];
-            tot += partial[((size_t)b * (n_obj + 1) + n_obj) * C + c];
-        }
-        const float pv = pos / (cnt + eps);                                         // ATT:173
-        out_pos[(size_t)o * C + c] = pv;
-        out_neg[(size_t)o * C + c] = (tot - pos) / ((total_pixels - cnt) + eps);    // ATT:166,174
-        sq += pv * pv;
+    const int cl = threadIdx.x & 127, slice = threadIdx.x >> 7;
+    const int per = (n_blocks + 7) / 8;
+    const int b0 = slice * per, b1 = min(n_blocks, b0 + per);
+    if (cl == 0) {
+        float cnt = 0.0f;
+        for (int b = b0; b < b1; ++b) cnt += pcount[(size_t)b * n_obj + o];
+        lcnt[slice] = cnt;
     }
-    sq = aoc_wave_sum(sq);
-    if (aoc_lane() == 0) wsum[threadIdx.x >> 6] = sq;
+    float sq = 0.0f;
+    for (int c0 = 0; c0 < C; c0 += 128) {
+        const int c = c0 + cl;
+        float pos = 0.0f, tot = 0.0f;
+        if (c < C) {
+            int b = b0;
+            for (; b + 4 <= b1; b += 4) {
+                float p[4], t[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    p[u] = partial[((size_t)(b + u) * (n_obj + 1) + o) * C + c];
+                    t[u] = partial[((size_t)(b + u) * (n_obj + 1) + n_obj) * C + c];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { pos += p[u]; tot += t[u]; }
+            }
+            for (; b < b1; ++b) {
+                pos += partial[((size_t)b * (n_obj + 1) + o) * C + c];
+                tot += partial[((size_t)b * (n_obj + 1) + n_obj) * C + c];
+            }
+        }
+        __syncthreads();
+        lpos[slice][cl] = pos;
+        ltot[slice][cl] = tot;
+        __syncthreads();
+        if (slice == 0 && c < C) {
+            float cnt = 0.0f, ps = 0.0f, ts = 0.0f;
+            for (int q = 0; q < 8; ++q) { cnt += lcnt[q]; ps += lpos[q][cl]; ts += ltot[q][cl]; }
+            const float pv = ps / (cnt + eps);                                         // ATT:173
+            out_pos[(size_t)o * C + c] = pv;
+            out_neg[(size_t)o * C + c] = (ts - ps) / ((total_pixels - cnt) + eps);     // ATT:166,174
+            sq += pv * pv;
+        }
+    }
+    if (slice == 0) {
+        sq = aoc_wave_sum(sq);
+        if (aoc_lane() == 0) lsq[threadIdx.x >> 6] = sq;
+    }
     __syncthreads();
-    if (threadIdx.x == 0 && out_pos_sqnorm) out_pos_sqnorm[o] = wsum[0] + wsum[1];
+    if (threadIdx.x == 0 && out_pos_sqnorm) out_pos_sqnorm[o] = lsq[0] + lsq[1];
 }
 
 // ------------------------------------------------------------------------------------------ FiLM
@@ -283,8 +338,8 @@ int aoc_masked_mean_pool(const float *emb, const float *labels, int n_frames, in
     const int nb = n_frames * cpf;
     float *partial = static_cast<float *>(workspace);
     float *pcount = reinterpret_cast<float *>(static_cast<char *>(workspace) + aoc_align_up((size_t)nb * (n_obj + 1) * C * sizeof(float), 256));
-    hipLaunchKernelGGL(masked_pool_partial_kernel, dim3(nb), dim3(128), (size_t)n_obj * MP_PIX * sizeof(float), st, emb, labels, hw, C, n_obj, cpf, labels_pixel_major, partial, pcount);
-    hipLaunchKernelGGL(masked_pool_final_kernel, dim3(n_obj), dim3(128), 0, st, partial, pcount, nb, C, n_obj, (float)((double)hw * n_frames), epsilon, out_pos, out_neg, out_pos_sqnorm);
+    hipLaunchKernelGGL(masked_pool_partial_kernel, dim3(nb), dim3(256), ((size_t)n_obj * MP_PIX + (size_t)MP_SPLIT * (n_obj + 1) * 64) * sizeof(float), st, emb, labels, hw, C, n_obj, cpf, labels_pixel_major, partial, pcount);
+    hipLaunchKernelGGL(masked_pool_final_kernel, dim3(n_obj), dim3(1024), 0, st, partial, pcount, nb, C, n_obj, (float)((double)hw * n_frames), epsilon, out_pos, out_neg, out_pos_sqnorm);
     AOC_RETURN_IF_LAUNCH_FAILED();
     return AOC_OK;
 }

@@ -193,19 +193,27 @@ struct DenseBTile {
     uint32_t wrong;
 };
 
-template <int NA, int OMAX, int TMAX, bool EXACT>
-__global__ __launch_bounds__(256, 2) void dense_match_partial_kernel(const float *__restrict__ query, int64_t m, int C,
-                                                                   const float *__restrict__ pool, const int32_t *__restrict__ fg_rows,
-                                                                   const int32_t *__restrict__ n_fg_ptr, const float *__restrict__ r2_all,
-                                                                   const uint32_t *__restrict__ wrong_bits, int n_obj,
-                                                                   float *__restrict__ partial) {
+// NW waves per block (NW * 64 threads); block = NW * NA * 16 query pixels; one LDS chunk buffer shared by all
+// waves; the NEXT chunk's row ids and rows are fetched into registers while the current chunk is multiplied
+// (loads stay in flight across the barrier, written to LDS after it), so the matrix pipe only idles for the
+// LDS write pass.
+template <int NA, int OMAX, int TMAX, bool EXACT, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void dense_match_partial_kernel(const float *__restrict__ query, int64_t m, int C,
+                                                                          const float *__restrict__ pool, const int32_t *__restrict__ fg_rows,
+                                                                          const int32_t *__restrict__ n_fg_ptr, const float *__restrict__ r2_all,
+                                                                          const uint32_t *__restrict__ wrong_bits, int n_obj,
+                                                                          float *__restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int NT = NW * 64;
     constexpr int NB4 = (TMAX + 3) / 4;
+    constexpr int ROWS = DM_NB * 16;                                   // reference pixels per chunk
+    constexpr int STAGE_ITERS = (ROWS * TMAX + NT - 1) / NT;           // float4 loads per thread per chunk
+    constexpr int META_ITERS = (ROWS + NT - 1) / NT;
     const int TP = EXACT ? NB4 * 4 : aoc_tile_tp(C);
     const int RS = EXACT ? (4 * NB4 * 4 + 4) : aoc_tile_row_stride(C);
-    float *lr2 = lds + (size_t)DM_NB * 16 * RS;
-    uint32_t *lwrong = reinterpret_cast<uint32_t *>(lr2 + DM_NB * 16);
-    int32_t *lrow = reinterpret_cast<int32_t *>(lwrong + DM_NB * 16);
+    float *lr2 = lds + (size_t)ROWS * RS;
+    uint32_t *lwrong = reinterpret_cast<uint32_t *>(lr2 + ROWS);
+    int32_t *lrow = reinterpret_cast<int32_t *>(lwrong + ROWS);        // [2][ROWS] row ids of chunk c+1 / c+2
 
     const int n_fg = *n_fg_ptr;
     const int n_tiles = (n_fg + 15) / 16;
@@ -215,8 +223,9 @@ __global__ __launch_bounds__(256, 2) void dense_match_partial_kernel(const float
 
     const int lane = aoc_lane(), wave = threadIdx.x >> 6;
     const int j = lane & 15, g = lane >> 4;
-    const int64_t block_row0 = (int64_t)blockIdx.x * (64 * NA);
+    const int64_t block_row0 = (int64_t)blockIdx.x * (16 * NA * NW);
     const int64_t wave_row0 = block_row0 + (int64_t)wave * 16 * NA;
+    const int c4 = C >> 2;
 
     float a[NA][TMAX], q2r[NA][4];
 #pragma unroll
@@ -242,19 +251,6 @@ __global__ __launch_bounds__(256, 2) void dense_match_partial_kernel(const float
         t.r2 = lr2[ti * 16 + j];
         t.wrong = lwrong[ti * 16 + j];
     };
-    auto epilogue = [&](const f32x4 (&acc)[NA], float r2, uint32_t wrong) {
-        float padv[OMAX];   // per-column padding of every object (AEM:84-86); objects >= n_obj are never written
-#pragma unroll
-        for (int o = 0; o < OMAX; ++o) padv[o] = ((wrong >> o) & 1u) ? AOC_PAD_DISTANCE : 0.0f;
-#pragma unroll
-        for (int ia = 0; ia < NA; ++ia)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float d = (q2r[ia][r] + r2) - 2.0f * acc[ia][r];   // AEM:43
-#pragma unroll
-                for (int o = 0; o < OMAX; ++o) mn[o][ia][r] = aoc_fmin_raw(mn[o][ia][r], d + padv[o]);   // AEM:88
-            }
-    };
     auto step = [&](const DenseBTile<NB4> &t) {
         f32x4 acc[NA];
 #pragma unroll
@@ -271,51 +267,100 @@ __global__ __launch_bounds__(256, 2) void dense_match_partial_kernel(const float
                 }
             }
         }
-        epilogue(acc, t.r2, t.wrong);
+        float padv[OMAX];   // per-column padding of every object (AEM:84-86); objects >= n_obj are never written
+#pragma unroll
+        for (int o = 0; o < OMAX; ++o) padv[o] = ((t.wrong >> o) & 1u) ? AOC_PAD_DISTANCE : 0.0f;
+#pragma unroll
+        for (int ia = 0; ia < NA; ++ia)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float d = (q2r[ia][r] + t.r2) - 2.0f * acc[ia][r];   // AEM:43
+#pragma unroll
+                for (int o = 0; o < OMAX; ++o) mn[o][ia][r] = aoc_fmin_raw(mn[o][ia][r], d + padv[o]);   // AEM:88
+            }
     };
 
+    // ---- staging pipeline state (registers)
+    struct Staged {
+        float4 v[STAGE_ITERS];
+        float r2[META_ITERS];
+        uint32_t wrong[META_ITERS];
+    } stg;
+    int32_t ids_next[META_ITERS];
+    auto load_ids = [&](int chunk) {          // row ids of `chunk` -> registers (-1 = padding)
+#pragma unroll
+        for (int it = 0; it < META_ITERS; ++it) {
+            const int c = it * NT + threadIdx.x;
+            const int p = chunk * 16 + c;
+            ids_next[it] = (c < ROWS && chunk < tile_end && p < min(n_fg, tile_end * 16)) ? fg_rows[p] : -1;
+        }
+    };
+    auto store_ids = [&](int buf) {
+#pragma unroll
+        for (int it = 0; it < META_ITERS; ++it) {
+            const int c = it * NT + threadIdx.x;
+            if (c < ROWS) lrow[buf * ROWS + c] = ids_next[it];
+        }
+    };
+    auto issue_rows = [&](int chunk, int buf) {   // rows + per-row metadata of `chunk` (ids in lrow[buf]) -> registers
+#pragma unroll
+        for (int it = 0; it < STAGE_ITERS; ++it) {
+            const int idx = it * NT + threadIdx.x;
+            const int rr = idx / c4, t = idx - rr * c4;
+            const int row = (idx < ROWS * c4) ? lrow[buf * ROWS + rr] : -1;
+            stg.v[it] = (row >= 0) ? reinterpret_cast<const float4 *>(pool + (size_t)row * C)[t] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int it = 0; it < META_ITERS; ++it) {
+            const int c = it * NT + threadIdx.x;
+            const int row = (c < ROWS) ? lrow[buf * ROWS + c] : -1;
+            stg.r2[it] = (row >= 0) ? r2_all[chunk * 16 + c] : INFINITY;
+            stg.wrong[it] = (row >= 0) ? wrong_bits[row] : 0xffffffffu;
+        }
+    };
+    auto commit_rows = [&]() {
+#pragma unroll
+        for (int it = 0; it < STAGE_ITERS; ++it) {
+            const int idx = it * NT + threadIdx.x;
+            if (idx < ROWS * c4) {
+                const int rr = idx / c4, t = idx - rr * c4;
+                float *d = lds + (size_t)rr * RS + t;
+                d[0] = stg.v[it].x; d[TP] = stg.v[it].y; d[2 * TP] = stg.v[it].z; d[3 * TP] = stg.v[it].w;
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < META_ITERS; ++it) {
+            const int c = it * NT + threadIdx.x;
+            if (c < ROWS) { lr2[c] = stg.r2[it]; lwrong[c] = stg.wrong[it]; }
+        }
+    };
+
+    // zero the stream padding once (never overwritten: rows only write their T real entries per stream)
+    {
+        const int padn = TP - c4;
+        for (int idx = threadIdx.x; idx < ROWS * 4 * padn; idx += NT) {
+            const int rr = idx / (4 * padn), rem = idx - rr * 4 * padn;
+            lds[(size_t)rr * RS + (rem / padn) * TP + c4 + (rem % padn)] = 0.0f;
+        }
+    }
+    // prologue: ids(chunk0) -> LDS, rows(chunk0) -> regs -> LDS, ids(chunk1) -> LDS
+    load_ids(tile_beg);
+    store_ids(0);
+    __syncthreads();
+    issue_rows(tile_beg, 0);
+    load_ids(tile_beg + DM_NB);
+    commit_rows();
+    store_ids(1);
+    __syncthreads();
+
+    int parity = 1;                                   // lrow[parity] holds the ids of the NEXT chunk
     for (int chunk = tile_beg; chunk < tile_end; chunk += DM_NB) {
         const int nt = min(DM_NB, tile_end - chunk);
-        __syncthreads();   // previous chunk fully consumed
-        // ---- staging with full memory-level parallelism: (1) the chunk's row ids, (2) every row load of the
-        // thread issued back to back, (3) the LDS writes.  (A naive loop serialises id -> row -> write per element.)
-        for (int c = threadIdx.x; c < DM_NB * 16; c += blockDim.x) {
-            const int p = chunk * 16 + c;
-            const bool in = c < nt * 16 && p < n_fg;
-            const int row = in ? fg_rows[p] : -1;
-            lrow[c] = row;
-            lr2[c] = in ? r2_all[p] : INFINITY;
-            lwrong[c] = in ? wrong_bits[row] : 0xffffffffu;
+        const bool more = chunk + DM_NB < tile_end;
+        if (more) {
+            issue_rows(chunk + DM_NB, parity);        // in flight under this chunk's MFMAs
+            load_ids(chunk + 2 * DM_NB);
         }
-        __syncthreads();
-        {
-            const int c4 = C >> 2;
-            const int total = nt * 16 * c4;
-            constexpr int DM_STAGE_ITERS = (DM_NB * 16 * TMAX + 255) / 256;   // float4 loads per thread per chunk
-            float4 v[DM_STAGE_ITERS];
-            int dst[DM_STAGE_ITERS];
-#pragma unroll
-            for (int it = 0; it < DM_STAGE_ITERS; ++it) {
-                const int idx = it * 256 + threadIdx.x;
-                const int rr = idx / c4, t = idx - rr * c4;
-                const int row = (idx < total) ? lrow[rr] : -1;
-                v[it] = (row >= 0) ? reinterpret_cast<const float4 *>(pool + (size_t)row * C)[t] : make_float4(0.f, 0.f, 0.f, 0.f);
-                dst[it] = (idx < total) ? rr * RS + t : -1;
-            }
-#pragma unroll
-            for (int it = 0; it < DM_STAGE_ITERS; ++it) {
-                if (dst[it] >= 0) {
-                    float *d = lds + dst[it];
-                    d[0] = v[it].x; d[TP] = v[it].y; d[2 * TP] = v[it].z; d[3 * TP] = v[it].w;
-                }
-            }
-            const int padn = TP - c4;   // zero the stream padding read by the last ds_read_b128 of a stream
-            for (int idx = threadIdx.x; idx < nt * 16 * 4 * padn; idx += blockDim.x) {
-                const int rr = idx / (4 * padn), rem = idx - rr * 4 * padn;
-                lds[(size_t)rr * RS + (rem / padn) * TP + c4 + (rem % padn)] = 0.0f;
-            }
-        }
-        __syncthreads();
         // two register tiles ping-pong so the LDS reads of tile t+1 are in flight under tile t's MFMAs
         DenseBTile<NB4> t0, t1;
         load_tile(0, t0);
@@ -325,6 +370,13 @@ __global__ __launch_bounds__(256, 2) void dense_match_partial_kernel(const float
             if (ti + 2 < nt) load_tile(ti + 2, t0);
             if (ti + 1 < nt) step(t1);
         }
+        __syncthreads();                              // every wave is done reading this chunk
+        if (more) {
+            commit_rows();
+            store_ids(parity ^ 1);                    // ids of chunk+2 replace the ids of the chunk just consumed
+            parity ^= 1;
+        }
+        __syncthreads();
     }
     // reduce over the 16 columns a lane group holds and write this split's partial minima
 #pragma unroll
@@ -363,12 +415,23 @@ __global__ __launch_bounds__(256) void dense_match_finalize_kernel(const float *
     out[row * pstride + o * ostride] = v;
 }
 
+constexpr int DM_NW = 8;   // waves per block
 inline int dense_nsplit(int64_t m, int na) {
-    const int64_t row_blocks = (m + 64 * na - 1) / (64 * na);
-    int64_t s = (1024 + row_blocks - 1) / row_blocks;
-    if (s < 1) s = 1;
-    if (s > 64) s = 64;
-    return (int)s;
+    // one 8-wave block per CU at a time (registers): pick the n-split so that row_blocks * nsplit fills whole
+    // rounds of 256 CUs (tail effect) with blocks that are still long enough to amortise their prologue
+    const int64_t row_blocks = (m + 16 * DM_NW * na - 1) / (16 * DM_NW * na);
+    int best = 1;
+    double best_eff = 0.0;
+    for (int k = 1; k <= 4; ++k) {
+        int64_t ns = (256 * k) / row_blocks;
+        if (ns < 1) ns = 1;
+        if (ns > 64) ns = 64;
+        const int64_t blocks = row_blocks * ns;
+        const int64_t rounds = (blocks + 255) / 256;
+        const double eff = (double)blocks / (256.0 * rounds);
+        if (eff > best_eff + 0.02 || (k == 2 && eff > best_eff - 0.02)) { best_eff = eff; best = (int)ns; }
+    }
+    return best;
 }
 inline int dense_na(int n_obj) { return n_obj <= 4 ? 2 : 1; }
 
@@ -451,13 +514,13 @@ int aoc_dense_match_min(const float *query, int64_t m, int C, const float *pool,
     float *partial = reinterpret_cast<float *>(static_cast<char *>(workspace) + aoc_align_up((size_t)n_fg_capacity * sizeof(float) + 16, 256));
     const int na = dense_na(n_obj);
     const int ns = dense_nsplit(m, na);
-    const int row_blocks = (int)((m + 64 * na - 1) / (64 * na));
+    const int row_blocks = (int)((m + 16 * DM_NW * na - 1) / (16 * DM_NW * na));
     const int RS = aoc_tile_row_stride(C);
-    const size_t lds = (size_t)DM_NB * 16 * RS * sizeof(float) + DM_NB * 16 * (sizeof(float) + sizeof(uint32_t) + sizeof(int32_t));
+    const size_t lds = (size_t)DM_NB * 16 * RS * sizeof(float) + DM_NB * 16 * (sizeof(float) + sizeof(uint32_t) + 2 * sizeof(int32_t));
 
     hipLaunchKernelGGL(gather_sqnorm_kernel, dim3((unsigned)((n_fg_capacity + 255) / 256)), dim3(256), 0, st, pool, C, fg_rows, n_fg, r2);
     const dim3 grid(row_blocks, ns);
-#define AOC_DM(NA, OM, TM, EX) hipLaunchKernelGGL((dense_match_partial_kernel<NA, OM, TM, EX>), grid, dim3(256), lds, st, query, m, C, pool, fg_rows, n_fg, r2, wrong_bits, n_obj, partial)
+#define AOC_DM(NA, OM, TM, EX) hipLaunchKernelGGL((dense_match_partial_kernel<NA, OM, TM, EX, DM_NW>), grid, dim3(DM_NW * 64), lds, st, query, m, C, pool, fg_rows, n_fg, r2, wrong_bits, n_obj, partial)
     if (C == 100) {
         if (n_obj <= 4) AOC_DM(2, 4, 25, true); else if (n_obj <= 8) AOC_DM(1, 8, 25, true); else AOC_DM(1, 16, 25, true);
     } else {
