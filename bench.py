@@ -261,7 +261,7 @@ def main():
         return dict(flops=2.0 * iters * n * kmax * C, bytes=float(iters) * n * C * 4 * 2 + n * 4)
 
     timer = OpTimer(["dense_match_min", "proxy_corr_min", "kmeans_segmented", "build_proxies", "label_prep", "local_window_match",
-                     "masked_mean_pool", "cond_gate_pool", "channel_scale", "fg2bg_min", "resize_bilinear_hwc", "resize_bilinear_planes",
+                     "masked_mean_pool", "cond_gate_pool", "channel_scale", "film_scale", "fg2bg_min", "resize_bilinear_hwc", "resize_bilinear_planes",
                      "plane_mean", "film_gain", "linear", "label_mix", "label_bits", "resize_nearest_bits", "kmeans_plan"])
     timer.install(dict(dense_match_min=meta_dense, proxy_corr_min=meta_proxy, kmeans_segmented=meta_kmeans))
 

@@ -230,6 +230,9 @@ int aoc_film_gain(const float *head, const float *weight, const float *bias, int
                   int head_dim, int channels, float *gain, aoc_stream_t stream);
 int aoc_channel_scale(const float *x, const float *gain, int64_t planes, int64_t hw, float *y,
                       aoc_stream_t stream);
+/* Both steps in one launch (what IA_gate.forward does, ATT:12-17): x [n_obj, channels, hw]. */
+int aoc_film_scale(const float *x, const float *head, const float *weight, const float *bias,
+                   int n_obj, int head_dim, int channels, int64_t hw, float *y, aoc_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * conditioning_layer gate + pool: CL:23-43 (paper Eq. 7):

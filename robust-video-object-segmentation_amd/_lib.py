@@ -37,6 +37,7 @@ SIGNATURES = {
     "aoc_masked_mean_pool": (_i, [_vp, _vp, _i, _i64, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _sz, _vp]),
     "aoc_film_gain": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "aoc_channel_scale": (_i, [_vp, _vp, _i64, _i64, _vp, _vp]),
+    "aoc_film_scale": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i64, _vp, _vp]),
     "aoc_cond_gate_pool_workspace_bytes": (_sz, [_i, _i, _i64]),
     "aoc_cond_gate_pool": (_i, [_vp, _i, _i, _i64, _vp, _vp, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "aoc_linear": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),

@@ -17,8 +17,7 @@ class IA_gate(nn.Module):
         self.IA = nn.Linear(in_dim, out_dim)
 
     def forward(self, x, IA_head):
-        gain = ops.film_gain(IA_head, self.IA.weight.detach(), self.IA.bias.detach())   # ATT:13-14
-        return ops.channel_scale(x, gain)                                                 # ATT:15-16
+        return ops.film_scale(x, IA_head, self.IA.weight.detach(), self.IA.bias.detach())   # ATT:13-16 in one launch
 
 
 def _pool_inputs(embeddings, labels):

@@ -54,5 +54,4 @@ class conditioning_block(nn.Module):
         cl_out_2 = self.CL_2(x_delta)                                        # CLB:75 inter-object code
         cl_out_3 = self.CL_3(proxy_IA_head)                                  # CLB:78 proxy code
         code = torch.cat([cl_out_1, cl_out_2, cl_out_3], dim=1)
-        gain = ops.film_gain(code, self.mlp_layer.weight.detach(), self.mlp_layer.bias.detach())   # CLB:81-82
-        return ops.channel_scale(x, gain)                                    # CLB:83-84
+        return ops.film_scale(x, code, self.mlp_layer.weight.detach(), self.mlp_layer.bias.detach())   # CLB:81-84

@@ -201,6 +201,45 @@ __global__ __launch_bounds__(256) void channel_scale_kernel(const float *__restr
     }
 }
 
+// FiLM gate in one launch: every block first computes its plane's gain 1 + tanh(head[o,:].W[c,:] + b[c]) (a D-long
+// dot product, block-reduced), then streams its slice of the plane.  Saves the separate gain launch + round trip.
+__global__ __launch_bounds__(256) void film_scale_kernel(const float *__restrict__ x, const float *__restrict__ head, const float *__restrict__ weight,
+                                                          const float *__restrict__ bias, int D, int channels, int64_t hw, float *__restrict__ y) {
+    __shared__ float wsum[4];
+    const int64_t plane = blockIdx.y;
+    const int o = (int)(plane / channels), c = (int)(plane - (int64_t)o * channels);
+    const float *h = head + (size_t)o * D, *w = weight + (size_t)c * D;
+    float acc = 0.0f;
+    for (int d = threadIdx.x; d < D; d += blockDim.x) acc += w[d] * h[d];
+    acc = aoc_wave_sum(acc);
+    if (aoc_lane() == 0) wsum[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    const float g = 1.0f + tanhf((wsum[0] + wsum[1] + wsum[2] + wsum[3]) + (bias ? bias[c] : 0.0f));
+    const float *xp = x + plane * hw;
+    float *yp = y + plane * hw;
+    const uintptr_t addr = reinterpret_cast<uintptr_t>(xp);
+    int64_t headn = ((16 - (addr & 15)) & 15) / 4;
+    if (headn > hw) headn = hw;
+    const bool same_align = ((reinterpret_cast<uintptr_t>(yp) & 15) == (addr & 15));
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t nthreads = (int64_t)gridDim.x * blockDim.x;
+    if (same_align) {
+        if (tid < headn) yp[tid] = g * xp[tid];
+        const int64_t body4 = (hw - headn) / 4;
+        const float4 *x4 = reinterpret_cast<const float4 *>(xp + headn);
+        float4 *y4 = reinterpret_cast<float4 *>(yp + headn);
+        for (int64_t i = tid; i < body4; i += nthreads) {
+            float4 v = x4[i];
+            v.x *= g; v.y *= g; v.z *= g; v.w *= g;
+            y4[i] = v;
+        }
+        const int64_t tail0 = headn + body4 * 4;
+        if (tid < hw - tail0) yp[tail0 + tid] = g * xp[tail0 + tid];
+    } else {
+        for (int64_t i = tid; i < hw; i += nthreads) yp[i] = g * xp[i];
+    }
+}
+
 // ------------------------------------------------------------------------------------------ conditioning layer
 // scores[n,p] = sum_c w[c] z[n,c,p] + b      (CL:27, the 1x1 conv C -> 1)
 __global__ __launch_bounds__(256) void cond_scores_kernel(const float *__restrict__ z, int C, int64_t hw, const float *__restrict__ phi_w,
@@ -210,7 +249,15 @@ __global__ __launch_bounds__(256) void cond_scores_kernel(const float *__restric
     if (p >= hw) return;
     const float *zp = z + (size_t)n * C * hw + p;
     float s = 0.0f;
-    for (int c = 0; c < C; ++c) s += phi_w[c] * zp[(size_t)c * hw];
+    int c = 0;
+    for (; c + 8 <= C; c += 8) {          // 8 independent loads in flight per thread
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = zp[(size_t)(c + u) * hw];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += phi_w[c + u] * v[u];
+    }
+    for (; c < C; ++c) s += phi_w[c] * zp[(size_t)c * hw];
     scores[(size_t)n * hw + p] = s + phi_b[0];
 }
 
@@ -265,7 +312,15 @@ __global__ __launch_bounds__(256) void cond_masked_gap_kernel(const float *__res
     const float *zp = z + ((size_t)n * C + c) * hw;
     const float *sp = scores + (size_t)n * hw;
     float acc = 0.0f;
-    for (int64_t p = threadIdx.x; p < hw; p += blockDim.x) acc += (sp[p] > thr) ? zp[p] : 0.0f;
+    int64_t p = threadIdx.x;
+    for (; p + 3 * (int64_t)blockDim.x < hw; p += 4 * (int64_t)blockDim.x) {
+        float zv[4], sv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { zv[u] = zp[p + u * blockDim.x]; sv[u] = sp[p + u * blockDim.x]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc += (sv[u] > thr) ? zv[u] : 0.0f;
+    }
+    for (; p < hw; p += blockDim.x) acc += (sp[p] > thr) ? zp[p] : 0.0f;
     acc = aoc_wave_sum(acc);
     if (aoc_lane() == 0) wsum[threadIdx.x >> 6] = acc;
     __syncthreads();
@@ -299,7 +354,15 @@ __global__ __launch_bounds__(256) void plane_mean_kernel(const float *__restrict
     __shared__ float wsum[4];
     const float *xp = x + (size_t)blockIdx.x * hw;
     float acc = 0.0f;
-    for (int64_t p = threadIdx.x; p < hw; p += blockDim.x) acc += xp[p];
+    int64_t p = threadIdx.x;
+    for (; p + 7 * (int64_t)blockDim.x < hw; p += 8 * (int64_t)blockDim.x) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = xp[p + u * blockDim.x];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += v[u];
+    }
+    for (; p < hw; p += blockDim.x) acc += xp[p];
     acc = aoc_wave_sum(acc);
     if (aoc_lane() == 0) wsum[threadIdx.x >> 6] = acc;
     __syncthreads();
@@ -358,6 +421,19 @@ int aoc_channel_scale(const float *x, const float *gain, int64_t planes, int64_t
     if (bx < 1) bx = 1;
     if (bx > 8) bx = 8;
     hipLaunchKernelGGL(channel_scale_kernel, dim3(bx, (unsigned)planes), dim3(256), 0, aoc_hip_stream(stream), x, gain, hw, y);
+    AOC_RETURN_IF_LAUNCH_FAILED();
+    return AOC_OK;
+}
+
+int aoc_film_scale(const float *x, const float *head, const float *weight, const float *bias, int n_obj, int head_dim, int channels,
+                   int64_t hw, float *y, aoc_stream_t stream) {
+    if (!x || !head || !weight || !y || n_obj < 1 || head_dim < 1 || channels < 1 || hw < 1) return AOC_ERR_INVALID_ARG;
+    const int64_t planes = (int64_t)n_obj * channels;
+    if (planes > 65535) return AOC_ERR_UNSUPPORTED;
+    int bx = (int)((hw / 4 + 255) / 256);
+    if (bx < 1) bx = 1;
+    if (bx > 8) bx = 8;
+    hipLaunchKernelGGL(film_scale_kernel, dim3(bx, (unsigned)planes), dim3(256), 0, aoc_hip_stream(stream), x, head, weight, bias, head_dim, channels, hw, y);
     AOC_RETURN_IF_LAUNCH_FAILED();
     return AOC_OK;
 }

@@ -852,8 +852,15 @@ __global__ __launch_bounds__(128) void km_chunk_predict_kernel(const int32_t *__
     const int base = cchunk[oc];
     for (int f = threadIdx.x; f < C; f += blockDim.x) {
         float pre = 0.0f;
-        for (int c = 0; c < nch; ++c) {
-            const float end = pre + csum[(size_t)(base + c) * C + f];
+        for (int c0 = 0; c0 < nch; c0 += 8) {
+          float cs[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) cs[u] = (c0 + u < nch) ? csum[(size_t)(base + c0 + u) * C + f] : 0.0f;   // 8 loads in flight
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int c = c0 + u;
+            if (c >= nch) break;
+            const float end = pre + cs[u];
             int e = KC_UNSAFE;
             if (pre > 1e-30f && end < 1e30f && end >= pre) {
                 const int e_lo = (int)((__float_as_uint(pre * 0.9995f) >> 23) & 0xff) - 127;
@@ -862,6 +869,7 @@ __global__ __launch_bounds__(128) void km_chunk_predict_kernel(const int32_t *__
             }
             cexp[(size_t)(base + c) * C + f] = (int8_t)e;
             pre = end;
+          }
         }
     }
 }

@@ -272,6 +272,19 @@ def channel_scale(x, gain, out=None):
     return y
 
 
+def film_scale(x, head, weight, bias, out=None):
+    """y[o,c,:,:] = (1 + tanh(head[o,:] . weight[c,:] + bias[c])) * x[o,c,:,:] in one launch (ATT:12-17, CLB:81-84)."""
+    x, head, weight = _f32c(x), _f32c(head), _f32c(weight)
+    bias = _f32c(bias) if bias is not None else None
+    _need_gpu(x, head, weight, bias)
+    n_obj, channels = x.shape[0], x.shape[1]
+    assert head.shape[0] == n_obj and weight.shape[0] == channels and weight.shape[1] == head.shape[1]
+    hw = x.numel() // (n_obj * channels)
+    y = torch.empty_like(x) if out is None else out
+    _lib.check(_lib.lib().aoc_film_scale(_p(x), _p(head), _p(weight), _p(bias), n_obj, head.shape[1], channels, hw, _p(y), _stream()), "aoc_film_scale")
+    return y
+
+
 def cond_gate_pool(z, phi_w, phi_b, k_rank, want_debug=False):
     """CL:23-43 -> gap [N, C] (optionally also scores [N,HW] and threshold [N])."""
     z, phi_w, phi_b = _f32c(z), _f32c(phi_w).reshape(-1), _f32c(phi_b).reshape(-1)
