@@ -6,6 +6,8 @@
 // Query pixels are the A rows, proxies / reference pixels the B columns.  Step t of the K loop
 // multiplies channel 4t + kq on both sides (kq = l >> 4), so the B image in LDS is "k-permuted"
 // (see aoc_common.h) and each lane streams its channels with ds_read_b128.
+#include <stdlib.h>
+
 #include "aoc_common.h"
 
 namespace {
@@ -19,10 +21,16 @@ struct ProxyTile {
     int32_t flags;        // bit0: column-wise (every column is its own set), bit1: first tile of set, bit2: last tile of set
     int64_t out_offset;   // element offset of the set's output plane (kind 1: of column 0)
     int64_t col_stride;   // kind 1: output offset step between consecutive columns
+    int32_t oc;           // first output column of this tile in the launch's output-column list
+    int32_t pad_;
 };
+constexpr int PC_MAX_OUT = 64;   // output columns (sets) per launch that go through the per-wave transpose buffer
 struct ProxyTileTable {
     ProxyTile t[PC_MAX_TILES];
     int32_t n;
+    int32_t n_out;                     // output columns in this launch (0 = too many: direct stores)
+    int64_t oc_offset[PC_MAX_OUT];     // element offset of each output column
+    int32_t oc_bias[PC_MAX_OUT];       // index into set_bias
 };
 
 // Stage 16-column operand tiles into the k-permuted LDS image.  row_of(c) gives the source row
@@ -30,15 +38,30 @@ struct ProxyTileTable {
 template <typename RowFn>
 __device__ __forceinline__ void stage_tile_rows(float *__restrict__ lds, int n_rows, int C, int TP, int RS, RowFn row_of) {
     const int c4 = C >> 2;
-    for (int idx = threadIdx.x; idx < n_rows * c4; idx += blockDim.x) {
-        const int rr = idx / c4, t = idx - rr * c4;
-        const float *src = row_of(rr);
-        float4 v = src ? reinterpret_cast<const float4 *>(src)[t] : make_float4(0.f, 0.f, 0.f, 0.f);
-        float *d = lds + (size_t)rr * RS + t;
-        d[0] = v.x;
-        d[TP] = v.y;
-        d[2 * TP] = v.z;
-        d[3 * TP] = v.w;
+    const int total = n_rows * c4;
+    constexpr int BATCH = 16;     // loads in flight per thread: a naive load->write loop would serialise on latency
+    for (int base = 0; base < total; base += BATCH * (int)blockDim.x) {
+        float4 v[BATCH];
+        int dst[BATCH];
+#pragma unroll
+        for (int it = 0; it < BATCH; ++it) {
+            const int idx = base + it * (int)blockDim.x + (int)threadIdx.x;
+            dst[it] = -1;
+            v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < total) {
+                const int rr = idx / c4, t = idx - rr * c4;
+                const float *src = row_of(rr);
+                if (src) v[it] = reinterpret_cast<const float4 *>(src)[t];
+                dst[it] = rr * RS + t;
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < BATCH; ++it) {
+            if (dst[it] >= 0) {
+                float *d = lds + dst[it];
+                d[0] = v[it].x; d[TP] = v[it].y; d[2 * TP] = v[it].z; d[3 * TP] = v[it].w;
+            }
+        }
     }
     // zero the TP - T padding of every stream (read by the last ds_read_b128 of a stream)
     const int T = c4, padn = TP - T;
@@ -86,16 +109,31 @@ __device__ __forceinline__ f32x4 mfma_tile(const float (&a)[TMAX], const float *
 }
 
 // ------------------------------------------------------------------------------------------
-// proxy_corr_min: one block stages every proxy tile once; each wave walks 16-pixel row tiles.
-template <int TMAX>
+// proxy_corr_min: one block per CU stages every proxy tile once; each wave walks 16-pixel row tiles.
+// Inner loop as in dense_match: compile-time K loop (EXACT), two register B tiles ping-pong so the LDS reads
+// of tile t+1 fly under tile t's MFMAs; the set minimum uses DPP row reductions (no LDS crossbar shuffles).
+__device__ __forceinline__ float aoc_min16_dpp(float v) {     // lane 15 of each 16-lane row gets the row minimum
+    const int inf = 0x7f800000;
+    v = aoc_fmin_raw(v, __int_as_float(__builtin_amdgcn_update_dpp(inf, __float_as_int(v), 0x111, 0xf, 0xf, false)));
+    v = aoc_fmin_raw(v, __int_as_float(__builtin_amdgcn_update_dpp(inf, __float_as_int(v), 0x112, 0xf, 0xf, false)));
+    v = aoc_fmin_raw(v, __int_as_float(__builtin_amdgcn_update_dpp(inf, __float_as_int(v), 0x114, 0xf, 0xf, false)));
+    v = aoc_fmin_raw(v, __int_as_float(__builtin_amdgcn_update_dpp(inf, __float_as_int(v), 0x118, 0xf, 0xf, false)));
+    return v;
+}
+
+template <int TMAX, bool EXACT>
 __global__ __launch_bounds__(256) void proxy_corr_min_kernel(const float *__restrict__ query, int64_t m, int C,
                                                               const float *__restrict__ proxies, const float *__restrict__ proxy_sqnorm,
                                                               ProxyTileTable tiles, const float *__restrict__ set_bias,
                                                               float *__restrict__ out, int64_t pstride, int transform) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int TP = aoc_tile_tp(C), RS = aoc_tile_row_stride(C);
+    constexpr int NB4 = (TMAX + 3) / 4;
+    const int TP = EXACT ? NB4 * 4 : aoc_tile_tp(C);
+    const int RS = EXACT ? (4 * NB4 * 4 + 4) : aoc_tile_row_stride(C);
     const int ncols_total = tiles.n * 16;
     float *lp2 = lds + (size_t)ncols_total * RS;
+    float *wbuf_all = lp2 + ncols_total;                      // [4 waves][16 rows][n_out + 1] raw distances
+    const int nout = tiles.n_out, wld = nout + 1;
     stage_tile_rows(lds, ncols_total, C, TP, RS, [&](int c) -> const float * {
         const ProxyTile &pt = tiles.t[c >> 4];
         return ((c & 15) < pt.ncols) ? proxies + (size_t)(pt.proxy_begin + (c & 15)) * C : nullptr;
@@ -121,6 +159,20 @@ __global__ __launch_bounds__(256) void proxy_corr_min_kernel(const float *__rest
     const int lane = aoc_lane(), wave = threadIdx.x >> 6;
     const int j = lane & 15, g = lane >> 4;
     const int64_t n_row_tiles = (m + 15) / 16;
+    float *wbuf = wbuf_all + (size_t)wave * 16 * wld;
+
+    struct BTile {
+        float4 b[NB4];
+        float p2;
+    };
+    auto load_tile = [&](int ti, BTile &t) {
+        const float *bstream = lds + (size_t)(ti * 16 + j) * RS + g * TP;
+#pragma unroll
+        for (int u = 0; u < NB4; ++u)
+            t.b[u] = (EXACT || 4 * u < TP) ? *reinterpret_cast<const float4 *>(bstream + 4 * u) : make_float4(0.f, 0.f, 0.f, 0.f);
+        t.p2 = lp2[ti * 16 + j];
+    };
+
     for (int64_t rt = (int64_t)blockIdx.x * 4 + wave; rt < n_row_tiles; rt += (int64_t)gridDim.x * 4) {
         const int64_t row0 = rt * 16;
         float a[TMAX], q2;
@@ -129,40 +181,71 @@ __global__ __launch_bounds__(256) void proxy_corr_min_kernel(const float *__rest
 #pragma unroll
         for (int r = 0; r < 4; ++r) q2r[r] = __shfl(q2, g * 4 + r);
         float setmin[4] = {INFINITY, INFINITY, INFINITY, INFINITY};
-        for (int ti = 0; ti < tiles.n; ++ti) {
+
+        auto step = [&](int ti, const BTile &t) {
             const ProxyTile pt = tiles.t[ti];
-            const f32x4 acc = mfma_tile<TMAX>(a, lds + (size_t)(ti * 16 + j) * RS + g * TP, TP);
-            const float p2 = lp2[ti * 16 + j];
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int u = 0; u < NB4; ++u) {
+                const float bb[4] = {t.b[u].x, t.b[u].y, t.b[u].z, t.b[u].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (4 * u + e < TMAX) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[4 * u + e < TMAX ? 4 * u + e : 0], bb[e], acc, 0, 0, 0);
+            }
             float d[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) d[r] = (q2r[r] + p2) - 2.0f * acc[r];   // AEM:43
+            for (int r = 0; r < 4; ++r) d[r] = (q2r[r] + t.p2) - 2.0f * acc[r];   // AEM:43
             if (pt.flags & 1) {   // column-wise: k = 1 proxies, no min (AEM:127)
                 if (j < pt.ncols) {
-                    const int s = pt.set + j;
-                    const float b = set_bias ? set_bias[s] : 0.0f;
+                    if (nout > 0) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int64_t row = row0 + g * 4 + r;
-                        if (row < m) out[row * pstride + pt.out_offset + j * pt.col_stride] = transform ? aoc_proto_transform(d[r], b) : d[r];
+                        for (int r = 0; r < 4; ++r) wbuf[(g * 4 + r) * wld + pt.oc + j] = d[r];
+                    } else {
+                        const float b = set_bias ? set_bias[pt.set + j] : 0.0f;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int64_t row = row0 + g * 4 + r;
+                            if (row < m) out[row * pstride + pt.out_offset + j * pt.col_stride] = transform ? aoc_proto_transform(d[r], b) : d[r];
+                        }
                     }
                 }
             } else {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) setmin[r] = (pt.flags & 2) ? d[r] : fminf(setmin[r], d[r]);
+                for (int r = 0; r < 4; ++r) setmin[r] = (pt.flags & 2) ? d[r] : aoc_fmin_raw(setmin[r], d[r]);
                 if (pt.flags & 4) {
-                    float v = 0.0f;
+                    const float b = set_bias ? set_bias[pt.set] : 0.0f;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        float mr = aoc_min16(setmin[r]);   // AEM:109 min over the set's proxies
-                        if (j == r) v = mr;
-                    }
-                    if (v == INFINITY) v = AOC_PAD_DISTANCE;   // absent object: AEM:310-313
-                    const int64_t row = row0 + g * 4 + j;
-                    if (j < 4 && row < m) {
-                        const float b = set_bias ? set_bias[pt.set] : 0.0f;
-                        out[row * pstride + pt.out_offset] = transform ? aoc_proto_transform(v, b) : v;
+                        float v = aoc_min16_dpp(setmin[r]);               // AEM:109 min over the set's proxies (valid in lane 15 of the row)
+                        if (v == INFINITY) v = AOC_PAD_DISTANCE;          // absent object: AEM:310-313
+                        if (nout > 0) {
+                            if (j == 15) wbuf[(g * 4 + r) * wld + pt.oc] = v;
+                        } else {
+                            const int64_t row = row0 + g * 4 + r;
+                            if (j == 15 && row < m) out[row * pstride + pt.out_offset] = transform ? aoc_proto_transform(v, b) : v;
+                        }
                     }
                 }
+            }
+        };
+
+        BTile t0, t1;
+        load_tile(0, t0);
+        for (int ti = 0; ti < tiles.n; ti += 2) {
+            if (ti + 1 < tiles.n) load_tile(ti + 1, t1);
+            step(ti, t0);
+            if (ti + 2 < tiles.n) load_tile(ti + 2, t0);
+            if (ti + 1 < tiles.n) step(ti + 1, t1);
+        }
+        // transposed epilogue: every lane transforms and stores its share of the 16 x n_out raw distances, so the
+        // expf work is spread over the wave and each output column gets one 64-byte store run
+        for (int idx = lane; idx < 16 * nout; idx += 64) {
+            const int oc = idx >> 4, r = idx & 15;
+            const int64_t row = row0 + r;
+            if (row < m) {
+                const float v = wbuf[r * wld + oc];
+                const float b = set_bias ? set_bias[tiles.oc_bias[oc]] : 0.0f;
+                out[row * pstride + tiles.oc_offset[oc]] = transform ? aoc_proto_transform(v, b) : v;
             }
         }
     }
@@ -417,19 +500,21 @@ __global__ __launch_bounds__(256) void dense_match_finalize_kernel(const float *
 
 constexpr int DM_NW = 8;   // waves per block
 inline int dense_nsplit(int64_t m, int na) {
-    // one 8-wave block per CU at a time (registers): pick the n-split so that row_blocks * nsplit fills whole
-    // rounds of 256 CUs (tail effect) with blocks that are still long enough to amortise their prologue
+    // One 8-wave block per CU at a time (registers).  Pick the n-split so that row_blocks * nsplit fills whole
+    // rounds of 256 CUs (tail effect); among near-equal fills prefer MORE, shorter blocks: CUs then free up
+    // often, which lets the latency-bound kernels of other streams (k-means chain) interleave with this one.
     const int64_t row_blocks = (m + 16 * DM_NW * na - 1) / (16 * DM_NW * na);
+    static const int max_rounds = getenv("AOC_DENSE_ROUNDS") ? atoi(getenv("AOC_DENSE_ROUNDS")) : 4;
     int best = 1;
     double best_eff = 0.0;
-    for (int k = 1; k <= 4; ++k) {
+    for (int k = 1; k <= max_rounds; ++k) {
         int64_t ns = (256 * k) / row_blocks;
         if (ns < 1) ns = 1;
         if (ns > 64) ns = 64;
         const int64_t blocks = row_blocks * ns;
         const int64_t rounds = (blocks + 255) / 256;
         const double eff = (double)blocks / (256.0 * rounds);
-        if (eff > best_eff + 0.02 || (k == 2 && eff > best_eff - 0.02)) { best_eff = eff; best = (int)ns; }
+        if (eff >= best_eff - 0.005) { best_eff = eff > best_eff ? eff : best_eff; best = (int)ns; }
     }
     return best;
 }
@@ -450,22 +535,33 @@ int aoc_proxy_corr_min(const float *query, int64_t m, int C, const float *proxie
     hipStream_t st = aoc_hip_stream(stream);
     const int RS = aoc_tile_row_stride(C);
     const size_t tile_bytes = (size_t)16 * RS * sizeof(float) + 16 * sizeof(float);
-    int max_tiles = (int)((size_t)150 * 1024 / tile_bytes);
+    int max_tiles = (int)((size_t)130 * 1024 / tile_bytes);   // leaves room for the per-wave transpose buffer
     if (max_tiles > PC_MAX_TILES) max_tiles = PC_MAX_TILES;
     if (max_tiles < 4) return AOC_ERR_UNSUPPORTED;
     const int64_t n_row_tiles = (m + 15) / 16;
     int grid = (int)((n_row_tiles + 3) / 4);
-    if (grid > 1024) grid = 1024;
+    if (grid > 512) grid = 512;        // two blocks per CU (LDS permitting): tiles staged once per block, waves walk the row tiles
 
     ProxyTileTable tab;
     tab.n = 0;
+    tab.n_out = 0;
+    bool out_overflow = false;
+    auto add_out = [&](int64_t off, int bias_idx) -> int {
+        if (tab.n_out >= PC_MAX_OUT) { out_overflow = true; return 0; }
+        tab.oc_offset[tab.n_out] = off;
+        tab.oc_bias[tab.n_out] = bias_idx;
+        return tab.n_out++;
+    };
     auto flush = [&]() -> int {
         if (tab.n == 0) return AOC_OK;
-        const size_t lds = (size_t)tab.n * tile_bytes;
-#define AOC_PC(TM) hipLaunchKernelGGL(proxy_corr_min_kernel<TM>, dim3(grid), dim3(256), lds, st, query, m, C, proxies, proxy_sqnorm, tab, set_bias, out, out_pixel_stride, transform)
-        if (C == 100) AOC_PC(25); else if (C <= 128) AOC_PC(32); else AOC_PC(64);
+        if (out_overflow) tab.n_out = 0;       // too many output columns for the transpose buffer: direct stores
+        const size_t lds = (size_t)tab.n * tile_bytes + (size_t)4 * 16 * (tab.n_out + 1) * sizeof(float);
+#define AOC_PC(TM, EX) hipLaunchKernelGGL((proxy_corr_min_kernel<TM, EX>), dim3(grid), dim3(256), lds, st, query, m, C, proxies, proxy_sqnorm, tab, set_bias, out, out_pixel_stride, transform)
+        if (C == 100) AOC_PC(25, true); else if (C <= 128) AOC_PC(32, false); else AOC_PC(64, false);
 #undef AOC_PC
         tab.n = 0;
+        tab.n_out = 0;
+        out_overflow = false;
         return hipGetLastError() == hipSuccess ? AOC_OK : AOC_ERR_LAUNCH;
     };
     int s = 0;
@@ -479,15 +575,18 @@ int aoc_proxy_corr_min(const float *query, int64_t m, int C, const float *proxie
                    set_out_offset_host[s + run] - set_out_offset_host[s + run - 1] == step)
                 ++run;
             if (tab.n + 1 > max_tiles) { int rc = flush(); if (rc) return rc; }
-            tab.t[tab.n++] = ProxyTile{set_begin_host[s], run, s, 1, set_out_offset_host[s], step};
+            const int oc0 = tab.n_out;
+            for (int c = 0; c < run; ++c) add_out(set_out_offset_host[s + c], s + c);
+            tab.t[tab.n++] = ProxyTile{set_begin_host[s], run, s, 1, set_out_offset_host[s], step, oc0, 0};
             s += run;
         } else {
             const int nt = size == 0 ? 1 : (size + 15) / 16;
             if (nt > max_tiles) return AOC_ERR_UNSUPPORTED;
             if (tab.n + nt > max_tiles) { int rc = flush(); if (rc) return rc; }
+            const int oc0 = add_out(set_out_offset_host[s], s);
             for (int t = 0; t < nt; ++t) {
                 const int cols = size == 0 ? 0 : ((t == nt - 1) ? size - 16 * t : 16);
-                tab.t[tab.n++] = ProxyTile{set_begin_host[s] + 16 * t, cols, s, (t == 0 ? 2 : 0) | (t == nt - 1 ? 4 : 0), set_out_offset_host[s], 0};
+                tab.t[tab.n++] = ProxyTile{set_begin_host[s] + 16 * t, cols, s, (t == 0 ? 2 : 0) | (t == nt - 1 ? 4 : 0), set_out_offset_host[s], 0, oc0, 0};
             }
             ++s;
         }
