@@ -35,6 +35,7 @@ from aoc_amd import hotpath, ops, sharding  # noqa: E402
 from aoc_amd import synthetic as syn  # noqa: E402
 
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
+PEAK_F16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_f16, dense
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
 
 
@@ -107,10 +108,12 @@ class ClipWorkload:
             self.init_rows[t] = (torch.from_numpy(init).to(device), rows)
             if t % mc.MEM_EVERY == 0:
                 ref_idx.append(t)
+        self.dense_state = {"capacity_frames": rmax}      # fp16 split records of the pool, converted once per appended frame
         self.reset()
 
     def reset(self):
         self.t, self.R = 1, 1
+        self.dense_state["frames"] = 0
         self.pool_emb[0].copy_(self.emb[0])
         self.pool_lab[0].copy_(self.lab[0])
 
@@ -133,11 +136,12 @@ def make_activations(gates, O, h, w, device, seed):
     return [torch.randn(O, c, hh, ww, generator=g).to(device) for (_, c, hh, ww, _) in gates.plan(h, w)]
 
 
-def frame_step(wl, gates, acts):
+def frame_step(wl, gates, acts, dense_precision="split"):
     ref_emb, ref_lab = wl.refs()
     t = wl.t
     feat, head, _ = hotpath.proto_mask_features(wl.mc, ref_emb, ref_lab, wl.emb[t - 1], wl.lab[t - 1], wl.emb[t], wl.bias,
-                                                cluster_state=dict(init_rows=wl.init_rows[t][0]), side_stream=wl.side)
+                                                cluster_state=dict(init_rows=wl.init_rows[t][0]), side_stream=wl.side,
+                                                dense_state=wl.dense_state, dense_precision=dense_precision)
     outs = gates(acts, head)
     wl.advance()
     return feat, outs
@@ -220,6 +224,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="cfg2", choices=list(syn.CONFIGS))
     ap.add_argument("--streams", type=int, default=1, help="independent sequences stepped concurrently on separate HIP streams")
+    ap.add_argument("--dense", default="split", choices=["split", "fp32"],
+                    help="dense-matching arithmetic: fp16-split products with fp32 accumulate (fp32-equivalent) or exact-fp32 MFMA")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="run the k-means branch on the main stream (no intra-frame stream overlap)")
     args = ap.parse_args()
@@ -252,6 +258,9 @@ def main():
         m, n = query_flat.shape[0], pool.shape[0]      # synthetic labels: every pool pixel is kept
         return dict(flops=2.0 * m * n * C, bytes=(m + n) * C * 4 + n * 4 + m * O * 4)
 
+    def meta_dense_split(query_flat, query_split, pool, pool_split, prep, *a, **k):
+        return meta_dense(query_flat, pool[:prep.n], prep)
+
     def meta_proxy(query_flat, proxies, *a, **k):
         m, npx = query_flat.shape[0], proxies.shape[0]
         return dict(flops=2.0 * m * npx * C, bytes=m * C * 4 + npx * C * 4 + m * (3 * O) * 4)
@@ -260,19 +269,19 @@ def main():
         n = pool.shape[0]
         return dict(flops=2.0 * iters * n * kmax * C, bytes=float(iters) * n * C * 4 * 2 + n * 4)
 
-    timer = OpTimer(["dense_match_min", "proxy_corr_min", "kmeans_segmented", "build_proxies", "label_prep", "local_window_match",
+    timer = OpTimer(["dense_match_min", "dense_match_min_split", "split_rows", "proxy_corr_min", "kmeans_segmented", "build_proxies", "label_prep", "local_window_match",
                      "masked_mean_pool", "cond_gate_pool", "channel_scale", "film_scale", "fg2bg_min", "resize_bilinear_hwc", "resize_bilinear_planes",
                      "plane_mean", "film_gain", "linear", "label_mix", "label_bits", "resize_nearest_bits", "kmeans_plan"])
-    timer.install(dict(dense_match_min=meta_dense, proxy_corr_min=meta_proxy, kmeans_segmented=meta_kmeans))
+    timer.install(dict(dense_match_min=meta_dense, dense_match_min_split=meta_dense_split, proxy_corr_min=meta_proxy, kmeans_segmented=meta_kmeans))
 
     def run_steps(n):
         for _ in range(n):
             for wl, st in zip(workloads, streams):
                 if n_streams > 1:
                     with torch.cuda.stream(st):
-                        frame_step(wl, gates, acts)
+                        frame_step(wl, gates, acts, args.dense)
                 else:
-                    frame_step(wl, gates, acts)
+                    frame_step(wl, gates, acts, args.dense)
 
     def barrier():
         torch.cuda.synchronize()
@@ -284,7 +293,18 @@ def main():
         barrier()
         timer.enabled = (n_streams == 1)     # per-op events are only meaningful on a single stream
         t0 = time.perf_counter()
-        run_steps(args.steps)
+        if os.environ.get("AOC_BENCH_PROFILE"):
+            import cProfile, pstats
+            pr = cProfile.Profile()
+            pr.enable()
+            run_steps(args.steps)
+            pr.disable()
+            host_s = time.perf_counter() - t0
+            pstats.Stats(pr, stream=sys.stderr).sort_stats("cumulative").print_stats(45)
+            print(f"host time to enqueue {args.steps} steps: {host_s * 1e3:.1f} ms", file=sys.stderr)
+        else:
+            run_steps(args.steps)
+        host_enqueue_s = time.perf_counter() - t0
         barrier()
         elapsed = time.perf_counter() - t0
         timer.enabled = False
@@ -316,6 +336,16 @@ def main():
                 roofline = dict(kernel="dense_match_partial_kernel (aoc_dense_match_min)", bound="mfma", achieved=k["tflops"],
                                 peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s", frac=round(k["tflops"] / PEAK_FP32_MFMA_TFLOPS, 4), traffic=None,
                                 avg_launch_ms=k["avg_ms"], algorithmic_flops_per_launch=k["avg_flops"])
+            elif dom == "dense_match_min_split":
+                # algorithmic flops (2 m n C) against the fp16 pipe the kernel runs on; the instruction stream
+                # executes 3 split products on K padded 100 -> 112, i.e. 3.36x the algorithmic flops
+                executed = k["tflops"] * 3.0 * 112.0 / C
+                roofline = dict(kernel="dense_split_kernel (aoc_dense_match_min_split)", bound="mfma", achieved=k["tflops"],
+                                peak=PEAK_F16_MFMA_TFLOPS, unit="TFLOP/s", frac=round(k["tflops"] / PEAK_F16_MFMA_TFLOPS, 4), traffic=None,
+                                avg_launch_ms=k["avg_ms"], algorithmic_flops_per_launch=k["avg_flops"],
+                                executed_tflops=round(executed, 1), pipe_frac=round(executed / PEAK_F16_MFMA_TFLOPS, 4),
+                                note="fp32-equivalent products from 3 fp16 MFMAs (hi*hi + hi*lo + lo*hi, fp32 accumulate); "
+                                     "frac prices the ALGORITHMIC fp32 flops against the fp16 peak, pipe_frac the executed ones")
             elif "gbs" in k:
                 roofline = dict(kernel=dom, bound="hbm", achieved=k["gbs"], peak=PEAK_HBM_GBS, unit="GB/s",
                                 frac=round(k["gbs"] / PEAK_HBM_GBS, 4), traffic=None, avg_launch_ms=k["avg_ms"],
@@ -369,7 +399,10 @@ def main():
                                    f"C={C}, {cfg.frames}-frame clips, MEM_EVERY={mc.MEM_EVERY} (R=1..{1 + (cfg.frames - 2) // mc.MEM_EVERY}), "
                                    "20 Lloyd iterations, local windows [2..12]",
                        "sequences_per_gpu": n_streams, "frames_per_step": n_streams, "sharding": "sequences over ranks, no data-path collective",
-                       "intra_frame_overlap": "k-means branch on a side HIP stream" if not args.no_overlap else "none"},
+                       "intra_frame_overlap": "k-means branch on a side HIP stream" if not args.no_overlap else "none",
+                       "dense_precision": ("fp16-split products (hi*hi + hi*lo + lo*hi), fp32 accumulate: fp32-equivalent; exact-fp32 take-over "
+                                           "on overflow / soft labels" if args.dense == "split" else "exact fp32 MFMA")},
+            "host_enqueue_ms_per_step": round(host_enqueue_s / args.steps * 1e3, 3),
             "roofline": roofline, "roofline_correlation_kernel": corr_roof, "cpu_baseline": cpu, "parity": parity, "kernels": kernels,
         }
         print(json.dumps(line))

@@ -169,6 +169,41 @@ int aoc_dense_match_min(const float *query, int64_t m, int C,
                         int transform, void *workspace, size_t workspace_bytes, aoc_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Dense pixel-level matching on the fp16 matrix pipe with fp32-equivalent products (same reference
+ * lines as aoc_dense_match_min).  Each embedding row is converted ONCE into a "split record":
+ * x * 2^10 = hi + lo with hi, lo fp16 (|error| <= 2^-24 |x|), plus the three fp16 pieces of -16 |x|^2 in
+ * spare k-slots.  q.r is then qh.rh + qh.rl + ql.rh accumulated in fp32 by v_mfma_f32_32x32x16_f16
+ * (the dropped ql.rl term is < 2^-24 |q.r|): deviations from the fp32 reference stay at the level of the
+ * reference's own fp32 rounding (a few 1e-7 on distances of O(1); tests pin <= 5e-6 on the outputs).
+ *
+ * The fast kernels need (a) every |x| * 2^10 <= 65000 and |x|^2 <= 4000 and (b) every kept pool row right
+ * for exactly one object (one-hot labels, as in the reference's eval loop).  Both are checked on the
+ * device; when either fails the SAME call runs the exact-fp32 kernels of aoc_dense_match_min instead, on
+ * the same stream, with no host round trip -- results are then bit-identical to aoc_dense_match_min.
+ *
+ *  aoc_split_record_bytes(C)   bytes per record (448) or 0 when C is unsupported (C % 4 != 0 or C > 100)
+ *  aoc_split_rows              x [n, C] -> records [n * record_bytes], sqnorm [n] (may be NULL);
+ *                              *overflow_flag |= 1 when a value does not fit (flag is sticky, caller zeroes it)
+ *  aoc_dense_match_min_split   query/pool [*, C] fp32 (only read by the fp32 take-over), query_rec/pool_rec
+ *                              their records, query_sqnorm [m]; n = pool rows; right_bits, wrong_bits, fg_rows,
+ *                              obj_rows, counts, obj_offsets as produced by aoc_label_prep on the n pool rows;
+ *                              out / strides / transform as aoc_dense_match_min.  n_obj <= 16.
+ */
+size_t aoc_split_record_bytes(int C);
+int aoc_split_rows(const float *x, int64_t n, int C, void *records, float *sqnorm,
+                   int32_t *overflow_flag, aoc_stream_t stream);
+size_t aoc_dense_match_split_workspace_bytes(int64_t m, int64_t n, int n_obj);
+int aoc_dense_match_min_split(const float *query, const void *query_rec, const float *query_sqnorm,
+                              int64_t m, int C, const float *pool, const void *pool_rec,
+                              const int32_t *overflow_flag, int64_t n,
+                              const uint32_t *right_bits, const uint32_t *wrong_bits,
+                              const int32_t *fg_rows, const int32_t *obj_rows,
+                              const int32_t *counts, const int32_t *obj_offsets,
+                              const float *obj_bias, int n_obj,
+                              float *out, int64_t out_pixel_stride, int64_t out_obj_stride,
+                              int transform, void *workspace, size_t workspace_bytes, aoc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Local (windowed) matching: AEM:921-963 + 968-1060 (and the identical local_matching_proxy,
  * AEM:1064-1156) without the F.unfold materialisation.  Works on maps already at matching
  * resolution (the bilinear down / up-sampling of AEM:938-941,1054-1056 are aoc_resize_*).

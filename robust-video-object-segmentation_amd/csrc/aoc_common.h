@@ -52,3 +52,10 @@ __device__ __forceinline__ float aoc_wave_sum(float v) {
 // its stream with ds_read_b128.  Row stride = 4*TP + 4 floats (the +4 staggers rows by 16 B).
 __host__ __device__ __forceinline__ int aoc_tile_tp(int C) { return ((C / 4) + 3) / 4 * 4; }
 __host__ __device__ __forceinline__ int aoc_tile_row_stride(int C) { return 4 * aoc_tile_tp(C) + 4; }
+
+// aoc_dense_match_min with a device-side gate: every kernel of the call returns at once when gate != NULL and
+// *gate == 0 (the split-fp16 kernels of dense_split.hip own the call then).  Defined in correlation.hip.
+int aoc_dense_match_min_gated(const float *query, int64_t m, int C, const float *pool, const int32_t *fg_rows, const int32_t *n_fg,
+                              int64_t n_fg_capacity, const uint32_t *wrong_bits, const float *obj_bias, int n_obj, float *out,
+                              int64_t out_pixel_stride, int64_t out_obj_stride, int transform, void *workspace, size_t workspace_bytes,
+                              const int32_t *gate, aoc_stream_t stream);

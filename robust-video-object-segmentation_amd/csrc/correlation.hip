@@ -258,7 +258,9 @@ __global__ __launch_bounds__(256) void proxy_corr_min_kernel(const float *__rest
 constexpr int DM_NB = 8;
 
 __global__ __launch_bounds__(256) void gather_sqnorm_kernel(const float *__restrict__ pool, int C, const int32_t *__restrict__ fg_rows,
-                                                             const int32_t *__restrict__ n_fg, float *__restrict__ r2) {
+                                                             const int32_t *__restrict__ n_fg, float *__restrict__ r2,
+                                                             const int32_t *__restrict__ gate) {
+    if (gate && *gate == 0) return;            // the split-fp16 kernels own this call (dense_split.hip)
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= *n_fg) return;
     const float *x = pool + (size_t)fg_rows[p] * C;
@@ -285,7 +287,8 @@ __global__ __launch_bounds__(NW * 64, 2) void dense_match_partial_kernel(const f
                                                                           const float *__restrict__ pool, const int32_t *__restrict__ fg_rows,
                                                                           const int32_t *__restrict__ n_fg_ptr, const float *__restrict__ r2_all,
                                                                           const uint32_t *__restrict__ wrong_bits, int n_obj,
-                                                                          float *__restrict__ partial) {
+                                                                          float *__restrict__ partial, const int32_t *__restrict__ gate) {
+    if (gate && *gate == 0) return;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int NT = NW * 64;
     constexpr int NB4 = (TMAX + 3) / 4;
@@ -482,7 +485,9 @@ __global__ __launch_bounds__(NW * 64, 2) void dense_match_partial_kernel(const f
 
 __global__ __launch_bounds__(256) void dense_match_finalize_kernel(const float *__restrict__ partial, int n_split, int64_t m, int n_obj,
                                                                     const int32_t *__restrict__ n_fg_ptr, const float *__restrict__ obj_bias,
-                                                                    float *__restrict__ out, int64_t pstride, int64_t ostride, int transform) {
+                                                                    float *__restrict__ out, int64_t pstride, int64_t ostride, int transform,
+                                                                    const int32_t *__restrict__ gate) {
+    if (gate && *gate == 0) return;
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= m * n_obj) return;
     const int64_t row = idx / n_obj;
@@ -604,6 +609,16 @@ int aoc_dense_match_min(const float *query, int64_t m, int C, const float *pool,
                         int64_t n_fg_capacity, const uint32_t *wrong_bits, const float *obj_bias, int n_obj,
                         float *out, int64_t out_pixel_stride, int64_t out_obj_stride, int transform,
                         void *workspace, size_t workspace_bytes, aoc_stream_t stream) {
+    return aoc_dense_match_min_gated(query, m, C, pool, fg_rows, n_fg, n_fg_capacity, wrong_bits, obj_bias, n_obj, out, out_pixel_stride,
+                                     out_obj_stride, transform, workspace, workspace_bytes, nullptr, stream);
+}
+
+}  // extern "C"
+
+int aoc_dense_match_min_gated(const float *query, int64_t m, int C, const float *pool, const int32_t *fg_rows, const int32_t *n_fg,
+                              int64_t n_fg_capacity, const uint32_t *wrong_bits, const float *obj_bias, int n_obj,
+                              float *out, int64_t out_pixel_stride, int64_t out_obj_stride, int transform,
+                              void *workspace, size_t workspace_bytes, const int32_t *gate, aoc_stream_t stream) {
     if (!query || !pool || !fg_rows || !n_fg || !wrong_bits || !out || !workspace) return AOC_ERR_INVALID_ARG;
     if (m < 1 || C < 4 || n_obj < 1 || n_fg_capacity < 1 || n_fg_capacity >= (1ll << 31)) return AOC_ERR_INVALID_ARG;
     if ((C & 3) || C > 128 || n_obj > 16) return AOC_ERR_UNSUPPORTED;
@@ -617,9 +632,9 @@ int aoc_dense_match_min(const float *query, int64_t m, int C, const float *pool,
     const int RS = aoc_tile_row_stride(C);
     const size_t lds = (size_t)DM_NB * 16 * RS * sizeof(float) + DM_NB * 16 * (sizeof(float) + sizeof(uint32_t) + 2 * sizeof(int32_t));
 
-    hipLaunchKernelGGL(gather_sqnorm_kernel, dim3((unsigned)((n_fg_capacity + 255) / 256)), dim3(256), 0, st, pool, C, fg_rows, n_fg, r2);
+    hipLaunchKernelGGL(gather_sqnorm_kernel, dim3((unsigned)((n_fg_capacity + 255) / 256)), dim3(256), 0, st, pool, C, fg_rows, n_fg, r2, gate);
     const dim3 grid(row_blocks, ns);
-#define AOC_DM(NA, OM, TM, EX) hipLaunchKernelGGL((dense_match_partial_kernel<NA, OM, TM, EX, DM_NW>), grid, dim3(DM_NW * 64), lds, st, query, m, C, pool, fg_rows, n_fg, r2, wrong_bits, n_obj, partial)
+#define AOC_DM(NA, OM, TM, EX) hipLaunchKernelGGL((dense_match_partial_kernel<NA, OM, TM, EX, DM_NW>), grid, dim3(DM_NW * 64), lds, st, query, m, C, pool, fg_rows, n_fg, r2, wrong_bits, n_obj, partial, gate)
     if (C == 100) {
         if (n_obj <= 4) AOC_DM(2, 4, 25, true); else if (n_obj <= 8) AOC_DM(1, 8, 25, true); else AOC_DM(1, 16, 25, true);
     } else {
@@ -628,9 +643,7 @@ int aoc_dense_match_min(const float *query, int64_t m, int C, const float *pool,
 #undef AOC_DM
     const int64_t total = m * n_obj;
     hipLaunchKernelGGL(dense_match_finalize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, partial, ns, m, n_obj, n_fg,
-                       obj_bias, out, out_pixel_stride, out_obj_stride, transform);
+                       obj_bias, out, out_pixel_stride, out_obj_stride, transform, gate);
     AOC_RETURN_IF_LAUNCH_FAILED();
     return AOC_OK;
 }
-
-}  // extern "C"

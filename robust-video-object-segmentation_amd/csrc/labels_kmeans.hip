@@ -1,6 +1,8 @@
 // Label preparation, segmented k-means (bit-identical to scipy kmeans2) and adaptive-proxy
 // construction.  Reference: AEM:252-286 (adaptive_embedding_for_matching.py) + scipy.cluster.vq.
 #include "aoc_common.h"
+#include <stdlib.h>
+#include <string.h>
 
 namespace {
 
@@ -405,6 +407,7 @@ __global__ __launch_bounds__(64) void km_accumulate_kernel(const float *__restri
 }
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 constexpr uint32_t KU_INVALID_OFF = 0xFFFFFF00u;   // beyond the buffer descriptor's range: raw buffer loads return 0
 
 // ==========================================================================================
@@ -431,6 +434,11 @@ __device__ unsigned long long aoc_ks_stats[8];   // attempts, folded feature-att
 #define KS_STAT(i, n) do { if (threadIdx.x == 0) atomicAdd(&aoc_ks_stats[i], (unsigned long long)(n)); } while (0)
 #else
 #define KS_STAT(i, n) do { } while (0)
+#endif
+#ifdef AOC_KS_STATS
+#define KS_CLK() ((long long)__builtin_readcyclecounter())
+#else
+#define KS_CLK() 0ll
 #endif
 constexpr int KS_T = 8;          // blocks (of 64 members) folded between two cross-lane reductions
 
@@ -844,7 +852,7 @@ __global__ __launch_bounds__(256) void km_chunk_sum_kernel(const float *__restri
 constexpr int KC_UNSAFE = -128;
 __global__ __launch_bounds__(128) void km_chunk_predict_kernel(const int32_t *__restrict__ seg_k, const int32_t *__restrict__ counts,
                                                                 const int32_t *__restrict__ cchunk, const float *__restrict__ csum, int kmax,
-                                                                int C, int8_t *__restrict__ cexp) {
+                                                                int C, int8_t *__restrict__ cexp, int start_chunk) {
     const int s = blockIdx.y, j = blockIdx.x;
     if (j >= seg_k[s]) return;
     const int oc = s * kmax + j;
@@ -865,7 +873,7 @@ __global__ __launch_bounds__(128) void km_chunk_predict_kernel(const int32_t *__
             if (pre > 1e-30f && end < 1e30f && end >= pre) {
                 const int e_lo = (int)((__float_as_uint(pre * 0.9995f) >> 23) & 0xff) - 127;
                 const int e_hi = (int)((__float_as_uint(end * 1.0005f) >> 23) & 0xff) - 127;
-                if (e_lo == e_hi && e_lo >= -100 && e_lo <= 100) e = e_lo;
+                if (e_lo == e_hi && e_lo >= -100 && e_lo <= 100 && c >= start_chunk) e = e_lo;
             }
             cexp[(size_t)(base + c) * C + f] = (int8_t)e;
             pre = end;
@@ -1026,67 +1034,170 @@ __global__ __launch_bounds__(256) void km_chunk_fold_kernel(const float *__restr
 // crossing, unusable summary) the chunk's rows are folded block by block, with the literal serial additions
 // where a block itself crosses.  Summaries of 64 chunks sit in registers (v_readlane), rows of the next chunk
 // that will need them are prefetched, so memory latency stays off the chain.
-struct KsChunk {
-    u32x4 x[KS_T];
+template <int NF>
+struct KsChunkT {
+    uint32_t x[KS_T][NF];
 };
 
-template <int MODE>
+// One chunk (KS_T blocks of 64 members) of feature F, exactly, from running sum s.  All blocks are folded at once in
+// the integer domain of the current binade -- they are independent, so the memory-free arithmetic pipelines instead
+// of paying the dependent-latency of KS_T serial block steps -- and a scalar walk over the block totals finds the
+// block (if any) where n would leave the binade; only that block takes the crossing-aware path (ks_block_exact),
+// after which the remaining blocks are folded again in the new binade.  Ties, negative or non-finite values and
+// s == 0 fall back to the per-block path, which ends in the literal serial additions.
+template <int F, int NF>
+__device__ __forceinline__ float ks_chunk_exact(float s, const KsChunkT<NF> &ch, int nblk, int lane, bool dbg = false) {
+    int from = 0;
+    if (dbg) KS_STAT(5, 1);                               // calls
+#pragma unroll 1
+    for (int round = 0; round < 3 && from < nblk; ++round) {
+        const KsBinade bb = ks_binade(s);
+        if (!bb.ok) break;
+        int r[KS_T];
+        unsigned long long tie[KS_T], odd[KS_T];
+        bool bad = false;
+#pragma unroll
+        for (int b = 0; b < KS_T; ++b) {
+            const float y = __uint_as_float(ch.x[b][F]) * bb.inv_u;
+            const float rn = rintf(y);
+            const bool is_tie = fabsf(rn - y) == 0.5f;
+            const int rr = is_tie ? (int)floorf(y) : (int)rn;             // ties start from floor(y); the walk re-rounds them
+            r[b] = (b >= from) ? rr : 0;
+            bad |= (b >= from) && !(__float_as_uint(y) < 0x4B800000u);    // y in [+0, 2^24)
+            tie[b] = __ballot(is_tie && b >= from);
+            odd[b] = __ballot((r[b] & 1) != 0);
+        }
+        if (__ballot(bad) != 0ull) break;
+        int t[KS_T];
+#pragma unroll
+        for (int b = 0; b < KS_T; ++b) t[b] = ks_wave_sum(r[b]);
+        // scalar walk over the block totals: ties are re-rounded from the running parity (a tie leaves n even)
+        int n = bb.n_in, par = bb.n_in & 1, bcross = -1;
+#pragma unroll
+        for (int b = 0; b < KS_T; ++b) {
+            if (b >= from && b < nblk && bcross < 0) {
+                int bump = 0, base_par = par, lo = 0;
+                unsigned long long tm = tie[b];
+                while (tm) {
+                    const int tl = __builtin_ctzll(tm);
+                    tm &= tm - 1;
+                    const unsigned long long below_t = (tl == 0) ? 0ull : (~0ull >> (64 - tl));
+                    const unsigned long long below_lo = (lo == 0) ? 0ull : (~0ull >> (64 - lo));
+                    const int pb = base_par ^ (__popcll(odd[b] & below_t & ~below_lo) & 1);   // parity of n in front of lane tl
+                    bump += pb ^ (int)((odd[b] >> tl) & 1ull);                                 // n + floor(y) odd -> round up
+                    base_par = 0;
+                    lo = tl + 1;
+                }
+                const unsigned long long rest = (lo >= 64) ? 0ull : (~0ull << lo);
+                const int inc = t[b] + bump;
+                if (n + inc > 0xFFFFFF) {
+                    bcross = b;
+                } else {
+                    n += inc;
+                    par = base_par ^ (__popcll(odd[b] & rest) & 1);
+                }
+            }
+        }
+        s = (float)n * bb.u;
+        if (bcross < 0) return s;
+        float xc = 0.0f;
+#pragma unroll
+        for (int b = 0; b < KS_T; ++b)
+            if (b == bcross) xc = __uint_as_float(ch.x[b][F]);
+        s = ks_block_exact(s, xc, lane);
+        from = bcross + 1;
+        if (dbg) KS_STAT(6, 1);                           // crossings resolved
+    }
+#pragma unroll
+    for (int b = 0; b < KS_T; ++b)
+        if (b >= from && b < nblk) { s = ks_block_exact(s, __uint_as_float(ch.x[b][F]), lane); if (dbg) KS_STAT(7, 1); }
+    return s;
+}
+
+template <int MODE, int NF>
 __global__ __launch_bounds__(64) void km_sum_scan_kernel(const float *__restrict__ pool, uint32_t pool_bytes, int C,
                                                           const int32_t *__restrict__ seg_off, const int32_t *__restrict__ seg_k,
                                                           const int32_t *__restrict__ counts, const int32_t *__restrict__ cbase,
                                                           const uint32_t *__restrict__ moff, int kmax, float *__restrict__ dst,
                                                           const int32_t *__restrict__ cchunk, const int8_t *__restrict__ cexp,
-                                                          const int32_t *__restrict__ cinc0, const int32_t *__restrict__ cinc1) {
+                                                          const int32_t *__restrict__ cinc0, const int32_t *__restrict__ cinc1,
+                                                          int start_chunk, const float *__restrict__ head_state) {
     const int s = blockIdx.z, j = blockIdx.y, q = blockIdx.x;
     if (j >= seg_k[s]) return;
     const int cnt = counts[s * kmax + j];
+    if (start_chunk > 0 && cnt <= start_chunk * KS_CHUNK) return;       // finished by km_ordered_sum_kernel
     const int lane = threadIdx.x;
-    float *out = (MODE == 0) ? dst + ((size_t)s * kmax + j) * C + 4 * q : dst + (((size_t)s * 2 + 1) * kmax + j) * C + 4 * q;
+    float *out = (MODE == 0) ? dst + ((size_t)s * kmax + j) * C + NF * q : dst + (((size_t)s * 2 + 1) * kmax + j) * C + NF * q;
     if (cnt == 0) {
-        if (MODE == 1 && lane == 0) *reinterpret_cast<float4 *>(out) = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (MODE == 1 && lane < NF) out[lane] = 0.0f;
         return;
     }
     const bool have_summ = cexp != nullptr;
-    const size_t srow = have_summ ? ((size_t)cchunk[s * kmax + j] * C + 4 * q) : 0;
+    const size_t srow = have_summ ? ((size_t)cchunk[s * kmax + j] * C + NF * q) : 0;
     const uint32_t *list = moff + seg_off[s] + cbase[s * kmax + j];
     __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(pool), 0, pool_bytes, 0x00020000);
-    const uint32_t qoff = (uint32_t)q * 16u;
+    const uint32_t qoff = (uint32_t)q * (NF * 4u);
+    typedef KsChunkT<NF> KsChunk;
     const int n_chunks = (cnt + KS_CHUNK - 1) / KS_CHUNK;
 
-    auto fetch_rows = [&](int c, KsChunk &ch) {
-        uint32_t o[KS_T];
+    auto load_offs = [&](int c, uint32_t (&o)[KS_T]) {
 #pragma unroll
         for (int b = 0; b < KS_T; ++b) {
             const int m = (c * KS_T + b) * 64 + lane;
             o[b] = (m < cnt) ? list[m] + qoff : KU_INVALID_OFF;
         }
+    };
+    auto load_rows = [&](const uint32_t (&o)[KS_T], KsChunk &ch) {
 #pragma unroll
-        for (int b = 0; b < KS_T; ++b) ch.x[b] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o[b], 0, 0);
+        for (int b = 0; b < KS_T; ++b) {
+            if constexpr (NF == 4) {
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o[b], 0, 0);
+                ch.x[b][0] = v.x; ch.x[b][1] = v.y; ch.x[b][2] = v.z; ch.x[b][3] = v.w;
+            } else if constexpr (NF == 2) {
+                const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, o[b], 0, 0);
+                ch.x[b][0] = v.x; ch.x[b][1] = v.y;
+            } else {
+                ch.x[b][0] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, o[b], 0, 0);
+            }
+        }
+    };
+    auto fetch_rows = [&](int c, KsChunk &ch) {
+        uint32_t o[KS_T];
+        load_offs(c, o);
+        load_rows(o, ch);
     };
 
     // summaries of chunks [batch0, batch0 + 64) in registers (lane l = chunk batch0 + l), next batch prefetched
-    uint32_t se4 = 0x80808080u, ne4 = 0x80808080u;
-    int4 si0 = make_int4(0, 0, 0, 0), si1 = make_int4(0, 0, 0, 0), ni0 = si0, ni1 = si0;
+    struct Summ { int e[NF]; int i0[NF], i1[NF]; };
+    Summ sc, sx;
+#pragma unroll
+    for (int f = 0; f < NF; ++f) { sc.e[f] = sx.e[f] = KC_UNSAFE; sc.i0[f] = sc.i1[f] = sx.i0[f] = sx.i1[f] = 0; }
     int batch0 = 0;
     unsigned long long need_cur = ~0ull, need_next = ~0ull;
-    auto unsafe4 = [](uint32_t e4) -> bool {
-        const uint32_t u = (uint32_t)(uint8_t)KC_UNSAFE;
-        return ((e4 & 0xff) == u) || (((e4 >> 8) & 0xff) == u) || (((e4 >> 16) & 0xff) == u) || ((e4 >> 24) == u);
+    auto unsafe_any = [](const Summ &m) -> bool {
+        bool u = false;
+#pragma unroll
+        for (int f = 0; f < NF; ++f) u |= (m.e[f] == KC_UNSAFE);
+        return u;
     };
-    auto fetch_batch = [&](int b0, uint32_t &e4, int4 &i0, int4 &i1) {
+    auto fetch_batch = [&](int b0, Summ &m) {
         const int c = b0 + lane;
-        e4 = 0x80808080u;
+#pragma unroll
+        for (int f = 0; f < NF; ++f) m.e[f] = KC_UNSAFE;
         if (have_summ && c < n_chunks) {
-            e4 = *reinterpret_cast<const uint32_t *>(cexp + srow + (size_t)c * C);
-            i0 = *reinterpret_cast<const int4 *>(cinc0 + srow + (size_t)c * C);
-            i1 = *reinterpret_cast<const int4 *>(cinc1 + srow + (size_t)c * C);
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+                m.e[f] = cexp[srow + (size_t)c * C + f];
+                m.i0[f] = cinc0[srow + (size_t)c * C + f];
+                m.i1[f] = cinc1[srow + (size_t)c * C + f];
+            }
         }
     };
     if (have_summ) {
-        fetch_batch(0, se4, si0, si1);
-        fetch_batch(64, ne4, ni0, ni1);
-        need_cur = __ballot(unsafe4(se4));
-        need_next = __ballot(unsafe4(ne4));
+        fetch_batch(0, sc);
+        fetch_batch(64, sx);
+        need_cur = __ballot(unsafe_any(sc));
+        need_next = __ballot(unsafe_any(sx));
     }
     // first chunk >= from (inside the two known batches) whose rows will be needed; n_chunks if none is known
     auto next_needed = [&](int from) -> int {
@@ -1103,73 +1214,248 @@ __global__ __launch_bounds__(64) void km_sum_scan_kernel(const float *__restrict
         return n_chunks;
     };
 
-    float st[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool ks_big = cnt > 30000 && q == 0;     // instrumentation target (AOC_KS_STATS builds only)
+    long long ks_t0 = KS_CLK(), ks_tsum = 0, ks_tex = 0;
+    (void)ks_big; (void)ks_t0; (void)ks_tsum; (void)ks_tex;
+    // running sums: while a sum sits in a plain binade it is kept as (exponent, n = s / ulp) in integers, so a verified
+    // chunk summary is applied with a handful of scalar operations; st[] holds the float whenever that form is not valid
+    float st[NF];
+    int se[NF], sn[NF];
+#pragma unroll
+    for (int f = 0; f < NF; ++f) { st[f] = 0.0f; se[f] = KC_UNSAFE; sn[f] = 0; }
+    auto to_int = [&](int f) {
+        const KsBinade bb = ks_binade(st[f]);
+        se[f] = bb.ok ? (int)((__float_as_uint(st[f]) >> 23) & 0xff) - 127 : KC_UNSAFE;
+        sn[f] = bb.n_in;
+    };
+    auto to_float = [&](int f) -> float {
+        return (se[f] != KC_UNSAFE) ? (float)sn[f] * __uint_as_float((uint32_t)(se[f] - 23 + 127) << 23) : st[f];
+    };
+    if (start_chunk > 0) {
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+            st[f] = head_state[((size_t)s * kmax + j) * C + NF * q + f];
+            to_int(f);
+        }
+    }
+    // rows of the next chunk that will need them (pending) are in flight in nxt; the member offsets of the one after
+    // that (pending2) are already in registers, so its rows cost one memory latency, not two, when their turn comes
     KsChunk cur, nxt;
-    int pending = next_needed(0);
-    if (pending < n_chunks) fetch_rows(pending, nxt);
+    uint32_t onext[KS_T];
+    int pending = next_needed(start_chunk), pending2 = n_chunks;
+    if (pending < n_chunks) {
+        fetch_rows(pending, nxt);
+        pending2 = next_needed(pending + 1);
+        if (pending2 < n_chunks) load_offs(pending2, onext);
+    }
 
-    for (int c = 0; c < n_chunks; ++c) {
+    for (int c = start_chunk; c < n_chunks; ++c) {
         if (have_summ && c - batch0 >= 64) {                  // advance to the prefetched batch, prefetch the one after
             batch0 += 64;
-            se4 = ne4; si0 = ni0; si1 = ni1;
+            sc = sx;
             need_cur = need_next;
-            fetch_batch(batch0 + 64, ne4, ni0, ni1);
-            need_next = __ballot(unsafe4(ne4));
+            fetch_batch(batch0 + 64, sx);
+            need_next = __ballot(unsafe_any(sx));
             if (pending >= n_chunks) {                        // nothing was known to be needed: look again
                 pending = next_needed(c);
                 if (pending < n_chunks) fetch_rows(pending, nxt);
             }
+            if (pending < n_chunks && pending2 >= n_chunks) {
+                pending2 = next_needed(pending + 1);
+                if (pending2 < n_chunks) load_offs(pending2, onext);
+            }
         }
-        bool skip[4] = {false, false, false, false};
-        if (have_summ) {
-            const int l = c - batch0;
-            const uint32_t e4 = __builtin_amdgcn_readlane(se4, l);
-            const int inc0[4] = {__builtin_amdgcn_readlane(si0.x, l), __builtin_amdgcn_readlane(si0.y, l), __builtin_amdgcn_readlane(si0.z, l),
-                                 __builtin_amdgcn_readlane(si0.w, l)};
-            const int inc1[4] = {__builtin_amdgcn_readlane(si1.x, l), __builtin_amdgcn_readlane(si1.y, l), __builtin_amdgcn_readlane(si1.z, l),
-                                 __builtin_amdgcn_readlane(si1.w, l)};
+        bool skip[NF];
+        bool all_skip = true;
+        const long long ks_ta = KS_CLK();
 #pragma unroll
-            for (int f = 0; f < 4; ++f) {
-                const int e = (int)(int8_t)((e4 >> (8 * f)) & 0xff);
-                const KsBinade bb = ks_binade(st[f]);
-                const int ecur = (int)((__float_as_uint(st[f]) >> 23) & 0xff) - 127;
-                if (e != KC_UNSAFE && bb.ok && ecur == e) {           // prediction verified against the exact sum
-                    const long long n_out = (long long)bb.n_in + ((bb.n_in & 1) ? inc1[f] : inc0[f]);
-                    if (n_out <= 0xFFFFFF) {                          // n never left the binade inside the chunk
-                        st[f] = (float)(int)n_out * bb.u;
+        for (int f = 0; f < NF; ++f) {
+            skip[f] = false;
+            if (have_summ) {
+                const int l = c - batch0;
+                const int e = __builtin_amdgcn_readlane(sc.e[f], l);
+                if (e != KC_UNSAFE && e == se[f]) {                   // prediction verified against the exact sum
+                    const int inc = (sn[f] & 1) ? __builtin_amdgcn_readlane(sc.i1[f], l) : __builtin_amdgcn_readlane(sc.i0[f], l);
+                    const int n_out = sn[f] + inc;
+                    if (n_out <= 0xFFFFFF && n_out >= sn[f]) {        // n never left the binade inside the chunk
+                        sn[f] = n_out;
                         skip[f] = true;
                     }
                 }
             }
-            KS_STAT(5, (skip[0] ? 1 : 0) + (skip[1] ? 1 : 0) + (skip[2] ? 1 : 0) + (skip[3] ? 1 : 0));
+            all_skip &= skip[f];
         }
-        if (skip[0] && skip[1] && skip[2] && skip[3]) continue;
+        ks_tsum += KS_CLK() - ks_ta;
+        if (all_skip) continue;
+        const long long ks_tb = KS_CLK();
         // ---- this chunk needs its rows
         if (pending == c) {
             cur = nxt;
+            pending = pending2;
+            if (pending < n_chunks) load_rows(onext, nxt);             // offsets arrived long ago: one latency to go
+            pending2 = (pending < n_chunks) ? next_needed(pending + 1) : n_chunks;
+            if (pending2 < n_chunks) load_offs(pending2, onext);
         } else {
             fetch_rows(c, cur);                                        // not prefetched (mispredicted summary): rare
-            KS_STAT(6, 1);
         }
-        pending = next_needed(c + 1);
-        if (pending < n_chunks) fetch_rows(pending, nxt);              // in flight while this chunk is folded
         const int blocks_here = min(KS_T, (cnt - c * KS_CHUNK + 63) / 64);
-#pragma unroll
-        for (int b = 0; b < KS_T; ++b) {
-            if (b < blocks_here) {
-                const float xv[4] = {__uint_as_float(cur.x[b].x), __uint_as_float(cur.x[b].y), __uint_as_float(cur.x[b].z), __uint_as_float(cur.x[b].w)};
-#pragma unroll
-                for (int f = 0; f < 4; ++f) {
-                    if (skip[f]) continue;
-                    st[f] = ks_block_exact(st[f], xv[f], lane);
-                    KS_STAT(3, 1);
-                }
-            }
+#ifdef AOC_KS_STATS
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (ks_big) KS_STAT(3, KS_CLK() - ks_tb);      // big wave: cycles waiting for the rows
+#endif
+        if (!skip[0]) { st[0] = ks_chunk_exact<0, NF>(to_float(0), cur, blocks_here, lane, ks_big); to_int(0); }
+        if constexpr (NF > 1) { if (!skip[1]) { st[1] = ks_chunk_exact<1, NF>(to_float(1), cur, blocks_here, lane, ks_big); to_int(1); } }
+        if constexpr (NF > 2) {
+            if (!skip[2]) { st[2] = ks_chunk_exact<2, NF>(to_float(2), cur, blocks_here, lane, ks_big); to_int(2); }
+            if (!skip[3]) { st[3] = ks_chunk_exact<3, NF>(to_float(3), cur, blocks_here, lane, ks_big); to_int(3); }
         }
+        ks_tex += KS_CLK() - ks_tb;
+        if (ks_big) KS_STAT(2, 1);
     }
+#pragma unroll
+    for (int f = 0; f < NF; ++f) st[f] = to_float(f);
+    if (ks_big) { KS_STAT(0, KS_CLK() - ks_t0); KS_STAT(1, ks_tsum); KS_STAT(4, ks_tex); }
     if (lane == 0) {
         const float fc = (float)cnt;
-        *reinterpret_cast<float4 *>(out) = make_float4(st[0] / fc, st[1] / fc, st[2] / fc, st[3] / fc);
+#pragma unroll
+        for (int f = 0; f < NF; ++f) out[f] = st[f] / fc;
+    }
+}
+
+// ==========================================================================================
+// Ordered sums, literally: one workgroup per (cluster, group of 28 features), lanes = features.  The consumer wave
+// adds the member rows one after another in float32 -- the scipy sequence itself, so nothing is assumed about the
+// data (sign, range, NaN) -- while seven producer waves gather the group's 112 bytes of every member row through
+// the ordered member list into a double-buffered LDS batch: member offsets OS_DEPTH + 1 batches ahead, row pieces
+// OS_DEPTH batches ahead (all in flight across the barriers), so the chain only ever waits on LDS and costs a few
+// cycles per member.  Splitting the features over workgroups keeps the per-CU gather rate low enough for that.
+// MODE 0: centroids[s,j,:] = sum / count (empty cluster untouched, vq.py:820-823)
+// MODE 1: proxies[s,1,j,:] = mean of the listed rows (AEM:280), zeros when empty
+constexpr int OS_BATCH = 128;                   // rows per LDS buffer
+constexpr int OS_FP = 7;                        // 16-byte pieces (4 features each) per feature group
+constexpr int OS_LD = 32;                       // LDS row stride in floats
+constexpr int OS_NPROD = 7;                     // producer waves (448 lanes: exactly 2 pieces per lane per batch)
+constexpr int OS_PP = OS_BATCH * OS_FP / (OS_NPROD * 64);
+constexpr int OS_DEPTH = 6;                     // batches of row pieces in flight per lane (even)
+static_assert(OS_PP * OS_NPROD * 64 == OS_BATCH * OS_FP && OS_DEPTH % 2 == 0 && OS_FP * 4 <= OS_LD, "ordered-sum geometry");
+inline int os_groups(int C) { return (C / 4 + OS_FP - 1) / OS_FP; }
+
+template <int MODE>
+__global__ __launch_bounds__((OS_NPROD + 1) * 64) void km_ordered_sum_kernel(const float *__restrict__ pool, uint32_t pool_bytes, int C,
+                                                                              const int32_t *__restrict__ seg_off, const int32_t *__restrict__ seg_k,
+                                                                              const int32_t *__restrict__ counts, const int32_t *__restrict__ cbase,
+                                                                              const uint32_t *__restrict__ moff, int kmax, float *__restrict__ dst,
+                                                                              int member_cap, float *__restrict__ head_state) {
+    __shared__ __attribute__((aligned(16))) float os_lds[2 * OS_BATCH * OS_LD];
+    const int s = blockIdx.y, j = blockIdx.x, grp = blockIdx.z;
+    if (j >= seg_k[s]) return;
+    const int oc = s * kmax + j;
+    const int cnt_all = counts[oc];
+    const int f0 = grp * OS_FP * 4;
+    const int nfeat = min(OS_FP * 4, C - f0);
+    float *out = ((MODE == 0) ? dst + (size_t)oc * C : dst + (((size_t)s * 2 + 1) * kmax + j) * C) + f0;
+    if (cnt_all == 0) {
+        if (MODE == 1 && (int)threadIdx.x < nfeat) out[threadIdx.x] = 0.0f;
+        return;
+    }
+    // head mode: a cluster larger than member_cap only gets its first member_cap members summed here (the running
+    // sums go to head_state and the chunk-parallel stitch continues from there)
+    const bool head_only = member_cap > 0 && cnt_all > member_cap;
+    const int cnt = head_only ? member_cap : cnt_all;
+    const int wave = threadIdx.x >> 6, lane = aoc_lane();
+    const int nb = (cnt + OS_BATCH - 1) / OS_BATCH;
+
+    if (wave == 0) {
+        // ---- consumer: the sequential float32 sum (rows past the count are zeros: s + 0.0f == s)
+        const bool active = lane < nfeat;
+        const float *col = os_lds + (active ? lane : 0);
+        float sum = 0.0f;
+        for (int b = 0; b < nb; ++b) {
+            __syncthreads();                                   // batch b is in buffer b & 1
+            const float *t = col + (b & 1) * OS_BATCH * OS_LD;
+            float xa[16], xb[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) xa[u] = t[u * OS_LD];
+#pragma unroll
+            for (int g = 0; g < OS_BATCH / 16; g += 2) {
+#pragma unroll
+                for (int u = 0; u < 16; ++u) xb[u] = t[((g + 1) * 16 + u) * OS_LD];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) sum = sum + xa[u];
+                if (g + 2 < OS_BATCH / 16) {
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) xa[u] = t[((g + 2) * 16 + u) * OS_LD];
+                }
+#pragma unroll
+                for (int u = 0; u < 16; ++u) sum = sum + xb[u];
+            }
+        }
+        if (active) {
+            if (head_only) head_state[(size_t)oc * C + f0 + lane] = sum;
+            else out[lane] = sum / (float)cnt;
+        }
+        return;
+    }
+
+    // ---- producers
+    const uint32_t *list = moff + seg_off[s] + cbase[oc];
+    __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(pool), 0, pool_bytes, 0x00020000);
+    const int p = (wave - 1) * 64 + lane;
+    const int c4 = C >> 2;
+    int prow[OS_PP];
+    uint32_t pbyte[OS_PP];
+    bool pvalid[OS_PP];
+#pragma unroll
+    for (int i = 0; i < OS_PP; ++i) {
+        const int idx = i * (OS_NPROD * 64) + p;
+        prow[i] = idx / OS_FP;
+        const int piece = idx - prow[i] * OS_FP;
+        pvalid[i] = grp * OS_FP + piece < c4;
+        pbyte[i] = (uint32_t)(grp * OS_FP + piece) * 16u;
+    }
+    auto load_offs = [&](int b, uint32_t (&o)[OS_PP]) {
+#pragma unroll
+        for (int i = 0; i < OS_PP; ++i) {
+            const int m = b * OS_BATCH + prow[i];
+            o[i] = (b < nb && pvalid[i] && m < cnt) ? list[m] + pbyte[i] : KU_INVALID_OFF;
+        }
+    };
+    auto load_rows = [&](const uint32_t (&o)[OS_PP], u32x4 (&d)[OS_PP]) {
+#pragma unroll
+        for (int i = 0; i < OS_PP; ++i) d[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, o[i], 0, 0);   // out of range -> zeros
+    };
+    auto write_rows = [&](int b, const u32x4 (&d)[OS_PP]) {
+        float *base = os_lds + (b & 1) * OS_BATCH * OS_LD;
+#pragma unroll
+        for (int i = 0; i < OS_PP; ++i)
+            *reinterpret_cast<u32x4 *>(base + prow[i] * OS_LD + ((pbyte[i] >> 2) - f0)) = d[i];
+    };
+    u32x4 d[OS_DEPTH][OS_PP];
+    uint32_t o[2][OS_PP];
+    {
+        uint32_t po[OS_DEPTH + 2][OS_PP];
+#pragma unroll
+        for (int k = 0; k < OS_DEPTH + 2; ++k) load_offs(k, po[k]);
+#pragma unroll
+        for (int k = 0; k < OS_DEPTH; ++k) load_rows(po[k], d[k]);
+        write_rows(0, d[0]);
+        load_rows(po[OS_DEPTH], d[0]);                          // batch OS_DEPTH
+#pragma unroll
+        for (int i = 0; i < OS_PP; ++i) o[1][i] = po[OS_DEPTH + 1][i];
+    }
+    // at the top of iteration b: batches b + 1 .. b + DEPTH are in d[(b + 1) % DEPTH] ... (in flight), the offsets of
+    // batch b + 1 + DEPTH in o[(b + 1) & 1]
+    for (int b0 = 0; b0 < nb; b0 += OS_DEPTH) {
+#pragma unroll
+        for (int k = 0; k < OS_DEPTH; ++k) {
+            const int b = b0 + k;
+            if (b < nb) {
+                __syncthreads();                               // the consumer is done with buffer (b + 1) & 1
+                if (b + 1 < nb) write_rows(b + 1, d[(k + 1) % OS_DEPTH]);
+                load_offs(b + 2 + OS_DEPTH, o[k & 1]);
+                load_rows(o[(k + 1) & 1], d[(k + 1) % OS_DEPTH]);   // batch b + 1 + DEPTH
+            }
+        }
     }
 }
 
@@ -1215,7 +1501,7 @@ struct KsWorkspace {
     // chunk summaries
     int nch_cap;
     int32_t *cchunk, *owner_cluster, *owner_local, *cinc0, *cinc1;
-    float *csum;
+    float *csum, *head;
     int8_t *cexp;
 };
 inline int ks_chunk_capacity(int64_t cap, int n_seg, int kmax) { return (int)(cap / KS_CHUNK) + n_seg * (kmax + 1) + 2; }
@@ -1224,7 +1510,8 @@ inline size_t ks_workspace_bytes(int64_t cap, int n_seg, int kmax) {
     const size_t nch = (size_t)ks_chunk_capacity(cap, n_seg, kmax);
     return aoc_align_up((size_t)cap * 4, 256) + aoc_align_up((size_t)cap * 2, 256) + 2 * aoc_align_up((size_t)n_seg * nb * kmax * 4, 256) +
            3 * aoc_align_up((size_t)n_seg * kmax * 4, 256) + aoc_align_up(((size_t)cap + 64) * 4, 256) + 2 * aoc_align_up(nch * 4, 256) +
-           3 * aoc_align_up(nch * AOC_MAX_CHANNELS / 2 * 4, 256) + aoc_align_up(nch * AOC_MAX_CHANNELS / 2, 256);
+           3 * aoc_align_up(nch * AOC_MAX_CHANNELS / 2 * 4, 256) + aoc_align_up(nch * AOC_MAX_CHANNELS / 2, 256) +
+           aoc_align_up((size_t)n_seg * kmax * (AOC_MAX_CHANNELS / 2) * 4, 256);
 }
 inline KsWorkspace ks_carve(void *workspace, int64_t cap, int n_seg, int kmax) {
     KsWorkspace w;
@@ -1246,8 +1533,47 @@ inline KsWorkspace ks_carve(void *workspace, int64_t cap, int n_seg, int kmax) {
     w.csum = reinterpret_cast<float *>(p); p += aoc_align_up(nch * AOC_MAX_CHANNELS / 2 * 4, 256);
     w.cinc0 = reinterpret_cast<int32_t *>(p); p += aoc_align_up(nch * AOC_MAX_CHANNELS / 2 * 4, 256);
     w.cinc1 = reinterpret_cast<int32_t *>(p); p += aoc_align_up(nch * AOC_MAX_CHANNELS / 2 * 4, 256);
-    w.cexp = reinterpret_cast<int8_t *>(p);
+    w.cexp = reinterpret_cast<int8_t *>(p); p += aoc_align_up(nch * AOC_MAX_CHANNELS / 2, 256);
+    w.head = reinterpret_cast<float *>(p);
     return w;
+}
+
+// Ordered per-cluster sums of the member lists in ws.moff -> dst (MODE 0 centroids / MODE 1 proxy set 1).
+//   "hybrid" (default): the first KS_HEAD_CHUNKS chunks of every cluster -- where the running sum crosses a binade at
+//             every doubling -- are summed literally, lanes = features (km_ordered_sum_kernel); larger clusters continue
+//             with the chunk-parallel integer folds and the serial stitch (their crossings are rare from there on);
+//   "ordered": literal sums only;   "scan": chunk-parallel pipeline only.   (AOC_KM_SUM, developer switch.)
+constexpr int KS_HEAD_CHUNKS = 2;
+inline int ks_sum_mode() {
+    static const int mode = [] {
+        const char *e = getenv("AOC_KM_SUM");
+        if (e && strcmp(e, "scan") == 0) return 0;
+        if (e && strcmp(e, "ordered") == 0) return 1;
+        return 2;
+    }();
+    return mode;
+}
+template <int MODE>
+inline void ks_launch_sums(hipStream_t st, const float *pool, uint32_t pool_bytes, int C, const int32_t *seg_offsets, const int32_t *seg_k,
+                           const int32_t *counts, const KsWorkspace &ws, int kmax, int n_seg, float *dst) {
+    const int mode = ks_sum_mode();
+    const int start = (mode == 2) ? KS_HEAD_CHUNKS : 0;
+    if (mode != 0) {
+        const int cap = (mode == 2) ? KS_HEAD_CHUNKS * KS_CHUNK : 0;
+        hipLaunchKernelGGL(km_ordered_sum_kernel<MODE>, dim3(kmax, n_seg, os_groups(C)), dim3((OS_NPROD + 1) * 64), 0, st, pool, pool_bytes, C, seg_offsets,
+                           seg_k, counts, ws.cbase, ws.moff, kmax, dst, cap, ws.head);
+        if (mode == 1) return;
+    }
+    hipLaunchKernelGGL(km_chunk_sum_kernel, dim3(ws.nch_cap), dim3(256), 0, st, pool, C, seg_offsets, counts, ws.cbase, ws.moff, kmax, ws.owner_cluster,
+                       ws.owner_local, ws.csum);
+    hipLaunchKernelGGL(km_chunk_predict_kernel, dim3(kmax, n_seg), dim3(128), 0, st, seg_k, counts, ws.cchunk, ws.csum, kmax, C, ws.cexp, start);
+    hipLaunchKernelGGL(km_chunk_fold_kernel, dim3(ws.nch_cap, (C + KC_FG - 1) / KC_FG), dim3(256), 0, st, pool, C, seg_offsets, counts, ws.cbase, ws.moff,
+                       kmax, ws.owner_cluster, ws.owner_local, ws.cexp, ws.cinc0, ws.cinc1);
+    static const int nf = getenv("AOC_KS_NF") ? atoi(getenv("AOC_KS_NF")) : 1;       // features per stitch wave (developer switch)
+#define AOC_KSS(NF) hipLaunchKernelGGL((km_sum_scan_kernel<MODE, NF>), dim3(C / NF, kmax, n_seg), dim3(64), 0, st, pool, pool_bytes, C, seg_offsets, seg_k, \
+                                       counts, ws.cbase, ws.moff, kmax, dst, ws.cchunk, ws.cexp, ws.cinc0, ws.cinc1, start, ws.head)
+    if (nf == 4) AOC_KSS(4); else if (nf == 2) AOC_KSS(2); else AOC_KSS(1);
+#undef AOC_KSS
 }
 
 inline int label_blocks(int64_t n) { return (int)((n + LP_BLOCK - 1) / LP_BLOCK); }
@@ -1347,13 +1673,7 @@ int aoc_kmeans_segmented_ex(const float *pool, int64_t pool_rows, int C, const i
                                cluster_counts, ws.cbase, ws.cchunk, ws.owner_cluster, ws.owner_local, ws.nch_cap);
             hipLaunchKernelGGL(km_scatter_kernel, agrid, dim3(256), 0, st, rows, (const int32_t *)nullptr, seg_offsets, seg_k, labels, ws.rank16,
                                ws.blockoff, ws.cbase, ws.nb_max, kmax, (uint32_t)C * 4u, ws.moff);
-            hipLaunchKernelGGL(km_chunk_sum_kernel, dim3(ws.nch_cap), dim3(256), 0, st, pool, C, seg_offsets, cluster_counts, ws.cbase, ws.moff, kmax,
-                               ws.owner_cluster, ws.owner_local, ws.csum);
-            hipLaunchKernelGGL(km_chunk_predict_kernel, dim3(kmax, n_seg), dim3(128), 0, st, seg_k, cluster_counts, ws.cchunk, ws.csum, kmax, C, ws.cexp);
-            hipLaunchKernelGGL(km_chunk_fold_kernel, dim3(ws.nch_cap, (C + KC_FG - 1) / KC_FG), dim3(256), 0, st, pool, C, seg_offsets, cluster_counts, ws.cbase, ws.moff, kmax,
-                               ws.owner_cluster, ws.owner_local, ws.cexp, ws.cinc0, ws.cinc1);
-            hipLaunchKernelGGL(km_sum_scan_kernel<0>, dim3(C / 4, kmax, n_seg), dim3(64), 0, st, pool, pool_bytes, C, seg_offsets, seg_k,
-                               cluster_counts, ws.cbase, ws.moff, kmax, centroids, ws.cchunk, ws.cexp, ws.cinc0, ws.cinc1);
+            ks_launch_sums<0>(st, pool, pool_bytes, C, seg_offsets, seg_k, cluster_counts, ws, kmax, n_seg, centroids);
             continue;
         }
         if ((C % 4) == 0 && C <= 100)
@@ -1385,7 +1705,7 @@ int aoc_build_proxies(const float *pool, int64_t pool_rows, int C, const int32_t
     hipStream_t st = aoc_hip_stream(stream);
     const dim3 grid(kmax, n_seg);
     const int nf = (C + 63) / 64;
-    const bool fast = (C % 4) == 0 && pool_rows > 0 && rows_capacity > 0 && (uint64_t)pool_rows * C * 4 < 0xFFFFFF00ull && workspace &&
+    const bool fast = (C % 4) == 0 && C <= 128 && pool_rows > 0 && rows_capacity > 0 && (uint64_t)pool_rows * C * 4 < 0xFFFFFF00ull && workspace &&
                       workspace_bytes >= aoc_build_proxies_workspace_bytes(rows_capacity, n_seg, kmax);
     if (fast) {
         KsWorkspace ws = ks_carve(workspace, rows_capacity, n_seg, kmax);
@@ -1395,17 +1715,7 @@ int aoc_build_proxies(const float *pool, int64_t pool_rows, int C, const int32_t
                            ws.cchunk, ws.owner_cluster, ws.owner_local, ws.nch_cap);
         hipLaunchKernelGGL(km_scatter_kernel, agrid, dim3(256), 0, st, (const int32_t *)nullptr, fg_rows, seg_offsets, seg_k, labels, ws.rank16,
                            ws.blockoff, ws.cbase, ws.nb_max, kmax, (uint32_t)C * 4u, ws.moff);
-        const bool summ = C <= 128;
-        if (summ) {
-            hipLaunchKernelGGL(km_chunk_sum_kernel, dim3(ws.nch_cap), dim3(256), 0, st, pool, C, seg_offsets, ws.counts, ws.cbase, ws.moff, kmax,
-                               ws.owner_cluster, ws.owner_local, ws.csum);
-            hipLaunchKernelGGL(km_chunk_predict_kernel, dim3(kmax, n_seg), dim3(128), 0, st, seg_k, ws.counts, ws.cchunk, ws.csum, kmax, C, ws.cexp);
-            hipLaunchKernelGGL(km_chunk_fold_kernel, dim3(ws.nch_cap, (C + KC_FG - 1) / KC_FG), dim3(256), 0, st, pool, C, seg_offsets, ws.counts, ws.cbase, ws.moff, kmax,
-                               ws.owner_cluster, ws.owner_local, ws.cexp, ws.cinc0, ws.cinc1);
-        }
-        hipLaunchKernelGGL(km_sum_scan_kernel<1>, dim3(C / 4, kmax, n_seg), dim3(64), 0, st, pool, (uint32_t)((uint64_t)pool_rows * C * 4), C, seg_offsets,
-                           seg_k, ws.counts, ws.cbase, ws.moff, kmax, proxies, summ ? ws.cchunk : (const int32_t *)nullptr,
-                           summ ? ws.cexp : (const int8_t *)nullptr, ws.cinc0, ws.cinc1);
+        ks_launch_sums<1>(st, pool, (uint32_t)((uint64_t)pool_rows * C * 4), C, seg_offsets, seg_k, ws.counts, ws, kmax, n_seg, proxies);
         hipLaunchKernelGGL(km_proxy_finish_kernel, grid, dim3(64), 0, st, centroids, seg_k, ws.counts, kmax, C, proxies, proxy_sqnorm);
         AOC_RETURN_IF_LAUNCH_FAILED();
         return AOC_OK;

@@ -54,7 +54,7 @@ def channel_slices(cfg):
 
 
 def proto_mask_features(cfg, ref_emb, ref_labels, prev_emb, prev_labels, cur_emb, dis_bias, init_rows=None,
-                        cluster_state=None, side_stream=None):
+                        cluster_state=None, side_stream=None, dense_state=None, dense_precision=None):
     """All matching branches of one frame -> (features [O, 24, h, w], attention_head [O, 4C], aux).
 
     ref_emb     [R, h, w, C]  reference pool (channel-last)          ref_labels [R, h, w, O] float one-hot
@@ -65,6 +65,10 @@ def proto_mask_features(cfg, ref_emb, ref_labels, prev_emb, prev_labels, cur_emb
     side_stream  optional torch.cuda.Stream: the adaptive-proxy branch (k-means: a long chain of small,
                  latency-bound launches) runs there, concurrently with the MFMA-bound dense matching on the
                  current stream; the two join in front of the correlation launch.  Only with cluster_state.
+    dense_state  optional dict owned by the caller and kept across the frames of ONE sequence: caches the fp16 split
+                 records of the reference pool, so only frames appended since the last call are converted.  The pool
+                 must be append-only while the dict lives (the reference's memory policy, eval_manager_mm.py:329-361).
+    dense_precision  "split" (default, ops.DENSE_PRECISION) or "fp32": see ops.dense_match.
     """
     R, h, w, C = ref_emb.shape
     O = ref_labels.shape[-1]
@@ -118,7 +122,22 @@ def proto_mask_features(cfg, ref_emb, ref_labels, prev_emb, prev_labels, cur_emb
     attention_head = torch.cat([ref_pos, ref_neg, prev_pos, prev_neg], dim=1)          # ATT:188, [O, 4C]
 
     # ---- dense pixel-level matching, AEM:688-817 -> channel 0
-    ops.dense_match_min(query_flat, pool, prep, bias, feat, 1, obj_stride, True)
+    pool_split = None
+    if dense_state is not None and (dense_precision or ops.DENSE_PRECISION) == "split" and ops.split_record_bytes(C):
+        pool_split = dense_state.get("pool_split")
+        done = dense_state.get("frames", 0)
+        if pool_split is None or pool_split.records.shape[0] < R * hw or done > R:
+            cap = max(R, dense_state.get("capacity_frames", R)) * hw
+            pool_split = ops.SplitRows()
+            pool_split.records = torch.empty(cap, ops.split_record_bytes(C), dtype=torch.uint8, device=dev)
+            pool_split.sqnorm = torch.empty(cap, dtype=torch.float32, device=dev)
+            pool_split.overflow = torch.zeros(1, dtype=torch.int32, device=dev)
+            pool_split.n = cap
+            done = 0
+        if done < R:
+            ops.split_rows(pool[done * hw:R * hw], out=pool_split, row0=done * hw)
+        dense_state["pool_split"], dense_state["frames"] = pool_split, R
+    ops.dense_match(query_flat, pool, prep, bias, feat, 1, obj_stride, True, precision=dense_precision, pool_split=pool_split)
 
     # ---- local matching against the previous frame and against its per-pixel proxy map (aocnet.py:255,325-337)
     radii = list(cfg.MODEL_MULTI_LOCAL_DISTANCE)

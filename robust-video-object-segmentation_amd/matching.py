@@ -174,8 +174,8 @@ def global_matching_for_eval(all_reference_embeddings, query_embeddings, all_ref
     pool, labels_flat = _flatten_pool(all_reference_embeddings, all_reference_labels, h, w, atrous_rate, atrous_obj_pixel_num)
     prep = ops.label_prep(labels_flat)
     planes = torch.empty(obj_nums, h, w, dtype=torch.float32, device=dev)
-    ops.dense_match_min(query_embeddings.reshape(-1, embedding_dim), pool, prep, _bias_vec(dis_bias, obj_nums, dev),
-                        planes, 1, h * w, True)
+    ops.dense_match(query_embeddings.reshape(-1, embedding_dim), pool, prep, _bias_vec(dis_bias, obj_nums, dev),
+                    planes, 1, h * w, True)
     if ori_size is not None:
         # the all-unlabelled early-out of the reference keeps the map at (h, w) even with ori_size
         if int(prep.counts[obj_nums]) == 0:

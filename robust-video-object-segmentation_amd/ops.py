@@ -5,6 +5,7 @@ and passes raw pointers + the current HIP stream to libaoc_hip.so.  PyTorch is p
 All functions require CUDA(HIP) tensors and raise otherwise -- there is no CPU path.
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -162,6 +163,86 @@ def dense_match_min(query_flat, pool, prep, obj_bias, out, out_pixel_stride, out
                                      _p(obj_bias), n_obj, _p(out), int(out_pixel_stride), int(out_obj_stride), int(bool(transform)),
                                      _p(ws), ws.numel(), _stream()), "aoc_dense_match_min")
     return out
+
+
+class SplitRows:
+    """fp16 split records of embedding rows (aoc_split_rows): records [n, 448] uint8, sqnorm [n], overflow flag [1]."""
+    __slots__ = ("records", "sqnorm", "overflow", "n")
+
+
+def split_record_bytes(C):
+    return int(_lib.lib().aoc_split_record_bytes(int(C)))
+
+
+def split_rows(x_flat, out=None, row0=0, overflow=None):
+    """x [n, C] fp32 -> SplitRows.  With `out` (a SplitRows with capacity) the records are written at row `row0` of it
+    (the reference pool grows in place: only the appended frame is converted)."""
+    x_flat = _f32c(x_flat)
+    _need_gpu(x_flat)
+    n, C = x_flat.shape
+    rb = split_record_bytes(C)
+    if rb == 0:
+        raise _lib.AocHipError(f"split records need C % 4 == 0 and C <= 100 (got {C})")
+    dev = x_flat.device
+    if out is None:
+        out = SplitRows()
+        out.records = torch.empty(n, rb, dtype=torch.uint8, device=dev)
+        out.sqnorm = torch.empty(n, dtype=torch.float32, device=dev)
+        out.overflow = overflow if overflow is not None else torch.zeros(1, dtype=torch.int32, device=dev)
+        out.n = n
+        row0 = 0
+    rec = out.records[row0:row0 + n]
+    sq = out.sqnorm[row0:row0 + n]
+    assert rec.shape[0] == n
+    _lib.check(_lib.lib().aoc_split_rows(_p(x_flat), n, C, _p(rec), _p(sq), _p(out.overflow), _stream()), "aoc_split_rows")
+    return out
+
+
+def dense_match_min_split(query_flat, query_split, pool, pool_split, prep, obj_bias, out, out_pixel_stride, out_obj_stride, transform=True):
+    """aoc_dense_match_min_split: fp16-split matrix pipe with the exact-fp32 kernels as device-side take-over."""
+    query_flat = _f32c(query_flat)
+    pool = _f32c(pool)
+    _need_gpu(query_flat, pool, out, query_split.records, pool_split.records)
+    m, C = query_flat.shape
+    n_obj = prep.n_obj
+    n = prep.n
+    assert pool.shape[0] >= n and pool_split.records.shape[0] >= n and query_split.records.shape[0] >= m
+    L = _lib.lib()
+    ws = _ws(L.aoc_dense_match_split_workspace_bytes(m, n, n_obj), pool.device)
+    if obj_bias is not None:
+        obj_bias = _f32c(obj_bias)
+    # one sticky flag covers both operands
+    flag = pool_split.overflow
+    if query_split.overflow.data_ptr() != flag.data_ptr():
+        flag = torch.maximum(flag, query_split.overflow)
+    _lib.check(L.aoc_dense_match_min_split(_p(query_flat), _p(query_split.records), _p(query_split.sqnorm), m, C, _p(pool), _p(pool_split.records),
+                                           _p(flag), n, _p(prep.right_bits), _p(prep.wrong_bits), _p(prep.fg_rows), _p(prep.obj_rows),
+                                           _p(prep.counts), _p(prep.obj_offsets), _p(obj_bias), n_obj, _p(out), int(out_pixel_stride),
+                                           int(out_obj_stride), int(bool(transform)), _p(ws), ws.numel(), _stream()),
+               "aoc_dense_match_min_split")
+    return out
+
+
+# "split" = fp16-split matrix pipe with fp32-equivalent products (default); "fp32" = exact-fp32 MFMA everywhere.
+DENSE_PRECISION = os.environ.get("AOC_DENSE_PRECISION", "split")
+
+
+def dense_match(query_flat, pool, prep, obj_bias, out, out_pixel_stride, out_obj_stride, transform=True, precision=None,
+                query_split=None, pool_split=None):
+    """Dense matching front door: picks the split-fp16 entry point when the shape supports it (C % 4 == 0, C <= 100,
+    <= 16 objects) and the precision mode allows, else the exact-fp32 one.  `query_split` / `pool_split` are optional
+    cached SplitRows (otherwise the rows are converted here)."""
+    precision = precision or DENSE_PRECISION
+    if precision not in ("split", "fp32"):
+        raise ValueError(f"unknown dense precision {precision!r}")
+    C = query_flat.shape[1]
+    if precision == "fp32" or split_record_bytes(C) == 0 or prep.n_obj > 16:
+        return dense_match_min(query_flat, pool, prep, obj_bias, out, out_pixel_stride, out_obj_stride, transform)
+    if pool_split is None:
+        pool_split = split_rows(pool[:prep.n])
+    if query_split is None:
+        query_split = split_rows(query_flat, overflow=pool_split.overflow)
+    return dense_match_min_split(query_flat, query_split, pool, pool_split, prep, obj_bias, out, out_pixel_stride, out_obj_stride, transform)
 
 
 # ------------------------------------------------------------------------------------------ local matching + resize

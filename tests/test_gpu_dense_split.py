@@ -1,0 +1,133 @@
+"""Split-fp16 dense matching (aoc_dense_match_min_split) against the exact-fp32 kernels and the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ATOL = 5e-6          # on proto-mask outputs (sigmoid slope <= 0.5)
+ATOL_RAW = 1e-5      # on raw squared distances of magnitude O(1..10)
+
+
+@pytest.fixture(scope="module")
+def aoc():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    import aoc_amd
+    aoc_amd._lib.lib()
+    return aoc_amd
+
+
+def _dense(aoc, q, pool, labels, bias, precision, transform=True):
+    ops = aoc.ops
+    prep = ops.label_prep(labels.cuda())
+    m, O = q.shape[0], labels.shape[1]
+    out = torch.empty(O, m, device="cuda")
+    ops.dense_match(q.cuda(), pool.cuda(), prep, None if bias is None else bias.cuda(), out, 1, m, transform, precision=precision)
+    return out.cpu()
+
+
+def _data(seed, n, m, c=100, o=4, scale=0.3, signed=False):
+    rng = np.random.RandomState(seed)
+    f = (lambda a: a) if signed else (lambda a: np.maximum(a, 0))
+    pool = torch.from_numpy((f(rng.randn(n, c)) * scale).astype(np.float32))
+    q = torch.from_numpy((f(rng.randn(m, c)) * scale).astype(np.float32))
+    ids = rng.randint(0, o, n)
+    lab = torch.from_numpy((ids[:, None] == np.arange(o)).astype(np.float32))
+    return q, pool, lab
+
+
+@pytest.mark.parametrize("n,m,o,c,signed", [(5000, 3000, 4, 100, False), (777, 1001, 3, 100, True), (4097, 513, 9, 100, False),
+                                             (1500, 700, 2, 64, False), (33, 65, 16, 100, False), (40000, 2000, 4, 100, False)])
+def test_split_matches_fp32_and_oracle(aoc, n, m, o, c, signed):
+    from oracle import matching as om
+    q, pool, lab = _data(n + m, n, m, c, o, signed=signed)
+    bias = torch.linspace(-0.3, 0.3, o)
+    raw_s = _dense(aoc, q, pool, lab, None, "split", transform=False)
+    raw_f = _dense(aoc, q, pool, lab, None, "fp32", transform=False)
+    assert float((raw_s - raw_f).abs().max()) < ATOL_RAW
+    got = _dense(aoc, q, pool, lab, bias, "split")
+    if n * m <= 2e7:
+        want = om.proto_transform(om.nearest_neighbor_features_per_object(pool, q, lab).squeeze(-1), bias.view(1, -1))
+        np.testing.assert_allclose(got.t().numpy(), want.numpy(), rtol=0, atol=ATOL)
+    # the nearest reference pixel (argmin) agrees wherever the two best candidates are not within rounding of each other
+    assert float((_dense(aoc, q, pool, lab, bias, "fp32") - got).abs().max()) < ATOL
+
+
+def test_split_absent_object_and_single_pixels(aoc):
+    from oracle import matching as om
+    q, pool, lab = _data(5, 300, 200, o=5)
+    lab[:, 3] = 0                                   # object 3 absent: 5e4 + nearest other pixel (AEM:84-88)
+    lab[:, 4] = 0
+    lab[lab.sum(1) == 0, 0] = 1
+    lab[7] = 0
+    lab[7, 4] = 1                                   # object 4: one pixel
+    bias = torch.zeros(5)
+    got = _dense(aoc, q, pool, lab, bias, "split", transform=False)
+    want = om.nearest_neighbor_features_per_object(pool, q, lab).squeeze(-1)
+    np.testing.assert_allclose(got.t().numpy(), want.numpy(), rtol=1e-6, atol=ATOL_RAW)
+
+
+def test_take_over_on_soft_labels_is_bit_identical_to_fp32(aoc):
+    """Labels that are not one-hot (soft / multi-object / unlabeled-but-kept rows) hand the call to the fp32 kernels."""
+    q, pool, lab = _data(9, 2000, 600, o=3)
+    lab[::7] = torch.tensor([0.5, 0.5, 0.0])        # neither wrong for 0 nor 1, right for none
+    lab[1::11] = torch.tensor([1.0, 1.0, 0.0])      # right for two objects
+    a = _dense(aoc, q, pool, lab, torch.zeros(3), "split")
+    b = _dense(aoc, q, pool, lab, torch.zeros(3), "fp32")
+    assert torch.equal(a, b)
+
+
+def test_take_over_on_fp16_overflow_is_bit_identical_to_fp32(aoc):
+    q, pool, lab = _data(10, 1000, 300, o=2)
+    pool[17, 3] = 80.0                              # 80 * 1024 > 65504
+    a = _dense(aoc, q, pool, lab, torch.zeros(2), "split")
+    b = _dense(aoc, q, pool, lab, torch.zeros(2), "fp32")
+    assert torch.equal(a, b)
+    q2, pool2, lab2 = _data(11, 1000, 300, o=2, scale=8.0)   # |x|^2 beyond the norm-slot range
+    a = _dense(aoc, q2, pool2, lab2, torch.zeros(2), "split", transform=False)
+    b = _dense(aoc, q2, pool2, lab2, torch.zeros(2), "fp32", transform=False)
+    assert torch.equal(a, b)
+
+
+def test_tiny_and_huge_dynamic_range(aoc):
+    """Values far below the fp16 normal range (after scaling) must not lose more than fp32 rounding."""
+    from oracle import matching as om
+    q, pool, lab = _data(12, 900, 400, o=3)
+    pool[:, :10] *= 1e-4
+    q[:, :10] *= 1e-4
+    pool[:, 10:20] *= 10.0
+    q[:, 10:20] *= 10.0
+    got = _dense(aoc, q, pool, lab, None, "split", transform=False).t().double()
+    want = om.nearest_neighbor_features_per_object(pool, q, lab).squeeze(-1).double()
+    # |q|^2 + |r|^2 is O(300) here, so (|q|^2 + |r|^2) - 2 q.r cancels ~5 bits: judge both fp32 paths against float64
+    p64, q64 = pool.double(), q.double()
+    d64 = (q64.pow(2).sum(1)[:, None] + p64.pow(2).sum(1)[None, :]) - 2.0 * q64 @ p64.t()
+    truth = torch.stack([d64[:, lab[:, o] > 0.5].min(1)[0] for o in range(3)], 1)
+    err_split, err_fp32 = float((got - truth).abs().max()), float((want - truth).abs().max())
+    assert err_split <= max(2.0 * err_fp32, ATOL_RAW), (err_split, err_fp32)
+
+
+def test_nothing_labelled(aoc):
+    q, pool, lab = _data(13, 200, 100, o=2)
+    lab[:] = 0
+    assert torch.equal(_dense(aoc, q, pool, lab, torch.zeros(2), "split"), torch.ones(2, 100))
+
+
+def test_pool_cache_across_frames(aoc):
+    """hotpath dense_state: records of earlier frames are reused; result equals the uncached call."""
+    syn, hot = aoc.synthetic, aoc.hotpath
+    cfg = syn.CONFIGS["tiny"]
+    clip = syn.make_clip(cfg, 4, frames=5)
+    emb = torch.from_numpy(clip["emb"]).cuda()
+    lab = torch.from_numpy(np.stack([syn.one_hot(l, cfg.n_obj) for l in clip["lab"]])).cuda()
+    mc = hot.MatchingConfig()
+    bias = torch.zeros(cfg.n_obj, device="cuda")
+    state = {"capacity_frames": 4}
+    for R in (1, 2, 3):
+        rows = syn.kmeans_init_rows(R, [int((clip["lab"][:R] == o).sum()) for o in range(cfg.n_obj)], 16)
+        f1, _, _ = hot.proto_mask_features(mc, emb[:R], lab[:R], emb[3], lab[3], emb[4], bias, init_rows=rows, dense_state=state)
+        f2, _, _ = hot.proto_mask_features(mc, emb[:R], lab[:R], emb[3], lab[3], emb[4], bias, init_rows=rows)
+        f3, _, _ = hot.proto_mask_features(mc, emb[:R], lab[:R], emb[3], lab[3], emb[4], bias, init_rows=rows, dense_precision="fp32")
+        assert torch.equal(f1, f2)
+        assert float((f1 - f3).abs().max()) < ATOL
+    assert state["frames"] == 3

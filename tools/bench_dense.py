@@ -1,29 +1,48 @@
-#!/usr/bin/env python3
-"""Developer micro-benchmark (GPU box): aoc_dense_match_min alone at cfg2 sizes for several pool sizes."""
-import os, sys
-import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT)
+"""Developer micro-benchmark: dense matching alone (fp32-exact vs split-fp16) at cfg2 size."""
+import sys, time
+import numpy as np
+import torch
+sys.path.insert(0, ".")
 import aoc_amd
 from aoc_amd import ops, synthetic as syn
-cfg = syn.CONFIGS[sys.argv[1] if len(sys.argv) > 1 else "cfg2"]
+
+R = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+cfg = syn.CONFIGS["cfg2"]
+clip = syn.make_clip(cfg, 0, frames=R + 1)
+emb = torch.from_numpy(clip["emb"]).cuda()
+lab = torch.from_numpy(np.stack([syn.one_hot(l, cfg.n_obj) for l in clip["lab"]])).cuda()
 hw, C, O = cfg.h * cfg.w, cfg.c, cfg.n_obj
-torch.manual_seed(0)
-q = (torch.relu(torch.randn(hw, C)) * 0.3).cuda()
-for R in (1, 3, 6, 12):
-    pool = (torch.relu(torch.randn(R * hw, C)) * 0.3).cuda()
-    lab = torch.zeros(R * hw, O)
-    lab[torch.arange(R * hw), torch.randint(0, O, (R * hw,))] = 1
-    prep = ops.label_prep(lab.cuda())
-    out = torch.empty(O, hw, device="cuda")
-    bias = torch.zeros(O, device="cuda")
-    for _ in range(2):
-        ops.dense_match_min(q, pool, prep, bias, out, 1, hw, True)
-    e0, e1 = torch.cuda.Event(True), torch.cuda.Event(True)
-    n = 5
+pool = emb[:R].reshape(-1, C)
+q = emb[R].reshape(-1, C)
+prep = ops.label_prep(lab[:R].reshape(-1, O))
+out = torch.empty(O, hw, device="cuda")
+bias = torch.zeros(O, device="cuda")
+ps = ops.split_rows(pool)
+qs = ops.split_rows(q, overflow=ps.overflow)
+flops = 2.0 * hw * R * hw * C
+for mode in ("fp32", "split"):
+    f = (lambda: ops.dense_match_min(q, pool, prep, bias, out, 1, hw, True)) if mode == "fp32" else \
+        (lambda: ops.dense_match_min_split(q, qs, pool, ps, prep, bias, out, 1, hw, True))
+    for _ in range(3):
+        f()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
+    n = 10
     for _ in range(n):
-        ops.dense_match_min(q, pool, prep, bias, out, 1, hw, True)
-    e1.record(); torch.cuda.synchronize()
+        f()
+    e1.record()
+    torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / n
-    print(f"R={R:2d} n={R*hw:7d}  {ms:8.3f} ms  {2.0*hw*R*hw*C/ms/1e9:7.1f} TFLOP/s  ({100*2.0*hw*R*hw*C/ms/1e9/157.3:.1f}% of fp32 MFMA peak)")
+    print(f"{mode}: R={R} {ms:.3f} ms/call  {flops / ms / 1e9:.1f} fp32-equivalent TFLOP/s", flush=True)
+    res = out.clone()
+    if mode == "fp32":
+        ref = res
+print("max |split - fp32| =", float((res - ref).abs().max()))
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(20):
+    ops.split_rows(q, out=qs)
+e1.record()
+torch.cuda.synchronize()
+print("split_rows(query): %.1f us" % (e0.elapsed_time(e1) / 20 * 1e3))

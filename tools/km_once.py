@@ -25,3 +25,10 @@ for _ in range(reps):
     out = ops.kmeans_segmented(emb, prep.obj_rows, prep.obj_offsets, seg_k, init, 16, 20, rows_capacity=prep.obj_rows.numel())
 torch.cuda.synchronize()
 print("R", R, "max cluster", int(out[2].max()))
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(5):
+    out = ops.kmeans_segmented(emb, prep.obj_rows, prep.obj_offsets, seg_k, init, 16, 20, rows_capacity=prep.obj_rows.numel())
+e1.record()
+torch.cuda.synchronize()
+print("R", R, "kmeans %.3f ms/call (%s)" % (e0.elapsed_time(e1) / 5, os.environ.get("AOC_KM_SUM", "ordered")))

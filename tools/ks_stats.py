@@ -26,9 +26,9 @@ L.aoc_debug_ks_stats(buf, 1)
 cp = aoc_amd.matching.cluster_proxies(emb, lab)
 torch.cuda.synchronize()
 L.aoc_debug_ks_stats(buf, 0)
-names = ["attempts", "folded feature-blocks", "missed feature-blocks", "careful ok", "serial blocks", "chunk summaries applied (feature-chunks)", "unprefetched chunk reloads"]
+names = ["big wave: total cycles", "big wave: summary-step cycles", "big wave: chunks needing rows", "big wave: cycles waiting for rows", "big wave: exact-path cycles (incl. waiting for rows)", "big wave: chunk-exact calls", "big wave: crossings resolved", "big wave: fallback block-exact calls"]
 print("R =", R, "rows", emb.shape[0], "counts", cp["counts"], "max cluster", int(cp["cluster_counts"].max()))
-for n, v in zip(names, list(buf)): print(f"{n:24s} {v}")
+for n, v in zip(names, list(buf)): print(f"{n:56s} {v}")
 t0 = torch.cuda.Event(True); t1 = torch.cuda.Event(True)
 np.random.seed(0); t0.record(); cp = aoc_amd.matching.cluster_proxies(emb, lab); t1.record(); torch.cuda.synchronize()
 print("cluster_proxies ms", t0.elapsed_time(t1))
