@@ -258,17 +258,25 @@ __global__ __launch_bounds__(SP_NW * 64, 1) void dense_split_kernel(const uint4 
                 for (int iq = 0; iq < SP_NQ; ++iq)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[iq][r] = 0.0f;
+                // A fragments one k-step ahead of the MFMAs that consume them (norm slots first: partial sums stay small)
+                f16x8 ah = __builtin_bit_cast(f16x8, arow[(SP_KS - 1) * 4 + h]);
+                f16x8 al = __builtin_bit_cast(f16x8, arow[(SP_KS - 1) * 4 + 2 + h]);
 #pragma unroll
                 for (int kk = 0; kk < SP_KS; ++kk) {
-                    const int ks = (kk == 0) ? SP_KS - 1 : kk - 1;       // norm slots first: partial sums stay small
-                    const f16x8 ah = __builtin_bit_cast(f16x8, arow[ks * 4 + h]);
-                    const f16x8 al = __builtin_bit_cast(f16x8, arow[ks * 4 + 2 + h]);
+                    const int ks = (kk == 0) ? SP_KS - 1 : kk - 1;
+                    f16x8 nh = ah, nl = al;
+                    if (kk + 1 < SP_KS) {
+                        nh = __builtin_bit_cast(f16x8, arow[kk * 4 + h]);          // k-step kk (the next one in this order)
+                        nl = __builtin_bit_cast(f16x8, arow[kk * 4 + 2 + h]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);                             // keep the reads ahead of this k-step's MFMAs
 #pragma unroll
                     for (int iq = 0; iq < SP_NQ; ++iq) acc[iq] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[iq][ks], acc[iq], 0, 0, 0);
 #pragma unroll
                     for (int iq = 0; iq < SP_NQ; ++iq) acc[iq] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[iq][ks], acc[iq], 0, 0, 0);
 #pragma unroll
                     for (int iq = 0; iq < SP_NQ; ++iq) acc[iq] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[iq][ks], acc[iq], 0, 0, 0);
+                    ah = nh; al = nl;
                 }
 #pragma unroll
                 for (int iq = 0; iq < SP_NQ; ++iq) best[iq] = __builtin_fmaxf(best[iq], max16(acc[iq]));

@@ -1543,7 +1543,7 @@ inline KsWorkspace ks_carve(void *workspace, int64_t cap, int n_seg, int kmax) {
 //             every doubling -- are summed literally, lanes = features (km_ordered_sum_kernel); larger clusters continue
 //             with the chunk-parallel integer folds and the serial stitch (their crossings are rare from there on);
 //   "ordered": literal sums only;   "scan": chunk-parallel pipeline only.   (AOC_KM_SUM, developer switch.)
-constexpr int KS_HEAD_CHUNKS = 2;
+constexpr int KS_HEAD_CHUNKS = 4;
 inline int ks_sum_mode() {
     static const int mode = [] {
         const char *e = getenv("AOC_KM_SUM");
