@@ -19,6 +19,7 @@ the dominant kernel measured with HIP events inside the timed region, and a CPU 
 timed on the host cores, rank 0, N = 1 only).
 """
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -39,6 +40,35 @@ PEAK_F16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_f16, 
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
 
 
+class HipEventPairs:
+    """hipEvent_t pairs created through the HIP runtime (ctypes) for aoc_dense_match_set_probe: the library records them
+    immediately around its matrix kernel, on the stream of the call."""
+
+    def __init__(self):
+        self.hip = ctypes.CDLL("libamdhip64.so")
+        self.hip.hipEventCreate.argtypes = [ctypes.POINTER(ctypes.c_void_p)]
+        self.hip.hipEventElapsedTime.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.c_void_p, ctypes.c_void_p]
+        self.hip.hipEventDestroy.argtypes = [ctypes.c_void_p]
+        self.pairs = []
+
+    def arm(self):
+        a, b = ctypes.c_void_p(), ctypes.c_void_p()
+        assert self.hip.hipEventCreate(ctypes.byref(a)) == 0 and self.hip.hipEventCreate(ctypes.byref(b)) == 0
+        aoc_amd._lib.check(aoc_amd._lib.lib().aoc_dense_match_set_probe(a, b), "aoc_dense_match_set_probe")
+        self.pairs.append((a, b))
+
+    def elapsed_ms(self):
+        out = []
+        for a, b in self.pairs:
+            ms = ctypes.c_float()
+            if self.hip.hipEventElapsedTime(ctypes.byref(ms), a, b) == 0:
+                out.append(ms.value)
+            self.hip.hipEventDestroy(a)
+            self.hip.hipEventDestroy(b)
+        self.pairs = []
+        return out
+
+
 class OpTimer:
     """HIP-event timing of every call of selected aoc_amd.ops functions on the stream they are
     launched on (torch's current stream), inside the timed region."""
@@ -49,6 +79,9 @@ class OpTimer:
         self.meta = {n: [] for n in names}
         self.enabled = False
         self._orig = {}
+        self.kernel_probe = HipEventPairs()
+        self.dense_done = None
+        self.probed = ("dense_match_min_split", "dense_match_min")
 
     def install(self, meta_fns):
         for n in self.names:
@@ -59,9 +92,17 @@ class OpTimer:
                 if not self.enabled:
                     return _fn(*a, **k)
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                if _n in self.probed and self.dense_done is not None:
+                    # only one dense kernel fits per CU, so the dense kernels of the two sequences run back to back anyway;
+                    # making that order explicit keeps the queueing of one behind the other out of the timed interval
+                    torch.cuda.current_stream().wait_event(self.dense_done)
                 e0.record()
+                if _n in self.probed:
+                    self.kernel_probe.arm()
                 out = _fn(*a, **k)
                 e1.record()
+                if _n in self.probed:
+                    self.dense_done = e1
                 self.records[_n].append((e0, e1))
                 self.meta[_n].append(meta_fns[_n](*a, **k) if _n in meta_fns else None)
                 return out
@@ -223,7 +264,7 @@ def main():
     ap.add_argument("--steps", type=int, default=59)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="cfg2", choices=list(syn.CONFIGS))
-    ap.add_argument("--streams", type=int, default=1, help="independent sequences stepped concurrently on separate HIP streams")
+    ap.add_argument("--streams", type=int, default=2, help="independent sequences stepped concurrently on separate HIP streams")
     ap.add_argument("--dense", default="split", choices=["split", "fp32"],
                     help="dense-matching arithmetic: fp16-split products with fp32 accumulate (fp32-equivalent) or exact-fp32 MFMA")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -291,7 +332,7 @@ def main():
     with torch.no_grad():
         run_steps(args.warmup)
         barrier()
-        timer.enabled = (n_streams == 1)     # per-op events are only meaningful on a single stream
+        timer.enabled = True                 # HIP events around every op, on the stream the op is launched on
         t0 = time.perf_counter()
         if os.environ.get("AOC_BENCH_PROFILE"):
             import cProfile, pstats
@@ -316,6 +357,7 @@ def main():
     frames_local = args.steps * n_streams
     metrics = sharding.allreduce_metrics(dict(frames=frames_local, objects=frames_local * (O - 1), gpu_seconds=elapsed), device=dev)
 
+    probe_ms = timer.kernel_probe.elapsed_ms()
     if rank == 0:
         summ = timer.summary()
         kernels = {}
@@ -329,14 +371,22 @@ def main():
                          gbs=round(by / (s["avg_ms"] * 1e-3) / 1e9, 2))
             kernels[name] = k
         roofline = None
-        if kernels:
-            dom = max(kernels, key=lambda n: kernels[n]["total_ms"])
-            k = kernels[dom]
+        dense_ops = [n for n in ("dense_match_min_split", "dense_match_min") if n in kernels]
+        if dense_ops:
+            # the single kernel with the largest share of GPU time (profiles/: dense_split_kernel); the k-means op is a chain of
+            # ~160 small launches per call and is reported as its own object below
+            dom = max(dense_ops, key=lambda n: kernels[n]["total_ms"])
+            k = dict(kernels[dom])
+            if probe_ms:
+                # the matrix kernel alone (hipEvents recorded by the library right around its launch); k["avg_ms"] spans the op
+                k["op_avg_ms"] = k["avg_ms"]
+                k["avg_ms"] = round(float(np.mean(probe_ms)), 4)
+                k["tflops"] = round(k["avg_flops"] / (k["avg_ms"] * 1e-3) / 1e12, 3)
             if dom == "dense_match_min":
                 roofline = dict(kernel="dense_match_partial_kernel (aoc_dense_match_min)", bound="mfma", achieved=k["tflops"],
                                 peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s", frac=round(k["tflops"] / PEAK_FP32_MFMA_TFLOPS, 4), traffic=None,
                                 avg_launch_ms=k["avg_ms"], algorithmic_flops_per_launch=k["avg_flops"])
-            elif dom == "dense_match_min_split":
+            else:
                 # algorithmic flops (2 m n C) against the fp16 pipe the kernel runs on; the instruction stream
                 # executes 3 split products on K padded 100 -> 112, i.e. 3.36x the algorithmic flops
                 executed = k["tflops"] * 3.0 * 112.0 / C
@@ -344,15 +394,24 @@ def main():
                                 peak=PEAK_F16_MFMA_TFLOPS, unit="TFLOP/s", frac=round(k["tflops"] / PEAK_F16_MFMA_TFLOPS, 4), traffic=None,
                                 avg_launch_ms=k["avg_ms"], algorithmic_flops_per_launch=k["avg_flops"],
                                 executed_tflops=round(executed, 1), pipe_frac=round(executed / PEAK_F16_MFMA_TFLOPS, 4),
-                                note="fp32-equivalent products from 3 fp16 MFMAs (hi*hi + hi*lo + lo*hi, fp32 accumulate); "
-                                     "frac prices the ALGORITHMIC fp32 flops against the fp16 peak, pipe_frac the executed ones")
-            elif "gbs" in k:
-                roofline = dict(kernel=dom, bound="hbm", achieved=k["gbs"], peak=PEAK_HBM_GBS, unit="GB/s",
-                                frac=round(k["gbs"] / PEAK_HBM_GBS, 4), traffic=None, avg_launch_ms=k["avg_ms"],
-                                algorithmic_bytes_per_launch=k["avg_bytes"])
-            else:
-                roofline = dict(kernel=dom, bound="hbm", achieved=None, peak=PEAK_HBM_GBS, unit="GB/s", frac=None, traffic=None,
-                                avg_launch_ms=k["avg_ms"])
+                                note="fp32-equivalent products from 3 fp16 MFMAs (hi*hi + hi*lo + lo*hi, fp32 accumulate); frac prices the "
+                                     "ALGORITHMIC fp32 flops against the dense fp16 peak, pipe_frac the executed ones; avg_launch_ms = hipEvents "
+                                     "recorded by the library immediately around the kernel while the other sequence's stream shares the GPU",
+                                op_avg_ms=k.get("op_avg_ms"), traffic_source=None)
+                pmc_file = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_dense_split.json")
+                if os.path.exists(pmc_file):
+                    # PMC counters cannot be read from inside the run: separate rocprofv3 --pmc passes of this command, committed
+                    with open(pmc_file) as fh:
+                        pmc = json.load(fh)
+                    roofline["traffic"] = pmc["traffic_bytes_per_launch"]
+                    roofline["traffic_source"] = "profiles/r01_pmc_dense_split.json (FETCH_SIZE x2 + WRITE_SIZE per dispatch, separate --pmc passes)"
+        km = kernels.get("kmeans_segmented")
+        km_roof = None
+        if km and "gbs" in km:
+            km_roof = dict(kernel="aoc_kmeans_segmented_ex (20 Lloyd iterations: assign+rank, block scan, scatter, ordered sums)", bound="hbm",
+                           achieved=km["gbs"], peak=PEAK_HBM_GBS, unit="GB/s", frac=round(km["gbs"] / PEAK_HBM_GBS, 4),
+                           avg_launch_ms=km["avg_ms"], algorithmic_bytes_per_launch=km["avg_bytes"],
+                           note="a dependent chain of ~160 launches whose ordered float32 sums are latency-bound by construction")
         corr = kernels.get("proxy_corr_min")
         corr_roof = None
         if corr and "gbs" in corr:
@@ -403,7 +462,7 @@ def main():
                        "dense_precision": ("fp16-split products (hi*hi + hi*lo + lo*hi), fp32 accumulate: fp32-equivalent; exact-fp32 take-over "
                                            "on overflow / soft labels" if args.dense == "split" else "exact fp32 MFMA")},
             "host_enqueue_ms_per_step": round(host_enqueue_s / args.steps * 1e3, 3),
-            "roofline": roofline, "roofline_correlation_kernel": corr_roof, "cpu_baseline": cpu, "parity": parity, "kernels": kernels,
+            "roofline": roofline, "roofline_correlation_kernel": corr_roof, "roofline_kmeans_chain": km_roof, "cpu_baseline": cpu, "parity": parity, "kernels": kernels,
         }
         print(json.dumps(line))
     if world > 1:

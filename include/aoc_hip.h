@@ -203,6 +203,12 @@ int aoc_dense_match_min_split(const float *query, const void *query_rec, const f
                               float *out, int64_t out_pixel_stride, int64_t out_obj_stride,
                               int transform, void *workspace, size_t workspace_bytes, aoc_stream_t stream);
 
+/* Measurement probe: the NEXT aoc_dense_match_min / aoc_dense_match_min_split call made by the calling thread records
+ * `start` immediately before and `stop` immediately after its matrix kernel (dense_match_partial_kernel /
+ * dense_split_kernel) on the call's stream, then the probe is cleared.  Both are hipEvent_t created by the caller
+ * (bench.py uses it to time that one kernel live, next to the rocprofv3 figure).  NULL, NULL disarms. */
+int aoc_dense_match_set_probe(void *start_event, void *stop_event);
+
 /* ------------------------------------------------------------------------------------------
  * Local (windowed) matching: AEM:921-963 + 968-1060 (and the identical local_matching_proxy,
  * AEM:1064-1156) without the F.unfold materialisation.  Works on maps already at matching

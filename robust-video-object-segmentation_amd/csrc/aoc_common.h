@@ -59,3 +59,7 @@ int aoc_dense_match_min_gated(const float *query, int64_t m, int C, const float 
                               int64_t n_fg_capacity, const uint32_t *wrong_bits, const float *obj_bias, int n_obj, float *out,
                               int64_t out_pixel_stride, int64_t out_obj_stride, int transform, void *workspace, size_t workspace_bytes,
                               const int32_t *gate, aoc_stream_t stream);
+
+// measurement probe of aoc_dense_match_set_probe (thread-local; defined in correlation.hip)
+struct AocDenseProbe { hipEvent_t start, stop; };
+AocDenseProbe aoc_take_dense_probe();

@@ -615,6 +615,17 @@ int aoc_dense_match_min(const float *query, int64_t m, int C, const float *pool,
 
 }  // extern "C"
 
+static thread_local AocDenseProbe g_dense_probe = {nullptr, nullptr};
+AocDenseProbe aoc_take_dense_probe() {
+    const AocDenseProbe p = g_dense_probe;
+    g_dense_probe = AocDenseProbe{nullptr, nullptr};
+    return p;
+}
+extern "C" int aoc_dense_match_set_probe(void *start_event, void *stop_event) {
+    g_dense_probe = AocDenseProbe{static_cast<hipEvent_t>(start_event), static_cast<hipEvent_t>(stop_event)};
+    return AOC_OK;
+}
+
 int aoc_dense_match_min_gated(const float *query, int64_t m, int C, const float *pool, const int32_t *fg_rows, const int32_t *n_fg,
                               int64_t n_fg_capacity, const uint32_t *wrong_bits, const float *obj_bias, int n_obj,
                               float *out, int64_t out_pixel_stride, int64_t out_obj_stride, int transform,
@@ -634,6 +645,8 @@ int aoc_dense_match_min_gated(const float *query, int64_t m, int C, const float 
 
     hipLaunchKernelGGL(gather_sqnorm_kernel, dim3((unsigned)((n_fg_capacity + 255) / 256)), dim3(256), 0, st, pool, C, fg_rows, n_fg, r2, gate);
     const dim3 grid(row_blocks, ns);
+    const AocDenseProbe probe = gate ? AocDenseProbe{nullptr, nullptr} : aoc_take_dense_probe();
+    if (probe.start) (void)hipEventRecord(probe.start, st);
 #define AOC_DM(NA, OM, TM, EX) hipLaunchKernelGGL((dense_match_partial_kernel<NA, OM, TM, EX, DM_NW>), grid, dim3(DM_NW * 64), lds, st, query, m, C, pool, fg_rows, n_fg, r2, wrong_bits, n_obj, partial, gate)
     if (C == 100) {
         if (n_obj <= 4) AOC_DM(2, 4, 25, true); else if (n_obj <= 8) AOC_DM(1, 8, 25, true); else AOC_DM(1, 16, 25, true);
@@ -641,6 +654,7 @@ int aoc_dense_match_min_gated(const float *query, int64_t m, int C, const float 
         if (n_obj <= 4) AOC_DM(2, 4, 32, false); else if (n_obj <= 8) AOC_DM(1, 8, 32, false); else AOC_DM(1, 16, 32, false);
     }
 #undef AOC_DM
+    if (probe.stop) (void)hipEventRecord(probe.stop, st);
     const int64_t total = m * n_obj;
     hipLaunchKernelGGL(dense_match_finalize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, partial, ns, m, n_obj, n_fg,
                        obj_bias, out, out_pixel_stride, out_obj_stride, transform, gate);

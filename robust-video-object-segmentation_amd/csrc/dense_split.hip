@@ -142,15 +142,26 @@ __global__ __launch_bounds__(SP_NW * 64, 1) void dense_split_kernel(const uint4 
     constexpr int ITERS = (CHUNKS + NT - 1) / NT;
     int32_t *lobj = reinterpret_cast<int32_t *>(lds4 + 2 * ROWS * SP_LDS_ROW);   // [2][SP_NB]
 
+    // XCD-aware block -> (query block, tile split) map: workgroups are dealt round-robin to the 8 XCDs, each with its own
+    // L2; give every XCD a contiguous range of the (split-major) work list so that the ~gridDim.x blocks that stream the
+    // same reference tiles share one L2 instead of pulling them through all eight
+    int bx, by;
+    {
+        const int nb = gridDim.x * gridDim.y, lin = blockIdx.y * gridDim.x + blockIdx.x;
+        const int xcd = lin & 7, slot = lin >> 3, q = nb >> 3, r = nb & 7;
+        const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+        by = v / gridDim.x;
+        bx = v - by * gridDim.x;
+    }
     const int n_tiles = *n_tiles_ptr;
     const int tps = (n_tiles + gridDim.y - 1) / gridDim.y;
-    const int tile_beg = blockIdx.y * tps;
+    const int tile_beg = by * tps;
     const int tile_end = min(n_tiles, tile_beg + tps);
     if (tile_beg >= tile_end) return;
 
     const int lane = aoc_lane(), wave = threadIdx.x >> 6;
     const int col = lane & 31, h = lane >> 5;
-    const int64_t wave_row0 = (int64_t)blockIdx.x * SP_ROWS_PER_BLOCK + (int64_t)wave * (SP_NQ * 32);
+    const int64_t wave_row0 = (int64_t)bx * SP_ROWS_PER_BLOCK + (int64_t)wave * (SP_NQ * 32);
 
     // ---- stationary query operands
     f16x8 bh[SP_NQ][SP_KS], bl[SP_NQ][SP_KS];
@@ -229,7 +240,7 @@ __global__ __launch_bounds__(SP_NW * 64, 1) void dense_split_kernel(const uint4 
         for (int iq = 0; iq < SP_NQ; ++iq) {
             const float v = __builtin_fmaxf(best[iq], __shfl_xor(best[iq], 32));
             const int64_t row = wave_row0 + iq * 32 + col;
-            if (h == 0 && row < m) partial[((size_t)blockIdx.y * m + row) * n_obj + cur] = v;
+            if (h == 0 && row < m) partial[((size_t)by * m + row) * n_obj + cur] = v;
             best[iq] = -INFINITY;
         }
     };
@@ -415,8 +426,11 @@ int aoc_dense_match_min_split(const float *query, const void *query_rec, const f
     const int ns = split_nsplit(m);
     const dim3 grid((unsigned)((m + SP_ROWS_PER_BLOCK - 1) / SP_ROWS_PER_BLOCK), ns);
     const size_t lds = (size_t)2 * SP_NB * SP_TILE * SP_LDS_ROW * 16 + 2 * SP_NB * sizeof(int32_t);
+    const AocDenseProbe probe = aoc_take_dense_probe();
+    if (probe.start) (void)hipEventRecord(probe.start, st);
     hipLaunchKernelGGL(dense_split_kernel, grid, dim3(SP_NW * 64), lds, st, static_cast<const uint4 *>(query_rec), m,
                        static_cast<const uint4 *>(pool_rec), w.tile_rows, w.tile_obj, w.n_tiles, w.gate, n_obj, w.partial);
+    if (probe.stop) (void)hipEventRecord(probe.stop, st);
     hipLaunchKernelGGL(dense_split_finalize_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, w.partial, ns, m, n_obj, counts, w.gate,
                        query_sqnorm, obj_bias, out, out_pixel_stride, out_obj_stride, transform);
     AOC_RETURN_IF_LAUNCH_FAILED();

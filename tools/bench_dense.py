@@ -2,7 +2,7 @@
 import sys, time
 import numpy as np
 import torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import aoc_amd
 from aoc_amd import ops, synthetic as syn
 
