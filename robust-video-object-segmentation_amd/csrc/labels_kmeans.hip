@@ -805,11 +805,12 @@ __global__ __launch_bounds__(256) void km_chunk_sum_kernel(const float *__restri
                                                             const int32_t *__restrict__ counts, const int32_t *__restrict__ cbase,
                                                             const uint32_t *__restrict__ moff, int kmax,
                                                             const int32_t *__restrict__ owner_cluster, const int32_t *__restrict__ owner_local,
-                                                            float *__restrict__ csum) {
+                                                            float *__restrict__ csum, int start_chunk) {
     __shared__ __attribute__((aligned(16))) float tile[64 * KC_TILE_LD];
     const int chunk = blockIdx.x;
     const int oc = owner_cluster[chunk];
     if (oc < 0) return;
+    if (owner_local[chunk] < start_chunk) return;       // head chunks are summed literally (km_ordered_sum_kernel)
     const int s = oc / kmax;
     const int cnt = counts[oc];
     const uint32_t *list = moff + seg_off[s] + cbase[oc];
@@ -852,15 +853,17 @@ __global__ __launch_bounds__(256) void km_chunk_sum_kernel(const float *__restri
 constexpr int KC_UNSAFE = -128;
 __global__ __launch_bounds__(128) void km_chunk_predict_kernel(const int32_t *__restrict__ seg_k, const int32_t *__restrict__ counts,
                                                                 const int32_t *__restrict__ cchunk, const float *__restrict__ csum, int kmax,
-                                                                int C, int8_t *__restrict__ cexp, int start_chunk) {
+                                                                int C, int8_t *__restrict__ cexp, int start_chunk,
+                                                                const float *__restrict__ head_state) {
     const int s = blockIdx.y, j = blockIdx.x;
     if (j >= seg_k[s]) return;
     const int oc = s * kmax + j;
     const int nch = (counts[oc] + KS_CHUNK - 1) / KS_CHUNK;
+    if (nch <= start_chunk) return;
     const int base = cchunk[oc];
     for (int f = threadIdx.x; f < C; f += blockDim.x) {
-        float pre = 0.0f;
-        for (int c0 = 0; c0 < nch; c0 += 8) {
+        float pre = (start_chunk > 0) ? head_state[(size_t)oc * C + f] : 0.0f;     // exact sum of the head chunks
+        for (int c0 = start_chunk; c0 < nch; c0 += 8) {
           float cs[8];
 #pragma unroll
           for (int u = 0; u < 8; ++u) cs[u] = (c0 + u < nch) ? csum[(size_t)(base + c0 + u) * C + f] : 0.0f;   // 8 loads in flight
@@ -873,7 +876,7 @@ __global__ __launch_bounds__(128) void km_chunk_predict_kernel(const int32_t *__
             if (pre > 1e-30f && end < 1e30f && end >= pre) {
                 const int e_lo = (int)((__float_as_uint(pre * 0.9995f) >> 23) & 0xff) - 127;
                 const int e_hi = (int)((__float_as_uint(end * 1.0005f) >> 23) & 0xff) - 127;
-                if (e_lo == e_hi && e_lo >= -100 && e_lo <= 100 && c >= start_chunk) e = e_lo;
+                if (e_lo == e_hi && e_lo >= -100 && e_lo <= 100) e = e_lo;
             }
             cexp[(size_t)(base + c) * C + f] = (int8_t)e;
             pre = end;
@@ -938,12 +941,14 @@ __global__ __launch_bounds__(256) void km_chunk_fold_kernel(const float *__restr
                                                              const int32_t *__restrict__ counts, const int32_t *__restrict__ cbase,
                                                              const uint32_t *__restrict__ moff, int kmax,
                                                              const int32_t *__restrict__ owner_cluster, const int32_t *__restrict__ owner_local,
-                                                             int8_t *__restrict__ cexp, int32_t *__restrict__ cinc0, int32_t *__restrict__ cinc1) {
+                                                             int8_t *__restrict__ cexp, int32_t *__restrict__ cinc0, int32_t *__restrict__ cinc1,
+                                                             int start_chunk) {
     __shared__ float tile[2][64 * KC_G_LD];
     __shared__ uint32_t loffs[KS_CHUNK];
     const int chunk = blockIdx.x, grp = blockIdx.y;
     const int oc = owner_cluster[chunk];
     if (oc < 0) return;
+    if (owner_local[chunk] < start_chunk) return;
     const int f0 = grp * KC_FG;
     const int s = oc / kmax;
     const int cnt = counts[oc];
@@ -1565,10 +1570,10 @@ inline void ks_launch_sums(hipStream_t st, const float *pool, uint32_t pool_byte
         if (mode == 1) return;
     }
     hipLaunchKernelGGL(km_chunk_sum_kernel, dim3(ws.nch_cap), dim3(256), 0, st, pool, C, seg_offsets, counts, ws.cbase, ws.moff, kmax, ws.owner_cluster,
-                       ws.owner_local, ws.csum);
-    hipLaunchKernelGGL(km_chunk_predict_kernel, dim3(kmax, n_seg), dim3(128), 0, st, seg_k, counts, ws.cchunk, ws.csum, kmax, C, ws.cexp, start);
+                       ws.owner_local, ws.csum, start);
+    hipLaunchKernelGGL(km_chunk_predict_kernel, dim3(kmax, n_seg), dim3(128), 0, st, seg_k, counts, ws.cchunk, ws.csum, kmax, C, ws.cexp, start, ws.head);
     hipLaunchKernelGGL(km_chunk_fold_kernel, dim3(ws.nch_cap, (C + KC_FG - 1) / KC_FG), dim3(256), 0, st, pool, C, seg_offsets, counts, ws.cbase, ws.moff,
-                       kmax, ws.owner_cluster, ws.owner_local, ws.cexp, ws.cinc0, ws.cinc1);
+                       kmax, ws.owner_cluster, ws.owner_local, ws.cexp, ws.cinc0, ws.cinc1, start);
     static const int nf = getenv("AOC_KS_NF") ? atoi(getenv("AOC_KS_NF")) : 1;       // features per stitch wave (developer switch)
 #define AOC_KSS(NF) hipLaunchKernelGGL((km_sum_scan_kernel<MODE, NF>), dim3(C / NF, kmax, n_seg), dim3(64), 0, st, pool, pool_bytes, C, seg_offsets, seg_k, \
                                        counts, ws.cbase, ws.moff, kmax, dst, ws.cchunk, ws.cexp, ws.cinc0, ws.cinc1, start, ws.head)
