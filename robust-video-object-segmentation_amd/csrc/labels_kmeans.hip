@@ -2,6 +2,7 @@
 // construction.  Reference: AEM:252-286 (adaptive_embedding_for_matching.py) + scipy.cluster.vq.
 #include "aoc_common.h"
 #include <stdlib.h>
+#include <algorithm>
 #include <string.h>
 
 namespace {
@@ -637,6 +638,201 @@ __global__ __launch_bounds__(256) void km_assign_rank_kernel(const float *__rest
     if ((int)threadIdx.x < k)
         hist[((size_t)s * nb_max + blockIdx.x) * kmax + threadIdx.x] =
             wcnt[threadIdx.x] + wcnt[kmax + threadIdx.x] + wcnt[2 * kmax + threadIdx.x] + wcnt[3 * kmax + threadIdx.x];
+}
+
+// Assignment on the fp32 matrix pipe (iterations 2..20; the first one also produces the row norms and uses the
+// kernel above).  v_mfma_f32_16x16x4_f32 accumulates each output as one k-ordered fmaf chain -- the OpenBLAS order
+// scipy's vq sees -- so labels stay bit-identical while the rows are fetched with coalesced 16-byte loads instead of
+// one row per lane.  Block = 4 waves x 64 rows (the 256-row blocks the rank/histogram logic is built on).  Clusters
+// are the A operand (code book, 25 VGPR per 16 clusters, resident), rows the B operand: each wave stages its 16-row
+// tiles in a private, double-buffered, k-permuted LDS image (lane (j, kq) reads x[j][4t + kq] with ds_read_b128).
+// D: lane holds row j = lane & 15 and clusters (lane >> 4) * 4 + r: the argmin is 4 in-lane compares and two
+// cross-group exchanges, ties to the lowest index like scipy's strict <.
+template <int TMAX, int KT>
+__global__ __launch_bounds__(256, 3) void km_assign_mfma_kernel(const float *__restrict__ pool, int C, const int32_t *__restrict__ rows,
+                                                              const int32_t *__restrict__ seg_off, const int32_t *__restrict__ seg_k, int n_seg,
+                                                              const float *__restrict__ centroids, int kmax, int32_t *__restrict__ labels,
+                                                              uint16_t *__restrict__ rank16, int32_t *__restrict__ hist, int nb_max,
+                                                              const float *__restrict__ rownorm) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int TP = (TMAX + 3) / 4 * 4;             // floats per kq-stream (padded to float4)
+    constexpr int RS = 4 * TP + 4;                     // row stride of the k-permuted image
+    constexpr int NB4 = TP / 4;
+    constexpr int PIECES = (16 * TMAX + 63) / 64;      // float4 pieces per lane per 16-row tile
+    const int c4 = C >> 2;
+    const int lane = aoc_lane(), wave = threadIdx.x >> 6;
+    const int j = lane & 15, g = lane >> 4;
+
+    float *cimg = lds;                                           // [KT*16][RS] code book, k-permuted
+    float *lcn = cimg + (size_t)KT * 16 * RS;                    // [KT*16] |c|^2 (+inf beyond k)
+    float *wimg = lcn + KT * 16 + (size_t)wave * 16 * RS;        // this wave's row-tile image
+    int32_t *wcnt = reinterpret_cast<int32_t *>(lcn + KT * 16 + (size_t)4 * 16 * RS);       // [4][kmax]
+
+    // zero the stream padding of this wave's images and of the code book (never overwritten afterwards)
+    if (TP > c4) {
+        for (int idx = lane; idx < 16 * 4 * (TP - c4); idx += 64) {
+            const int rr = idx / (4 * (TP - c4)), rem = idx - rr * 4 * (TP - c4);
+            wimg[(size_t)rr * RS + (rem / (TP - c4)) * TP + c4 + rem % (TP - c4)] = 0.0f;
+        }
+        for (int idx = threadIdx.x; idx < KT * 16 * 4 * (TP - c4); idx += 256) {
+            const int rr = idx / (4 * (TP - c4)), rem = idx - rr * 4 * (TP - c4);
+            cimg[(size_t)rr * RS + (rem / (TP - c4)) * TP + c4 + rem % (TP - c4)] = 0.0f;
+        }
+    }
+
+    float4 ca[KT][NB4];
+    float cn[KT][4];
+    int cur_seg = -1, k = 0, beg = 0, len = 0;
+    // persistent blocks walk the list of (segment, 256-row block) work items: no empty workgroups, and the code book is
+    // staged once per block and segment instead of once per 256 rows
+    for (int w = blockIdx.x;; w += gridDim.x) {
+        int s = 0, bx = w;
+        for (; s < n_seg; ++s) {
+            const int ls = seg_off[s + 1] - seg_off[s];
+            const int nbs = (seg_k[s] > 0) ? (ls + 255) / 256 : 0;
+            if (bx < nbs) break;
+            bx -= nbs;
+        }
+        if (s >= n_seg) break;
+        // ---- this item's rows: all loads of TPF tiles are issued before anything waits (ids -> pieces in registers)
+        constexpr int TPF = 2;                             // tiles in flight per wave (register budget: 3 blocks per CU)
+        const int ibeg = seg_off[s], ilen = seg_off[s + 1] - ibeg;
+        const int wave_row0 = bx * 256 + wave * 64;
+        float4 pv[TPF][PIECES];
+        auto issue_tile = [&](int tile, float4 (&v)[PIECES]) {
+#pragma unroll
+            for (int i = 0; i < PIECES; ++i) {
+                const int idx = i * 64 + lane;
+                const int rr = idx / c4, t = idx - rr * c4;
+                const int p = wave_row0 + tile * 16 + rr;
+                const bool ok = idx < 16 * c4 && p < ilen;
+                v[i] = ok ? reinterpret_cast<const float4 *>(pool + (size_t)rows[ibeg + p] * C)[t] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        };
+        auto write_tile = [&](const float4 (&v)[PIECES]) {
+#pragma unroll
+            for (int i = 0; i < PIECES; ++i) {
+                const int idx = i * 64 + lane;
+                if (idx < 16 * c4) {
+                    const int rr = idx / c4, t = idx - rr * c4;
+                    float *d = wimg + (size_t)rr * RS + t;
+                    d[0] = v[i].x; d[TP] = v[i].y; d[2 * TP] = v[i].z; d[3 * TP] = v[i].w;
+                }
+            }
+        };
+#pragma unroll
+        for (int t = 0; t < TPF; ++t) issue_tile(t, pv[t]);
+        if (s != cur_seg) {
+            cur_seg = s;
+            k = seg_k[s];
+            beg = seg_off[s];
+            len = seg_off[s + 1] - beg;
+            __syncthreads();                                   // previous users of cimg / lcn are done
+            const float *csrc = centroids + (size_t)s * kmax * C;
+            for (int idx = threadIdx.x; idx < KT * 16 * c4; idx += 256) {
+                const int cc = idx / c4, t = idx - cc * c4;
+                const float4 v = (cc < k) ? reinterpret_cast<const float4 *>(csrc + (size_t)cc * C)[t] : make_float4(0.f, 0.f, 0.f, 0.f);
+                float *d = cimg + (size_t)cc * RS + t;
+                d[0] = v.x; d[TP] = v.y; d[2 * TP] = v.z; d[3 * TP] = v.w;
+            }
+            __syncthreads();
+            // |c|^2 from the staged image (scipy code_sqr order: k = 0..C-1, multiply then add)
+            if ((int)threadIdx.x < KT * 16) {
+                float nrm = INFINITY;
+                if ((int)threadIdx.x < k) {
+                    const float *im = cimg + (size_t)threadIdx.x * RS;
+                    nrm = 0.0f;
+#pragma unroll
+                    for (int t = 0; t < TMAX; ++t) {
+                        if (t < c4) {
+#pragma unroll
+                            for (int kq = 0; kq < 4; ++kq) {
+                                const float v = im[kq * TP + t];
+                                const float prod = v * v;
+                                nrm = nrm + prod;
+                            }
+                        }
+                    }
+                }
+                lcn[threadIdx.x] = nrm;
+            }
+            __syncthreads();
+            // A operands: lane (i = j, kq = g) holds c[16 kt + i][4t + kq]
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) {
+                const float *st = cimg + (size_t)(kt * 16 + j) * RS + g * TP;
+#pragma unroll
+                for (int u = 0; u < NB4; ++u) ca[kt][u] = *reinterpret_cast<const float4 *>(st + 4 * u);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) cn[kt][r] = lcn[kt * 16 + g * 4 + r];
+            }
+        }
+
+        int best = -1;                                     // label of row (wave_row0 + lane) once all four tiles are done
+#pragma unroll
+        for (int tile = 0; tile < 4; ++tile) {
+            write_tile(pv[tile % TPF]);
+            if (tile + TPF < 4) issue_tile(tile + TPF, pv[tile % TPF]);
+            // B operand: lane (j, kq = g) reads its stream of row j
+            const float *bs = wimg + (size_t)j * RS + g * TP;
+            float4 xb[NB4];
+#pragma unroll
+            for (int u = 0; u < NB4; ++u) xb[u] = *reinterpret_cast<const float4 *>(bs + 4 * u);
+            const int prow = wave_row0 + tile * 16 + j;
+            const float xs = (prow < len) ? rownorm[beg + prow] : 0.0f;
+            float low = INFINITY;
+            int arg = 0;
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) {
+                f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int u = 0; u < NB4; ++u) {
+                    const float aa[4] = {ca[kt][u].x, ca[kt][u].y, ca[kt][u].z, ca[kt][u].w};
+                    const float bb[4] = {xb[u].x, xb[u].y, xb[u].z, xb[u].w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (4 * u + e < TMAX) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aa[e], bb[e], acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float mm = -2.0f * acc[r];
+                    const float dist = (mm + xs) + cn[kt][r];
+                    if (dist < low) { low = dist; arg = kt * 16 + g * 4 + r; }
+                }
+            }
+            // the four lane groups hold disjoint cluster ranges of the same row: lowest distance, then lowest index
+#pragma unroll
+            for (int off = 16; off <= 32; off <<= 1) {
+                const float d2 = __shfl_xor(low, off);
+                const int a2 = __shfl_xor(arg, off);
+                if (d2 < low || (d2 == low && a2 < arg)) { low = d2; arg = a2; }
+            }
+            const int mine = __shfl(arg, lane & 15);       // every lane: label of row (lane & 15) of this tile
+            if ((lane >> 4) == tile) best = mine;
+        }
+        const int p = wave_row0 + lane;
+        const bool valid = p < len;
+        if (!valid) best = -1;
+        if (valid) labels[beg + p] = best;
+        // stable rank of the row among the rows of its block that share its label
+        const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+        int rank = 0;
+        for (int kk = 0; kk < k; ++kk) {
+            const unsigned long long mk = __ballot(best == kk);
+            if (best == kk) rank = __popcll(mk & lt);
+            if (lane == 0) wcnt[wave * kmax + kk] = __popcll(mk);
+        }
+        __syncthreads();
+        if (valid) {
+            int woff = 0;
+            for (int ww = 0; ww < wave; ++ww) woff += wcnt[ww * kmax + best];
+            rank16[beg + p] = (uint16_t)(woff + rank);
+        }
+        if ((int)threadIdx.x < k)
+            hist[((size_t)s * nb_max + bx) * kmax + threadIdx.x] =
+                wcnt[threadIdx.x] + wcnt[kmax + threadIdx.x] + wcnt[2 * kmax + threadIdx.x] + wcnt[3 * kmax + threadIdx.x];
+        __syncthreads();                                       // wcnt is reused by the next work item
+    }
 }
 
 // rank + histogram from EXISTING labels (proxy construction after the last iteration)
@@ -1658,6 +1854,7 @@ int aoc_kmeans_segmented_ex(const float *pool, int64_t pool_rows, int C, const i
     // scan-sum pipeline: rows addressed by 32-bit byte offsets through a bounds-checked buffer descriptor
     const bool fast = (C % 4) == 0 && C <= 128 && pool_rows > 0 && (uint64_t)pool_rows * C * 4 < 0xFFFFFF00ull;
     const uint32_t pool_bytes = fast ? (uint32_t)((uint64_t)pool_rows * C * 4) : 0u;
+    static const bool mfma_assign = !(getenv("AOC_KM_ASSIGN") && strcmp(getenv("AOC_KM_ASSIGN"), "valu") == 0);   // developer switch
 
     hipLaunchKernelGGL(km_init_kernel, dim3(kmax, n_seg), dim3(64), 0, st, pool, C, rows, seg_offsets, seg_k, init_rows, kmax,
                        centroids, cnorm, cluster_counts);
@@ -1667,13 +1864,23 @@ int aoc_kmeans_segmented_ex(const float *pool, int64_t pool_rows, int C, const i
     const int nf = (C + 63) / 64;
     for (int it = 0; it < iters; ++it) {
         const int first = (it == 0);
-        if (fast) {
+        if (fast && !first && mfma_assign && C == 100 && kmax <= 64) {
+            const int kt = (kmax + 15) / 16;
+            const size_t alds = ((size_t)kt * 16 * 116 + kt * 16 + (size_t)4 * 16 * 116) * sizeof(float) + (size_t)4 * kmax * sizeof(int32_t);
+            const unsigned pgrid = (unsigned)std::min<int64_t>((rows_capacity + 255) / 256 + n_seg, 768);    // persistent: 3 blocks per CU
+#define AOC_KA(KT) hipLaunchKernelGGL((km_assign_mfma_kernel<25, KT>), dim3(pgrid), dim3(256), alds, st, pool, C, rows, seg_offsets, seg_k, n_seg, centroids, \
+                                      kmax, labels, ws.rank16, ws.hist, ws.nb_max, rownorm)
+            if (kt == 1) AOC_KA(1); else if (kt == 2) AOC_KA(2); else if (kt == 3) AOC_KA(3); else AOC_KA(4);
+#undef AOC_KA
+        } else if (fast) {
             if (C <= 100)
                 hipLaunchKernelGGL(km_assign_rank_kernel<25>, agrid, dim3(256), lds_fast, st, pool, C, rows, seg_offsets, seg_k, centroids, kmax, labels,
                                    ws.rank16, ws.hist, ws.nb_max, rownorm, first);
             else
                 hipLaunchKernelGGL(km_assign_rank_kernel<32>, agrid, dim3(256), lds_fast, st, pool, C, rows, seg_offsets, seg_k, centroids, kmax, labels,
                                    ws.rank16, ws.hist, ws.nb_max, rownorm, first);
+        }
+        if (fast) {
             hipLaunchKernelGGL(km_blockscan_kernel, dim3(n_seg), dim3(1024), 0, st, seg_offsets, seg_k, ws.hist, ws.blockoff, ws.nb_max, kmax,
                                cluster_counts, ws.cbase, ws.cchunk, ws.owner_cluster, ws.owner_local, ws.nch_cap);
             hipLaunchKernelGGL(km_scatter_kernel, agrid, dim3(256), 0, st, rows, (const int32_t *)nullptr, seg_offsets, seg_k, labels, ws.rank16,
