@@ -150,6 +150,8 @@ class ClipWorkload:
             if t % mc.MEM_EVERY == 0:
                 ref_idx.append(t)
         self.dense_state = {"capacity_frames": rmax}      # fp16 split records of the pool, converted once per appended frame
+        self.ahead = None                                  # adaptive proxies of the NEXT frame, already enqueued on the side stream
+        self.pool_event = None                             # recorded after the last change of the pool
         self.reset()
 
     def reset(self):
@@ -157,6 +159,8 @@ class ClipWorkload:
         self.dense_state["frames"] = 0
         self.pool_emb[0].copy_(self.emb[0])
         self.pool_lab[0].copy_(self.lab[0])
+        self.pool_event = torch.cuda.Event()
+        self.pool_event.record()
 
     def refs(self):
         return self.pool_emb[:self.R], self.pool_lab[:self.R]
@@ -167,6 +171,8 @@ class ClipWorkload:
             self.pool_emb[self.R].copy_(self.emb[self.t])
             self.pool_lab[self.R].copy_(self.lab[self.t])
             self.R += 1
+            self.pool_event = torch.cuda.Event()
+            self.pool_event.record()                       # the next k-means chain must see the appended frame
         self.t += 1
         if self.t >= self.T:
             self.reset()
@@ -177,14 +183,26 @@ def make_activations(gates, O, h, w, device, seed):
     return [torch.randn(O, c, hh, ww, generator=g).to(device) for (_, c, hh, ww, _) in gates.plan(h, w)]
 
 
-def frame_step(wl, gates, acts, dense_precision="split"):
+def frame_step(wl, gates, acts, dense_precision="split", pipeline=True):
     ref_emb, ref_lab = wl.refs()
     t = wl.t
-    feat, head, _ = hotpath.proto_mask_features(wl.mc, ref_emb, ref_lab, wl.emb[t - 1], wl.lab[t - 1], wl.emb[t], wl.bias,
-                                                cluster_state=dict(init_rows=wl.init_rows[t][0]), side_stream=wl.side,
-                                                dense_state=wl.dense_state, dense_precision=dense_precision)
+    if wl.side is not None and pipeline:
+        # the k-means chain of a frame only depends on the pool (which changes every MEM_EVERY frames): it was enqueued on
+        # the side stream right after the previous frame's pool update, and runs under that frame's other work
+        ahead = wl.ahead if wl.ahead is not None else hotpath.launch_cluster_proxies(wl.mc, ref_emb, ref_lab, wl.init_rows[t][0], wl.side,
+                                                                                         wait_event=wl.pool_event)
+        wl.ahead = None
+        feat, head, _ = hotpath.proto_mask_features(wl.mc, ref_emb, ref_lab, wl.emb[t - 1], wl.lab[t - 1], wl.emb[t], wl.bias,
+                                                    cluster_ahead=ahead, dense_state=wl.dense_state, dense_precision=dense_precision)
+    else:
+        feat, head, _ = hotpath.proto_mask_features(wl.mc, ref_emb, ref_lab, wl.emb[t - 1], wl.lab[t - 1], wl.emb[t], wl.bias,
+                                                    cluster_state=dict(init_rows=wl.init_rows[t][0]), side_stream=wl.side,
+                                                    dense_state=wl.dense_state, dense_precision=dense_precision)
     outs = gates(acts, head)
-    wl.advance()
+    wl.advance()                                           # pool append / sequence restart happen here (after the frame's outputs)
+    if wl.side is not None and pipeline:
+        ref_emb, ref_lab = wl.refs()
+        wl.ahead = hotpath.launch_cluster_proxies(wl.mc, ref_emb, ref_lab, wl.init_rows[wl.t][0], wl.side, wait_event=wl.pool_event)
     return feat, outs
 
 
@@ -268,6 +286,10 @@ def main():
     ap.add_argument("--dense", default="split", choices=["split", "fp32"],
                     help="dense-matching arithmetic: fp16-split products with fp32 accumulate (fp32-equivalent) or exact-fp32 MFMA")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cu-reserve", type=int, default=64,
+                    help="keep the main streams off this many CUs (HIP CU mask) so the side-stream k-means chain always finds free CUs")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="start a frame's k-means chain with the frame instead of right after the previous frame's pool update")
     ap.add_argument("--no-overlap", action="store_true", help="run the k-means branch on the main stream (no intra-frame stream overlap)")
     args = ap.parse_args()
 
@@ -281,6 +303,8 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # RCCL over xGMI
+    if args.cu_reserve > 0:
+        os.environ.setdefault("AOC_DENSE_CUS", str(256 - args.cu_reserve))   # the dense kernel sizes its grid in whole rounds of CUs
     aoc_amd._lib.lib()
 
     cfg = syn.CONFIGS[args.config]
@@ -291,7 +315,25 @@ def main():
     # sequences are sharded over ranks: rank r owns sequences r*n_streams .. (+n_streams)
     workloads = [ClipWorkload(cfg, seed=1 + rank * n_streams + s, device=dev, mc=mc, overlap=not args.no_overlap) for s in range(n_streams)]
     acts = make_activations(gates, cfg.n_obj, cfg.h, cfg.w, dev, seed=7)
-    streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)] if n_streams > 1 else [torch.cuda.current_stream()]
+    def make_main_stream():
+        """Main stream of one sequence.  With --cu-reserve N its workgroups are kept off N of the 256 CUs (HIP CU mask), so
+        that the latency-bound k-means chain on the side stream always finds free CUs next to the dense kernel, whose
+        blocks fill a CU's register file and do not yield."""
+        if args.cu_reserve <= 0:
+            return torch.cuda.Stream(device=dev)
+        hip = ctypes.CDLL("libamdhip64.so")
+        n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
+        words = (n_cu + 31) // 32
+        mask = [0] * words
+        for cu in range(n_cu - args.cu_reserve):           # contiguous: interleaved masks were observed to be ignored
+            mask[cu // 32] |= 1 << (cu % 32)
+        arr = (ctypes.c_uint32 * words)(*mask)
+        handle = ctypes.c_void_p()
+        rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(handle), ctypes.c_uint32(words), arr)
+        assert rc == 0, f"hipExtStreamCreateWithCUMask failed: {rc}"
+        return torch.cuda.ExternalStream(handle.value, device=dev)
+
+    streams = [make_main_stream() for _ in range(n_streams)] if (n_streams > 1 or args.cu_reserve > 0) else [torch.cuda.current_stream()]
 
     hw, C, O = cfg.h * cfg.w, cfg.c, cfg.n_obj
 
@@ -318,11 +360,11 @@ def main():
     def run_steps(n):
         for _ in range(n):
             for wl, st in zip(workloads, streams):
-                if n_streams > 1:
+                if n_streams > 1 or args.cu_reserve > 0:
                     with torch.cuda.stream(st):
-                        frame_step(wl, gates, acts, args.dense)
+                        frame_step(wl, gates, acts, args.dense, not args.no_pipeline)
                 else:
-                    frame_step(wl, gates, acts, args.dense)
+                    frame_step(wl, gates, acts, args.dense, not args.no_pipeline)
 
     def barrier():
         torch.cuda.synchronize()
@@ -458,7 +500,11 @@ def main():
                                    f"C={C}, {cfg.frames}-frame clips, MEM_EVERY={mc.MEM_EVERY} (R=1..{1 + (cfg.frames - 2) // mc.MEM_EVERY}), "
                                    "20 Lloyd iterations, local windows [2..12]",
                        "sequences_per_gpu": n_streams, "frames_per_step": n_streams, "sharding": "sequences over ranks, no data-path collective",
-                       "intra_frame_overlap": "k-means branch on a side HIP stream" if not args.no_overlap else "none",
+                       "intra_frame_overlap": ("none" if args.no_overlap else "k-means chain on a side HIP stream" +
+                                               ("" if args.no_pipeline else ", enqueued as soon as the pool it depends on is final "
+                                                "(right after the previous frame's memory update)")),
+                       "cu_reserve": (f"main streams masked off {args.cu_reserve} of 256 CUs (hipExtStreamCreateWithCUMask), left to the side-stream "
+                                      "k-means chains" if args.cu_reserve > 0 else "none"),
                        "dense_precision": ("fp16-split products (hi*hi + hi*lo + lo*hi), fp32 accumulate: fp32-equivalent; exact-fp32 take-over "
                                            "on overflow / soft labels" if args.dense == "split" else "exact fp32 MFMA")},
             "host_enqueue_ms_per_step": round(host_enqueue_s / args.steps * 1e3, 3),

@@ -346,15 +346,17 @@ __global__ __launch_bounds__(256) void dense_split_finalize_kernel(const float *
 inline int split_nsplit(int64_t m) {
     const int64_t row_blocks = (m + SP_ROWS_PER_BLOCK - 1) / SP_ROWS_PER_BLOCK;
     static const int max_rounds = getenv("AOC_DENSE_ROUNDS") ? atoi(getenv("AOC_DENSE_ROUNDS")) : 4;
+    // CUs the launching stream may use (256 unless the caller runs it under a HIP CU mask and says so)
+    static const int n_cu = (getenv("AOC_DENSE_CUS") && atoi(getenv("AOC_DENSE_CUS")) > 0) ? atoi(getenv("AOC_DENSE_CUS")) : 256;
     int best = 1;
     double best_eff = 0.0;
     for (int k = 1; k <= max_rounds; ++k) {
-        int64_t ns = (256 * k) / row_blocks;
+        int64_t ns = ((int64_t)n_cu * k) / row_blocks;
         if (ns < 1) ns = 1;
         if (ns > 64) ns = 64;
         const int64_t blocks = row_blocks * ns;
-        const int64_t rounds = (blocks + 255) / 256;
-        const double eff = (double)blocks / (256.0 * rounds);
+        const int64_t rounds = (blocks + n_cu - 1) / n_cu;
+        const double eff = (double)blocks / ((double)n_cu * rounds);
         if (eff >= best_eff - 0.005) { best_eff = eff > best_eff ? eff : best_eff; best = (int)ns; }
     }
     return best;

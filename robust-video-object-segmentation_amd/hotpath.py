@@ -53,8 +53,48 @@ def channel_slices(cfg):
     return s
 
 
+class ClusterProxiesAhead:
+    """Adaptive proxies of ONE frame computed ahead of time on a side stream (launch_cluster_proxies): the k-means
+    chain only depends on the reference pool, its labels and the initial rows -- not on the frame before -- so while the
+    pool is unchanged (4 of 5 frames with MEM_EVERY = 5) the chain of frame t+1 can run under frame t's other work."""
+    __slots__ = ("prep", "table", "sqn", "prep_event", "done_event", "aux", "R")
+
+
+def launch_cluster_proxies(cfg, ref_emb, ref_labels, init_rows_dev, side_stream, wait_event=None):
+    """Label prep + sticky K + 20 Lloyd iterations + proxy construction (AEM:252-286) of the pool, enqueued on
+    `side_stream` without any host synchronisation.  `init_rows_dev` [O, K] int32 device tensor (rows drawn like scipy's
+    minit='points').  `wait_event`: the side stream first waits for it (e.g. the pool append of the previous frame).
+    Returns a ClusterProxiesAhead to pass to proto_mask_features(cluster_ahead=...)."""
+    R, h, w, C = ref_emb.shape
+    O = ref_labels.shape[-1]
+    hw = h * w
+    kmax = cfg.CLUSTER_NUM
+    dev = ref_emb.device
+    out = ClusterProxiesAhead()
+    out.R = R
+    with torch.cuda.stream(side_stream):
+        if wait_event is not None:
+            side_stream.wait_event(wait_event)
+        pool = ref_emb.reshape(R * hw, C)
+        out.table = torch.empty(O * 2 * kmax + O, C, dtype=torch.float32, device=dev)
+        out.sqn = torch.empty(O * 2 * kmax + O, dtype=torch.float32, device=dev)
+        out.prep = ops.label_prep(ref_labels.reshape(R * hw, O))
+        out.prep_event = torch.cuda.Event()
+        out.prep_event.record(side_stream)
+        seg_k = ops.kmeans_plan(out.prep.counts, O, kmax)
+        cen, lab, _ = ops.kmeans_segmented(pool, out.prep.obj_rows, out.prep.obj_offsets, seg_k, init_rows_dev, kmax, KMEANS_ITERS,
+                                           rows_capacity=out.prep.obj_rows.numel())
+        proxies, psq = ops.build_proxies(pool, out.prep.fg_rows, out.prep.obj_offsets, seg_k, lab, cen)
+        out.table[:O * 2 * kmax].copy_(proxies.reshape(-1, C))
+        out.sqn[:O * 2 * kmax].copy_(psq.reshape(-1))
+        out.done_event = torch.cuda.Event()
+        out.done_event.record(side_stream)
+    out.aux = dict(prep=out.prep, centroids=cen, labels=lab, proxies=proxies, proxy_sqnorm=psq, seg_k=seg_k)
+    return out
+
+
 def proto_mask_features(cfg, ref_emb, ref_labels, prev_emb, prev_labels, cur_emb, dis_bias, init_rows=None,
-                        cluster_state=None, side_stream=None, dense_state=None, dense_precision=None):
+                        cluster_state=None, side_stream=None, dense_state=None, dense_precision=None, cluster_ahead=None):
     """All matching branches of one frame -> (features [O, 24, h, w], attention_head [O, 4C], aux).
 
     ref_emb     [R, h, w, C]  reference pool (channel-last)          ref_labels [R, h, w, O] float one-hot
@@ -69,6 +109,8 @@ def proto_mask_features(cfg, ref_emb, ref_labels, prev_emb, prev_labels, cur_emb
                  records of the reference pool, so only frames appended since the last call are converted.  The pool
                  must be append-only while the dict lives (the reference's memory policy, eval_manager_mm.py:329-361).
     dense_precision  "split" (default, ops.DENSE_PRECISION) or "fp32": see ops.dense_match.
+    cluster_ahead  a ClusterProxiesAhead of this frame's pool (launch_cluster_proxies): the adaptive proxies were
+                 enqueued earlier on a side stream; this call only waits for them in front of the correlation launch.
     """
     R, h, w, C = ref_emb.shape
     O = ref_labels.shape[-1]
@@ -87,9 +129,19 @@ def proto_mask_features(cfg, ref_emb, ref_labels, prev_emb, prev_labels, cur_emb
     kmax = cfg.CLUSTER_NUM
 
     # ---- adaptive proxies (k-means, AEM:252-286) + k = 1 proxies (ATT:155-189) in ONE proxy table
-    table = torch.empty(O * 2 * kmax + O, C, dtype=torch.float32, device=dev)
-    sqn = torch.empty(O * 2 * kmax + O, dtype=torch.float32, device=dev)
-    if cluster_state is None:
+    if cluster_ahead is not None:
+        assert cluster_ahead.R == R, "cluster_ahead was launched for another pool size"
+        main = torch.cuda.current_stream()
+        main.wait_event(cluster_ahead.prep_event)
+        table, sqn, prep, cp = cluster_ahead.table, cluster_ahead.sqn, cluster_ahead.prep, cluster_ahead.aux
+        for t in (table, sqn, prep.right_bits, prep.wrong_bits, prep.fg_rows, prep.obj_rows, prep.counts, prep.obj_offsets):
+            t.record_stream(main)
+    else:
+        table = torch.empty(O * 2 * kmax + O, C, dtype=torch.float32, device=dev)
+        sqn = torch.empty(O * 2 * kmax + O, dtype=torch.float32, device=dev)
+    if cluster_ahead is not None:
+        pass
+    elif cluster_state is None:
         cp = cluster_proxies(pool, labels_flat, kmax, init_rows)
         prep = cp["prep"] if cp is not None else ops.label_prep(labels_flat)
         if cp is not None:
@@ -168,7 +220,9 @@ def proto_mask_features(cfg, ref_emb, ref_labels, prev_emb, prev_labels, cur_emb
         set_size.append(1)
         set_off.append(o * obj_stride + ch["proxy"] * hw)
     set_bias = torch.cat([bias.repeat_interleave(2), bias])
-    if cluster_state is not None and side_stream is not None:
+    if cluster_ahead is not None:
+        torch.cuda.current_stream().wait_event(cluster_ahead.done_event)   # join: the proxy table is complete
+    elif cluster_state is not None and side_stream is not None:
         torch.cuda.current_stream().wait_stream(side_stream)        # join: the proxy table is complete
     ops.proxy_corr_min(query_flat, table, sqn, set_begin, set_size, set_off, set_bias, feat, 1, True)
 

@@ -131,3 +131,29 @@ def test_pool_cache_across_frames(aoc):
         assert torch.equal(f1, f2)
         assert float((f1 - f3).abs().max()) < ATOL
     assert state["frames"] == 3
+
+
+def test_cluster_proxies_launched_ahead_equal_inline(aoc):
+    """hotpath.launch_cluster_proxies (k-means chain enqueued ahead on a side stream) == the inline cluster branch."""
+    syn, hot = aoc.synthetic, aoc.hotpath
+    cfg = syn.CONFIGS["tiny"]
+    clip = syn.make_clip(cfg, 6, frames=5)
+    emb = torch.from_numpy(clip["emb"]).cuda()
+    lab = torch.from_numpy(np.stack([syn.one_hot(l, cfg.n_obj) for l in clip["lab"]])).cuda()
+    mc = hot.MatchingConfig()
+    bias = torch.zeros(cfg.n_obj, device="cuda")
+    side = torch.cuda.Stream()
+    for R in (1, 3):
+        rows = syn.kmeans_init_rows(R, [int((clip["lab"][:R] == o).sum()) for o in range(cfg.n_obj)], 16)
+        init = np.zeros((cfg.n_obj, 16), np.int32)
+        for o, r in enumerate(rows):
+            if r is not None:
+                init[o, :len(r)] = r
+        init = torch.from_numpy(init).cuda()
+        ev = torch.cuda.Event()
+        ev.record()
+        ahead = hot.launch_cluster_proxies(mc, emb[:R], lab[:R], init, side, wait_event=ev)
+        f1, h1, _ = hot.proto_mask_features(mc, emb[:R], lab[:R], emb[3], lab[3], emb[4], bias, cluster_ahead=ahead)
+        f2, h2, _ = hot.proto_mask_features(mc, emb[:R], lab[:R], emb[3], lab[3], emb[4], bias, cluster_state=dict(init_rows=init))
+        torch.cuda.synchronize()
+        assert torch.equal(f1, f2) and torch.equal(h1, h2)
