@@ -150,8 +150,10 @@ class ClipWorkload:
             if t % mc.MEM_EVERY == 0:
                 ref_idx.append(t)
         self.dense_state = {"capacity_frames": rmax}      # fp16 split records of the pool, converted once per appended frame
-        self.ahead = None                                  # adaptive proxies of the NEXT frame, already enqueued on the side stream
+        self.ahead = {}                                    # frame -> adaptive proxies already enqueued on a side stream
+        self.sides = [self.side] + [torch.cuda.Stream(device=device, priority=-1) for _ in range(max(0, mc.MEM_EVERY - 1))] if overlap else []
         self.pool_event = None                             # recorded after the last change of the pool
+        self.chains = mc.MEM_EVERY                         # k-means chains enqueued ahead (bench --chains)
         self.reset()
 
     def reset(self):
@@ -187,11 +189,16 @@ def frame_step(wl, gates, acts, dense_precision="split", pipeline=True):
     ref_emb, ref_lab = wl.refs()
     t = wl.t
     if wl.side is not None and pipeline:
-        # the k-means chain of a frame only depends on the pool (which changes every MEM_EVERY frames): it was enqueued on
-        # the side stream right after the previous frame's pool update, and runs under that frame's other work
-        ahead = wl.ahead if wl.ahead is not None else hotpath.launch_cluster_proxies(wl.mc, ref_emb, ref_lab, wl.init_rows[t][0], wl.side,
-                                                                                         wait_event=wl.pool_event)
-        wl.ahead = None
+        # the k-means chain of a frame only depends on the pool (which changes every MEM_EVERY frames): the chains of all
+        # frames that will see the same pool are enqueued on side streams right after the pool update and run under the
+        # other work of the frames before them
+        if t not in wl.ahead:
+            launch_chains(wl)
+        ahead = wl.ahead.pop(t)
+        if t % wl.mc.MEM_EVERY != 0 and t + 1 < wl.T and (t + 1) not in wl.ahead:
+            # the next frame sees the same pool: its chain goes onto the side stream now, behind this frame's chain, and
+            # does not wait for anything this frame still has to do on the main stream
+            wl.ahead[t + 1] = hotpath.launch_cluster_proxies(wl.mc, ref_emb, ref_lab, wl.init_rows[t + 1][0], wl.side, wait_event=wl.pool_event)
         feat, head, _ = hotpath.proto_mask_features(wl.mc, ref_emb, ref_lab, wl.emb[t - 1], wl.lab[t - 1], wl.emb[t], wl.bias,
                                                     cluster_ahead=ahead, dense_state=wl.dense_state, dense_precision=dense_precision)
     else:
@@ -200,10 +207,24 @@ def frame_step(wl, gates, acts, dense_precision="split", pipeline=True):
                                                     dense_state=wl.dense_state, dense_precision=dense_precision)
     outs = gates(acts, head)
     wl.advance()                                           # pool append / sequence restart happen here (after the frame's outputs)
-    if wl.side is not None and pipeline:
-        ref_emb, ref_lab = wl.refs()
-        wl.ahead = hotpath.launch_cluster_proxies(wl.mc, ref_emb, ref_lab, wl.init_rows[wl.t][0], wl.side, wait_event=wl.pool_event)
+    if wl.side is not None and pipeline and wl.t not in wl.ahead:
+        launch_chains(wl)
     return feat, outs
+
+
+def launch_chains(wl):
+    """Enqueue the k-means chains of frame wl.t and of the following frames up to the next pool update (they all see the
+    pool as it is now), one side stream each."""
+    ref_emb, ref_lab = wl.refs()
+    t = wl.t
+    for k in [k for k in wl.ahead if k < t or k >= wl.T]:
+        del wl.ahead[k]
+    for i, side in enumerate(wl.sides[:wl.chains]):
+        if t + i >= wl.T:
+            break
+        wl.ahead[t + i] = hotpath.launch_cluster_proxies(wl.mc, ref_emb, ref_lab, wl.init_rows[t + i][0], side, wait_event=wl.pool_event)
+        if (t + i) % wl.mc.MEM_EVERY == 0:
+            break                                          # that frame is appended to the pool: later frames see another pool
 
 
 def _block_weights(mod):
@@ -288,6 +309,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cu-reserve", type=int, default=64,
                     help="keep the main streams off this many CUs (HIP CU mask) so the side-stream k-means chain always finds free CUs")
+    ap.add_argument("--chains", type=int, default=1, help="k-means chains (frames) enqueued ahead per sequence, at most MEM_EVERY")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="start a frame's k-means chain with the frame instead of right after the previous frame's pool update")
     ap.add_argument("--no-overlap", action="store_true", help="run the k-means branch on the main stream (no intra-frame stream overlap)")
@@ -314,6 +336,8 @@ def main():
     n_streams = max(1, args.streams)
     # sequences are sharded over ranks: rank r owns sequences r*n_streams .. (+n_streams)
     workloads = [ClipWorkload(cfg, seed=1 + rank * n_streams + s, device=dev, mc=mc, overlap=not args.no_overlap) for s in range(n_streams)]
+    for wl in workloads:
+        wl.chains = max(1, min(args.chains, mc.MEM_EVERY))
     acts = make_activations(gates, cfg.n_obj, cfg.h, cfg.w, dev, seed=7)
     def make_main_stream():
         """Main stream of one sequence.  With --cu-reserve N its workgroups are kept off N of the 256 CUs (HIP CU mask), so
@@ -352,9 +376,9 @@ def main():
         n = pool.shape[0]
         return dict(flops=2.0 * iters * n * kmax * C, bytes=float(iters) * n * C * 4 * 2 + n * 4)
 
-    timer = OpTimer(["dense_match_min", "dense_match_min_split", "split_rows", "proxy_corr_min", "kmeans_segmented", "build_proxies", "label_prep", "local_window_match",
-                     "masked_mean_pool", "cond_gate_pool", "channel_scale", "film_scale", "fg2bg_min", "resize_bilinear_hwc", "resize_bilinear_planes",
-                     "plane_mean", "film_gain", "linear", "label_mix", "label_bits", "resize_nearest_bits", "kmeans_plan"])
+    # HIP-event pairs only around the ops the roofline objects need (an event pair costs ~25 us of host time, and the host
+    # enqueues ~60 ops per frame); every kernel's duration is in the rocprofv3 summary under profiles/
+    timer = OpTimer(["dense_match_min", "dense_match_min_split", "proxy_corr_min", "kmeans_segmented", "local_window_match"])
     timer.install(dict(dense_match_min=meta_dense, dense_match_min_split=meta_dense_split, proxy_corr_min=meta_proxy, kmeans_segmented=meta_kmeans))
 
     def run_steps(n):

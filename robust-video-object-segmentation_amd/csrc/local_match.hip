@@ -8,6 +8,8 @@
 // minima in LDS with ds_min_f32.  "ring" = max(|dy|,|dx|) bucketed by the nested window radii, so
 // the nested-window minima of AEM:1036-1046 are a prefix-min over rings at the end.
 #include "aoc_common.h"
+#include <stdlib.h>
+#include <string.h>
 
 namespace {
 
@@ -167,6 +169,177 @@ __global__ __launch_bounds__(256) void local_window_kernel(const float *__restri
 }
 
 // ------------------------------------------------------------------------------------------
+// Same computation, laid out for latency: block = ONE query row x 16 columns, and the block's four waves split the
+// 2R + 1 candidate rows between them (wave w takes rows cy_beg + w, + 4, ...).  Each wave stages its candidate row
+// in a wave-private LDS image (the next row's loads are in flight in registers while the current one is
+// multiplied), so there is no workgroup barrier inside the loop, four times as many workgroups (427 instead of
+// 112 on a 61 x 107 map) and a critical path of ~7 instead of ~28 candidate rows.  The four waves' per-(pixel,
+// ring, object) minima are merged at the end.
+template <int TMAX>
+__global__ __launch_bounds__(256) void local_window_row_kernel(const float *__restrict__ query, const float *__restrict__ prev,
+                                                                const uint32_t *__restrict__ right_bits, int H, int W, int C,
+                                                                LocalRadii radii, const float *__restrict__ obj_bias, int n_obj,
+                                                                float *__restrict__ out, int transform) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int TP = (TMAX + 3) / 4 * 4, RS = 4 * TP + 4, NB4 = TP / 4;
+    const int R = radii.r[radii.n - 1];
+    const int NC = 16 + 2 * R;                          // candidates per row
+    const int NG = (NC + 15) / 16;
+    const int NCP = NG * 16;
+    const int nr = radii.n;
+    const int acc_per_wave = 16 * nr * n_obj;
+    const int lane = aoc_lane(), wave = threadIdx.x >> 6;
+    const int j = lane & 15, g = lane >> 4;
+    const int c4 = C >> 2;
+    // per wave: [NCP][RS] image, [NCP] |y|^2, [NCP] label bits; then [R+1] ring classes and the accumulators
+    const size_t wave_floats = (size_t)NCP * RS + 2 * NCP;
+    float *wimg = lds + (size_t)wave * wave_floats;
+    float *ly2 = wimg + (size_t)NCP * RS;
+    uint32_t *lbits = reinterpret_cast<uint32_t *>(ly2 + NCP);
+    int32_t *lcls = reinterpret_cast<int32_t *>(lds + 4 * wave_floats);
+    float *lacc = reinterpret_cast<float *>(lcls + 32);             // [4 waves][16][n_radii][n_obj]
+    float *my_acc = lacc + wave * acc_per_wave;
+
+    const int x0 = blockIdx.x * 16;
+    const int y = blockIdx.y;
+
+    for (int i = lane; i < acc_per_wave; i += 64) my_acc[i] = AOC_PAD_DISTANCE;      // AEM:1032 pad
+    if (threadIdx.x <= R) {
+        int c = 0;
+        while (radii.r[c] < (int)threadIdx.x) ++c;
+        lcls[threadIdx.x] = c;
+    }
+    // stream padding of this wave's image, once
+    for (int idx = lane; idx < NCP * 4 * (TP - c4); idx += 64) {
+        const int c = idx / (4 * (TP - c4)), rem = idx - c * 4 * (TP - c4);
+        wimg[(size_t)c * RS + (rem / (TP - c4)) * TP + c4 + rem % (TP - c4)] = 0.0f;
+    }
+
+    float a[TMAX], q2r[4];
+    {   // A fragment: the 16 query pixels of row y
+        const int qx = min(x0 + j, W - 1);
+        const float *src = query + ((size_t)y * W + qx) * C + g;
+        float part = 0.0f;
+#pragma unroll
+        for (int t = 0; t < TMAX; ++t) {
+            a[t] = (t < c4) ? src[4 * t] : 0.0f;
+            part += a[t] * a[t];
+        }
+        part += __shfl_xor(part, 16);
+        part += __shfl_xor(part, 32);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) q2r[r] = __shfl(part, g * 4 + r);
+    }
+    __syncthreads();                                    // lcls
+
+    constexpr int PIECES = (48 * TMAX + 63) / 64;      // float4 pieces per lane per candidate row (up to 48 candidates: R <= 16)
+    float4 pv[PIECES];
+    uint32_t pbits = 0u;
+    auto issue_row = [&](int cy) {
+#pragma unroll
+        for (int i = 0; i < PIECES; ++i) {
+            const int idx = i * 64 + lane;
+            const int c = idx / c4, t = idx - c * c4;
+            const int cx = x0 - R + c;
+            const bool ok = idx < NCP * c4 && c < NC && cx >= 0 && cx < W;
+            pv[i] = ok ? reinterpret_cast<const float4 *>(prev + ((size_t)cy * W + cx) * C)[t] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        const int cx = x0 - R + lane;
+        pbits = (lane < NC && cx >= 0 && cx < W) ? (right_bits[(size_t)cy * W + cx] & ~AOC_ROW_KEPT_BIT) : 0u;   // AEM:1023-1028 (pad 0)
+    };
+    auto write_row = [&]() {
+#pragma unroll
+        for (int i = 0; i < PIECES; ++i) {
+            const int idx = i * 64 + lane;
+            if (idx < NCP * c4) {
+                const int c = idx / c4, t = idx - c * c4;
+                float *d = wimg + (size_t)c * RS + t;
+                d[0] = pv[i].x; d[TP] = pv[i].y; d[2 * TP] = pv[i].z; d[3 * TP] = pv[i].w;
+            }
+        }
+        if (lane < NCP) lbits[lane] = pbits;
+    };
+
+    const int cy_beg = max(0, y - R), cy_end = min(H - 1, y + R);
+    int cy = cy_beg + wave;
+    if (cy <= cy_end) issue_row(cy);
+    for (; cy <= cy_end; cy += 4) {
+        write_row();
+        if (cy + 4 <= cy_end) issue_row(cy + 4);       // in flight under this row's arithmetic
+        // |y|^2 of the staged candidates (lane = candidate; four independent partial sums)
+        if (lane < NCP) {
+            const float *r = wimg + (size_t)lane * RS;
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+            for (int u = 0; u < NB4; ++u) {
+                const float4 v0 = *reinterpret_cast<const float4 *>(r + 4 * u);
+                const float4 v1 = *reinterpret_cast<const float4 *>(r + TP + 4 * u);
+                const float4 v2 = *reinterpret_cast<const float4 *>(r + 2 * TP + 4 * u);
+                const float4 v3 = *reinterpret_cast<const float4 *>(r + 3 * TP + 4 * u);
+                s0 += v0.x * v0.x + v0.y * v0.y + v0.z * v0.z + v0.w * v0.w;
+                s1 += v1.x * v1.x + v1.y * v1.y + v1.z * v1.z + v1.w * v1.w;
+                s2 += v2.x * v2.x + v2.y * v2.y + v2.z * v2.z + v2.w * v2.w;
+                s3 += v3.x * v3.x + v3.y * v3.y + v3.z * v3.z + v3.w * v3.w;
+            }
+            ly2[lane] = (s0 + s1) + (s2 + s3);
+        }
+        const int dy = cy - y;
+        const int ady = dy < 0 ? -dy : dy;
+        for (int gi = 0; gi < NG; ++gi) {
+            const float *bstream = wimg + (size_t)(gi * 16 + j) * RS + g * TP;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int u = 0; u < NB4; ++u) {
+                const float4 b = *reinterpret_cast<const float4 *>(bstream + 4 * u);
+                const float bb[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (4 * u + e < TMAX) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[4 * u + e < TMAX ? 4 * u + e : 0], bb[e], acc, 0, 0, 0);
+            }
+            const int c = gi * 16 + j;
+            const int cx = x0 - R + c;
+            const uint32_t bits = lbits[c];
+            const float y2 = ly2[c];
+            if (bits != 0u) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int qi = g * 4 + r;
+                    const int qx = x0 + qi;
+                    int dx = cx - qx;
+                    dx = dx < 0 ? -dx : dx;
+                    if (dx <= R && qx < W) {
+                        const float d = (q2r[r] + y2) - 2.0f * acc[r];   // AEM:961
+                        const int cls = lcls[max(ady, dx)];
+                        uint32_t b = bits;
+                        while (b) {                                     // AEM:1032 where(mask, d, pad)
+                            const int o = __builtin_ctz(b);
+                            b &= b - 1;
+                            if (o < n_obj) lds_fmin(&my_acc[(qi * nr + cls) * n_obj + o], d);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // merge the four waves, prefix-min over rings -> nested windows; channel order [max, r_0, r_1, ...] (AEM:1034-1046)
+    for (int idx = threadIdx.x; idx < 16 * n_obj; idx += blockDim.x) {
+        const int qi = idx / n_obj, o = idx - qi * n_obj;
+        const int qx = x0 + qi;
+        if (qx >= W) continue;
+        const float bias = obj_bias ? obj_bias[o] : 0.0f;
+        float run = INFINITY;
+        for (int cls = 0; cls < nr; ++cls) {
+            const int e = (qi * nr + cls) * n_obj + o;
+            const float v = fminf(fminf(lacc[e], lacc[acc_per_wave + e]), fminf(lacc[2 * acc_per_wave + e], lacc[3 * acc_per_wave + e]));
+            run = fminf(run, v);
+            const int ch = (cls == nr - 1) ? 0 : cls + 1;
+            out[(((size_t)o * nr + ch) * H + y) * W + qx] = transform ? aoc_proto_transform(run, bias) : run;   // AEM:1049
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Resize helpers (torch semantics, fp32).
 __device__ __forceinline__ void bilinear_src(int dst, float scale, int in_size, int &i0, int &i1, float &l0, float &l1) {
     const float real = scale * (float)dst;                 // align_corners=True: area_pixel_compute_source_index
@@ -250,8 +423,23 @@ int aoc_local_window_match(const float *query, const float *prev, const uint32_t
     const size_t lds = (size_t)NG * 16 * RS * sizeof(float) + (size_t)NG * 16 * 8 + 32 * sizeof(int32_t) +
                        (size_t)4 * 16 * n_radii * n_obj * sizeof(float);
     if (lds > 150 * 1024) return AOC_ERR_UNSUPPORTED;
-    const dim3 grid((W + 15) / 16, (H + 3) / 4);
     hipStream_t st = aoc_hip_stream(stream);
+    // row-per-block layout (wave-private candidate images) whenever it fits: C == 100 / 128 tiles, R <= 16
+    {
+        const int TPc = (C == 100) ? 28 : 32, RSc = 4 * TPc + 4;
+        const size_t lds_row = ((size_t)4 * ((size_t)NG * 16 * RSc + 2 * NG * 16) + 32 + (size_t)4 * 16 * n_radii * n_obj) * sizeof(float);
+        static const bool use_row = !(getenv("AOC_LOCAL_KERNEL") && strcmp(getenv("AOC_LOCAL_KERNEL"), "block") == 0);   // developer switch
+        if (use_row && (C == 100 || C == 128) && R <= 16 && lds_row <= 150 * 1024) {
+            const dim3 rgrid((W + 15) / 16, H);
+            if (C == 100)
+                hipLaunchKernelGGL(local_window_row_kernel<25>, rgrid, dim3(256), lds_row, st, query, prev, right_bits, H, W, C, radii, obj_bias, n_obj, out, transform);
+            else
+                hipLaunchKernelGGL(local_window_row_kernel<32>, rgrid, dim3(256), lds_row, st, query, prev, right_bits, H, W, C, radii, obj_bias, n_obj, out, transform);
+            AOC_RETURN_IF_LAUNCH_FAILED();
+            return AOC_OK;
+        }
+    }
+    const dim3 grid((W + 15) / 16, (H + 3) / 4);
     if (C == 100)
         hipLaunchKernelGGL(local_window_kernel<25>, grid, dim3(256), lds, st, query, prev, right_bits, H, W, C, radii, obj_bias, n_obj, out, transform);
     else
