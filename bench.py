@@ -151,7 +151,6 @@ class ClipWorkload:
                 ref_idx.append(t)
         self.dense_state = {"capacity_frames": rmax}      # fp16 split records of the pool, converted once per appended frame
         self.ahead = {}                                    # frame -> adaptive proxies already enqueued on a side stream
-        self.sides = [self.side] + [torch.cuda.Stream(device=device, priority=-1) for _ in range(max(0, mc.MEM_EVERY - 1))] if overlap else []
         self.pool_event = None                             # recorded after the last change of the pool
         self.chains = mc.MEM_EVERY                         # k-means chains enqueued ahead (bench --chains)
         self.reset()
@@ -214,17 +213,20 @@ def frame_step(wl, gates, acts, dense_precision="split", pipeline=True):
 
 def launch_chains(wl):
     """Enqueue the k-means chains of frame wl.t and of the following frames up to the next pool update (they all see the
-    pool as it is now), one side stream each."""
+    pool as it is now) on the side stream: the first frame alone (it is needed first), the others batched into one chain."""
     ref_emb, ref_lab = wl.refs()
     t = wl.t
     for k in [k for k in wl.ahead if k < t or k >= wl.T]:
         del wl.ahead[k]
-    for i, side in enumerate(wl.sides[:wl.chains]):
-        if t + i >= wl.T:
-            break
-        wl.ahead[t + i] = hotpath.launch_cluster_proxies(wl.mc, ref_emb, ref_lab, wl.init_rows[t + i][0], side, wait_event=wl.pool_event)
-        if (t + i) % wl.mc.MEM_EVERY == 0:
-            break                                          # that frame is appended to the pool: later frames see another pool
+    frames = [t]
+    while frames[-1] % wl.mc.MEM_EVERY != 0 and frames[-1] + 1 < wl.T and len(frames) < wl.chains:
+        frames.append(frames[-1] + 1)                      # a frame with t % MEM_EVERY == 0 is appended: later ones see another pool
+    wl.ahead[t] = hotpath.launch_cluster_proxies(wl.mc, ref_emb, ref_lab, wl.init_rows[t][0], wl.side, wait_event=wl.pool_event)
+    if len(frames) > 1:
+        rest = hotpath.launch_cluster_proxies_batch(wl.mc, ref_emb, ref_lab, [wl.init_rows[f][0] for f in frames[1:]], wl.side,
+                                                    wait_event=wl.pool_event)
+        for f, a in zip(frames[1:], rest):
+            wl.ahead[f] = a
 
 
 def _block_weights(mod):
@@ -309,7 +311,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cu-reserve", type=int, default=64,
                     help="keep the main streams off this many CUs (HIP CU mask) so the side-stream k-means chain always finds free CUs")
-    ap.add_argument("--chains", type=int, default=1, help="k-means chains (frames) enqueued ahead per sequence, at most MEM_EVERY")
+    ap.add_argument("--chains", type=int, default=3,
+                    help="frames whose k-means is enqueued right after a pool update (1 = only the next frame; the others are batched into one chain)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="start a frame's k-means chain with the frame instead of right after the previous frame's pool update")
     ap.add_argument("--no-overlap", action="store_true", help="run the k-means branch on the main stream (no intra-frame stream overlap)")

@@ -77,6 +77,15 @@ int aoc_label_bits(const float *labels, int64_t n, int n_obj, uint32_t *right_bi
 int aoc_kmeans_plan(const int32_t *counts, int n_seg, int cluster_num, int32_t *seg_k,
                     aoc_stream_t stream);
 
+/* Segment lists replicated n_rep times: the k-means of several frames that see the SAME pool (the reference re-clusters
+ * the whole pool every frame with fresh initial rows, AEM:268-276; the pool only changes every MEM_EVERY frames,
+ * eval_manager_mm.py:356-361) can then advance together in one aoc_kmeans_segmented_ex call with n_rep * n_seg segments.
+ * rows_out [n_rep * rows_capacity], seg_offsets_out [n_rep * n_seg + 1], seg_k_out [n_rep * n_seg]; replica f's segment s
+ * is rows_out[seg_offsets_out[f * n_seg + s] ...).  Device-side (the segment sizes never reach the host). */
+int aoc_kmeans_replicate(const int32_t *rows, const int32_t *seg_offsets, const int32_t *seg_k, int n_seg, int n_rep,
+                         int64_t rows_capacity, int32_t *rows_out, int32_t *seg_offsets_out, int32_t *seg_k_out,
+                         aoc_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Segmented Lloyd k-means, bit-identical to scipy.cluster.vq.kmeans2(X, K, minit='matrix',
  * iter=iters) as called at AEM:276 (one "segment" = one object's rows; all segments advance in
@@ -85,7 +94,8 @@ int aoc_kmeans_plan(const int32_t *counts, int n_seg, int cluster_num, int32_t *
  * (ties -> lowest index), per-cluster sums in row order, division by (float)count, empty cluster
  * keeps its centroid.
  *
- *  pool         [*, C]        embeddings the row ids refer to
+ *  pool         [*, C]        embeddings the row ids refer to (pool_rows of them in the _ex form: a segment lists DISTINCT
+ *                             pool rows, so no segment is longer than pool_rows -- the per-segment grids rely on it)
  *  rows         packed row ids (aoc_label_prep's obj_rows); segment s = rows[seg_offsets[s] .. seg_offsets[s+1])
  *  seg_offsets  [n_seg + 1]   device
  *  seg_k        [n_seg]       device; 0 = segment skipped (reference: centroid None, AEM:271-273)

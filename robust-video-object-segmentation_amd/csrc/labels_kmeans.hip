@@ -835,6 +835,20 @@ __global__ __launch_bounds__(256, 3) void km_assign_mfma_kernel(const float *__r
     }
 }
 
+// Segment lists replicated n_rep times (k-means of several frames that see the same pool, advanced together in the same
+// launches): rows_out[f * total + i] = rows[i], seg_off_out[f * n_seg + s] = f * total + seg_off[s], total = seg_off[n_seg].
+__global__ __launch_bounds__(256) void km_replicate_kernel(const int32_t *__restrict__ rows, const int32_t *__restrict__ seg_off,
+                                                            const int32_t *__restrict__ seg_k, int n_seg, int n_rep, int64_t capacity,
+                                                            int32_t *__restrict__ rows_out, int32_t *__restrict__ seg_off_out,
+                                                            int32_t *__restrict__ seg_k_out) {
+    const int64_t total = seg_off[n_seg];
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int f = blockIdx.y;
+    if (i < total && i < capacity) rows_out[f * total + i] = rows[i];
+    if (i <= n_seg && (i < n_seg || f == n_rep - 1)) seg_off_out[f * n_seg + i] = (int32_t)(f * total + seg_off[i]);
+    if (i < n_seg) seg_k_out[f * n_seg + i] = seg_k[i];
+}
+
 // rank + histogram from EXISTING labels (proxy construction after the last iteration)
 __global__ __launch_bounds__(256) void km_rank_only_kernel(const int32_t *__restrict__ seg_off, const int32_t *__restrict__ seg_k,
                                                             const int32_t *__restrict__ labels, int kmax, uint16_t *__restrict__ rank16,
@@ -1714,11 +1728,11 @@ inline size_t ks_workspace_bytes(int64_t cap, int n_seg, int kmax) {
            3 * aoc_align_up(nch * AOC_MAX_CHANNELS / 2 * 4, 256) + aoc_align_up(nch * AOC_MAX_CHANNELS / 2, 256) +
            aoc_align_up((size_t)n_seg * kmax * (AOC_MAX_CHANNELS / 2) * 4, 256);
 }
-inline KsWorkspace ks_carve(void *workspace, int64_t cap, int n_seg, int kmax) {
+inline KsWorkspace ks_carve(void *workspace, int64_t cap, int n_seg, int kmax, int64_t seg_bound = 0) {
     KsWorkspace w;
     char *p = static_cast<char *>(workspace);
     const size_t nb = (size_t)(cap + 255) / 256 + 1;
-    w.nb_max = (int)nb;
+    w.nb_max = (int)((seg_bound > 0 && seg_bound < cap) ? (size_t)(seg_bound + 255) / 256 + 1 : nb);   // stride of the per-block histograms
     w.rownorm = reinterpret_cast<float *>(p); p += aoc_align_up((size_t)cap * 4, 256);
     w.rank16 = reinterpret_cast<uint16_t *>(p); p += aoc_align_up((size_t)cap * 2, 256);
     w.hist = reinterpret_cast<int32_t *>(p); p += aoc_align_up((size_t)n_seg * nb * kmax * 4, 256);
@@ -1849,7 +1863,10 @@ int aoc_kmeans_segmented_ex(const float *pool, int64_t pool_rows, int C, const i
     if (workspace_bytes < aoc_kmeans_workspace_bytes(rows_capacity, n_seg, kmax, C)) return AOC_ERR_WORKSPACE;
     hipStream_t st = aoc_hip_stream(stream);
     float *cnorm = static_cast<float *>(workspace);
-    KsWorkspace ws = ks_carve(static_cast<char *>(workspace) + aoc_align_up((size_t)n_seg * kmax * sizeof(float), 256), rows_capacity, n_seg, kmax);
+    // a segment lists distinct pool rows, so no segment is longer than the pool: bounds the per-segment grids
+    const int64_t seg_bound = (pool_rows > 0 && pool_rows < rows_capacity) ? pool_rows : rows_capacity;
+    KsWorkspace ws = ks_carve(static_cast<char *>(workspace) + aoc_align_up((size_t)n_seg * kmax * sizeof(float), 256), rows_capacity, n_seg, kmax,
+                              seg_bound);
     float *rownorm = ws.rownorm;
     // scan-sum pipeline: rows addressed by 32-bit byte offsets through a bounds-checked buffer descriptor
     const bool fast = (C % 4) == 0 && C <= 128 && pool_rows > 0 && (uint64_t)pool_rows * C * 4 < 0xFFFFFF00ull;
@@ -1858,7 +1875,7 @@ int aoc_kmeans_segmented_ex(const float *pool, int64_t pool_rows, int C, const i
 
     hipLaunchKernelGGL(km_init_kernel, dim3(kmax, n_seg), dim3(64), 0, st, pool, C, rows, seg_offsets, seg_k, init_rows, kmax,
                        centroids, cnorm, cluster_counts);
-    const dim3 agrid((unsigned)((rows_capacity + 255) / 256), (unsigned)n_seg);
+    const dim3 agrid((unsigned)((seg_bound + 255) / 256), (unsigned)n_seg);
     const size_t lds = ((size_t)kmax * C + kmax) * sizeof(float);
     const size_t lds_fast = lds + (size_t)4 * kmax * sizeof(int32_t);
     const int nf = (C + 63) / 64;
@@ -1867,7 +1884,7 @@ int aoc_kmeans_segmented_ex(const float *pool, int64_t pool_rows, int C, const i
         if (fast && !first && mfma_assign && C == 100 && kmax <= 64) {
             const int kt = (kmax + 15) / 16;
             const size_t alds = ((size_t)kt * 16 * 116 + kt * 16 + (size_t)4 * 16 * 116) * sizeof(float) + (size_t)4 * kmax * sizeof(int32_t);
-            const unsigned pgrid = (unsigned)std::min<int64_t>((rows_capacity + 255) / 256 + n_seg, 768);    // persistent: 3 blocks per CU
+            const unsigned pgrid = (unsigned)std::min<int64_t>(std::min<int64_t>(rows_capacity, seg_bound * n_seg) / 256 + n_seg, 768);    // persistent: 3 blocks per CU
 #define AOC_KA(KT) hipLaunchKernelGGL((km_assign_mfma_kernel<25, KT>), dim3(pgrid), dim3(256), alds, st, pool, C, rows, seg_offsets, seg_k, n_seg, centroids, \
                                       kmax, labels, ws.rank16, ws.hist, ws.nb_max, rownorm)
             if (kt == 1) AOC_KA(1); else if (kt == 2) AOC_KA(2); else if (kt == 3) AOC_KA(3); else AOC_KA(4);
@@ -1903,6 +1920,17 @@ int aoc_kmeans_segmented_ex(const float *pool, int64_t pool_rows, int C, const i
     return AOC_OK;
 }
 
+int aoc_kmeans_replicate(const int32_t *rows, const int32_t *seg_offsets, const int32_t *seg_k, int n_seg, int n_rep, int64_t rows_capacity,
+                         int32_t *rows_out, int32_t *seg_offsets_out, int32_t *seg_k_out, aoc_stream_t stream) {
+    if (!rows || !seg_offsets || !seg_k || !rows_out || !seg_offsets_out || !seg_k_out) return AOC_ERR_INVALID_ARG;
+    if (n_seg < 1 || n_rep < 1 || rows_capacity < 1 || (int64_t)n_rep * rows_capacity >= (1ll << 31)) return AOC_ERR_INVALID_ARG;
+    const int64_t span = rows_capacity > n_seg + 1 ? rows_capacity : n_seg + 1;
+    hipLaunchKernelGGL(km_replicate_kernel, dim3((unsigned)((span + 255) / 256), (unsigned)n_rep), dim3(256), 0, aoc_hip_stream(stream), rows, seg_offsets,
+                       seg_k, n_seg, n_rep, rows_capacity, rows_out, seg_offsets_out, seg_k_out);
+    AOC_RETURN_IF_LAUNCH_FAILED();
+    return AOC_OK;
+}
+
 size_t aoc_build_proxies_workspace_bytes(int64_t rows_capacity, int n_seg, int kmax) {
     if (rows_capacity < 0 || n_seg < 1 || kmax < 1) return 0;
     return ks_workspace_bytes(rows_capacity, n_seg, kmax);
@@ -1920,8 +1948,9 @@ int aoc_build_proxies(const float *pool, int64_t pool_rows, int C, const int32_t
     const bool fast = (C % 4) == 0 && C <= 128 && pool_rows > 0 && rows_capacity > 0 && (uint64_t)pool_rows * C * 4 < 0xFFFFFF00ull && workspace &&
                       workspace_bytes >= aoc_build_proxies_workspace_bytes(rows_capacity, n_seg, kmax);
     if (fast) {
-        KsWorkspace ws = ks_carve(workspace, rows_capacity, n_seg, kmax);
-        const dim3 agrid((unsigned)((rows_capacity + 255) / 256), (unsigned)n_seg);
+        const int64_t seg_bound = (pool_rows < rows_capacity) ? pool_rows : rows_capacity;
+        KsWorkspace ws = ks_carve(workspace, rows_capacity, n_seg, kmax, seg_bound);
+        const dim3 agrid((unsigned)((seg_bound + 255) / 256), (unsigned)n_seg);
         hipLaunchKernelGGL(km_rank_only_kernel, agrid, dim3(256), 0, st, seg_offsets, seg_k, labels, kmax, ws.rank16, ws.hist, ws.nb_max);
         hipLaunchKernelGGL(km_blockscan_kernel, dim3(n_seg), dim3(1024), 0, st, seg_offsets, seg_k, ws.hist, ws.blockoff, ws.nb_max, kmax, ws.counts, ws.cbase,
                            ws.cchunk, ws.owner_cluster, ws.owner_local, ws.nch_cap);

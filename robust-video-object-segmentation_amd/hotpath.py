@@ -93,6 +93,51 @@ def launch_cluster_proxies(cfg, ref_emb, ref_labels, init_rows_dev, side_stream,
     return out
 
 
+def launch_cluster_proxies_batch(cfg, ref_emb, ref_labels, init_rows_list, side_stream, wait_event=None):
+    """launch_cluster_proxies for several frames that see the same pool: their k-means chains (same rows, different
+    initial rows) advance together as n_frames * O segments of ONE chain, so each of the ~160 latency-bound launches does
+    the work of all frames.  Returns one ClusterProxiesAhead per entry of init_rows_list."""
+    F = len(init_rows_list)
+    if F == 1:
+        return [launch_cluster_proxies(cfg, ref_emb, ref_labels, init_rows_list[0], side_stream, wait_event)]
+    R, h, w, C = ref_emb.shape
+    O = ref_labels.shape[-1]
+    hw = h * w
+    kmax = cfg.CLUSTER_NUM
+    dev = ref_emb.device
+    outs = []
+    with torch.cuda.stream(side_stream):
+        if wait_event is not None:
+            side_stream.wait_event(wait_event)
+        pool = ref_emb.reshape(R * hw, C)
+        prep = ops.label_prep(ref_labels.reshape(R * hw, O))
+        prep_event = torch.cuda.Event()
+        prep_event.record(side_stream)
+        seg_k = ops.kmeans_plan(prep.counts, O, kmax)
+        cap = prep.obj_rows.numel()
+        rows_f, off_f, k_f = ops.kmeans_replicate(prep.obj_rows, prep.obj_offsets, seg_k, F, rows_capacity=cap)
+        init = torch.cat([r.reshape(O, kmax) for r in init_rows_list], dim=0)
+        cen, lab, _ = ops.kmeans_segmented(pool, rows_f, off_f, k_f, init, kmax, KMEANS_ITERS, rows_capacity=F * cap)
+        proxies, psq = ops.build_proxies(pool, prep.fg_rows, off_f, k_f, lab, cen)          # [F*O, 2, K, C]
+        done = None
+        for f in range(F):
+            out = ClusterProxiesAhead()
+            out.R = R
+            out.prep, out.prep_event = prep, prep_event
+            out.table = torch.empty(O * 2 * kmax + O, C, dtype=torch.float32, device=dev)
+            out.sqn = torch.empty(O * 2 * kmax + O, dtype=torch.float32, device=dev)
+            out.table[:O * 2 * kmax].copy_(proxies[f * O:(f + 1) * O].reshape(-1, C))
+            out.sqn[:O * 2 * kmax].copy_(psq[f * O:(f + 1) * O].reshape(-1))
+            out.aux = dict(prep=prep, centroids=cen[f * O:(f + 1) * O], proxies=proxies[f * O:(f + 1) * O], proxy_sqnorm=psq[f * O:(f + 1) * O],
+                           seg_k=seg_k, labels=None)
+            outs.append(out)
+        done = torch.cuda.Event()
+        done.record(side_stream)
+        for out in outs:
+            out.done_event = done
+    return outs
+
+
 def proto_mask_features(cfg, ref_emb, ref_labels, prev_emb, prev_labels, cur_emb, dis_bias, init_rows=None,
                         cluster_state=None, side_stream=None, dense_state=None, dense_precision=None, cluster_ahead=None):
     """All matching branches of one frame -> (features [O, 24, h, w], attention_head [O, 4C], aux).

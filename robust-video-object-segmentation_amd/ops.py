@@ -109,6 +109,20 @@ def kmeans_segmented(pool, rows, seg_offsets, seg_k, init_rows, kmax, iters=20, 
     return centroids, labels, ccounts
 
 
+def kmeans_replicate(rows, seg_offsets, seg_k, n_rep, rows_capacity=None):
+    """Segment lists replicated n_rep times (aoc_kmeans_replicate) -> (rows [n_rep*cap], seg_offsets [n_rep*S+1], seg_k [n_rep*S])."""
+    _need_gpu(rows, seg_offsets, seg_k)
+    n_seg = seg_k.numel()
+    cap = int(rows.numel() if rows_capacity is None else rows_capacity)
+    dev = rows.device
+    rows_out = torch.empty(n_rep * cap, dtype=torch.int32, device=dev)
+    off_out = torch.empty(n_rep * n_seg + 1, dtype=torch.int32, device=dev)
+    k_out = torch.empty(n_rep * n_seg, dtype=torch.int32, device=dev)
+    _lib.check(_lib.lib().aoc_kmeans_replicate(_p(rows), _p(seg_offsets), _p(seg_k), n_seg, int(n_rep), cap, _p(rows_out), _p(off_out), _p(k_out),
+                                               _stream()), "aoc_kmeans_replicate")
+    return rows_out, off_out, k_out
+
+
 def build_proxies(pool, fg_rows, seg_offsets, seg_k, labels, centroids):
     """AEM:280-282 -> (proxies [S,2,kmax,C], proxy_sqnorm [S,2,kmax]); +inf norm = absent proxy."""
     pool = _f32c(pool)

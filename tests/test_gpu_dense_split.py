@@ -157,3 +157,31 @@ def test_cluster_proxies_launched_ahead_equal_inline(aoc):
         f2, h2, _ = hot.proto_mask_features(mc, emb[:R], lab[:R], emb[3], lab[3], emb[4], bias, cluster_state=dict(init_rows=init))
         torch.cuda.synchronize()
         assert torch.equal(f1, f2) and torch.equal(h1, h2)
+
+
+def test_batched_cluster_chains_equal_single_chains(aoc):
+    """launch_cluster_proxies_batch (several frames' k-means advanced as one chain over replicated segments) produces,
+    frame by frame, exactly the proxy tables of separate chains."""
+    syn, hot = aoc.synthetic, aoc.hotpath
+    cfg = syn.CONFIGS["tiny"]
+    clip = syn.make_clip(cfg, 8, frames=4)
+    emb = torch.from_numpy(clip["emb"]).cuda()
+    lab = torch.from_numpy(np.stack([syn.one_hot(l, cfg.n_obj) for l in clip["lab"]])).cuda()
+    mc = hot.MatchingConfig()
+    side = torch.cuda.Stream()
+    R = 2
+    inits = []
+    for f in range(3):
+        rows = syn.kmeans_init_rows(100 + f, [int((clip["lab"][:R] == o).sum()) for o in range(cfg.n_obj)], 16)
+        init = np.zeros((cfg.n_obj, 16), np.int32)
+        for o, r in enumerate(rows):
+            if r is not None:
+                init[o, :len(r)] = r
+        inits.append(torch.from_numpy(init).cuda())
+    batch = hot.launch_cluster_proxies_batch(mc, emb[:R], lab[:R], inits, side)
+    singles = [hot.launch_cluster_proxies(mc, emb[:R], lab[:R], i, side) for i in inits]
+    torch.cuda.synchronize()
+    n = cfg.n_obj * 2 * 16
+    for b, s in zip(batch, singles):
+        assert torch.equal(b.table[:n], s.table[:n])
+        assert torch.equal(b.sqn[:n], s.sqn[:n])
