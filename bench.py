@@ -467,6 +467,11 @@ def main():
                                      "ALGORITHMIC fp32 flops against the dense fp16 peak, pipe_frac the executed ones; avg_launch_ms = hipEvents "
                                      "recorded by the library immediately around the kernel while the other sequence's stream shares the GPU",
                                 op_avg_ms=k.get("op_avg_ms"), traffic_source=None)
+                if args.cu_reserve > 0:
+                    # the kernel is launched on a stream whose CU mask leaves cu_reserve CUs to the k-means chains
+                    cus = 256 - args.cu_reserve
+                    roofline["cus_available_to_kernel"] = cus
+                    roofline["pipe_frac_of_available_cus"] = round(executed / (PEAK_F16_MFMA_TFLOPS * cus / 256.0), 4)
                 pmc_file = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_dense_split.json")
                 if os.path.exists(pmc_file):
                     # PMC counters cannot be read from inside the run: separate rocprofv3 --pmc passes of this command, committed
