@@ -307,6 +307,23 @@ int aoc_label_mix(const float *labels, const float *rows, int64_t n, int n_obj, 
 /* Global average pool of planes [planes, hw] -> [planes]  (CLB:68). */
 int aoc_plane_mean(const float *x, int64_t planes, int64_t hw, float *out, aoc_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Eval-loop memory policy (the caller of the matching path).
+ *
+ * aoc_confident_labels: the per-pixel decision of one frame, eval_manager_mm.py:253-265,300-326,339-346,357-361 with
+ *   shannon_entropy.py:10-13.   probs [n_ch, n] = the (augmentation-averaged) class probabilities;
+ *   exist_bits: bit c = label c has appeared in a ground-truth map so far (other channels are zeroed);
+ *   join_label [n] or NULL: ground truth that introduces new objects (0 = keep the prediction, < 0 = unsure);
+ *   labels_out [n] = argmax (first maximum) with the join override; confident_out [n] (may be NULL) = the same label or
+ *   125 where the entropy -sum p log(p + 1e-6) over the seen channels exceeds unc_ratio; entropy_out [n] (may be NULL).
+ * aoc_label_onehot_nearest: aocnet.py:128-133,151: nearest-neighbour resize of an int label map [H, W] to [h, w] and
+ *   one-hot over n_obj ids -> float [h, w, n_obj] (label 125 or any id >= n_obj matches nothing: an all-zero row). */
+int aoc_confident_labels(const float *probs, int n_ch, int64_t n, uint32_t exist_bits, const int32_t *join_label,
+                         float unc_ratio, int32_t *labels_out, int32_t *confident_out, float *entropy_out,
+                         aoc_stream_t stream);
+int aoc_label_onehot_nearest(const int32_t *label, int H, int W, int h, int w, int n_obj, float *onehot_hwc,
+                             aoc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -417,3 +417,31 @@ def plane_mean(x):
     out = torch.empty(x.shape[0], x.shape[1], dtype=torch.float32, device=x.device)
     _lib.check(_lib.lib().aoc_plane_mean(_p(x), planes, hw, _p(out), _stream()), "aoc_plane_mean")
     return out
+
+
+# ------------------------------------------------------------------------------------------ eval-loop memory policy
+def confident_labels(probs_flat, exist_bits, join_label=None, unc_ratio=1.0):
+    """aoc_confident_labels: probs [n_ch, n] -> (labels [n], confident [n] with 125 = uncertain, entropy [n])."""
+    probs_flat = _f32c(probs_flat)
+    _need_gpu(probs_flat, join_label)
+    n_ch, n = probs_flat.shape
+    dev = probs_flat.device
+    labels = torch.empty(n, dtype=torch.int32, device=dev)
+    confident = torch.empty(n, dtype=torch.int32, device=dev)
+    entropy = torch.empty(n, dtype=torch.float32, device=dev)
+    if join_label is not None:
+        join_label = join_label.to(torch.int32).contiguous().reshape(-1)
+        assert join_label.numel() == n
+    _lib.check(_lib.lib().aoc_confident_labels(_p(probs_flat), n_ch, n, int(exist_bits) & 0xFFFFFFFF, _p(join_label), float(unc_ratio), _p(labels),
+                                               _p(confident), _p(entropy), _stream()), "aoc_confident_labels")
+    return labels, confident, entropy
+
+
+def label_onehot_nearest(label_hw, h, w, n_obj):
+    """aoc_label_onehot_nearest: int label map [H, W] -> float one-hot [h, w, n_obj] at matching resolution."""
+    _need_gpu(label_hw)
+    label_hw = label_hw.to(torch.int32).contiguous()
+    H, W = label_hw.shape
+    out = torch.empty(h, w, n_obj, dtype=torch.float32, device=label_hw.device)
+    _lib.check(_lib.lib().aoc_label_onehot_nearest(_p(label_hw), H, W, int(h), int(w), int(n_obj), _p(out), _stream()), "aoc_label_onehot_nearest")
+    return out

@@ -1,0 +1,109 @@
+"""Eval-loop memory policy on the GPU against its CPU restatement (oracle/eval_loop.py)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def aoc():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    import aoc_amd
+    aoc_amd._lib.lib()
+    return aoc_amd
+
+
+def _probs(rng, n_ch, H, W, sharp=3.0):
+    logits = torch.from_numpy(rng.randn(n_ch, H, W).astype(np.float32)) * sharp
+    return torch.softmax(logits, dim=0)
+
+
+@pytest.mark.parametrize("n_ch,seen,with_join", [(5, [0, 1, 2, 3, 4], False), (6, [0, 2, 3], False), (4, [0, 1], True), (11, list(range(8)), True)])
+def test_confident_labels_vs_oracle(aoc, n_ch, seen, with_join):
+    from oracle import eval_loop as oe
+    rng = np.random.RandomState(n_ch)
+    H, W = 37, 53
+    probs = _probs(rng, n_ch, H, W)
+    probs[:, 0, :5] = 1.0 / n_ch                      # exact ties: first maximum wins
+    probs[:, 1, :5] = 0.0                             # all-zero pixel
+    join = None
+    if with_join:
+        j = np.zeros((H, W), np.int64)
+        j[5:12, 7:20] = n_ch - 1                      # a new object appears
+        j[20:24, 30:40] = -1                          # "unsure" region of the annotation
+        join = torch.from_numpy(j)
+    bits = sum(1 << s for s in seen)
+    for unc in (0.3, 1.0):
+        lab, conf, ent = aoc.ops.confident_labels(probs.reshape(n_ch, -1).cuda(), bits, None if join is None else join.cuda(), unc)
+        wl, wc, wu = oe.frame_decision(probs[None], seen, join, unc)
+        assert np.array_equal(lab.cpu().numpy().reshape(H, W), wl.numpy())
+        np.testing.assert_allclose(ent.cpu().numpy().reshape(H, W), wu.numpy(), rtol=0, atol=2e-6)
+        # 125 marks can only differ where the entropy sits within rounding of the threshold
+        differ = conf.cpu().numpy().reshape(H, W) != wc.numpy()
+        assert not differ.any() or float(np.abs(wu.numpy()[differ] - unc).max()) < 2e-6
+
+
+@pytest.mark.parametrize("H,W,h,w,n_obj", [(480, 854, 121, 214, 4), (97, 131, 25, 33, 7), (33, 33, 33, 33, 3)])
+def test_label_onehot_nearest_vs_oracle(aoc, H, W, h, w, n_obj):
+    from oracle import eval_loop as oe
+    rng = np.random.RandomState(H)
+    lab = torch.from_numpy(rng.randint(0, n_obj, (H, W)).astype(np.int32))
+    lab[rng.rand(H, W) < 0.05] = 125                  # uncertain pixels match no object
+    got = aoc.ops.label_onehot_nearest(lab.cuda(), h, w, n_obj).cpu()
+    want = oe.label_onehot_nearest(lab, h, w, n_obj)
+    assert torch.equal(got, want)
+
+
+def test_memory_policy_sequence_vs_oracle(aoc):
+    """A 12-frame synthetic sequence with a new object joining at frame 4: pool growth, confident maps and the tensors
+    handed to the matching path equal the restatement; the pool then runs through proto_mask_features."""
+    from oracle import eval_loop as oe
+    syn, hot = aoc.synthetic, aoc.hotpath
+    cfg = syn.CONFIGS["tiny"]
+    clip = syn.make_clip(cfg, 9, frames=12)
+    rng = np.random.RandomState(0)
+    H, W = cfg.h * 4, cfg.w * 4
+    n_ch = cfg.n_obj
+    def upsample(ids):
+        return torch.from_numpy(np.kron(ids, np.ones((4, 4), np.int64))[:H, :W].astype(np.int32))
+    gpu = aoc.eval_loop.MemoryPolicy(mem_every=3, unc_ratio=0.6)
+    cpu = oe.MemoryPolicy(mem_every=3, unc_ratio=0.6)
+    emb = [torch.from_numpy(e) for e in clip["emb"]]
+    first = upsample(clip["lab"][0])
+    first[first == n_ch - 1] = 0                      # the last object is not annotated in frame 0
+    gpu.start(emb[0].cuda(), first.cuda())
+    cpu.start(emb[0], first.long())
+    for t in range(1, 12):
+        onehot = torch.from_numpy(syn.one_hot(clip["lab"][t], n_ch)).permute(2, 0, 1)
+        logits = torch.nn.functional.interpolate(onehot[None] * 4.0, size=(H, W), mode="bilinear", align_corners=True)[0]
+        probs = torch.softmax(logits + torch.from_numpy(rng.randn(n_ch, H, W).astype(np.float32)) * 0.5, dim=0)
+        gt = None
+        if t == 4:
+            g = upsample(clip["lab"][t])
+            g[g != n_ch - 1] = 0                      # ground truth that only introduces the new object
+            gt = g
+        gl, gc, _ = gpu.update(emb[t].cuda(), probs.cuda(), None if gt is None else gt.cuda())
+        cl, cc, _ = cpu.update(emb[t], probs, None if gt is None else gt.long())
+        assert np.array_equal(gl.cpu().numpy(), cl.numpy())
+        assert float((gc.cpu() != cc).float().mean()) < 1e-4      # entropy within rounding of the threshold
+    assert len(gpu.ref_embeddings) == len(cpu.ref_embeddings) == 1 + 1 + 3      # frame 0, GT frame 4, frames 3, 6, 9
+    assert sorted(gpu.label_all) == sorted(cpu.label_all_list)
+    ref_emb, ref_lab, prev_emb, prev_lab = gpu.reference_pool(cfg.h, cfg.w, n_ch)
+    assert tuple(ref_lab.shape) == (5, cfg.h, cfg.w, n_ch)
+    want0 = oe.label_onehot_nearest(cpu.ref_mask_confident[0], cfg.h, cfg.w, n_ch)
+    assert torch.equal(ref_lab[0].cpu(), want0)
+    feat, head, _ = hot.proto_mask_features(hot.MatchingConfig(), ref_emb, ref_lab, prev_emb, prev_lab, emb[11].cuda(),
+                                            torch.zeros(n_ch, device="cuda"), init_rows=None)
+    assert bool(torch.isfinite(feat).all()) and tuple(feat.shape) == (n_ch, 24, cfg.h, cfg.w)
+
+
+def test_entropy_kernel_vs_reference_golden(aoc):
+    """aoc_confident_labels' entropy map against the output of the reference's cal_shannon_entropy (committed golden vector)."""
+    from conftest import load_golden
+    g = load_golden("shannon_entropy")
+    p = torch.from_numpy(g["preds"])[0]
+    n_ch, H, W = p.shape
+    _, _, ent = aoc.ops.confident_labels(p.reshape(n_ch, -1).cuda(), (1 << n_ch) - 1, None, 0.5)
+    np.testing.assert_allclose(ent.cpu().numpy().reshape(H, W), g["uncertainty"][0, 0], rtol=0, atol=2e-6)

@@ -169,3 +169,14 @@ def test_conditioning_block_repair_is_consistent():
     a = 1 + torch.tanh(torch.cat([c1, delta @ w["CL_2.mlp_w"].t() + w["CL_2.mlp_b"],
                                   head @ w["CL_3.mlp_w"].t() + w["CL_3.mlp_b"]], 1) @ w["mlp_w"].t() + w["mlp_b"])
     np.testing.assert_allclose(y.numpy(), (a[:, :, None, None] * x).numpy(), rtol=1e-6, atol=1e-6)
+
+
+def test_shannon_entropy_matches_reference_output(golden):
+    """oracle/eval_loop.py::cal_shannon_entropy against the reference's own function (tests/golden/make_golden_entropy.py)."""
+    from oracle import eval_loop as oe
+    g = golden("shannon_entropy")
+    got = oe.cal_shannon_entropy(torch.from_numpy(g["preds"]))
+    np.testing.assert_array_equal(got.numpy(), g["uncertainty"])
+    # the frame decision with every label seen reduces to the same map
+    _, _, unc = oe.frame_decision(torch.from_numpy(g["preds"]), list(range(g["preds"].shape[1])))
+    np.testing.assert_array_equal(unc.numpy(), g["uncertainty"][0, 0])
