@@ -308,6 +308,21 @@ int aoc_label_mix(const float *labels, const float *rows, int64_t n, int n_obj, 
 int aoc_plane_mean(const float *x, int64_t planes, int64_t hw, float *out, aoc_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Decoder-side streams next to the FiLM gates.
+ *
+ * aoc_plane_reduce   out[plane] = sum over the plane of x (mode 0), x^2 (mode 1), |x| (mode 2)      (gct.py:19,27-30)
+ * aoc_gct_gate       GCT gate of gct.py:17-36 from those sums [N, C]: l2 mode (l1_mode = 0, sums of squares) or l1 mode
+ *                    (sums of x or |x|); gate [N, C] = 1 + tanh(embedding * norm + beta); y = x * gate is aoc_channel_scale
+ * aoc_object_logit   IA_logit, decoding_module.py:151-160: out[n, p] = sum_c x[n, c, p] * weight[n * weight_stride + c] +
+ *                    bias[n * bias_stride] (the per-object 1x1 grouped convolution with weights generated from the IA head;
+ *                    weight / bias are usually views of one [N, C + 1] linear output: weight_stride = bias_stride = C + 1) */
+int aoc_plane_reduce(const float *x, int64_t planes, int64_t hw, int mode, float *out, aoc_stream_t stream);
+int aoc_gct_gate(const float *plane_sums, const float *alpha, const float *gamma, const float *beta, int N, int C,
+                 float eps, int l1_mode, float *gate, aoc_stream_t stream);
+int aoc_object_logit(const float *x, int N, int C, int64_t hw, const float *weight, int64_t weight_stride,
+                     const float *bias, int64_t bias_stride, float *out, aoc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Eval-loop memory policy (the caller of the matching path).
  *
  * aoc_confident_labels: the per-pixel decision of one frame, eval_manager_mm.py:253-265,300-326,339-346,357-361 with

@@ -95,3 +95,28 @@ def conditioning_block(x, proxy_ia_head, p, beta_percentage=0.3):
     a = torch.nn.functional.linear(torch.cat([c1, c2, c3], dim=1), p["mlp_w"], p["mlp_b"])   # CLB:81
     a = 1. + torch.tanh(a)                                                 # CLB:82
     return a.unsqueeze(-1).unsqueeze(-1) * x                               # CLB:83-84
+
+
+def gct_forward(x, alpha, gamma, beta, epsilon=1e-5, mode="l2", after_relu=False):
+    """networks/layers/gct.py:17-36 restated (the file itself imports a module the reference does not ship, so it cannot
+    be imported: PARITY UNPINNED for this function).  x [N, C, H, W]; alpha/gamma/beta [1, C, 1, 1]."""
+    if mode == "l2":
+        embedding = (x.pow(2).sum((2, 3), keepdim=True) + epsilon).pow(0.5) * alpha
+        norm = gamma / (embedding.pow(2).mean(dim=1, keepdim=True) + epsilon).pow(0.5)
+    else:
+        _x = x if after_relu else torch.abs(x)
+        embedding = _x.sum((2, 3), keepdim=True) * alpha
+        norm = gamma / (torch.abs(embedding).mean(dim=1, keepdim=True) + epsilon)
+    gate = 1. + torch.tanh(embedding * norm + beta)
+    return x * gate
+
+
+def ia_logit(x, IA_head, weight, bias):
+    """decoding_module.py:151-160 restated: IA_final = Linear(head_dim, C + 1) given by (weight, bias)."""
+    import torch.nn.functional as F
+    n, c, h, w = x.size()
+    xv = x.reshape(1, n * c, h, w)
+    IA_output = F.linear(IA_head, weight, bias)
+    IA_weight = IA_output[:, :c].reshape(n, c, 1, 1)
+    IA_bias = IA_output[:, -1].reshape(-1)
+    return F.conv2d(xv, weight=IA_weight, bias=IA_bias, groups=n).view(n, 1, h, w)

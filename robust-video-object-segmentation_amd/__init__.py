@@ -14,5 +14,6 @@ from . import conditioning_layer  # noqa: F401
 from . import hotpath  # noqa: F401
 from . import sharding  # noqa: F401
 from . import eval_loop  # noqa: F401
+from . import gct  # noqa: F401
 
-__all__ = ["synthetic", "ops", "matching", "attention", "conditioning_layer", "hotpath", "sharding", "eval_loop"]
+__all__ = ["synthetic", "ops", "matching", "attention", "conditioning_layer", "hotpath", "sharding", "eval_loop", "gct"]

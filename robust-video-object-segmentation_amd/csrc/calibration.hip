@@ -369,6 +369,83 @@ __global__ __launch_bounds__(256) void plane_mean_kernel(const float *__restrict
     if (threadIdx.x == 0) out[blockIdx.x] = (wsum[0] + wsum[1] + wsum[2] + wsum[3]) / (float)hw;
 }
 
+// ------------------------------------------------------------------------------------------
+// Decoder-side streams that sit next to the FiLM gates.
+// plane_reduce: out[plane] = sum over the plane of x (mode 0), x^2 (mode 1) or |x| (mode 2)  (gct.py:19,27-30)
+__global__ __launch_bounds__(256) void plane_reduce_kernel(const float *__restrict__ x, int64_t hw, int mode, float *__restrict__ out) {
+    __shared__ float wsum[4];
+    const float *xp = x + (size_t)blockIdx.x * hw;
+    float acc = 0.0f;
+    int64_t p = threadIdx.x;
+    for (; p + 7 * (int64_t)blockDim.x < hw; p += 8 * (int64_t)blockDim.x) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = xp[p + u * blockDim.x];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += (mode == 1) ? v[u] * v[u] : (mode == 2 ? fabsf(v[u]) : v[u]);
+    }
+    for (; p < hw; p += blockDim.x) {
+        const float v = xp[p];
+        acc += (mode == 1) ? v * v : (mode == 2 ? fabsf(v) : v);
+    }
+    acc = aoc_wave_sum(acc);
+    if (aoc_lane() == 0) wsum[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) out[blockIdx.x] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+}
+
+// GCT gate (gct.py:17-36): per sample n, from the per-plane reductions s[n, c]:
+//   l2: e_c = sqrt(s_c + eps) * alpha_c,  norm_c = gamma_c / sqrt(mean_c(e_c^2) + eps)
+//   l1: e_c = s_c * alpha_c,              norm_c = gamma_c / (mean_c|e_c| + eps)
+//   gate[n, c] = 1 + tanh(e_c * norm_c + beta_c)
+__global__ __launch_bounds__(256) void gct_gate_kernel(const float *__restrict__ s, const float *__restrict__ alpha, const float *__restrict__ gamma,
+                                                       const float *__restrict__ beta, int C, float eps, int l1, float *__restrict__ gate) {
+    __shared__ float wsum[4];
+    __shared__ float mean_s;
+    const int n = blockIdx.x;
+    float part = 0.0f;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const float sv = s[(size_t)n * C + c];
+        const float e = l1 ? sv * alpha[c] : sqrtf(sv + eps) * alpha[c];
+        part += l1 ? fabsf(e) : e * e;
+    }
+    part = aoc_wave_sum(part);
+    if (aoc_lane() == 0) wsum[threadIdx.x >> 6] = part;
+    __syncthreads();
+    if (threadIdx.x == 0) mean_s = ((wsum[0] + wsum[1]) + (wsum[2] + wsum[3])) / (float)C;
+    __syncthreads();
+    const float m = mean_s;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const float sv = s[(size_t)n * C + c];
+        const float e = l1 ? sv * alpha[c] : sqrtf(sv + eps) * alpha[c];
+        const float norm = l1 ? gamma[c] / (m + eps) : gamma[c] / sqrtf(m + eps);
+        gate[(size_t)n * C + c] = 1.0f + tanhf(e * norm + beta[c]);
+    }
+}
+
+// IA_logit (decoding_module.py:151-160): logit[n, p] = sum_c x[n, c, p] * weight[n, c] + bias[n]: a 1x1 grouped convolution
+// whose weights are generated per object from the IA head
+__global__ __launch_bounds__(256) void object_logit_kernel(const float *__restrict__ x, int C, int64_t hw, const float *__restrict__ weight,
+                                                           int64_t weight_stride, const float *__restrict__ bias, int64_t bias_stride,
+                                                           float *__restrict__ out) {
+    const int n = blockIdx.y;
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= hw) return;
+    const float *xp = x + (size_t)n * C * hw + p;
+    const float *w = weight + (size_t)n * weight_stride;
+    float s = 0.0f;
+    int c = 0;
+    for (; c + 8 <= C; c += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = xp[(size_t)(c + u) * hw];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s += w[c + u] * v[u];
+    }
+    for (; c < C; ++c) s += w[c] * xp[(size_t)c * hw];
+    out[(size_t)n * hw + p] = s + bias[(size_t)n * bias_stride];
+}
+
 inline int pool_chunks(int64_t hw) { return (int)((hw + MP_PIX - 1) / MP_PIX); }
 
 }  // namespace
@@ -479,6 +556,31 @@ int aoc_label_mix(const float *labels, const float *rows, int64_t n, int n_obj, 
 int aoc_plane_mean(const float *x, int64_t planes, int64_t hw, float *out, aoc_stream_t stream) {
     if (!x || !out || planes < 1 || hw < 1) return AOC_ERR_INVALID_ARG;
     hipLaunchKernelGGL(plane_mean_kernel, dim3((unsigned)planes), dim3(256), 0, aoc_hip_stream(stream), x, hw, out);
+    AOC_RETURN_IF_LAUNCH_FAILED();
+    return AOC_OK;
+}
+
+int aoc_plane_reduce(const float *x, int64_t planes, int64_t hw, int mode, float *out, aoc_stream_t stream) {
+    if (!x || !out || planes < 1 || hw < 1 || mode < 0 || mode > 2) return AOC_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(plane_reduce_kernel, dim3((unsigned)planes), dim3(256), 0, aoc_hip_stream(stream), x, hw, mode, out);
+    AOC_RETURN_IF_LAUNCH_FAILED();
+    return AOC_OK;
+}
+
+int aoc_gct_gate(const float *plane_sums, const float *alpha, const float *gamma, const float *beta, int N, int C, float eps, int l1_mode,
+                 float *gate, aoc_stream_t stream) {
+    if (!plane_sums || !alpha || !gamma || !beta || !gate || N < 1 || C < 1) return AOC_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(gct_gate_kernel, dim3((unsigned)N), dim3(256), 0, aoc_hip_stream(stream), plane_sums, alpha, gamma, beta, C, eps, l1_mode, gate);
+    AOC_RETURN_IF_LAUNCH_FAILED();
+    return AOC_OK;
+}
+
+int aoc_object_logit(const float *x, int N, int C, int64_t hw, const float *weight, int64_t weight_stride, const float *bias,
+                     int64_t bias_stride, float *out, aoc_stream_t stream) {
+    if (!x || !weight || !bias || !out || N < 1 || C < 1 || hw < 1) return AOC_ERR_INVALID_ARG;
+    if (N > 65535) return AOC_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(object_logit_kernel, dim3((unsigned)((hw + 255) / 256), N), dim3(256), 0, aoc_hip_stream(stream), x, C, hw, weight, weight_stride,
+                       bias, bias_stride, out);
     AOC_RETURN_IF_LAUNCH_FAILED();
     return AOC_OK;
 }

@@ -1,0 +1,39 @@
+"""Decoder-side streams next to the FiLM gates: drop-in mirrors of ``networks/layers/gct.py:GCT`` (17-36)
+and of ``CalibrationDecoding.IA_logit`` (networks/aoc/decoding_module.py:151-160) on the HIP library.  Parameter names
+(``alpha``, ``gamma``, ``beta``) are the reference's, so a reference ``state_dict`` loads."""
+import torch
+from torch import nn
+
+from . import ops
+
+
+class GCT(nn.Module):
+    """Gated channel transformation, gct.py:7-36: y = x * (1 + tanh(embedding * norm + beta))."""
+
+    def __init__(self, num_channels, epsilon=1e-5, mode='l2', after_relu=False):
+        super(GCT, self).__init__()
+        self.alpha = nn.Parameter(torch.ones(1, num_channels, 1, 1))
+        self.gamma = nn.Parameter(torch.zeros(1, num_channels, 1, 1))
+        self.beta = nn.Parameter(torch.zeros(1, num_channels, 1, 1))
+        self.epsilon = epsilon
+        self.mode = mode
+        self.after_relu = after_relu
+
+    def forward(self, x):
+        if self.mode == 'l2':
+            sums = ops.plane_reduce(x, 1)                                   # gct.py:19
+            l1 = False
+        elif self.mode == 'l1':
+            sums = ops.plane_reduce(x, 0 if self.after_relu else 2)         # gct.py:23-27
+            l1 = True
+        else:
+            raise ValueError("Unknown mode!")                               # gct.py:29-31 prints and exits
+        gate = ops.gct_gate(sums, self.alpha.detach(), self.gamma.detach(), self.beta.detach(), self.epsilon, l1)
+        return ops.channel_scale(x, gate)                                   # gct.py:33-35
+
+
+def IA_logit(x, IA_head, IA_final):
+    """decoding_module.py:151-160: per-object 1x1 convolution whose C weights and bias come from ``IA_final(IA_head)``
+    (an ``nn.Linear(head_dim, C + 1)``).  x [N, C, H, W] -> logit [N, 1, H, W]."""
+    out = ops.linear(IA_head, IA_final.weight.detach(), IA_final.bias.detach())      # :154 [N, C + 1]
+    return ops.object_logit(x, out)

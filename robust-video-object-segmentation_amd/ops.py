@@ -445,3 +445,39 @@ def label_onehot_nearest(label_hw, h, w, n_obj):
     out = torch.empty(h, w, n_obj, dtype=torch.float32, device=label_hw.device)
     _lib.check(_lib.lib().aoc_label_onehot_nearest(_p(label_hw), H, W, int(h), int(w), int(n_obj), _p(out), _stream()), "aoc_label_onehot_nearest")
     return out
+
+
+# ------------------------------------------------------------------------------------------ decoder-side streams (8f-4)
+def plane_reduce(x, mode):
+    """x [N, C, H, W] -> [N, C] plane sums of x (mode 0), x^2 (1) or |x| (2)."""
+    x = _f32c(x)
+    _need_gpu(x)
+    N, C = x.shape[0], x.shape[1]
+    hw = x.numel() // (N * C)
+    out = torch.empty(N, C, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().aoc_plane_reduce(_p(x), N * C, hw, int(mode), _p(out), _stream()), "aoc_plane_reduce")
+    return out
+
+
+def gct_gate(plane_sums, alpha, gamma, beta, eps, l1_mode=False):
+    plane_sums = _f32c(plane_sums)
+    _need_gpu(plane_sums, alpha, gamma, beta)
+    N, C = plane_sums.shape
+    gate = torch.empty(N, C, dtype=torch.float32, device=plane_sums.device)
+    _lib.check(_lib.lib().aoc_gct_gate(_p(plane_sums), _p(_f32c(alpha).reshape(-1)), _p(_f32c(gamma).reshape(-1)), _p(_f32c(beta).reshape(-1)), N, C,
+                                       float(eps), int(bool(l1_mode)), _p(gate), _stream()), "aoc_gct_gate")
+    return gate
+
+
+def object_logit(x, weight_bias):
+    """x [N, C, H, W], weight_bias [N, C + 1] (weights then bias, decoding_module.py:154-156) -> [N, 1, H, W]."""
+    x = _f32c(x)
+    weight_bias = _f32c(weight_bias)
+    _need_gpu(x, weight_bias)
+    N, C, H, W = x.shape
+    assert weight_bias.shape == (N, C + 1)
+    out = torch.empty(N, 1, H, W, dtype=torch.float32, device=x.device)
+    base = weight_bias.data_ptr()
+    _lib.check(_lib.lib().aoc_object_logit(_p(x), N, C, H * W, ctypes.c_void_p(base), C + 1, ctypes.c_void_p(base + 4 * C), C + 1, _p(out), _stream()),
+               "aoc_object_logit")
+    return out

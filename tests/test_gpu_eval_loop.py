@@ -107,3 +107,36 @@ def test_entropy_kernel_vs_reference_golden(aoc):
     n_ch, H, W = p.shape
     _, _, ent = aoc.ops.confident_labels(p.reshape(n_ch, -1).cuda(), (1 << n_ch) - 1, None, 0.5)
     np.testing.assert_allclose(ent.cpu().numpy().reshape(H, W), g["uncertainty"][0, 0], rtol=0, atol=2e-6)
+
+
+@pytest.mark.parametrize("mode,after_relu", [("l2", False), ("l1", False), ("l1", True)])
+def test_gct_vs_oracle(aoc, mode, after_relu):
+    from oracle import calibration as ocal
+    rng = np.random.RandomState(3)
+    N, C, H, W = 3, 48, 31, 45
+    x = torch.from_numpy(rng.randn(N, C, H, W).astype(np.float32))
+    if after_relu:
+        x = x.clamp_min(0)
+    m = aoc.gct.GCT(C, mode=mode, after_relu=after_relu).cuda()
+    with torch.no_grad():
+        m.alpha.copy_(torch.from_numpy(rng.rand(1, C, 1, 1).astype(np.float32)) + 0.5)
+        m.gamma.copy_(torch.from_numpy(rng.randn(1, C, 1, 1).astype(np.float32)))
+        m.beta.copy_(torch.from_numpy(rng.randn(1, C, 1, 1).astype(np.float32)) * 0.3)
+        got = m(x.cuda()).cpu()
+        want = ocal.gct_forward(x, m.alpha.cpu(), m.gamma.cpu(), m.beta.cpu(), m.epsilon, mode, after_relu)
+    np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=2e-5, atol=2e-6)
+
+
+def test_ia_logit_vs_oracle(aoc):
+    from oracle import calibration as ocal
+    rng = np.random.RandomState(4)
+    N, C, H, W, D = 4, 37, 29, 41, 400
+    x = torch.from_numpy(rng.randn(N, C, H, W).astype(np.float32))
+    head = torch.from_numpy(rng.randn(N, D).astype(np.float32))
+    lin = torch.nn.Linear(D, C + 1)
+    with torch.no_grad():
+        got = aoc.gct.IA_logit(x.cuda(), head.cuda(), lin.cuda()).cpu()
+        lin = lin.cpu()
+        want = ocal.ia_logit(x, head, lin.weight, lin.bias)
+    assert tuple(got.shape) == (N, 1, H, W)
+    np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=1e-4, atol=2e-4)
