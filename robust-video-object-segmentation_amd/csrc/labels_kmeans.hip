@@ -1797,7 +1797,7 @@ inline int label_blocks(int64_t n) { return (int)((n + LP_BLOCK - 1) / LP_BLOCK)
 
 extern "C" {
 
-const char *aoc_version(void) { return "aoc_hip 0.1 (gfx950, fp32-exact)"; }
+const char *aoc_version(void) { return "aoc_hip 0.2 (gfx950)"; }
 
 size_t aoc_label_prep_workspace_bytes(int64_t n, int n_obj) {
     if (n < 0 || n_obj < 1) return 0;
