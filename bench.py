@@ -528,7 +528,7 @@ def main():
             "value": round(value, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed_max / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{cfg.name}: {cfg.h}x{cfg.w} stride-4 maps (480p), O={O} (3 objects + background), K={cfg.k} proxies, "
+            "config": {"workload": f"{cfg.name}: {cfg.h}x{cfg.w} stride-4 maps{' (480p)' if (cfg.h, cfg.w) == (121, 213) else ''}, O={O} ({O - 1} objects + background), K={cfg.k} proxies, "
                                    f"C={C}, {cfg.frames}-frame clips, MEM_EVERY={mc.MEM_EVERY} (R=1..{1 + (cfg.frames - 2) // mc.MEM_EVERY}), "
                                    "20 Lloyd iterations, local windows [2..12]",
                        "sequences_per_gpu": n_streams, "frames_per_step": n_streams, "sharding": "sequences over ranks, no data-path collective",

@@ -186,3 +186,38 @@ def test_kmeans_exact_on_signed_and_constant_data(aoc):
                                               torch.from_numpy(init).cuda(), k, 20)
     cb, l, ct = okm.kmeans2_matrix(x, x[init[0]], 20)
     assert np.array_equal(lab.cpu().numpy(), l) and np.array_equal(cen.cpu().numpy()[0], cb) and np.array_equal(cnt.cpu().numpy()[0], ct)
+
+
+def test_cfg4_full_size_kmeans_and_dense(aoc):
+    """cfg4 (181x321 maps, O=9, K=64): bit-exact k-means for the two smallest objects' segments and for the background,
+    dense branch on a sub-sample of query pixels, whole proto-mask tensor finite."""
+    from oracle import kmeans as okm
+    from oracle import matching as om
+    cfg, clip, emb, lab = _clip(aoc, "cfg4", 3)
+    O, K = cfg.n_obj, cfg.k
+    counts = [int((clip["lab"][0] == o).sum()) for o in range(O)]
+    rows = aoc.synthetic.kmeans_init_rows(21, counts, K)
+    pool, labels = emb[0].reshape(-1, cfg.c), lab[0].reshape(-1, O)
+    cp = aoc.matching.cluster_proxies(pool.cuda(), labels.cuda(), K, rows)
+    offs = cp["prep"].obj_offsets.cpu().numpy()
+    got_lab, got_cen = cp["labels"].cpu().numpy(), cp["centroids"].cpu().numpy()
+    kk = K
+    order = np.argsort(counts)
+    check = {int(order[0]), int(order[1]), int(order[-1])}
+    for o in range(O):
+        kk = min(kk, counts[o])
+        if o not in check or kk == 0:
+            continue
+        x = pool.numpy()[clip["lab"][0].reshape(-1) == o]
+        cb, l, cnt = okm.kmeans2_matrix(x, x[rows[o][:kk]], 20)
+        assert np.array_equal(got_lab[offs[o]:offs[o + 1]], l), f"object {o}"
+        assert np.array_equal(got_cen[o, :kk], cb)
+    bias = torch.linspace(-0.2, 0.2, O)
+    got = aoc.matching.global_matching_for_eval([emb[0].cuda()], emb[2].cuda(), [lab[0].cuda()], 4, bias.cuda(), None, 1, False, 0)[0, :, :, :, 0]
+    sel = torch.arange(0, cfg.h * cfg.w, 211)
+    want = om.proto_transform(om.nearest_neighbor_features_per_object(pool, emb[2].reshape(-1, cfg.c)[sel], labels).squeeze(-1), bias.view(1, -1))
+    np.testing.assert_allclose(got.reshape(-1, O).cpu()[sel].numpy(), want.numpy(), rtol=0, atol=ATOL)
+    from aoc_amd import hotpath
+    mc = hotpath.MatchingConfig(CLUSTER_NUM=K)
+    feat, head, _ = hotpath.proto_mask_features(mc, emb[:1].cuda(), lab[:1].cuda(), emb[1].cuda(), lab[1].cuda(), emb[2].cuda(), bias.cuda(), init_rows=rows)
+    assert tuple(feat.shape) == (O, 24, cfg.h, cfg.w) and bool(torch.isfinite(feat).all())
