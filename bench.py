@@ -166,6 +166,41 @@ class ClipWorkload:
     def refs(self):
         return self.pool_emb[:self.R], self.pool_lab[:self.R]
 
+    def pretouch(self, gates, acts, dense_precision, pipeline):
+        """Setup, not a benchmark step: one frame at the LARGEST pool size, so that torch's caching allocator already owns
+        blocks of every size the clip will ask for (otherwise each pool growth inside the timed region calls hipMalloc,
+        which synchronises the device).  The pool is filled with copies of frame 0 for this; reset() restores it."""
+        rmax = self.pool_emb.shape[0]
+        self.pool_emb[:] = self.emb[0]
+        self.pool_lab[:] = self.lab[0]
+        self.R, self.t = rmax, self.T - 1
+        self.pool_event = torch.cuda.Event()
+        self.pool_event.record()
+        self.ahead.clear()
+        ref_emb, ref_lab = self.refs()
+        counts = [int((self.lab_ids[0] == o).sum()) * rmax for o in range(self.cfg.n_obj)]
+        rows = syn.kmeans_init_rows(12345, counts, self.mc.CLUSTER_NUM)
+        init = np.zeros((self.cfg.n_obj, self.mc.CLUSTER_NUM), np.int32)
+        for o, r in enumerate(rows):
+            if r is not None:
+                init[o, :len(r)] = r
+        init = torch.from_numpy(init).to(self.dev)
+        if self.side is not None and pipeline:
+            inits = [init] * max(1, self.chains - 1)
+            ahead = hotpath.launch_cluster_proxies(self.mc, ref_emb, ref_lab, init, self.side, wait_event=self.pool_event)
+            if self.chains > 1:
+                hotpath.launch_cluster_proxies_batch(self.mc, ref_emb, ref_lab, inits, self.side, wait_event=self.pool_event)
+            feat, head, _ = hotpath.proto_mask_features(self.mc, ref_emb, ref_lab, self.emb[1], self.lab[1], self.emb[2], self.bias,
+                                                        cluster_ahead=ahead, dense_state=self.dense_state, dense_precision=dense_precision)
+        else:
+            feat, head, _ = hotpath.proto_mask_features(self.mc, ref_emb, ref_lab, self.emb[1], self.lab[1], self.emb[2], self.bias,
+                                                        cluster_state=dict(init_rows=init), side_stream=self.side,
+                                                        dense_state=self.dense_state, dense_precision=dense_precision)
+        gates(acts, head)
+        torch.cuda.synchronize()
+        self.ahead.clear()
+        self.reset()
+
     def advance(self):
         """eval_manager_mm.py:309-312,356-361: append the frame to the pool every MEM_EVERY frames."""
         if self.t % self.mc.MEM_EVERY == 0:
@@ -399,6 +434,9 @@ def main():
             torch.distributed.barrier()
 
     with torch.no_grad():
+        for wl, st in zip(workloads, streams):             # allocator pre-touch at the largest pool size (setup)
+            with torch.cuda.stream(st):
+                wl.pretouch(gates, acts, args.dense, not args.no_pipeline)
         run_steps(args.warmup)
         barrier()
         timer.enabled = True                 # HIP events around every op, on the stream the op is launched on
@@ -490,7 +528,34 @@ def main():
         corr_roof = None
         if corr and "gbs" in corr:
             corr_roof = dict(kernel="proxy_corr_min_kernel", bound="hbm", achieved=corr["gbs"], peak=PEAK_HBM_GBS, unit="GB/s",
-                             frac=round(corr["gbs"] / PEAK_HBM_GBS, 4), avg_launch_ms=corr["avg_ms"], algorithmic_bytes_per_launch=corr["avg_bytes"])
+                             frac=round(corr["gbs"] / PEAK_HBM_GBS, 4), avg_launch_ms=corr["avg_ms"], algorithmic_bytes_per_launch=corr["avg_bytes"],
+                             note="in-run figure: the event pair also spans the time the launch waits behind the other streams' kernels")
+            # the kernel by itself: the same launch (one frame: 132 proxies x 25 773 pixels) 50 times back to back on an idle GPU
+            wl = workloads[0]
+            with torch.no_grad():
+                torch.cuda.synchronize()
+                kmax = mc.CLUSTER_NUM
+                table = torch.randn(O * 2 * kmax + O, C, device=dev) * 0.3
+                sqn = table.pow(2).sum(1)
+                feat = torch.empty(O, mc.proto_channels, cfg.h, cfg.w, device=dev)
+                stride = mc.proto_channels * hw
+                sb = [(o * 2 + f) * kmax for o in range(O) for f in range(2)] + [O * 2 * kmax + o for o in range(O)]
+                ss = [kmax] * (2 * O) + [1] * O
+                so = [o * stride + (1 + f) * hw for o in range(O) for f in range(2)] + [o * stride + 3 * hw for o in range(O)]
+                bias3 = torch.zeros(3 * O, device=dev)
+                q = wl.emb[1].reshape(hw, C)
+                run = lambda: timer._orig["proxy_corr_min"](q, table, sqn, sb, ss, so, bias3, feat, 1, True)
+                for _ in range(5):
+                    run()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(50):
+                    run()
+                e1.record()
+                torch.cuda.synchronize()
+                iso_ms = e0.elapsed_time(e1) / 50
+            iso_gbs = corr["avg_bytes"] / (iso_ms * 1e-3) / 1e9
+            corr_roof.update(isolated_avg_launch_ms=round(iso_ms, 4), isolated_achieved=round(iso_gbs, 1), isolated_frac=round(iso_gbs / PEAK_HBM_GBS, 4))
 
         cpu = None
         parity = None
