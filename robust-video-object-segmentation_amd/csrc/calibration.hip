@@ -282,9 +282,30 @@ __global__ __launch_bounds__(1024) void cond_kth_largest_kernel(const float *__r
         if (threadIdx.x < 256) hist[threadIdx.x] = 0;
         __syncthreads();
         const uint32_t prefix = sel_prefix;
-        for (int64_t i = threadIdx.x; i < hw; i += blockDim.x) {
-            const uint32_t key = float_order_key(s[i]);
-            if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+        // scores of one map share their sign/exponent byte, so a plain LDS atomic per element serialises 64 ways; the
+        // lanes of a wave that hit the same bin are counted with a ballot first (two rounds take care of the hot bins),
+        // whatever is left is spread over many bins and goes through ordinary atomics
+        const int lane = threadIdx.x & 63;
+        for (int64_t i0 = 0; i0 < hw; i0 += blockDim.x) {
+            const int64_t i = i0 + threadIdx.x;
+            uint32_t key = 0;
+            bool act = false;
+            if (i < hw) {
+                key = float_order_key(s[i]);
+                act = (key & mask) == prefix;
+            }
+            const uint32_t bin = (key >> shift) & 255u;
+#pragma unroll
+            for (int round = 0; round < 2; ++round) {
+                const unsigned long long m = __ballot(act);
+                if (m == 0ull) break;
+                const int leader = __builtin_ctzll(m);
+                const uint32_t lb = __shfl(bin, leader);
+                const unsigned long long same = __ballot(act && bin == lb);
+                if (lane == leader) atomicAdd(&hist[lb], (uint32_t)__popcll(same));
+                act = act && bin != lb;
+            }
+            if (act) atomicAdd(&hist[bin], 1u);
         }
         __syncthreads();
         if (threadIdx.x == 0) {

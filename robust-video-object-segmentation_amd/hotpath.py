@@ -151,7 +151,8 @@ def proto_mask_features(cfg, ref_emb, ref_labels, prev_emb, prev_labels, cur_emb
                  latency-bound launches) runs there, concurrently with the MFMA-bound dense matching on the
                  current stream; the two join in front of the correlation launch.  Only with cluster_state.
     dense_state  optional dict owned by the caller and kept across the frames of ONE sequence: caches the fp16 split
-                 records of the reference pool, so only frames appended since the last call are converted.  The pool
+                 records of the reference pool (only frames appended since the last call are converted) and the pooled
+                 reference heads, which only depend on the pool (recomputed when the number of pool frames changes).  The pool
                  must be append-only while the dict lives (the reference's memory policy, eval_manager_mm.py:329-361).
     dense_precision  "split" (default, ops.DENSE_PRECISION) or "fp32": see ops.dense_match.
     cluster_ahead  a ClusterProxiesAhead of this frame's pool (launch_cluster_proxies): the adaptive proxies were
@@ -213,8 +214,17 @@ def proto_mask_features(cfg, ref_emb, ref_labels, prev_emb, prev_labels, cur_emb
                 t.record_stream(main)
         cp = dict(prep=prep, centroids=cen, labels=lab, proxies=proxies, proxy_sqnorm=psq)
 
-    ref_pos, ref_neg = ops.masked_mean_pool(ref_emb.reshape(R, hw, C), ref_labels.reshape(R, hw, O), cfg.MODEL_EPSILON, pixel_major=True,
-                                            out_pos=table[O * 2 * kmax:], out_pos_sqnorm=sqn[O * 2 * kmax:])
+    cached = dense_state.get("ref_pool") if dense_state is not None else None
+    if cached is not None and cached[0] == R:
+        # the pooled reference heads are a function of the pool alone (ATT:155-170): unchanged since the last frame
+        _, ref_pos, ref_neg, ref_sq = cached
+        table[O * 2 * kmax:].copy_(ref_pos)
+        sqn[O * 2 * kmax:].copy_(ref_sq)
+    else:
+        ref_pos, ref_neg = ops.masked_mean_pool(ref_emb.reshape(R, hw, C), ref_labels.reshape(R, hw, O), cfg.MODEL_EPSILON, pixel_major=True,
+                                                out_pos=table[O * 2 * kmax:], out_pos_sqnorm=sqn[O * 2 * kmax:])
+        if dense_state is not None:
+            dense_state["ref_pool"] = (R, ref_pos.clone(), ref_neg, sqn[O * 2 * kmax:].clone())
     prev_pos, prev_neg = ops.masked_mean_pool(prev_emb.reshape(1, hw, C), prev_labels.reshape(1, hw, O), cfg.MODEL_EPSILON, pixel_major=True)
     attention_head = torch.cat([ref_pos, ref_neg, prev_pos, prev_neg], dim=1)          # ATT:188, [O, 4C]
 
