@@ -19,9 +19,10 @@ the dominant kernel measured with HIP events inside the timed region, and a CPU 
 timed on the host cores, rank 0, N = 1 only).
 """
 import argparse
+import os
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # main + dense + k-means stream per sequence: more than the default 4 hardware queues
 import ctypes
 import json
-import os
 import sys
 import time
 
@@ -154,6 +155,7 @@ class ClipWorkload:
         self.ahead = {}                                    # frame -> adaptive proxies already enqueued on a side stream
         self.pool_event = None                             # recorded after the last change of the pool
         self.chains = mc.MEM_EVERY                         # k-means chains enqueued ahead (bench --chains)
+        self.dense_stream = None                           # CU-masked stream for the dense kernel alone
         self.reset()
 
     def reset(self):
@@ -236,7 +238,8 @@ def frame_step(wl, gates, acts, dense_precision="split", pipeline=True):
             # does not wait for anything this frame still has to do on the main stream
             wl.ahead[t + 1] = hotpath.launch_cluster_proxies(wl.mc, ref_emb, ref_lab, wl.init_rows[t + 1][0], wl.side, wait_event=wl.pool_event)
         feat, head, _ = hotpath.proto_mask_features(wl.mc, ref_emb, ref_lab, wl.emb[t - 1], wl.lab[t - 1], wl.emb[t], wl.bias,
-                                                    cluster_ahead=ahead, dense_state=wl.dense_state, dense_precision=dense_precision)
+                                                    cluster_ahead=ahead, dense_state=wl.dense_state, dense_precision=dense_precision,
+                                                    dense_stream=wl.dense_stream)
     else:
         feat, head, _ = hotpath.proto_mask_features(wl.mc, ref_emb, ref_lab, wl.emb[t - 1], wl.lab[t - 1], wl.emb[t], wl.bias,
                                                     cluster_state=dict(init_rows=wl.init_rows[t][0]), side_stream=wl.side,
@@ -350,6 +353,9 @@ def main():
                     help="keep the main streams off this many CUs (HIP CU mask) so the side-stream k-means chain always finds free CUs")
     ap.add_argument("--chains", type=int, default=3,
                     help="frames whose k-means is enqueued right after a pool update (1 = only the next frame; the others are batched into one chain)")
+    ap.add_argument("--dense-stream", dest="mask_main", action="store_false",
+                    help="put only the dense kernel under the CU mask (on its own stream) instead of the whole main stream "
+                         "(measured slower: the unmasked light kernels then take the reserved CUs from the k-means chains)")
     ap.add_argument("--no-dense-order", action="store_true",
                     help="do not order the sequences' dense kernels explicitly (their live timing then includes queueing behind each other)")
     ap.add_argument("--no-pipeline", action="store_true",
@@ -399,7 +405,15 @@ def main():
         assert rc == 0, f"hipExtStreamCreateWithCUMask failed: {rc}"
         return torch.cuda.ExternalStream(handle.value, device=dev)
 
-    streams = [make_main_stream() for _ in range(n_streams)] if (n_streams > 1 or args.cu_reserve > 0) else [torch.cuda.current_stream()]
+    if args.mask_main:
+        streams = [make_main_stream() for _ in range(n_streams)] if (n_streams > 1 or args.cu_reserve > 0) else [torch.cuda.current_stream()]
+        dense_streams = [None] * n_streams
+    else:
+        # only the dense kernel runs under the CU mask (its own stream per sequence); everything else may use every CU
+        streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)] if n_streams > 1 else [torch.cuda.current_stream()]
+        dense_streams = [make_main_stream() if args.cu_reserve > 0 else None for _ in range(n_streams)]
+    for wl, ds in zip(workloads, dense_streams):
+        wl.dense_stream = ds
 
     hw, C, O = cfg.h * cfg.w, cfg.c, cfg.n_obj
 
@@ -427,7 +441,7 @@ def main():
     def run_steps(n):
         for _ in range(n):
             for wl, st in zip(workloads, streams):
-                if n_streams > 1 or args.cu_reserve > 0:
+                if n_streams > 1 or (args.cu_reserve > 0 and args.mask_main):
                     with torch.cuda.stream(st):
                         frame_step(wl, gates, acts, args.dense, not args.no_pipeline)
                 else:

@@ -139,7 +139,8 @@ def launch_cluster_proxies_batch(cfg, ref_emb, ref_labels, init_rows_list, side_
 
 
 def proto_mask_features(cfg, ref_emb, ref_labels, prev_emb, prev_labels, cur_emb, dis_bias, init_rows=None,
-                        cluster_state=None, side_stream=None, dense_state=None, dense_precision=None, cluster_ahead=None):
+                        cluster_state=None, side_stream=None, dense_state=None, dense_precision=None, cluster_ahead=None,
+                        dense_stream=None):
     """All matching branches of one frame -> (features [O, 24, h, w], attention_head [O, 4C], aux).
 
     ref_emb     [R, h, w, C]  reference pool (channel-last)          ref_labels [R, h, w, O] float one-hot
@@ -155,6 +156,9 @@ def proto_mask_features(cfg, ref_emb, ref_labels, prev_emb, prev_labels, cur_emb
                  reference heads, which only depend on the pool (recomputed when the number of pool frames changes).  The pool
                  must be append-only while the dict lives (the reference's memory policy, eval_manager_mm.py:329-361).
     dense_precision  "split" (default, ops.DENSE_PRECISION) or "fp32": see ops.dense_match.
+    dense_stream  optional stream for the dense matching kernel alone (e.g. one created with a HIP CU mask): the call forks
+                 to it for that kernel and joins in front of the background maps, so the light kernels of this frame (and
+                 of other sequences) are not queued behind the one kernel that fills every CU it may use.
     cluster_ahead  a ClusterProxiesAhead of this frame's pool (launch_cluster_proxies): the adaptive proxies were
                  enqueued earlier on a side stream; this call only waits for them in front of the correlation launch.
     """
@@ -244,7 +248,17 @@ def proto_mask_features(cfg, ref_emb, ref_labels, prev_emb, prev_labels, cur_emb
         if done < R:
             ops.split_rows(pool[done * hw:R * hw], out=pool_split, row0=done * hw)
         dense_state["pool_split"], dense_state["frames"] = pool_split, R
-    ops.dense_match(query_flat, pool, prep, bias, feat, 1, obj_stride, True, precision=dense_precision, pool_split=pool_split)
+    dense_done = None
+    if dense_stream is not None:
+        main = torch.cuda.current_stream()
+        dense_stream.wait_stream(main)
+        with torch.cuda.stream(dense_stream):
+            ops.dense_match(query_flat, pool, prep, bias, feat, 1, obj_stride, True, precision=dense_precision, pool_split=pool_split)
+            dense_done = torch.cuda.Event()
+            dense_done.record(dense_stream)
+        feat.record_stream(dense_stream)
+    else:
+        ops.dense_match(query_flat, pool, prep, bias, feat, 1, obj_stride, True, precision=dense_precision, pool_split=pool_split)
 
     # ---- local matching against the previous frame and against its per-pixel proxy map (aocnet.py:255,325-337)
     radii = list(cfg.MODEL_MULTI_LOCAL_DISTANCE)
@@ -284,6 +298,8 @@ def proto_mask_features(cfg, ref_emb, ref_labels, prev_emb, prev_labels, cur_emb
     # ---- previous-frame mask channel (aocnet.py:356 to_cat_previous_frame)
     feat[:, ch["prev_mask"]].copy_(prev_labels.permute(2, 0, 1))
 
+    if dense_done is not None:
+        torch.cuda.current_stream().wait_event(dense_done)           # join: channel 0 (dense) is complete
     # ---- background maps, AEM:9-23 (aocnet.py:349-353)
     if cfg.MODEL_MATCHING_BACKGROUND and O > 1:
         ops.fg2bg_min(base[ch["local"] * hw:], O, out=base[ch["local_bg"] * hw:], dis_obj_stride=obj_stride, out_obj_stride=obj_stride,
