@@ -307,6 +307,13 @@ int aoc_label_mix(const float *labels, const float *rows, int64_t n, int n_obj, 
 /* Global average pool of planes [planes, hw] -> [planes]  (CLB:68). */
 int aoc_plane_mean(const float *x, int64_t planes, int64_t hw, float *out, aoc_stream_t stream);
 
+/* conditioning_block codes in one launch, CLB:68-80: code[n] = [ W1 gap[n] + b1 | W2 (sum_m px[m] - px[n]) + b2 | W3 head[n] + b3 ]
+ * with gap [N, C] (aoc_cond_gate_pool), px = plane means [N, C] (aoc_plane_mean), head [N, D]; W1, W2 [C, C], W3 [D, D] are
+ * the mlp_layer weights of CL_1..CL_3 (row-major [out, in]); code [N, 2C + D] feeds aoc_film_scale. */
+int aoc_cond_codes(const float *gap, const float *plane_means, const float *head, const float *w1, const float *b1,
+                   const float *w2, const float *b2, const float *w3, const float *b3, int N, int C, int D,
+                   float *code, aoc_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Decoder-side streams next to the FiLM gates.
  *

@@ -49,9 +49,13 @@ class conditioning_block(nn.Module):
 
     def forward(self, x, proxy_IA_head):
         px1 = ops.plane_mean(x)                                              # CLB:68
-        x_delta = px1.sum(dim=0, keepdim=True) - px1                         # CLB:69 ([O, C] glue)
-        cl_out_1 = self.CL_1(x)                                              # CLB:72 intra-object code
-        cl_out_2 = self.CL_2(x_delta)                                        # CLB:75 inter-object code
-        cl_out_3 = self.CL_3(proxy_IA_head)                                  # CLB:78 proxy code
-        code = torch.cat([cl_out_1, cl_out_2, cl_out_3], dim=1)
+        beta_rank = int(self.CL_1.beta_percentage * x.size()[-1] * x.size()[-2])       # CL:32
+        if beta_rank < 1:
+            raise IndexError("conditioning_layer: beta_rank == 0 (the reference fails at beta_val[..., -1])")
+        gap = ops.cond_gate_pool(x, self.CL_1.phi_layer.weight.detach().reshape(-1), self.CL_1.phi_layer.bias.detach(), beta_rank)   # CLB:72 / CL:28-45
+        # CLB:69 (inter-object delta), the three mlp_layer products (CLB:72-78, CL:46) and the concatenation (CLB:80) in one launch
+        code = ops.cond_codes(gap, px1, proxy_IA_head,
+                              self.CL_1.mlp_layer.weight.detach(), self.CL_1.mlp_layer.bias.detach(),
+                              self.CL_2.mlp_layer.weight.detach(), self.CL_2.mlp_layer.bias.detach(),
+                              self.CL_3.mlp_layer.weight.detach(), self.CL_3.mlp_layer.bias.detach())
         return ops.film_scale(x, code, self.mlp_layer.weight.detach(), self.mlp_layer.bias.detach())   # CLB:81-84

@@ -467,6 +467,36 @@ __global__ __launch_bounds__(256) void object_logit_kernel(const float *__restri
     out[(size_t)n * hw + p] = s + bias[(size_t)n * bias_stride];
 }
 
+// conditioning_block codes in one launch (CLB:68-80): code[n] = [ W1 gap[n] + b1 | W2 (sum_m px[m] - px[n]) + b2 | W3 head[n] + b3 ]
+// (the three mlp_layer products, the inter-object delta of CLB:69 and the concatenation of CLB:80); one wave per output
+__global__ __launch_bounds__(64) void cond_codes_kernel(const float *__restrict__ gap, const float *__restrict__ px, const float *__restrict__ head,
+                                                         const float *__restrict__ w1, const float *__restrict__ b1, const float *__restrict__ w2,
+                                                         const float *__restrict__ b2, const float *__restrict__ w3, const float *__restrict__ b3,
+                                                         int N, int C, int D, float *__restrict__ code) {
+    const int o = blockIdx.x, n = blockIdx.y;
+    const int out_dim = 2 * C + D;
+    float acc = 0.0f, bias;
+    if (o < C) {
+        const float *xr = gap + (size_t)n * C, *wr = w1 + (size_t)o * C;
+        for (int d = threadIdx.x; d < C; d += 64) acc += xr[d] * wr[d];
+        bias = b1[o];
+    } else if (o < 2 * C) {
+        const float *wr = w2 + (size_t)(o - C) * C;
+        for (int d = threadIdx.x; d < C; d += 64) {
+            float tot = 0.0f;
+            for (int m = 0; m < N; ++m) tot += px[(size_t)m * C + d];          // CLB:69 px1.sum(dim=0) - px1
+            acc += (tot - px[(size_t)n * C + d]) * wr[d];
+        }
+        bias = b2[o - C];
+    } else {
+        const float *xr = head + (size_t)n * D, *wr = w3 + (size_t)(o - 2 * C) * D;
+        for (int d = threadIdx.x; d < D; d += 64) acc += xr[d] * wr[d];
+        bias = b3[o - 2 * C];
+    }
+    acc = aoc_wave_sum(acc);
+    if (threadIdx.x == 0) code[(size_t)n * out_dim + o] = acc + bias;
+}
+
 inline int pool_chunks(int64_t hw) { return (int)((hw + MP_PIX - 1) / MP_PIX); }
 
 }  // namespace
@@ -577,6 +607,16 @@ int aoc_label_mix(const float *labels, const float *rows, int64_t n, int n_obj, 
 int aoc_plane_mean(const float *x, int64_t planes, int64_t hw, float *out, aoc_stream_t stream) {
     if (!x || !out || planes < 1 || hw < 1) return AOC_ERR_INVALID_ARG;
     hipLaunchKernelGGL(plane_mean_kernel, dim3((unsigned)planes), dim3(256), 0, aoc_hip_stream(stream), x, hw, out);
+    AOC_RETURN_IF_LAUNCH_FAILED();
+    return AOC_OK;
+}
+
+int aoc_cond_codes(const float *gap, const float *plane_means, const float *head, const float *w1, const float *b1, const float *w2,
+                   const float *b2, const float *w3, const float *b3, int N, int C, int D, float *code, aoc_stream_t stream) {
+    if (!gap || !plane_means || !head || !w1 || !b1 || !w2 || !b2 || !w3 || !b3 || !code || N < 1 || C < 1 || D < 1) return AOC_ERR_INVALID_ARG;
+    if (N > 65535) return AOC_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(cond_codes_kernel, dim3(2 * C + D, N), dim3(64), 0, aoc_hip_stream(stream), gap, plane_means, head, w1, b1, w2, b2, w3, b3, N, C, D,
+                       code);
     AOC_RETURN_IF_LAUNCH_FAILED();
     return AOC_OK;
 }

@@ -481,3 +481,15 @@ def object_logit(x, weight_bias):
     _lib.check(_lib.lib().aoc_object_logit(_p(x), N, C, H * W, ctypes.c_void_p(base), C + 1, ctypes.c_void_p(base + 4 * C), C + 1, _p(out), _stream()),
                "aoc_object_logit")
     return out
+
+
+def cond_codes(gap, plane_means, head, w1, b1, w2, b2, w3, b3):
+    """aoc_cond_codes: the three conditioning codes of CLB:68-80 concatenated -> [N, 2C + D]."""
+    gap, plane_means, head = _f32c(gap), _f32c(plane_means), _f32c(head)
+    _need_gpu(gap, plane_means, head, w1, w2, w3)
+    N, C = gap.shape
+    D = head.shape[1]
+    code = torch.empty(N, 2 * C + D, dtype=torch.float32, device=gap.device)
+    _lib.check(_lib.lib().aoc_cond_codes(_p(gap), _p(plane_means), _p(head), _p(_f32c(w1)), _p(_f32c(b1)), _p(_f32c(w2)), _p(_f32c(b2)), _p(_f32c(w3)),
+                                         _p(_f32c(b3)), N, C, D, _p(code), _stream()), "aoc_cond_codes")
+    return code
