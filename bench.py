@@ -402,7 +402,11 @@ def main():
         arr = (ctypes.c_uint32 * words)(*mask)
         handle = ctypes.c_void_p()
         rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(handle), ctypes.c_uint32(words), arr)
-        assert rc == 0, f"hipExtStreamCreateWithCUMask failed: {rc}"
+        if rc != 0 or not handle.value:
+            print(f"bench: hipExtStreamCreateWithCUMask failed ({rc}); running without the CU reservation", file=sys.stderr)
+            args.cu_reserve = 0
+            os.environ.pop("AOC_DENSE_CUS", None)
+            return torch.cuda.Stream(device=dev)
         return torch.cuda.ExternalStream(handle.value, device=dev)
 
     if args.mask_main:
