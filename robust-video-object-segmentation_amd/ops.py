@@ -27,9 +27,16 @@ def _p(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
 
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_RAW_DEVICE = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def _stream():
-    # raw hipStream_t of torch's current stream (the private getters skip ~8 us of Stream-object construction per call)
-    return ctypes.c_void_p(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
+    # raw hipStream_t of torch's current stream (the private getters skip ~8 us of Stream-object construction per call;
+    # the public API is the fallback when a torch build does not have them)
+    if _RAW_STREAM is not None and _RAW_DEVICE is not None:
+        return ctypes.c_void_p(_RAW_STREAM(_RAW_DEVICE()))
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
 def _f32c(t):
