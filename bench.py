@@ -171,37 +171,40 @@ class ClipWorkload:
         return self.pool_emb[:self.R], self.pool_lab[:self.R]
 
     def pretouch(self, gates, acts, dense_precision, pipeline):
-        """Setup, not a benchmark step: one frame at the LARGEST pool size, so that torch's caching allocator already owns
-        blocks of every size the clip will ask for (otherwise each pool growth inside the timed region calls hipMalloc,
-        which synchronises the device).  The pool is filled with copies of frame 0 for this; reset() restores it."""
+        """Setup, not a benchmark step: one frame at EVERY pool size the clip will reach, largest first, so that torch's
+        caching allocator already owns a block for every request of the timed region (otherwise each pool growth calls
+        hipMalloc, which synchronises the device).  The pool is filled with copies of frame 0 for this; reset() restores it."""
         rmax = self.pool_emb.shape[0]
         self.pool_emb[:] = self.emb[0]
         self.pool_lab[:] = self.lab[0]
-        self.R, self.t = rmax, self.T - 1
-        self.pool_event = torch.cuda.Event()
-        self.pool_event.record()
-        self.ahead.clear()
-        ref_emb, ref_lab = self.refs()
-        counts = [int((self.lab_ids[0] == o).sum()) * rmax for o in range(self.cfg.n_obj)]
-        rows = syn.kmeans_init_rows(12345, counts, self.mc.CLUSTER_NUM)
-        init = np.zeros((self.cfg.n_obj, self.mc.CLUSTER_NUM), np.int32)
-        for o, r in enumerate(rows):
-            if r is not None:
-                init[o, :len(r)] = r
-        init = torch.from_numpy(init).to(self.dev)
-        if self.side is not None and pipeline:
-            inits = [init] * max(1, self.chains - 1)
-            ahead = hotpath.launch_cluster_proxies(self.mc, ref_emb, ref_lab, init, self.side, wait_event=self.pool_event)
-            if self.chains > 1:
-                hotpath.launch_cluster_proxies_batch(self.mc, ref_emb, ref_lab, inits, self.side, wait_event=self.pool_event)
-            feat, head, _ = hotpath.proto_mask_features(self.mc, ref_emb, ref_lab, self.emb[1], self.lab[1], self.emb[2], self.bias,
-                                                        cluster_ahead=ahead, dense_state=self.dense_state, dense_precision=dense_precision)
-        else:
-            feat, head, _ = hotpath.proto_mask_features(self.mc, ref_emb, ref_lab, self.emb[1], self.lab[1], self.emb[2], self.bias,
-                                                        cluster_state=dict(init_rows=init), side_stream=self.side,
-                                                        dense_state=self.dense_state, dense_precision=dense_precision)
-        gates(acts, head)
-        torch.cuda.synchronize()
+        for R in range(rmax, 0, -1):
+            self.R, self.t = R, self.T - 1
+            self.pool_event = torch.cuda.Event()
+            self.pool_event.record()
+            self.ahead.clear()
+            self.dense_state["frames"] = 0
+            self.dense_state.pop("ref_pool", None)
+            ref_emb, ref_lab = self.refs()
+            counts = [int((self.lab_ids[0] == o).sum()) * R for o in range(self.cfg.n_obj)]
+            rows = syn.kmeans_init_rows(12345, counts, self.mc.CLUSTER_NUM)
+            init = np.zeros((self.cfg.n_obj, self.mc.CLUSTER_NUM), np.int32)
+            for o, r in enumerate(rows):
+                if r is not None:
+                    init[o, :len(r)] = r
+            init = torch.from_numpy(init).to(self.dev)
+            if self.side is not None and pipeline:
+                ahead = hotpath.launch_cluster_proxies(self.mc, ref_emb, ref_lab, init, self.side, wait_event=self.pool_event)
+                for nb in range(2, self.chains):               # batched chains of every size the run can ask for
+                    hotpath.launch_cluster_proxies_batch(self.mc, ref_emb, ref_lab, [init] * nb, self.side, wait_event=self.pool_event)
+                feat, head, _ = hotpath.proto_mask_features(self.mc, ref_emb, ref_lab, self.emb[1], self.lab[1], self.emb[2], self.bias,
+                                                            cluster_ahead=ahead, dense_state=self.dense_state, dense_precision=dense_precision,
+                                                            dense_stream=self.dense_stream)
+            else:
+                feat, head, _ = hotpath.proto_mask_features(self.mc, ref_emb, ref_lab, self.emb[1], self.lab[1], self.emb[2], self.bias,
+                                                            cluster_state=dict(init_rows=init), side_stream=self.side,
+                                                            dense_state=self.dense_state, dense_precision=dense_precision)
+            gates(acts, head)
+            torch.cuda.synchronize()
         self.ahead.clear()
         self.reset()
 
