@@ -130,3 +130,27 @@ def test_mask_iou_sums():
     assert n == 3 and abs(s - (1.0 + 0.5 + 2 / 3)) < 1e-9
     s, n = sh.mask_iou_sums(a, a, 4)                                   # absent object: empty vs empty counts as 1
     assert s == 4.0
+
+
+def test_c_abi_rejects_bad_arguments_without_a_gpu():
+    """Status codes of the C ABI (include/aoc_hip.h: aoc_status) for calls that fail validation before any launch:
+    these run on the CPU-only container as well (no kernel is launched)."""
+    import ctypes
+    L = aoc_amd._lib.lib()
+    vp = ctypes.c_void_p
+    dummy = (ctypes.c_float * 16)()
+    p = ctypes.cast(dummy, vp)
+    INVALID, WORKSPACE, UNSUPPORTED = -1, -2, -4
+    # null pointers / negative sizes
+    assert L.aoc_fg2bg_min(None, 3, 1, 10, 10, p, 10, None) == INVALID
+    assert L.aoc_plane_mean(p, 0, 10, p, None) == INVALID
+    assert L.aoc_linear(p, p, p, 1, 0, 4, p, None) == INVALID
+    assert L.aoc_confident_labels(p, 40, 8, 0, None, 0.5, p, p, p, None) == UNSUPPORTED          # more than 32 channels
+    assert L.aoc_proxy_corr_min(p, 16, 6, p, p, 4, 1, p, p, p, p, p, 1, 1, None) == UNSUPPORTED   # C not a multiple of 4
+    # workspace too small is reported, not overrun
+    assert L.aoc_dense_match_workspace_bytes(100, 50, 3) > 0
+    i32 = (ctypes.c_int32 * 4)()
+    ip = ctypes.cast(i32, vp)
+    assert L.aoc_dense_match_min(p, 100, 100, p, ip, ip, 50, ip, p, 3, p, 1, 100, 1, p, 16, None) == WORKSPACE
+    assert L.aoc_split_record_bytes(100) == 448 and L.aoc_split_record_bytes(104) == 0 and L.aoc_split_record_bytes(98) == 0
+    assert L.aoc_dense_match_workspace_bytes(0, 5, 3) == 0
