@@ -633,8 +633,9 @@ def main():
             "host_enqueue_ms_per_step": round(host_enqueue_s / args.steps * 1e3, 3),
             "roofline": roofline, "roofline_correlation_kernel": corr_roof, "roofline_kmeans_chain": km_roof, "cpu_baseline": cpu, "parity": parity, "kernels": kernels,
         }
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
     if world > 1:
+        torch.distributed.barrier()                        # the other ranks wait for rank 0's report before tearing down
         torch.distributed.destroy_process_group()
 
 
