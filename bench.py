@@ -156,12 +156,15 @@ class ClipWorkload:
         self.pool_event = None                             # recorded after the last change of the pool
         self.chains = mc.MEM_EVERY                         # k-means chains enqueued ahead (bench --chains)
         self.dense_stream = None                           # CU-masked stream for the dense kernel alone
+        self.reuse_proxies = False                         # non-parity mode: one k-means per pool state
+        self.cached_ahead = None
         self.reset()
 
     def reset(self):
         self.t, self.R = 1, 1
         self.dense_state["frames"] = 0
         self.dense_state.pop("ref_pool", None)
+        self.cached_ahead = None
         self.pool_emb[0].copy_(self.emb[0])
         self.pool_lab[0].copy_(self.lab[0])
         self.pool_event = torch.cuda.Event()
@@ -233,10 +236,16 @@ def frame_step(wl, gates, acts, dense_precision="split", pipeline=True):
         # the k-means chain of a frame only depends on the pool (which changes every MEM_EVERY frames): the chains of all
         # frames that will see the same pool are enqueued on side streams right after the pool update and run under the
         # other work of the frames before them
-        if t not in wl.ahead:
-            launch_chains(wl)
-        ahead = wl.ahead.pop(t)
-        if t % wl.mc.MEM_EVERY != 0 and t + 1 < wl.T and (t + 1) not in wl.ahead:
+        if wl.reuse_proxies and wl.cached_ahead is not None and wl.cached_ahead.R == wl.R:
+            # NON-PARITY mode: the adaptive proxies computed for this pool are reused until the pool changes,
+            # instead of re-clustering the unchanged pool with fresh initial rows for every frame like the reference
+            ahead = wl.cached_ahead
+        else:
+            if t not in wl.ahead:
+                launch_chains(wl)
+            ahead = wl.ahead.pop(t)
+            wl.cached_ahead = ahead if wl.reuse_proxies else None
+        if not wl.reuse_proxies and t % wl.mc.MEM_EVERY != 0 and t + 1 < wl.T and (t + 1) not in wl.ahead:
             # the next frame sees the same pool: its chain goes onto the side stream now, behind this frame's chain, and
             # does not wait for anything this frame still has to do on the main stream
             wl.ahead[t + 1] = hotpath.launch_cluster_proxies(wl.mc, ref_emb, ref_lab, wl.init_rows[t + 1][0], wl.side, wait_event=wl.pool_event)
@@ -249,7 +258,7 @@ def frame_step(wl, gates, acts, dense_precision="split", pipeline=True):
                                                     dense_state=wl.dense_state, dense_precision=dense_precision)
     outs = gates(acts, head)
     wl.advance()                                           # pool append / sequence restart happen here (after the frame's outputs)
-    if wl.side is not None and pipeline and wl.t not in wl.ahead:
+    if wl.side is not None and pipeline and wl.t not in wl.ahead and not (wl.reuse_proxies and wl.cached_ahead is not None and wl.cached_ahead.R == wl.R):
         launch_chains(wl)
     return feat, outs
 
@@ -359,6 +368,9 @@ def main():
     ap.add_argument("--dense-stream", dest="mask_main", action="store_false",
                     help="put only the dense kernel under the CU mask (on its own stream) instead of the whole main stream "
                          "(measured slower: the unmasked light kernels then take the reserved CUs from the k-means chains)")
+    ap.add_argument("--reuse-proxies", action="store_true",
+                    help="NON-PARITY mode (SURVEY 8f-3): cluster the pool once per pool update instead of once per frame; the JSON "
+                         "line then says so in config.proxy_mode and is not comparable with the default")
     ap.add_argument("--no-dense-order", action="store_true",
                     help="do not order the sequences' dense kernels explicitly (their live timing then includes queueing behind each other)")
     ap.add_argument("--no-pipeline", action="store_true",
@@ -388,7 +400,8 @@ def main():
     # sequences are sharded over ranks: rank r owns sequences r*n_streams .. (+n_streams)
     workloads = [ClipWorkload(cfg, seed=1 + rank * n_streams + s, device=dev, mc=mc, overlap=not args.no_overlap) for s in range(n_streams)]
     for wl in workloads:
-        wl.chains = max(1, min(args.chains, mc.MEM_EVERY))
+        wl.chains = 1 if args.reuse_proxies else max(1, min(args.chains, mc.MEM_EVERY))
+        wl.reuse_proxies = args.reuse_proxies
     acts = make_activations(gates, cfg.n_obj, cfg.h, cfg.w, dev, seed=7)
     def make_main_stream():
         """Main stream of one sequence.  With --cu-reserve N its workgroups are kept off N of the 256 CUs (HIP CU mask), so
@@ -628,6 +641,8 @@ def main():
                                                 "(right after the previous frame's memory update)")),
                        "cu_reserve": (f"main streams masked off {args.cu_reserve} of 256 CUs (hipExtStreamCreateWithCUMask), left to the side-stream "
                                       "k-means chains" if args.cu_reserve > 0 else "none"),
+                       "proxy_mode": ("NON-PARITY: adaptive proxies reused until the pool changes (one k-means per MEM_EVERY frames)"
+                                      if args.reuse_proxies else "reference: the pool is re-clustered for every frame with that frame's initial rows"),
                        "dense_precision": ("fp16-split products (hi*hi + hi*lo + lo*hi), fp32 accumulate: fp32-equivalent; exact-fp32 take-over "
                                            "on overflow / soft labels" if args.dense == "split" else "exact fp32 MFMA")},
             "host_enqueue_ms_per_step": round(host_enqueue_s / args.steps * 1e3, 3),

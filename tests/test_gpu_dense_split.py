@@ -185,3 +185,52 @@ def test_batched_cluster_chains_equal_single_chains(aoc):
     for b, s in zip(batch, singles):
         assert torch.equal(b.table[:n], s.table[:n])
         assert torch.equal(b.sqn[:n], s.sqn[:n])
+
+
+def test_reused_proxies_accuracy(aoc):
+    """NON-PARITY mode: adaptive proxies computed once for a pool and reused for later frames that see the
+    same pool, instead of re-clustering with fresh initial rows.  The cluster channels then differ from the reference's by
+    construction -- exactly as two runs of the reference with different numpy seeds differ from each other.  The check:
+    every other channel is identical, and the reused proxies disagree with a fresh clustering no more than two fresh
+    clusterings (different initial rows) disagree with each other (object decision from the nearest-proxy channel, and
+    mean absolute feature difference)."""
+    syn, hot = aoc.synthetic, aoc.hotpath
+    cfg = syn.CONFIGS["cfg1"]
+    clip = syn.make_clip(cfg, 5, frames=6)
+    emb = torch.from_numpy(clip["emb"]).cuda()
+    lab = torch.from_numpy(np.stack([syn.one_hot(l, cfg.n_obj) for l in clip["lab"]])).cuda()
+    mc = hot.MatchingConfig()
+    bias = torch.zeros(cfg.n_obj, device="cuda")
+    side = torch.cuda.Stream()
+    ch = hot.channel_slices(mc)
+    counts = [int((clip["lab"][0] == o).sum()) for o in range(cfg.n_obj)]
+
+    def init_for(seed):
+        rows = syn.kmeans_init_rows(seed, counts, 16)
+        init = np.zeros((cfg.n_obj, 16), np.int32)
+        for o, r in enumerate(rows):
+            if r is not None:
+                init[o, :len(r)] = r
+        return torch.from_numpy(init).cuda()
+
+    def features(t, handle):
+        f, _, _ = hot.proto_mask_features(mc, emb[:1], lab[:1], emb[t - 1], lab[t - 1], emb[t], bias, cluster_ahead=handle)
+        torch.cuda.synchronize()
+        return f
+
+    cached = hot.launch_cluster_proxies(mc, emb[:1], lab[:1], init_for(1), side)
+    c0 = ch["cluster"]
+    dec = lambda f: f[:, c0].argmin(0)
+    agree_cached, agree_fresh, diff_cached, diff_fresh = [], [], [], []
+    for t in range(2, 6):
+        f_a = features(t, hot.launch_cluster_proxies(mc, emb[:1], lab[:1], init_for(10 + t), side))
+        f_b = features(t, hot.launch_cluster_proxies(mc, emb[:1], lab[:1], init_for(20 + t), side))
+        f_c = features(t, cached)
+        other = [i for i in range(f_a.shape[1]) if i not in (c0, c0 + 1)]
+        assert torch.equal(f_a[:, other], f_c[:, other])
+        agree_fresh.append(float((dec(f_a) == dec(f_b)).float().mean()))
+        agree_cached.append(float((dec(f_a) == dec(f_c)).float().mean()))
+        diff_fresh.append(float((f_a[:, c0:c0 + 2] - f_b[:, c0:c0 + 2]).abs().mean()))
+        diff_cached.append(float((f_a[:, c0:c0 + 2] - f_c[:, c0:c0 + 2]).abs().mean()))
+    assert np.mean(agree_cached) >= np.mean(agree_fresh) - 0.03, (agree_cached, agree_fresh)
+    assert np.mean(diff_cached) <= 1.25 * np.mean(diff_fresh) + 1e-4, (diff_cached, diff_fresh)
