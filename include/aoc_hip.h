@@ -307,6 +307,16 @@ int aoc_label_mix(const float *labels, const float *rows, int64_t n, int n_obj, 
 /* Global average pool of planes [planes, hw] -> [planes]  (CLB:68). */
 int aoc_plane_mean(const float *x, int64_t planes, int64_t hw, float *out, aoc_stream_t stream);
 
+/* DynamicPreHead, decoding_module.py:228-240 (1x1 convolution n_in -> n_out, GroupNorm(n_groups), ReLU) applied to the
+ * [n_obj, n_in, hw] proto-mask tensor, fused with the concatenation of aocnet.py:362: out [n_obj, C + n_out, hw] holds the
+ * current-frame embedding emb_hwc [hw, C] (expanded over the objects, transposed to channel-first) in channels [0, C) and the
+ * pre-head output in channels [C, C + n_out) -- the tensor CalibrationDecoding consumes.  emb_hwc may be NULL with C = 0.
+ * weight [n_out, n_in], bias / gamma / beta [n_out]; GroupNorm statistics (biased variance) are reduced in a fixed order. */
+size_t aoc_prehead_workspace_bytes(int n_obj, int n_out, int group_size, int64_t hw);
+int aoc_prehead(const float *feat, int n_obj, int n_in, int64_t hw, const float *weight, const float *bias, int n_out,
+                int n_groups, const float *gamma, const float *beta, float eps, const float *emb_hwc, int C, float *out,
+                void *workspace, size_t workspace_bytes, aoc_stream_t stream);
+
 /* conditioning_block codes in one launch, CLB:68-80: code[n] = [ W1 gap[n] + b1 | W2 (sum_m px[m] - px[n]) + b2 | W3 head[n] + b3 ]
  * with gap [N, C] (aoc_cond_gate_pool), px = plane means [N, C] (aoc_plane_mean), head [N, D]; W1, W2 [C, C], W3 [D, D] are
  * the mlp_layer weights of CL_1..CL_3 (row-major [out, in]); code [N, 2C + D] feeds aoc_film_scale. */

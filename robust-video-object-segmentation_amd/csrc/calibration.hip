@@ -497,6 +497,96 @@ __global__ __launch_bounds__(64) void cond_codes_kernel(const float *__restrict_
     if (threadIdx.x == 0) code[(size_t)n * out_dim + o] = acc + bias;
 }
 
+// ------------------------------------------------------------------------------------------
+// DynamicPreHead (decoding_module.py:228-240: 1x1 conv -> GroupNorm -> ReLU on the [O, 24, h, w] proto-mask tensor) fused with
+// the concatenation of aocnet.py:362 (current-frame embedding || pre-head output -> [O, C + E, h, w]).
+constexpr int PH_MAX_IN = 32, PH_MAX_OUT = 128, PH_PIX = 256;
+// pass 1: per (object, pixel chunk) partial sums of y and y^2 per GroupNorm group (y = W x + b), in double
+__global__ __launch_bounds__(PH_PIX) void prehead_stats_kernel(const float *__restrict__ feat, int n_in, int64_t hw, const float *__restrict__ w,
+                                                                const float *__restrict__ b, int n_out, int group_size, int n_chunks,
+                                                                double *__restrict__ partial) {
+    __shared__ float lw[PH_MAX_OUT * PH_MAX_IN + PH_MAX_OUT];
+    __shared__ double wred[PH_PIX / 64][2];
+    const int o = blockIdx.y;
+    for (int i = threadIdx.x; i < n_out * n_in; i += blockDim.x) lw[i] = w[i];
+    for (int i = threadIdx.x; i < n_out; i += blockDim.x) lw[n_out * n_in + i] = b[i];
+    __syncthreads();
+    const int64_t p = (int64_t)blockIdx.x * PH_PIX + threadIdx.x;
+    float x[PH_MAX_IN];
+#pragma unroll
+    for (int k = 0; k < PH_MAX_IN; ++k) x[k] = (k < n_in && p < hw) ? feat[((size_t)o * n_in + k) * hw + p] : 0.0f;
+    const int n_groups = n_out / group_size;
+    for (int g = 0; g < n_groups; ++g) {
+        float s1 = 0.0f, s2 = 0.0f;
+        for (int c = g * group_size; c < (g + 1) * group_size; ++c) {
+            float y = lw[n_out * n_in + c];
+#pragma unroll
+            for (int k = 0; k < PH_MAX_IN; ++k)
+                if (k < n_in) y = __builtin_fmaf(lw[c * n_in + k], x[k], y);
+            if (p < hw) { s1 += y; s2 += y * y; }
+        }
+        double d1 = (double)s1, d2 = (double)s2;
+        for (int off = 32; off > 0; off >>= 1) { d1 += __shfl_xor(d1, off); d2 += __shfl_xor(d2, off); }
+        if (aoc_lane() == 0) { wred[threadIdx.x >> 6][0] = d1; wred[threadIdx.x >> 6][1] = d2; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double t1 = 0.0, t2 = 0.0;
+            for (int wv = 0; wv < PH_PIX / 64; ++wv) { t1 += wred[wv][0]; t2 += wred[wv][1]; }
+            double *dst = partial + (((size_t)o * n_groups + g) * n_chunks + blockIdx.x) * 2;
+            dst[0] = t1; dst[1] = t2;
+        }
+        __syncthreads();
+    }
+}
+// pass 2: mean / rstd per (object, group) from the chunk partials (fixed order: deterministic)
+__global__ __launch_bounds__(64) void prehead_finalize_kernel(const double *__restrict__ partial, int n_chunks, double count, float eps,
+                                                               float *__restrict__ stats) {
+    const int og = blockIdx.x;
+    double t1 = 0.0, t2 = 0.0;
+    for (int c = threadIdx.x; c < n_chunks; c += 64) { t1 += partial[((size_t)og * n_chunks + c) * 2]; t2 += partial[((size_t)og * n_chunks + c) * 2 + 1]; }
+    for (int off = 32; off > 0; off >>= 1) { t1 += __shfl_xor(t1, off); t2 += __shfl_xor(t2, off); }
+    if (threadIdx.x == 0) {
+        const double mean = t1 / count;
+        double var = t2 / count - mean * mean;          // biased variance, like torch.nn.GroupNorm
+        if (var < 0.0) var = 0.0;
+        stats[og * 2] = (float)mean;
+        stats[og * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+}
+// pass 3: out[o, C + c, p] = relu((y - mean) * rstd * gamma_c + beta_c); out[o, k, p] = emb[p, k] for k < C
+__global__ __launch_bounds__(PH_PIX) void prehead_apply_kernel(const float *__restrict__ feat, int n_in, int64_t hw, const float *__restrict__ w,
+                                                                const float *__restrict__ b, int n_out, int group_size,
+                                                                const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                                const float *__restrict__ stats, const float *__restrict__ emb, int C,
+                                                                float *__restrict__ out) {
+    __shared__ float lw[PH_MAX_OUT * PH_MAX_IN + PH_MAX_OUT];
+    const int o = blockIdx.y;
+    for (int i = threadIdx.x; i < n_out * n_in; i += blockDim.x) lw[i] = w[i];
+    for (int i = threadIdx.x; i < n_out; i += blockDim.x) lw[n_out * n_in + i] = b[i];
+    __syncthreads();
+    const int64_t p = (int64_t)blockIdx.x * PH_PIX + threadIdx.x;
+    if (p >= hw) return;
+    float *dst = out + (size_t)o * (C + n_out) * hw + p;
+    if (emb) {
+        const float *e = emb + (size_t)p * C;
+        for (int k = 0; k < C; ++k) dst[(size_t)k * hw] = e[k];          // aocnet.py:188,362: the embedding, expanded over the objects
+    }
+    float x[PH_MAX_IN];
+#pragma unroll
+    for (int k = 0; k < PH_MAX_IN; ++k) x[k] = (k < n_in) ? feat[((size_t)o * n_in + k) * hw + p] : 0.0f;
+    const int n_groups = n_out / group_size;
+    for (int c = 0; c < n_out; ++c) {
+        float y = lw[n_out * n_in + c];
+#pragma unroll
+        for (int k = 0; k < PH_MAX_IN; ++k)
+            if (k < n_in) y = __builtin_fmaf(lw[c * n_in + k], x[k], y);
+        const int g = c / group_size;
+        const float mean = stats[((size_t)o * n_groups + g) * 2], rstd = stats[((size_t)o * n_groups + g) * 2 + 1];
+        const float v = (y - mean) * rstd * gamma[c] + beta[c];
+        dst[(size_t)(C + c) * hw] = v > 0.0f ? v : 0.0f;
+    }
+}
+
 inline int pool_chunks(int64_t hw) { return (int)((hw + MP_PIX - 1) / MP_PIX); }
 
 }  // namespace
@@ -607,6 +697,32 @@ int aoc_label_mix(const float *labels, const float *rows, int64_t n, int n_obj, 
 int aoc_plane_mean(const float *x, int64_t planes, int64_t hw, float *out, aoc_stream_t stream) {
     if (!x || !out || planes < 1 || hw < 1) return AOC_ERR_INVALID_ARG;
     hipLaunchKernelGGL(plane_mean_kernel, dim3((unsigned)planes), dim3(256), 0, aoc_hip_stream(stream), x, hw, out);
+    AOC_RETURN_IF_LAUNCH_FAILED();
+    return AOC_OK;
+}
+
+size_t aoc_prehead_workspace_bytes(int n_obj, int n_out, int group_size, int64_t hw) {
+    if (n_obj < 1 || n_out < 1 || group_size < 1 || hw < 1) return 0;
+    const size_t n_chunks = (size_t)((hw + PH_PIX - 1) / PH_PIX), n_groups = (size_t)(n_out / group_size);
+    return aoc_align_up((size_t)n_obj * n_groups * n_chunks * 2 * sizeof(double), 256) + aoc_align_up((size_t)n_obj * n_groups * 2 * sizeof(float), 256);
+}
+
+int aoc_prehead(const float *feat, int n_obj, int n_in, int64_t hw, const float *weight, const float *bias, int n_out, int n_groups,
+                const float *gamma, const float *beta, float eps, const float *emb_hwc, int C, float *out, void *workspace,
+                size_t workspace_bytes, aoc_stream_t stream) {
+    if (!feat || !weight || !bias || !gamma || !beta || !out || !workspace || n_obj < 1 || n_in < 1 || n_out < 1 || n_groups < 1 || hw < 1 || C < 0)
+        return AOC_ERR_INVALID_ARG;
+    if (n_in > PH_MAX_IN || n_out > PH_MAX_OUT || n_out % n_groups != 0 || n_obj > 65535 || (emb_hwc == nullptr && C != 0)) return AOC_ERR_UNSUPPORTED;
+    const int group_size = n_out / n_groups;
+    if (workspace_bytes < aoc_prehead_workspace_bytes(n_obj, n_out, group_size, hw)) return AOC_ERR_WORKSPACE;
+    hipStream_t st = aoc_hip_stream(stream);
+    const int n_chunks = (int)((hw + PH_PIX - 1) / PH_PIX);
+    double *partial = static_cast<double *>(workspace);
+    float *stats = reinterpret_cast<float *>(static_cast<char *>(workspace) + aoc_align_up((size_t)n_obj * n_groups * n_chunks * 2 * sizeof(double), 256));
+    hipLaunchKernelGGL(prehead_stats_kernel, dim3(n_chunks, n_obj), dim3(PH_PIX), 0, st, feat, n_in, hw, weight, bias, n_out, group_size, n_chunks, partial);
+    hipLaunchKernelGGL(prehead_finalize_kernel, dim3(n_obj * n_groups), dim3(64), 0, st, partial, n_chunks, (double)group_size * (double)hw, eps, stats);
+    hipLaunchKernelGGL(prehead_apply_kernel, dim3(n_chunks, n_obj), dim3(PH_PIX), 0, st, feat, n_in, hw, weight, bias, n_out, group_size, gamma, beta, stats,
+                       emb_hwc, C, out);
     AOC_RETURN_IF_LAUNCH_FAILED();
     return AOC_OK;
 }

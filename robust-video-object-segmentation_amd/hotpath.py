@@ -312,6 +312,24 @@ def proto_mask_features(cfg, ref_emb, ref_labels, prev_emb, prev_labels, cur_emb
     return feat, attention_head, dict(cluster=cp, prev_pos=prev_pos, ref_pos=ref_pos)
 
 
+class DynamicPreHead(nn.Module):
+    """decoding_module.py:228-240 (1x1 conv -> GroupNorm(embed_dim / 4) -> ReLU) on the HIP library, with the reference's
+    parameter names (``conv``, ``bn``).  ``forward(x)`` mirrors the reference; ``forward(x, cur_emb)`` also performs the
+    concatenation of aocnet.py:362 and returns the [O, C + embed_dim, h, w] tensor the decoder consumes."""
+
+    def __init__(self, in_dim=3, embed_dim=100, kernel_size=1):
+        super(DynamicPreHead, self).__init__()
+        if kernel_size != 1:
+            raise NotImplementedError("aoc_amd.DynamicPreHead: kernel_size 1 only (the reference's configs use the default)")
+        self.conv = nn.Conv2d(in_dim, embed_dim, kernel_size=kernel_size, stride=1, padding=int((kernel_size - 1) / 2))
+        self.bn = nn.GroupNorm(int(embed_dim / 4), embed_dim)
+        nn.init.kaiming_normal_(self.conv.weight, mode='fan_out', nonlinearity='relu')
+
+    def forward(self, x, cur_emb=None):
+        return ops.prehead(x, self.conv.weight.detach(), self.conv.bias.detach(), self.bn.num_groups, self.bn.weight.detach(),
+                           self.bn.bias.detach(), self.bn.eps, cur_emb)
+
+
 class CalibrationGates(nn.Module):
     """The ten IA gates and four conditioning blocks of CalibrationDecoding (decoding_module.py:22-84),
     with the reference's attribute names.  ``shapes(h, w)`` lists the activation each one modulates."""

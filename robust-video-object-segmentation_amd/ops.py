@@ -500,3 +500,23 @@ def cond_codes(gap, plane_means, head, w1, b1, w2, b2, w3, b3):
     _lib.check(_lib.lib().aoc_cond_codes(_p(gap), _p(plane_means), _p(head), _p(_f32c(w1)), _p(_f32c(b1)), _p(_f32c(w2)), _p(_f32c(b2)), _p(_f32c(w3)),
                                          _p(_f32c(b3)), N, C, D, _p(code), _stream()), "aoc_cond_codes")
     return code
+
+
+def prehead(feat, weight, bias, n_groups, gamma, beta, eps, emb_hwc=None):
+    """aoc_prehead: feat [O, n_in, h, w] -> [O, C + n_out, h, w] = (embedding expanded over the objects || ReLU(GN(conv1x1(feat))))."""
+    feat = _f32c(feat)
+    _need_gpu(feat, weight, bias, gamma, beta, emb_hwc)
+    O, n_in, h, w = feat.shape
+    weight = _f32c(weight).reshape(weight.shape[0], -1)
+    n_out = weight.shape[0]
+    assert weight.shape[1] == n_in, "DynamicPreHead runs with kernel_size = 1"
+    C = 0
+    if emb_hwc is not None:
+        emb_hwc = _f32c(emb_hwc)
+        C = emb_hwc.shape[-1]
+    L = _lib.lib()
+    out = torch.empty(O, C + n_out, h, w, dtype=torch.float32, device=feat.device)
+    ws = _ws(L.aoc_prehead_workspace_bytes(O, n_out, n_out // n_groups, h * w), feat.device)
+    _lib.check(L.aoc_prehead(_p(feat), O, n_in, h * w, _p(weight), _p(_f32c(bias)), n_out, int(n_groups), _p(_f32c(gamma)), _p(_f32c(beta)), float(eps),
+                             _p(emb_hwc), C, _p(out), _p(ws), ws.numel(), _stream()), "aoc_prehead")
+    return out

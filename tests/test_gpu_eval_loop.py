@@ -140,3 +140,25 @@ def test_ia_logit_vs_oracle(aoc):
         want = ocal.ia_logit(x, head, lin.weight, lin.bias)
     assert tuple(got.shape) == (N, 1, H, W)
     np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=1e-4, atol=2e-4)
+
+
+@pytest.mark.parametrize("O,h,w", [(4, 121, 213), (3, 17, 23)])
+def test_dynamic_prehead_vs_torch(aoc, O, h, w):
+    """hotpath.DynamicPreHead against the same torch modules the reference class is made of (decoding_module.py:228-240),
+    and the fused concatenation of aocnet.py:362."""
+    rng = np.random.RandomState(O)
+    x = torch.from_numpy(rng.uniform(-1, 1, (O, 24, h, w)).astype(np.float32))
+    emb = torch.from_numpy((np.maximum(rng.randn(h, w, 100), 0) * 0.3).astype(np.float32))
+    torch.manual_seed(0)
+    m = aoc.hotpath.DynamicPreHead(in_dim=24, embed_dim=64)
+    with torch.no_grad():
+        m.bn.weight.copy_(torch.from_numpy(rng.rand(64).astype(np.float32)) + 0.5)
+        m.bn.bias.copy_(torch.from_numpy(rng.randn(64).astype(np.float32)) * 0.2)
+        want = torch.relu(m.bn(m.conv(x)))                                   # the reference forward, on the CPU
+        mg = m.cuda()
+        got = mg(x.cuda()).cpu()
+        cat = mg(x.cuda(), emb.cuda()).cpu()
+    np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=1e-4, atol=2e-5)
+    assert tuple(cat.shape) == (O, 164, h, w)
+    assert torch.equal(cat[:, 100:], got)
+    assert torch.equal(cat[:, :100], emb.permute(2, 0, 1).unsqueeze(0).expand(O, -1, -1, -1))
