@@ -361,6 +361,7 @@ def main():
     ap.add_argument("--dense", default="split", choices=["split", "fp32"],
                     help="dense-matching arithmetic: fp16-split products with fp32 accumulate (fp32-equivalent) or exact-fp32 MFMA")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-exact-run", action="store_true", help="skip the informational second region with the exact-fp32 dense kernel")
     ap.add_argument("--cu-reserve", type=int, default=64,
                     help="keep the main streams off this many CUs (HIP CU mask) so the side-stream k-means chain always finds free CUs")
     ap.add_argument("--chains", type=int, default=3,
@@ -504,6 +505,26 @@ def main():
     metrics = sharding.allreduce_metrics(dict(frames=frames_local, objects=frames_local * (O - 1), gpu_seconds=elapsed), device=dev)
 
     probe_ms = timer.kernel_probe.elapsed_ms()
+
+    # second, informational region (N = 1 only): the same K steps with the exact-fp32 dense kernel (`--dense fp32`), so that the
+    # line also carries the figure of the all-fp32 arithmetic next to the headline
+    exact = None
+    if world == 1 and args.dense == "split" and not args.no_exact_run:
+        with torch.no_grad():
+            for wl in workloads:
+                wl.reset()
+                wl.ahead.clear()
+            saved = args.dense
+            args.dense = "fp32"
+            run_steps(min(args.warmup, 2))
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            run_steps(args.steps)
+            torch.cuda.synchronize()
+            e2 = time.perf_counter() - t1
+            args.dense = saved
+        exact = dict(value=round(args.steps * n_streams / e2, 3), unit="frames/s", ms_per_step=round(e2 / args.steps * 1e3, 4),
+                     note="same workload and steps with aoc_dense_match_min (v_mfma_f32_16x16x4_f32) instead of the fp16-split kernel")
     if rank == 0:
         summ = timer.summary()
         kernels = {}
@@ -646,6 +667,7 @@ def main():
                        "dense_precision": ("fp16-split products (hi*hi + hi*lo + lo*hi), fp32 accumulate: fp32-equivalent; exact-fp32 take-over "
                                            "on overflow / soft labels" if args.dense == "split" else "exact fp32 MFMA")},
             "host_enqueue_ms_per_step": round(host_enqueue_s / args.steps * 1e3, 3),
+            "exact_fp32_dense_run": exact,
             "roofline": roofline, "roofline_correlation_kernel": corr_roof, "roofline_kmeans_chain": km_roof, "cpu_baseline": cpu, "parity": parity, "kernels": kernels,
         }
         print(json.dumps(line), flush=True)
