@@ -361,7 +361,8 @@ def main():
     ap.add_argument("--dense", default="split", choices=["split", "fp32"],
                     help="dense-matching arithmetic: fp16-split products with fp32 accumulate (fp32-equivalent) or exact-fp32 MFMA")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-exact-run", action="store_true", help="skip the informational second region with the exact-fp32 dense kernel")
+    ap.add_argument("--exact-run", action="store_true",
+                    help="add an informational second region: the same K steps with the exact-fp32 dense kernel (reported as exact_fp32_dense_run)")
     ap.add_argument("--cu-reserve", type=int, default=64,
                     help="keep the main streams off this many CUs (HIP CU mask) so the side-stream k-means chain always finds free CUs")
     ap.add_argument("--chains", type=int, default=3,
@@ -509,7 +510,7 @@ def main():
     # second, informational region (N = 1 only): the same K steps with the exact-fp32 dense kernel (`--dense fp32`), so that the
     # line also carries the figure of the all-fp32 arithmetic next to the headline
     exact = None
-    if world == 1 and args.dense == "split" and not args.no_exact_run:
+    if world == 1 and args.dense == "split" and args.exact_run:
         with torch.no_grad():
             for wl in workloads:
                 wl.reset()
