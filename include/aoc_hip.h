@@ -86,6 +86,15 @@ int aoc_kmeans_replicate(const int32_t *rows, const int32_t *seg_offsets, const 
                          int64_t rows_capacity, int32_t *rows_out, int32_t *seg_offsets_out, int32_t *seg_k_out,
                          aoc_stream_t stream);
 
+/* The same with a cluster count per replica: replica f clusters with K = levels_host[f % n_levels], made sticky per replica from
+ * the segment sizes exactly like aoc_kmeans_plan (AEM:268).  This is the multi-level configuration (BASELINE.json configs[2],
+ * K in {8, 16, 32}; the reference's `cluster_num` argument, AEM:231-232, one call per level): n_rep = frames x levels replicas
+ * advance in ONE aoc_kmeans_segmented_ex chain with kmax = max level.  n_levels <= 8.  n_rep == 1 with rows_out == rows only
+ * writes seg_offsets_out / seg_k_out. */
+int aoc_kmeans_replicate_levels(const int32_t *rows, const int32_t *seg_offsets, int n_seg, int n_rep,
+                                const int32_t *levels_host, int n_levels, int64_t rows_capacity, int32_t *rows_out,
+                                int32_t *seg_offsets_out, int32_t *seg_k_out, aoc_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Segmented Lloyd k-means, bit-identical to scipy.cluster.vq.kmeans2(X, K, minit='matrix',
  * iter=iters) as called at AEM:276 (one "segment" = one object's rows; all segments advance in

@@ -98,8 +98,9 @@ def conditioning_block(x, proxy_ia_head, p, beta_percentage=0.3):
 
 
 def gct_forward(x, alpha, gamma, beta, epsilon=1e-5, mode="l2", after_relu=False):
-    """networks/layers/gct.py:17-36 restated (the file itself imports a module the reference does not ship, so it cannot
-    be imported: PARITY UNPINNED for this function).  x [N, C, H, W]; alpha/gamma/beta [1, C, 1, 1]."""
+    """networks/layers/gct.py:17-36 restated.  Pinned by tests/golden/gct_*.npz, produced by the real ``GCT`` class
+    (tests/golden/make_golden_r2.py registers empty stand-in modules for the ``networks.p2t`` import the file makes).
+    x [N, C, H, W]; alpha/gamma/beta [1, C, 1, 1]."""
     if mode == "l2":
         embedding = (x.pow(2).sum((2, 3), keepdim=True) + epsilon).pow(0.5) * alpha
         norm = gamma / (embedding.pow(2).mean(dim=1, keepdim=True) + epsilon).pow(0.5)
@@ -112,7 +113,8 @@ def gct_forward(x, alpha, gamma, beta, epsilon=1e-5, mode="l2", after_relu=False
 
 
 def ia_logit(x, IA_head, weight, bias):
-    """decoding_module.py:151-160 restated: IA_final = Linear(head_dim, C + 1) given by (weight, bias)."""
+    """decoding_module.py:151-160 restated: IA_final = Linear(head_dim, C + 1) given by (weight, bias).
+    Pinned by tests/golden/ia_logit.npz (the reference method itself, make_golden_r2.py)."""
     import torch.nn.functional as F
     n, c, h, w = x.size()
     xv = x.reshape(1, n * c, h, w)
@@ -120,3 +122,38 @@ def ia_logit(x, IA_head, weight, bias):
     IA_weight = IA_output[:, :c].reshape(n, c, 1, 1)
     IA_bias = IA_output[:, -1].reshape(-1)
     return F.conv2d(xv, weight=IA_weight, bias=IA_bias, groups=n).view(n, 1, h, w)
+
+
+def augment_background_logit(fg_logit, bg_logit):
+    """decoding_module.py:211-223: the background object's logit is raised by the minimum of the foreground objects'
+    relative-background logits.  fg_logit, bg_logit [N, 1, H, W] -> [1, N, H, W]."""
+    n = fg_logit.size(0)
+    pred = fg_logit
+    if n > 1:
+        aug, _ = torch.min(bg_logit[1:n], dim=0, keepdim=True)
+        pred = pred + torch.cat([aug, torch.zeros_like(aug).expand(n - 1, -1, -1, -1)], dim=0)
+    return pred.permute(1, 0, 2, 3)
+
+
+def dynamic_prehead(x, conv_w, conv_b, gn_w, gn_b, groups, eps=1e-5):
+    """decoding_module.py:228-240: 1x1 conv -> GroupNorm(embed_dim / 4) -> ReLU.  Pinned by tests/golden/dynamic_prehead.npz."""
+    import torch.nn.functional as F
+    y = F.conv2d(x, conv_w.reshape(conv_w.shape[0], -1, 1, 1), conv_b)
+    return F.relu(F.group_norm(y, int(groups), gn_w, gn_b, float(eps)))
+
+
+def bottleneck(x, p, stride=1, dilation=1, groups=32, eps=1e-5, gct_eps=1e-5):
+    """networks/layers/gct.py:38-90 (the decoder's residual block): GCT -> conv1x1 -> GN -> ReLU -> conv3x3 -> GN -> ReLU ->
+    conv1x1 -> GN -> (+ residual, optionally conv1x1 + GN) -> ReLU.  ``p`` = the module's state_dict.  Pinned by
+    tests/golden/bottleneck_64_128.npz.  Returns (out, stage1) with stage1 = ReLU(GN(conv1(GCT(x)))) (gct.py:69-72)."""
+    import torch.nn.functional as F
+    out = gct_forward(x, p["GCT1.alpha"], p["GCT1.gamma"], p["GCT1.beta"], gct_eps)
+    out = F.relu(F.group_norm(F.conv2d(out, p["conv1.weight"]), groups, p["bn1.weight"], p["bn1.bias"], eps))
+    stage1 = out
+    out = F.conv2d(out, p["conv2.weight"], stride=stride, dilation=dilation, padding=dilation)
+    out = F.relu(F.group_norm(out, groups, p["bn2.weight"], p["bn2.bias"], eps))
+    out = F.group_norm(F.conv2d(out, p["conv3.weight"]), groups, p["bn3.weight"], p["bn3.bias"], eps)
+    res = x
+    if "downsample.0.weight" in p:
+        res = F.group_norm(F.conv2d(x, p["downsample.0.weight"], stride=stride), groups, p["downsample.1.weight"], p["downsample.1.bias"], eps)
+    return F.relu(out + res), stage1

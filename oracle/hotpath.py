@@ -12,16 +12,21 @@ from . import matching as om
 
 
 def proto_mask_features(ref_emb, ref_labels, prev_emb, prev_labels, cur_emb, dis_bias, multi_local_distance=(2, 4, 6, 8, 10, 12),
-                        epsilon=1e-5, matching_background=True, init_rows=None):
+                        epsilon=1e-5, matching_background=True, init_rows=None, cluster_levels=None):
     """ref_emb [R,h,w,C], ref_labels [R,h,w,O] one-hot float, prev_emb/cur_emb [h,w,C], prev_labels [h,w,O].
-    Returns (features [O, 24, h, w], attention_head [O, 4C])."""
+    Returns (features [O, 24, h, w], attention_head [O, 4C]).  ``cluster_levels`` (e.g. (8, 16, 32), BASELINE.json
+    configs[2]) runs the adaptive-proxy branch once per level and concatenates the 2-channel results in level order
+    (22 + 2 * levels channels); ``init_rows`` is then a list per level."""
     R, h, w, C = ref_emb.shape
     O = ref_labels.shape[-1]
     refs = [ref_emb[i] for i in range(R)]
     labs = [ref_labels[i] for i in range(R)]
     bias = dis_bias.reshape(-1)
     g_fg = om.global_matching_for_eval(refs, cur_emb, labs, 4, bias)                               # aocnet.py:196
-    g_cl = om.global_matching_for_eval_cluster(refs, cur_emb, labs, 4, bias, init_rows=init_rows)  # aocnet.py:242
+    if cluster_levels is None:
+        g_cl = om.global_matching_for_eval_cluster(refs, cur_emb, labs, 4, bias, init_rows=init_rows)  # aocnet.py:242
+    else:
+        g_cl = om.global_matching_for_eval_cluster(refs, cur_emb, labs, 4, bias, init_rows=init_rows, cluster_num=list(cluster_levels))
     l_fg = om.local_matching(prev_emb, cur_emb, prev_labels, bias, list(multi_local_distance))     # aocnet.py:255
     ref_e = [e.permute(2, 0, 1).unsqueeze(0) for e in refs]
     ref_l = [l.permute(2, 0, 1).unsqueeze(1) for l in labs]

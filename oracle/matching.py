@@ -145,12 +145,31 @@ def global_matching_for_eval(all_reference_embeddings, query_embeddings, all_ref
     return _finish(nn, h, w, obj_nums, _as_bias(dis_bias, obj_nums), ori_size)
 
 
+def _train_twin_labels(reference_labels, h, w, atrous_rate, atrous_obj_pixel_num):
+    """AEM:437-446 (== AEM:368-377, 648-657): the training twins mask the labels of every "big" object with the
+    atrous grid whenever atrous_rate > 1 (the reference writes into the caller's tensor; the oracle works on a clone)."""
+    if atrous_rate <= 1:
+        return reference_labels
+    h_pad = (atrous_rate - h % atrous_rate) % atrous_rate
+    w_pad = (atrous_rate - w % atrous_rate) % atrous_rate
+    sel = torch.zeros(h + h_pad, w + w_pad)
+    sel = sel.view((h + h_pad) // atrous_rate, atrous_rate, (w + w_pad) // atrous_rate, atrous_rate)
+    sel[:, 0, :, 0] = 1.
+    sel = sel.reshape(h + h_pad, w + w_pad, 1)[:h, :w]
+    labels = reference_labels.clone()
+    big = labels.sum(dim=(0, 1)) > (atrous_obj_pixel_num * atrous_rate ** 2)
+    labels[:, :, big] = labels[:, :, big] * sel
+    return labels
+
+
 def global_matching(reference_embeddings, query_embeddings, reference_labels,
                     n_chunks=100, dis_bias=0., ori_size=None, atrous_rate=1,
                     use_float16=False, atrous_obj_pixel_num=0):
-    """AEM:616-685 (training twin, single reference frame, fp32, atrous_rate 1)."""
-    assert not use_float16 and atrous_rate == 1
-    return global_matching_for_eval([reference_embeddings], query_embeddings, [reference_labels],
+    """AEM:616-685 (training twin, single reference frame, fp32)."""
+    assert not use_float16
+    h, w, _ = query_embeddings.size()
+    labels = _train_twin_labels(reference_labels, h, w, atrous_rate, atrous_obj_pixel_num)
+    return global_matching_for_eval([reference_embeddings], query_embeddings, [labels],
                                     n_chunks, dis_bias, ori_size, 1, False, 0)
 
 
@@ -220,9 +239,26 @@ def nearest_neighbor_features_cluster(ref_flat, query_flat, labels_flat, cluster
 def global_matching_for_eval_cluster(all_reference_embeddings, query_embeddings, all_reference_labels,
                                      n_chunks=20, dis_bias=0., ori_size=None, atrous_rate=1,
                                      use_float16=False, atrous_obj_pixel_num=0,
-                                     init_rows=None, rng=None, return_proxies=False):
-    """AEM:480-613 (fp32 path) -> [1, h, w, O, 2]   (all-background early-out: [1,h,w,O,1] ones)."""
+                                     init_rows=None, rng=None, return_proxies=False, cluster_num=DEFAULT_CLUSTER_NUM):
+    """AEM:480-613 (fp32 path) -> [1, h, w, O, 2]   (all-background early-out: [1,h,w,O,1] ones).
+
+    ``cluster_num`` is the ``cluster_num`` argument of AEM:231-232 (default 16).  A sequence of values restates the
+    multi-level configuration (BASELINE.json configs[2], K in {8, 16, 32}): the reference function is run once per
+    level, in order, on the same inputs (numpy's global RandomState is consumed level by level) and the [.., 2]
+    outputs are concatenated on the last axis -> [1, h, w, O, 2 * levels].  ``init_rows`` is then a list per level."""
     assert not use_float16, "oracle restates the fp32 path"
+    if isinstance(cluster_num, (list, tuple)):
+        outs, prox = [], []
+        for li, k in enumerate(cluster_num):
+            o, p = global_matching_for_eval_cluster(all_reference_embeddings, query_embeddings, all_reference_labels, n_chunks,
+                                                    dis_bias, ori_size, atrous_rate, use_float16, atrous_obj_pixel_num,
+                                                    None if init_rows is None else init_rows[li], rng, True, int(k))
+            outs.append(o)
+            prox.append(p)
+        if outs[0].shape[-1] == 1:                                             # nothing labelled: every level early-outs
+            return (outs[0], None) if return_proxies else outs[0]
+        out = torch.cat(outs, 4)
+        return (out, prox) if return_proxies else out
     h, w, embedding_dim = query_embeddings.size()
     obj_nums = all_reference_labels[0].size(2)
     ref_flat, labels_flat = _flatten_reference_pool(all_reference_embeddings, all_reference_labels,
@@ -233,7 +269,7 @@ def global_matching_for_eval_cluster(all_reference_embeddings, query_embeddings,
         out = torch.ones(1, h, w, obj_nums, 1)                            # AEM:588-589
         return (out, None) if return_proxies else out
     feats, proxies = nearest_neighbor_features_cluster(ref_flat, query_flat, labels_flat,
-                                                       DEFAULT_CLUSTER_NUM, init_rows, rng, True)
+                                                       int(cluster_num), init_rows, rng, True)
     bias = _as_bias(dis_bias, obj_nums)
     out = torch.cat([_finish(f, h, w, obj_nums, bias, ori_size) for f in feats], 4)   # AEM:599-612
     return (out, proxies) if return_proxies else out
@@ -258,16 +294,33 @@ def global_matching_for_eval_proxy(all_reference_embeddings, query_embeddings, a
 def global_matching_proxy(reference_embeddings, query_embeddings, reference_labels,
                           n_chunks=100, dis_bias=0., ori_size=None, atrous_rate=1,
                           use_float16=False, atrous_obj_pixel_num=0):
-    """AEM:336-402 (training twin; fp32, atrous_rate 1).  Early-out to ones when no reference
+    """AEM:336-402 (training twin; fp32).  Early-out to ones when no reference
     pixel is labelled (AEM:382-386)."""
-    assert not use_float16 and atrous_rate == 1
+    assert not use_float16
     h, w, embedding_dim = query_embeddings.size()
     obj_nums = reference_labels.size(2)
-    labels_flat = reference_labels.reshape(-1, obj_nums)
+    labels_flat = _train_twin_labels(reference_labels, h, w, atrous_rate, atrous_obj_pixel_num).reshape(-1, obj_nums)
     if int((labels_flat.sum(1) > 0.9).sum()) == 0:
         return torch.ones(1, h, w, obj_nums, 1)
     return global_matching_for_eval_proxy(reference_embeddings, query_embeddings, [reference_labels],
                                           n_chunks, dis_bias, ori_size, 1, False, 0)
+
+
+def global_matching_cluster(reference_embeddings, query_embeddings, reference_labels,
+                            n_chunks=100, dis_bias=0., ori_size=None, atrous_rate=1,
+                            use_float16=False, atrous_obj_pixel_num=0, init_rows=None, rng=None):
+    """AEM:405-478 == matching.py:1324-1405 ``global_matching_cluster2`` (training twin of the adaptive-proxy
+    matching; the AEM copy calls a name that only matching.py defines).  Differences from the eval form: labels of
+    big objects are masked with the atrous grid (AEM:437-446) and the nothing-labelled early-out has TWO channels
+    (AEM:455-456).  -> [1, h, w, O, 2]"""
+    assert not use_float16
+    h, w, _ = query_embeddings.size()
+    obj_nums = reference_labels.size(2)
+    labels = _train_twin_labels(reference_labels, h, w, atrous_rate, atrous_obj_pixel_num)
+    if int((labels.reshape(-1, obj_nums).sum(1) > 0.9).sum()) == 0:
+        return torch.ones(1, h, w, obj_nums, 2)
+    return global_matching_for_eval_cluster([reference_embeddings], query_embeddings, [labels], n_chunks, dis_bias,
+                                            ori_size, 1, False, 0, init_rows, rng)
 
 
 # --------------------------------------------------------------------------- a8

@@ -17,6 +17,7 @@ class IA_gate(nn.Module):
         self.IA = nn.Linear(in_dim, out_dim)
 
     def forward(self, x, IA_head):
+        ops.inference_only("IA_gate", x, IA_head, self.IA.weight, self.IA.bias)
         return ops.film_scale(x, IA_head, self.IA.weight.detach(), self.IA.bias.detach())   # ATT:13-16 in one launch
 
 
@@ -39,6 +40,7 @@ def _pool_inputs(embeddings, labels):
 
 def calculate_attention_head_for_eval_p_m(ref_embeddings, ref_labels, prev_embedding, prev_label, epsilon=1e-5):
     """ATT:155-189 -> (total_head [O,4C], ref_head_pos, ref_head_neg, prev_head_pos, prev_head_neg)."""
+    ops.inference_only("calculate_attention_head_for_eval_p_m", prev_embedding, *ref_embeddings)
     re, rl = _pool_inputs(ref_embeddings, ref_labels)
     ref_pos, ref_neg = ops.masked_mean_pool(re, rl, epsilon)
     pe, pl = _pool_inputs([prev_embedding], [prev_label])

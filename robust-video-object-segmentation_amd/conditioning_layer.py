@@ -28,6 +28,7 @@ class conditioning_layer(nn.Module):
         nn.init.kaiming_normal_(self.phi_layer.weight, mode='fan_out', nonlinearity='relu')
 
     def forward(self, z_in):
+        ops.inference_only("conditioning_layer", z_in, *self.parameters())
         if z_in.dim() == 2:                                   # vector input (conditioning_block repair)
             return ops.linear(z_in, self.mlp_layer.weight.detach(), self.mlp_layer.bias.detach())
         beta_rank = int(self.beta_percentage * z_in.size()[-1] * z_in.size()[-2])      # CL:32
@@ -48,6 +49,7 @@ class conditioning_block(nn.Module):
         self.mlp_layer = nn.Linear(in_dim * 2 + proxy_dim, in_dim)
 
     def forward(self, x, proxy_IA_head):
+        ops.inference_only("conditioning_block", x, proxy_IA_head, *self.parameters())
         px1 = ops.plane_mean(x)                                              # CLB:68
         beta_rank = int(self.CL_1.beta_percentage * x.size()[-1] * x.size()[-2])       # CL:32
         if beta_rank < 1:

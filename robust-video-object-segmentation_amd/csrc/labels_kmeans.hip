@@ -849,6 +849,28 @@ __global__ __launch_bounds__(256) void km_replicate_kernel(const int32_t *__rest
     if (i < n_seg) seg_k_out[f * n_seg + i] = seg_k[i];
 }
 
+// The same with a per-replica cluster count: replica f clusters at level klev.k[f % klev.n] (multi-level proxies, K in {8, 16, 32};
+// several frames x levels in one chain), with the sticky rule of AEM:268 applied per replica from the segment sizes.
+struct KmLevels {
+    int32_t k[8];
+    int32_t n;
+};
+__global__ __launch_bounds__(256) void km_replicate_levels_kernel(const int32_t *__restrict__ rows, const int32_t *__restrict__ seg_off,
+                                                                   int n_seg, int n_rep, KmLevels klev, int64_t capacity,
+                                                                   int32_t *__restrict__ rows_out, int32_t *__restrict__ seg_off_out,
+                                                                   int32_t *__restrict__ seg_k_out) {
+    const int64_t total = seg_off[n_seg];
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int f = blockIdx.y;
+    if (i < total && i < capacity && rows_out != rows) rows_out[f * total + i] = rows[i];
+    if (i <= n_seg && (i < n_seg || f == n_rep - 1)) seg_off_out[f * n_seg + i] = (int32_t)(f * total + seg_off[i]);
+    if (i < n_seg) {
+        int k = klev.k[f % klev.n];
+        for (int s = 0; s <= (int)i; ++s) k = min(k, seg_off[s + 1] - seg_off[s]);     // AEM:268, sticky
+        seg_k_out[f * n_seg + i] = k;
+    }
+}
+
 // rank + histogram from EXISTING labels (proxy construction after the last iteration)
 __global__ __launch_bounds__(256) void km_rank_only_kernel(const int32_t *__restrict__ seg_off, const int32_t *__restrict__ seg_k,
                                                             const int32_t *__restrict__ labels, int kmax, uint16_t *__restrict__ rank16,
@@ -1927,6 +1949,25 @@ int aoc_kmeans_replicate(const int32_t *rows, const int32_t *seg_offsets, const 
     const int64_t span = rows_capacity > n_seg + 1 ? rows_capacity : n_seg + 1;
     hipLaunchKernelGGL(km_replicate_kernel, dim3((unsigned)((span + 255) / 256), (unsigned)n_rep), dim3(256), 0, aoc_hip_stream(stream), rows, seg_offsets,
                        seg_k, n_seg, n_rep, rows_capacity, rows_out, seg_offsets_out, seg_k_out);
+    AOC_RETURN_IF_LAUNCH_FAILED();
+    return AOC_OK;
+}
+
+int aoc_kmeans_replicate_levels(const int32_t *rows, const int32_t *seg_offsets, int n_seg, int n_rep, const int32_t *levels_host, int n_levels,
+                                int64_t rows_capacity, int32_t *rows_out, int32_t *seg_offsets_out, int32_t *seg_k_out, aoc_stream_t stream) {
+    if (!rows || !seg_offsets || !levels_host || !rows_out || !seg_offsets_out || !seg_k_out) return AOC_ERR_INVALID_ARG;
+    if (n_seg < 1 || n_rep < 1 || n_levels < 1 || rows_capacity < 1 || (int64_t)n_rep * rows_capacity >= (1ll << 31)) return AOC_ERR_INVALID_ARG;
+    if (n_levels > 8) return AOC_ERR_UNSUPPORTED;
+    if (rows_out == rows && n_rep != 1) return AOC_ERR_INVALID_ARG;
+    KmLevels kl;
+    kl.n = n_levels;
+    for (int i = 0; i < 8; ++i) {
+        kl.k[i] = i < n_levels ? levels_host[i] : 0;
+        if (i < n_levels && (levels_host[i] < 0 || levels_host[i] > AOC_MAX_CLUSTERS)) return AOC_ERR_INVALID_ARG;
+    }
+    const int64_t span = rows_capacity > n_seg + 1 ? rows_capacity : n_seg + 1;
+    hipLaunchKernelGGL(km_replicate_levels_kernel, dim3((unsigned)((span + 255) / 256), (unsigned)n_rep), dim3(256), 0, aoc_hip_stream(stream), rows,
+                       seg_offsets, n_seg, n_rep, kl, rows_capacity, rows_out, seg_offsets_out, seg_k_out);
     AOC_RETURN_IF_LAUNCH_FAILED();
     return AOC_OK;
 }

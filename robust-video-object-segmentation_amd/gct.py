@@ -20,6 +20,7 @@ class GCT(nn.Module):
         self.after_relu = after_relu
 
     def forward(self, x):
+        ops.inference_only("GCT", x, self.alpha, self.gamma, self.beta)
         if self.mode == 'l2':
             sums = ops.plane_reduce(x, 1)                                   # gct.py:19
             l1 = False
@@ -35,5 +36,6 @@ class GCT(nn.Module):
 def IA_logit(x, IA_head, IA_final):
     """decoding_module.py:151-160: per-object 1x1 convolution whose C weights and bias come from ``IA_final(IA_head)``
     (an ``nn.Linear(head_dim, C + 1)``).  x [N, C, H, W] -> logit [N, 1, H, W]."""
+    ops.inference_only("IA_logit", x, IA_head, IA_final.weight, IA_final.bias)
     out = ops.linear(IA_head, IA_final.weight.detach(), IA_final.bias.detach())      # :154 [N, C + 1]
     return ops.object_logit(x, out)

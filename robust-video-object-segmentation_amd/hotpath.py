@@ -9,7 +9,7 @@ kernel writes straight into its channel slice of the [O, 24, h, w] buffer (aocne
 permutes and concatenates five tensors instead).
 """
 from dataclasses import dataclass, field
-from typing import List
+from typing import List, Optional
 
 import torch
 from torch import nn
@@ -34,22 +34,29 @@ class MatchingConfig:
     MODEL_FLOAT16_MATCHING: bool = False                         # :78
     MEM_EVERY: int = 5                                           # :17
     CLUSTER_NUM: int = DEFAULT_CLUSTER_NUM                       # AEM:232
+    CLUSTER_LEVELS: Optional[List[int]] = None                   # multi-level proxies (BASELINE.json configs[2]: [8, 16, 32]); None = [CLUSTER_NUM]
     BETA_PERCENTAGE: float = 0.3
 
     @property
+    def cluster_levels(self):
+        """The ``cluster_num`` values (AEM:232) the adaptive-proxy branch runs with, in channel order."""
+        return [int(k) for k in self.CLUSTER_LEVELS] if self.CLUSTER_LEVELS else [int(self.CLUSTER_NUM)]
+
+    @property
     def proto_channels(self):
-        """in_dim of DynamicPreHead, aocnet.py:43-46."""
+        """in_dim of DynamicPreHead, aocnet.py:43-46 (24 with one cluster level; every further level adds its 2 channels)."""
         n_local = len(self.MODEL_MULTI_LOCAL_DISTANCE)
-        c = 2 * (2 + n_local) - 1 + 2
+        c = 2 * (2 + n_local) - 1 + 2 + 2 * (len(self.cluster_levels) - 1)
         return c + (1 + n_local if self.MODEL_MATCHING_BACKGROUND else 0)
 
 
 # channel layout of the proto-mask tensor (aocnet.py:355-358)
 def channel_slices(cfg):
     n = len(cfg.MODEL_MULTI_LOCAL_DISTANCE)
-    s = dict(global_fg=0, cluster=1, proxy=3, local=4, local_proxy=4 + n, prev_mask=4 + 2 * n)
+    c2 = 2 * len(cfg.cluster_levels)                   # cluster channels: (centroid, centroid_avg) per level
+    s = dict(global_fg=0, cluster=1, proxy=1 + c2, local=2 + c2, local_proxy=2 + c2 + n, prev_mask=2 + c2 + 2 * n)
     if cfg.MODEL_MATCHING_BACKGROUND:
-        s.update(local_bg=5 + 2 * n, global_bg=5 + 3 * n)
+        s.update(local_bg=3 + c2 + 2 * n, global_bg=3 + c2 + 3 * n)
     return s
 
 
@@ -60,82 +67,75 @@ class ClusterProxiesAhead:
     __slots__ = ("prep", "table", "sqn", "prep_event", "done_event", "aux", "R")
 
 
-def launch_cluster_proxies(cfg, ref_emb, ref_labels, init_rows_dev, side_stream, wait_event=None):
-    """Label prep + sticky K + 20 Lloyd iterations + proxy construction (AEM:252-286) of the pool, enqueued on
-    `side_stream` without any host synchronisation.  `init_rows_dev` [O, K] int32 device tensor (rows drawn like scipy's
-    minit='points').  `wait_event`: the side stream first waits for it (e.g. the pool append of the previous frame).
-    Returns a ClusterProxiesAhead to pass to proto_mask_features(cluster_ahead=...)."""
-    R, h, w, C = ref_emb.shape
-    O = ref_labels.shape[-1]
-    hw = h * w
-    kmax = cfg.CLUSTER_NUM
-    dev = ref_emb.device
-    out = ClusterProxiesAhead()
-    out.R = R
-    with torch.cuda.stream(side_stream):
-        if wait_event is not None:
-            side_stream.wait_event(wait_event)
-        pool = ref_emb.reshape(R * hw, C)
-        out.table = torch.empty(O * 2 * kmax + O, C, dtype=torch.float32, device=dev)
-        out.sqn = torch.empty(O * 2 * kmax + O, dtype=torch.float32, device=dev)
-        out.prep = ops.label_prep(ref_labels.reshape(R * hw, O))
-        out.prep_event = torch.cuda.Event()
-        out.prep_event.record(side_stream)
-        seg_k = ops.kmeans_plan(out.prep.counts, O, kmax)
-        cen, lab, _ = ops.kmeans_segmented(pool, out.prep.obj_rows, out.prep.obj_offsets, seg_k, init_rows_dev, kmax, KMEANS_ITERS,
-                                           rows_capacity=out.prep.obj_rows.numel())
-        proxies, psq = ops.build_proxies(pool, out.prep.fg_rows, out.prep.obj_offsets, seg_k, lab, cen)
-        out.table[:O * 2 * kmax].copy_(proxies.reshape(-1, C))
-        out.sqn[:O * 2 * kmax].copy_(psq.reshape(-1))
-        out.done_event = torch.cuda.Event()
-        out.done_event.record(side_stream)
-    out.aux = dict(prep=out.prep, centroids=cen, labels=lab, proxies=proxies, proxy_sqnorm=psq, seg_k=seg_k)
-    return out
+def proxy_table_rows(cfg, n_obj):
+    """Rows of one frame's proxy table: levels x objects x (centroid | centroid_avg) x kmax adaptive proxies, then the n_obj k = 1 proxies."""
+    levels = cfg.cluster_levels
+    return len(levels) * n_obj * 2 * max(levels) + n_obj
 
 
-def launch_cluster_proxies_batch(cfg, ref_emb, ref_labels, init_rows_list, side_stream, wait_event=None):
-    """launch_cluster_proxies for several frames that see the same pool: their k-means chains (same rows, different
-    initial rows) advance together as n_frames * O segments of ONE chain, so each of the ~160 latency-bound launches does
-    the work of all frames.  Returns one ClusterProxiesAhead per entry of init_rows_list."""
+def launch_cluster_proxies_batch(cfg, ref_emb, ref_labels, init_rows_list, side_stream=None, wait_event=None):
+    """Label prep + sticky K + 20 Lloyd iterations + proxy construction (AEM:252-286) of the pool for len(init_rows_list) frames
+    that see the same pool, times len(cfg.cluster_levels) levels, enqueued on ``side_stream`` (None = the current stream) without
+    any host synchronisation.  All frames x levels x objects advance as segments of ONE k-means chain (same rows, different initial
+    rows and K), so each of the ~160 latency-bound launches does the work of all of them; results are bit-identical to separate calls.
+
+    init_rows_list  per frame: int32 device tensor [levels * O, kmax] of segment-local initial rows (level-major; rows drawn like
+                    scipy's minit='points': permutation(n_i)[:K_i])
+    wait_event      the side stream first waits for it (e.g. the pool append of the previous frame); None = it waits for everything
+                    enqueued so far on the caller's current stream (which produced the pool)
+    Returns one ClusterProxiesAhead per frame, to pass to proto_mask_features(cluster_ahead=...)."""
     F = len(init_rows_list)
-    if F == 1:
-        return [launch_cluster_proxies(cfg, ref_emb, ref_labels, init_rows_list[0], side_stream, wait_event)]
     R, h, w, C = ref_emb.shape
     O = ref_labels.shape[-1]
     hw = h * w
-    kmax = cfg.CLUSTER_NUM
+    levels = cfg.cluster_levels
+    L, kmax = len(levels), max(levels)
+    n_ad = L * O * 2 * kmax
     dev = ref_emb.device
+    main = torch.cuda.current_stream()
+    side = main if side_stream is None else side_stream
     outs = []
-    with torch.cuda.stream(side_stream):
-        if wait_event is not None:
-            side_stream.wait_event(wait_event)
+    with torch.cuda.stream(side):
+        if side is not main:
+            if wait_event is not None:
+                side.wait_event(wait_event)
+            else:
+                side.wait_stream(main)
+            # the inputs were allocated on the caller's stream: the caching allocator must not hand their blocks out again
+            # while this stream still reads them
+            for t in (ref_emb, ref_labels, *init_rows_list):
+                t.record_stream(side)
         pool = ref_emb.reshape(R * hw, C)
         prep = ops.label_prep(ref_labels.reshape(R * hw, O))
         prep_event = torch.cuda.Event()
-        prep_event.record(side_stream)
-        seg_k = ops.kmeans_plan(prep.counts, O, kmax)
+        prep_event.record(side)
         cap = prep.obj_rows.numel()
-        rows_f, off_f, k_f = ops.kmeans_replicate(prep.obj_rows, prep.obj_offsets, seg_k, F, rows_capacity=cap)
-        init = torch.cat([r.reshape(O, kmax) for r in init_rows_list], dim=0)
-        cen, lab, _ = ops.kmeans_segmented(pool, rows_f, off_f, k_f, init, kmax, KMEANS_ITERS, rows_capacity=F * cap)
-        proxies, psq = ops.build_proxies(pool, prep.fg_rows, off_f, k_f, lab, cen)          # [F*O, 2, K, C]
-        done = None
+        rows_f, off_f, k_f = ops.kmeans_replicate_levels(prep.obj_rows, prep.obj_offsets, O, F * L, levels, rows_capacity=cap)
+        init = init_rows_list[0] if F == 1 else torch.cat([r.reshape(L * O, kmax) for r in init_rows_list], dim=0)
+        cen, lab, _ = ops.kmeans_segmented(pool, rows_f, off_f, k_f, init.reshape(F * L * O, kmax), kmax, KMEANS_ITERS, rows_capacity=F * L * cap)
+        proxies, psq = ops.build_proxies(pool, prep.fg_rows, off_f, k_f, lab, cen)          # [F*L*O, 2, kmax, C]
         for f in range(F):
             out = ClusterProxiesAhead()
             out.R = R
             out.prep, out.prep_event = prep, prep_event
-            out.table = torch.empty(O * 2 * kmax + O, C, dtype=torch.float32, device=dev)
-            out.sqn = torch.empty(O * 2 * kmax + O, dtype=torch.float32, device=dev)
-            out.table[:O * 2 * kmax].copy_(proxies[f * O:(f + 1) * O].reshape(-1, C))
-            out.sqn[:O * 2 * kmax].copy_(psq[f * O:(f + 1) * O].reshape(-1))
-            out.aux = dict(prep=prep, centroids=cen[f * O:(f + 1) * O], proxies=proxies[f * O:(f + 1) * O], proxy_sqnorm=psq[f * O:(f + 1) * O],
-                           seg_k=seg_k, labels=None)
+            out.table = torch.empty(n_ad + O, C, dtype=torch.float32, device=dev)
+            out.sqn = torch.empty(n_ad + O, dtype=torch.float32, device=dev)
+            sl = slice(f * L * O, (f + 1) * L * O)
+            out.table[:n_ad].copy_(proxies[sl].reshape(-1, C))
+            out.sqn[:n_ad].copy_(psq[sl].reshape(-1))
+            out.aux = dict(prep=prep, centroids=cen[sl], proxies=proxies[sl], proxy_sqnorm=psq[sl], seg_k=k_f[sl], seg_offsets=off_f,
+                           labels=lab if F == 1 else None)
             outs.append(out)
         done = torch.cuda.Event()
-        done.record(side_stream)
+        done.record(side)
         for out in outs:
             out.done_event = done
     return outs
+
+
+def launch_cluster_proxies(cfg, ref_emb, ref_labels, init_rows_dev, side_stream=None, wait_event=None):
+    """launch_cluster_proxies_batch for one frame."""
+    return launch_cluster_proxies_batch(cfg, ref_emb, ref_labels, [init_rows_dev], side_stream, wait_event)[0]
 
 
 def proto_mask_features(cfg, ref_emb, ref_labels, prev_emb, prev_labels, cur_emb, dis_bias, init_rows=None,
@@ -146,8 +146,9 @@ def proto_mask_features(cfg, ref_emb, ref_labels, prev_emb, prev_labels, cur_emb
     ref_emb     [R, h, w, C]  reference pool (channel-last)          ref_labels [R, h, w, O] float one-hot
     prev_emb    [h, w, C]     previous frame embedding               prev_labels [h, w, O]
     cur_emb     [h, w, C]     current (query) frame embedding        dis_bias   [O] or [O,1,1,1]
-    init_rows   optional explicit k-means initial rows per object (else drawn like scipy from np.random)
-    cluster_state  optional dict with device tensors (seg_k, init_rows) for the host-sync-free pipeline
+    init_rows   optional explicit k-means initial rows per object (per level then per object with several cluster levels);
+                else drawn like scipy from np.random
+    cluster_state  optional dict with a device tensor ``init_rows`` [levels * O, kmax] for the host-sync-free pipeline
     side_stream  optional torch.cuda.Stream: the adaptive-proxy branch (k-means: a long chain of small,
                  latency-bound launches) runs there, concurrently with the MFMA-bound dense matching on the
                  current stream; the two join in front of the correlation launch.  Only with cluster_state.
@@ -161,6 +162,7 @@ def proto_mask_features(cfg, ref_emb, ref_labels, prev_emb, prev_labels, cur_emb
                  of other sequences) are not queued behind the one kernel that fills every CU it may use.
     cluster_ahead  a ClusterProxiesAhead of this frame's pool (launch_cluster_proxies): the adaptive proxies were
                  enqueued earlier on a side stream; this call only waits for them in front of the correlation launch.
+    With several cluster levels (cfg.CLUSTER_LEVELS) the cluster channels are (centroid, centroid_avg) per level, in level order.
     """
     R, h, w, C = ref_emb.shape
     O = ref_labels.shape[-1]
@@ -176,59 +178,43 @@ def proto_mask_features(cfg, ref_emb, ref_labels, prev_emb, prev_labels, cur_emb
     pool = ref_emb.reshape(R * hw, C)
     labels_flat = ref_labels.reshape(R * hw, O)
     query_flat = cur_emb.reshape(hw, C)
-    kmax = cfg.CLUSTER_NUM
+    levels = cfg.cluster_levels
+    L, kmax = len(levels), max(levels)
+    n_ad = L * O * 2 * kmax
 
     # ---- adaptive proxies (k-means, AEM:252-286) + k = 1 proxies (ATT:155-189) in ONE proxy table
+    main = torch.cuda.current_stream()
+    if cluster_ahead is None and cluster_state is not None:
+        # host-sync-free variant: the chain is enqueued here (on side_stream when given) and joined in front of the correlation launch
+        cluster_ahead = launch_cluster_proxies(cfg, ref_emb, ref_labels, cluster_state["init_rows"], side_stream)
     if cluster_ahead is not None:
         assert cluster_ahead.R == R, "cluster_ahead was launched for another pool size"
-        main = torch.cuda.current_stream()
         main.wait_event(cluster_ahead.prep_event)
         table, sqn, prep, cp = cluster_ahead.table, cluster_ahead.sqn, cluster_ahead.prep, cluster_ahead.aux
         for t in (table, sqn, prep.right_bits, prep.wrong_bits, prep.fg_rows, prep.obj_rows, prep.counts, prep.obj_offsets):
             t.record_stream(main)
     else:
-        table = torch.empty(O * 2 * kmax + O, C, dtype=torch.float32, device=dev)
-        sqn = torch.empty(O * 2 * kmax + O, dtype=torch.float32, device=dev)
-    if cluster_ahead is not None:
-        pass
-    elif cluster_state is None:
-        cp = cluster_proxies(pool, labels_flat, kmax, init_rows)
+        table = torch.empty(n_ad + O, C, dtype=torch.float32, device=dev)
+        sqn = torch.empty(n_ad + O, dtype=torch.float32, device=dev)
+        cp = cluster_proxies(pool, labels_flat, levels if cfg.CLUSTER_LEVELS else levels[0], init_rows)
         prep = cp["prep"] if cp is not None else ops.label_prep(labels_flat)
         if cp is not None:
-            table[:O * 2 * kmax].copy_(cp["proxies"].reshape(-1, C))
-            sqn[:O * 2 * kmax].copy_(cp["proxy_sqnorm"].reshape(-1))
+            table[:n_ad].copy_(cp["proxies"].reshape(-1, C))
+            sqn[:n_ad].copy_(cp["proxy_sqnorm"].reshape(-1))
         else:
-            sqn[:O * 2 * kmax].fill_(float("inf"))       # nothing labelled -> every cluster feature is 1
-    else:
-        # host-sync-free variant: sticky K on the device, explicit init rows, proxies written in place
-        prep = ops.label_prep(labels_flat)
-        main = torch.cuda.current_stream()
-        fork = side_stream is not None
-        if fork:
-            side_stream.wait_stream(main)
-        with torch.cuda.stream(side_stream if fork else main):
-            seg_k = ops.kmeans_plan(prep.counts, O, kmax)
-            cen, lab, _ = ops.kmeans_segmented(pool, prep.obj_rows, prep.obj_offsets, seg_k, cluster_state["init_rows"], kmax,
-                                               KMEANS_ITERS, rows_capacity=prep.obj_rows.numel())
-            proxies, psq = ops.build_proxies(pool, prep.fg_rows, prep.obj_offsets, seg_k, lab, cen)
-            table[:O * 2 * kmax].copy_(proxies.reshape(-1, C))
-            sqn[:O * 2 * kmax].copy_(psq.reshape(-1))
-        if fork:
-            for t in (seg_k, cen, lab, proxies, psq):
-                t.record_stream(main)
-        cp = dict(prep=prep, centroids=cen, labels=lab, proxies=proxies, proxy_sqnorm=psq)
+            sqn[:n_ad].fill_(float("inf"))       # nothing labelled -> every cluster feature is 1
 
     cached = dense_state.get("ref_pool") if dense_state is not None else None
     if cached is not None and cached[0] == R:
         # the pooled reference heads are a function of the pool alone (ATT:155-170): unchanged since the last frame
         _, ref_pos, ref_neg, ref_sq = cached
-        table[O * 2 * kmax:].copy_(ref_pos)
-        sqn[O * 2 * kmax:].copy_(ref_sq)
+        table[n_ad:].copy_(ref_pos)
+        sqn[n_ad:].copy_(ref_sq)
     else:
         ref_pos, ref_neg = ops.masked_mean_pool(ref_emb.reshape(R, hw, C), ref_labels.reshape(R, hw, O), cfg.MODEL_EPSILON, pixel_major=True,
-                                                out_pos=table[O * 2 * kmax:], out_pos_sqnorm=sqn[O * 2 * kmax:])
+                                                out_pos=table[n_ad:], out_pos_sqnorm=sqn[n_ad:])
         if dense_state is not None:
-            dense_state["ref_pool"] = (R, ref_pos.clone(), ref_neg, sqn[O * 2 * kmax:].clone())
+            dense_state["ref_pool"] = (R, ref_pos.clone(), ref_neg, sqn[n_ad:].clone())
     prev_pos, prev_neg = ops.masked_mean_pool(prev_emb.reshape(1, hw, C), prev_labels.reshape(1, hw, O), cfg.MODEL_EPSILON, pixel_major=True)
     attention_head = torch.cat([ref_pos, ref_neg, prev_pos, prev_neg], dim=1)          # ATT:188, [O, 4C]
 
@@ -277,22 +263,24 @@ def proto_mask_features(cfg, ref_emb, ref_labels, prev_emb, prev_labels, cur_emb
         lf = ops.local_window_match(q2, prev_map, bits2, radii, bias, O, True)        # [O, nl, H2, W2]
         ops.resize_bilinear_planes(lf.view(O * nl, H2, W2), h, w, base[ch[key] * hw:], hw, 1, inner_count=nl, out_outer_stride=obj_stride)
 
-    # ---- one correlation launch: cluster (2 sets / object) + k = 1 proxy (1 set / object), AEM:316-319 + matching.py:2653
-    set_begin, set_size, set_off, set_bias = [], [], [], []
+    # ---- one correlation launch: cluster (2 sets / object / level) + k = 1 proxy (1 set / object), AEM:316-319 + matching.py:2653
+    set_begin, set_size, set_off, set_obj = [], [], [], []
+    for l, k in enumerate(levels):
+        for o in range(O):
+            for f in range(2):
+                set_begin.append(((l * O + o) * 2 + f) * kmax)
+                set_size.append(k)                      # slots >= the sticky K carry norm = +inf and are ignored
+                set_off.append(o * obj_stride + (ch["cluster"] + 2 * l + f) * hw)
+                set_obj.append(o)
     for o in range(O):
-        for f in range(2):
-            set_begin.append((o * 2 + f) * kmax)
-            set_size.append(kmax)
-            set_off.append(o * obj_stride + (ch["cluster"] + f) * hw)
-    for o in range(O):
-        set_begin.append(O * 2 * kmax + o)
+        set_begin.append(n_ad + o)
         set_size.append(1)
         set_off.append(o * obj_stride + ch["proxy"] * hw)
-    set_bias = torch.cat([bias.repeat_interleave(2), bias])
+        set_obj.append(o)
+    set_bias = bias.repeat_interleave(2).repeat(L) if L > 1 else bias.repeat_interleave(2)
+    set_bias = torch.cat([set_bias, bias])
     if cluster_ahead is not None:
         torch.cuda.current_stream().wait_event(cluster_ahead.done_event)   # join: the proxy table is complete
-    elif cluster_state is not None and side_stream is not None:
-        torch.cuda.current_stream().wait_stream(side_stream)        # join: the proxy table is complete
     ops.proxy_corr_min(query_flat, table, sqn, set_begin, set_size, set_off, set_bias, feat, 1, True)
 
     # ---- previous-frame mask channel (aocnet.py:356 to_cat_previous_frame)
@@ -326,6 +314,7 @@ class DynamicPreHead(nn.Module):
         nn.init.kaiming_normal_(self.conv.weight, mode='fan_out', nonlinearity='relu')
 
     def forward(self, x, cur_emb=None):
+        ops.inference_only("DynamicPreHead", x, cur_emb, *self.parameters())
         return ops.prehead(x, self.conv.weight.detach(), self.conv.bias.detach(), self.bn.num_groups, self.bn.weight.detach(),
                            self.bn.bias.detach(), self.bn.eps, cur_emb)
 

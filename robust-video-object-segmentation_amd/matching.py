@@ -83,53 +83,76 @@ def _emit(feature_planes, h, w, n_planes_per_obj, obj_nums, ori_size):
 
 
 # ------------------------------------------------------------------------------------------ cluster path (a2-a5)
+def _level_list(cluster_num):
+    multi = isinstance(cluster_num, (list, tuple))
+    levels = [int(k) for k in cluster_num] if multi else [int(cluster_num)]
+    if not levels or min(levels) < 1:
+        raise ValueError("cluster_num must be a positive integer or a non-empty sequence of them")
+    return levels, multi
+
+
 def cluster_proxies(pool, labels_flat, cluster_num=DEFAULT_CLUSTER_NUM, init_rows=None, rng=None, iters=KMEANS_ITERS):
     """Adaptive-proxy construction, AEM:252-286, on the device.
 
+    ``cluster_num``: the reference's ``cluster_num`` argument (AEM:231-232), or a sequence of them = the multi-level
+    configuration (BASELINE.json configs[2], K in {8, 16, 32}): the reference function run once per level, in order; here all
+    levels x objects advance as segments of ONE k-means chain (kmax = the largest level).
+
     Returns None when no row is labelled (AEM:588-589) or a dict with
-      prep, seg_k (host list), init_rows (host list), centroids [O,K,C], labels (packed, per object
-      segment), cluster_counts [O,K], proxies [O,2,K,C], proxy_sqnorm [O,2,K], counts (host).
+      prep, levels, seg_k / init_rows (host lists per object; per level then per object for a sequence), seg_offsets (device,
+      [L*O+1]: where (level, object)'s packed labels start), centroids [L*O,kmax,C], labels (packed), cluster_counts [L*O,kmax],
+      proxies [L*O,2,kmax,C], proxy_sqnorm [L*O,2,kmax], counts (host).
     The only host round trip is the read-back of the O+1 row counts, which the reference's control
     flow needs anyway: sticky ``K_i = min(K_{i-1}, n_i)`` (AEM:268) and the rows scipy's
     ``minit='points'`` draws from numpy's global RandomState (``permutation(n_i)[:K_i]``).
     """
+    levels, multi = _level_list(cluster_num)
     prep = ops.label_prep(labels_flat)
     n_obj = prep.n_obj
     counts = prep.counts.cpu().numpy()
     if int(counts[n_obj]) == 0:
         return None
     rng = np.random if rng is None else rng
-    seg_k, rows_host, k = [], np.zeros((n_obj, cluster_num), np.int32), cluster_num
-    drawn = []
-    for i in range(n_obj):
-        k = min(k, int(counts[i]))                       # AEM:268 (sticky)
-        seg_k.append(k)
-        if k == 0:
-            drawn.append(None)
-            continue
-        if init_rows is not None and init_rows[i] is not None:
-            r = np.asarray(init_rows[i], np.int64)[:k]
-        else:
-            r = np.asarray(rng.permutation(int(counts[i]))[:k], np.int64)   # scipy vq.py:519 on RandomState
-        rows_host[i, :k] = r
-        drawn.append(r)
+    L, kmax = len(levels), max(levels)
+    rows_host = np.zeros((L * n_obj, kmax), np.int32)
+    seg_k, drawn = [], []
+    for li, k in enumerate(levels):
+        seg_k.append([])
+        drawn.append([])
+        given = None if init_rows is None else (init_rows[li] if multi else init_rows)
+        for i in range(n_obj):
+            k = min(k, int(counts[i]))                   # AEM:268 (sticky, per call = per level)
+            seg_k[li].append(k)
+            if k == 0:
+                drawn[li].append(None)
+                continue
+            if given is not None and given[i] is not None:
+                r = np.asarray(given[i], np.int64)[:k]
+            else:
+                r = np.asarray(rng.permutation(int(counts[i]))[:k], np.int64)   # scipy vq.py:519 on RandomState
+            rows_host[li * n_obj + i, :k] = r
+            drawn[li].append(r)
     dev = pool.device
-    seg_k_dev = torch.tensor(seg_k, dtype=torch.int32, device=dev)
+    cap = prep.obj_rows.numel()
     init_dev = torch.from_numpy(rows_host).to(dev)
-    centroids, labels, ccounts = ops.kmeans_segmented(pool, prep.obj_rows, prep.obj_offsets, seg_k_dev, init_dev,
-                                                      cluster_num, iters, rows_capacity=prep.obj_rows.numel())
-    proxies, sqnorm = ops.build_proxies(pool, prep.fg_rows, prep.obj_offsets, seg_k_dev, labels, centroids)
-    return dict(prep=prep, seg_k=seg_k, init_rows=drawn, centroids=centroids, labels=labels, cluster_counts=ccounts,
-                proxies=proxies, proxy_sqnorm=sqnorm, counts=counts)
+    rows, offs, seg_k_dev = ops.kmeans_replicate_levels(prep.obj_rows, prep.obj_offsets, n_obj, L, levels, rows_capacity=cap)
+    centroids, labels, ccounts = ops.kmeans_segmented(pool, rows, offs, seg_k_dev, init_dev, kmax, iters, rows_capacity=L * cap)
+    proxies, sqnorm = ops.build_proxies(pool, prep.fg_rows, offs, seg_k_dev, labels, centroids)
+    return dict(prep=prep, levels=levels, seg_k=seg_k if multi else seg_k[0], init_rows=drawn if multi else drawn[0], seg_offsets=offs,
+                centroids=centroids, labels=labels, cluster_counts=ccounts, proxies=proxies, proxy_sqnorm=sqnorm, counts=counts)
 
 
 def global_matching_for_eval_cluster(all_reference_embeddings, query_embeddings, all_reference_labels,
                                      n_chunks=20, dis_bias=0., ori_size=None, atrous_rate=1, use_float16=True,
-                                     atrous_obj_pixel_num=0, init_rows=None):
-    """AEM:480-613.  -> [1, H, W, O, 2]; [1, h, w, O, 1] of ones when no reference pixel is labelled."""
+                                     atrous_obj_pixel_num=0, init_rows=None, cluster_num=DEFAULT_CLUSTER_NUM):
+    """AEM:480-613.  -> [1, H, W, O, 2]; [1, h, w, O, 1] of ones when no reference pixel is labelled.
+    ``cluster_num`` (AEM:232; matching.py:1711 ``cluster_number``) may be a sequence of levels -> [1, H, W, O, 2 * levels]."""
+    ops.inference_only("global_matching_for_eval_cluster", query_embeddings, dis_bias, *all_reference_embeddings)
     h, w, embedding_dim = query_embeddings.size()
     obj_nums = all_reference_labels[0].size(2)
     dev = query_embeddings.device
+    levels, _ = _level_list(cluster_num)
+    L = len(levels)
     pool, labels_flat = _flatten_pool(all_reference_embeddings, all_reference_labels, h, w, atrous_rate, atrous_obj_pixel_num)
     if use_float16:
         # kmeans2 raises TypeError on float16 -> except -> constant 5e4 -> (sigmoid(5e4+b)-.5)*2 == 1
@@ -137,26 +160,56 @@ def global_matching_for_eval_cluster(all_reference_embeddings, query_embeddings,
         if not bool((right < 0).any()):                                   # bit 31 set <=> row kept
             return torch.ones(1, h, w, obj_nums, 1, device=dev)
         H, W = (h, w) if ori_size is None else ori_size
-        return torch.ones(1, H, W, obj_nums, 2, device=dev)
-    cp = cluster_proxies(pool, labels_flat, DEFAULT_CLUSTER_NUM, init_rows)
+        return torch.ones(1, H, W, obj_nums, 2 * L, device=dev)
+    cp = cluster_proxies(pool, labels_flat, cluster_num, init_rows)
     if cp is None:
         return torch.ones(1, h, w, obj_nums, 1, device=dev)               # AEM:588-589
     kmax = cp["proxies"].shape[2]
     query_flat = query_embeddings.reshape(-1, embedding_dim)
     bias = _bias_vec(dis_bias, obj_nums, dev)
-    planes = torch.empty(obj_nums * 2, h, w, dtype=torch.float32, device=dev)
-    n_set = 2 * obj_nums                                                   # set s = (object, centroid | centroid_avg)
-    ops.proxy_corr_min(query_flat, cp["proxies"].reshape(-1, embedding_dim), cp["proxy_sqnorm"].reshape(-1),
-                       [s * kmax for s in range(n_set)], [kmax] * n_set, [s * h * w for s in range(n_set)],
-                       bias.repeat_interleave(2), planes, 1, True)
-    return _emit(planes, h, w, 2, obj_nums, ori_size)
+    planes = torch.empty(obj_nums * 2 * L, h, w, dtype=torch.float32, device=dev)
+    # set (level l, object o, centroid | centroid_avg f) -> plane o * 2L + 2l + f   (the concatenation order of AEM:599-612, per level)
+    begin, size, off, sbias = [], [], [], []
+    for l, k in enumerate(levels):
+        for o in range(obj_nums):
+            for f in range(2):
+                begin.append(((l * obj_nums + o) * 2 + f) * kmax)
+                size.append(min(k, kmax))
+                off.append((o * 2 * L + 2 * l + f) * h * w)
+                sbias.append(o)
+    ops.proxy_corr_min(query_flat, cp["proxies"].reshape(-1, embedding_dim), cp["proxy_sqnorm"].reshape(-1), begin, size, off,
+                       bias[torch.tensor(sbias, device=dev)], planes, 1, True)
+    return _emit(planes, h, w, 2 * L, obj_nums, ori_size)
+
+
+def _train_twin_labels(reference_labels, h, w, atrous_rate, atrous_obj_pixel_num):
+    """AEM:437-446 (== 368-377, 648-657): the training twins mask the labels of every "big" object with the atrous grid
+    whenever atrous_rate > 1.  Works on a clone (the reference writes into the caller's tensor)."""
+    if atrous_rate <= 1:
+        return reference_labels
+    h_pad = (atrous_rate - h % atrous_rate) % atrous_rate
+    w_pad = (atrous_rate - w % atrous_rate) % atrous_rate
+    sel = torch.zeros((h + h_pad) // atrous_rate, atrous_rate, (w + w_pad) // atrous_rate, atrous_rate, device=reference_labels.device)
+    sel[:, 0, :, 0] = 1.
+    sel = sel.reshape(h + h_pad, w + w_pad, 1)[:h, :w]
+    labels = reference_labels.clone()
+    big = labels.sum(dim=(0, 1)) > (atrous_obj_pixel_num * atrous_rate ** 2)
+    labels[:, :, big] = labels[:, :, big] * sel
+    return labels
 
 
 def global_matching_cluster(reference_embeddings, query_embeddings, reference_labels,
                             n_chunks=100, dis_bias=0., ori_size=None, atrous_rate=1, use_float16=True, atrous_obj_pixel_num=0):
-    """AEM:405-478 / matching.py:506-640 (training twin; single reference frame)."""
-    return global_matching_for_eval_cluster([reference_embeddings], query_embeddings, [reference_labels], n_chunks,
-                                            dis_bias, ori_size, atrous_rate, use_float16, 0)
+    """AEM:405-478 / matching.py:1324-1405 (training twin; single reference frame): atrous label masking of big objects
+    (AEM:437-446) and a TWO-channel nothing-labelled early-out (AEM:455-456).  Inference only (no autograd graph)."""
+    assert reference_embeddings.size()[:2] == reference_labels.size()[:2]     # AEM:430
+    h, w, _ = query_embeddings.size()
+    obj_nums = reference_labels.size(2)
+    labels = _train_twin_labels(reference_labels, h, w, atrous_rate, atrous_obj_pixel_num)
+    out = global_matching_for_eval_cluster([reference_embeddings], query_embeddings, [labels], n_chunks, dis_bias, ori_size, 1, use_float16, 0)
+    if out.shape[-1] == 1:
+        return torch.ones(1, h, w, obj_nums, 2, device=query_embeddings.device)
+    return out
 
 
 global_matching_cluster2 = global_matching_cluster   # name imported by aocnet.py:6
@@ -166,6 +219,7 @@ global_matching_cluster2 = global_matching_cluster   # name imported by aocnet.p
 def global_matching_for_eval(all_reference_embeddings, query_embeddings, all_reference_labels,
                              n_chunks=20, dis_bias=0., ori_size=None, atrous_rate=1, use_float16=True, atrous_obj_pixel_num=0):
     """AEM:688-817.  -> [1, H, W, O, 1]; ones when nothing is labelled (AEM:796-797).  No host sync."""
+    ops.inference_only("global_matching_for_eval", query_embeddings, dis_bias, *all_reference_embeddings)
     if use_float16:
         raise NotImplementedError("aoc_amd: float16 matching is not implemented (MODEL_FLOAT16_MATCHING=False in all configs)")
     h, w, embedding_dim = query_embeddings.size()
@@ -185,20 +239,11 @@ def global_matching_for_eval(all_reference_embeddings, query_embeddings, all_ref
 
 def global_matching(reference_embeddings, query_embeddings, reference_labels,
                     n_chunks=100, dis_bias=0., ori_size=None, atrous_rate=1, use_float16=True, atrous_obj_pixel_num=0):
-    """AEM:616-685 (training twin)."""
+    """AEM:616-685 (training twin).  Inference only (no autograd graph)."""
     assert reference_embeddings.size()[:2] == reference_labels.size()[:2]     # AEM:641
-    if atrous_rate > 1:
-        h, w, _ = query_embeddings.size()
-        h_pad = (atrous_rate - h % atrous_rate) % atrous_rate
-        w_pad = (atrous_rate - w % atrous_rate) % atrous_rate
-        sel = torch.zeros(h + h_pad, w + w_pad, device=query_embeddings.device)
-        sel = sel.view((h + h_pad) // atrous_rate, atrous_rate, (w + w_pad) // atrous_rate, atrous_rate)
-        sel[:, 0, :, 0] = 1.
-        sel = sel.reshape(h + h_pad, w + w_pad, 1)[:h, :w]
-        reference_labels = reference_labels.clone()
-        big = reference_labels.sum(dim=(0, 1)) > (atrous_obj_pixel_num * atrous_rate ** 2)      # AEM:656-657
-        reference_labels[:, :, big] = reference_labels[:, :, big] * sel
-    return global_matching_for_eval([reference_embeddings], query_embeddings, [reference_labels], n_chunks,
+    h, w, _ = query_embeddings.size()
+    labels = _train_twin_labels(reference_labels, h, w, atrous_rate, atrous_obj_pixel_num)      # AEM:648-657
+    return global_matching_for_eval([reference_embeddings], query_embeddings, [labels], n_chunks,
                                     dis_bias, ori_size, 1, use_float16, 0)
 
 
@@ -207,6 +252,7 @@ def global_matching_for_eval_proxy(all_reference_embeddings, query_embeddings, a
                                    n_chunks=20, dis_bias=0., ori_size=None, atrous_rate=1, use_float16=True, atrous_obj_pixel_num=0):
     """matching.py:2518-2662 (the AEM:819-873 copy references undefined names).  ``all_reference_embeddings``
     is the [O, C] tensor of mean-pooled proxies (aocnet.py:314-315); out[i,o] = d(q_i, proxy_o).  -> [1,H,W,O,1]"""
+    ops.inference_only("global_matching_for_eval_proxy", query_embeddings, dis_bias, all_reference_embeddings)
     if use_float16:
         raise NotImplementedError("aoc_amd: float16 matching is not implemented")
     h, w, embedding_dim = query_embeddings.size()
@@ -226,6 +272,7 @@ def global_matching_proxy(reference_embeddings, query_embeddings, reference_labe
     """AEM:336-402 (training twin): ones when no reference pixel is labelled (AEM:382-386)."""
     h, w, _ = query_embeddings.size()
     obj_nums = reference_labels.size(2)
+    reference_labels = _train_twin_labels(reference_labels, h, w, atrous_rate, atrous_obj_pixel_num)   # AEM:368-377
     right, _ = ops.label_bits(reference_labels.reshape(-1, obj_nums), want_wrong=False)
     if not bool((right < 0).any()):
         return torch.ones(1, h, w, obj_nums, 1, device=query_embeddings.device)
@@ -237,6 +284,7 @@ def global_matching_proxy(reference_embeddings, query_embeddings, reference_labe
 def local_matching(prev_frame_embedding, query_embedding, prev_frame_labels, dis_bias=0., multi_local_distance=[15],
                    ori_size=None, atrous_rate=1, use_float16=True, allow_downsample=True, allow_parallel=True):
     """AEM:968-1060.  -> [1, H, W, O, len(multi_local_distance)], channel order [max, d_0, d_1, ...]."""
+    ops.inference_only("local_matching", prev_frame_embedding, query_embedding, dis_bias)
     if use_float16:
         raise NotImplementedError("aoc_amd: float16 matching is not implemented")
     if atrous_rate != 1:
@@ -276,4 +324,5 @@ def foreground2background(dis, obj_num):
     concatenates on).  dis [O, c, ...] -> [O, 1, ...]."""
     if obj_num == 1:
         return dis
+    ops.inference_only("foreground2background", dis)
     return ops.fg2bg_min(dis, obj_num)

@@ -23,6 +23,17 @@ def _need_gpu(*tensors):
                                    f"got a tensor on {t.device}")
 
 
+def inference_only(what, *tensors):
+    """The HIP kernels have no backward: every mirror returns tensors WITHOUT an autograd graph.  Dropping the reference's
+    training-time names (IA_gate, conditioning_block, GCT, global_matching, ...) into a training run would therefore train
+    nothing, silently.  Raise instead when autograd is recording and an input or parameter wants a gradient."""
+    if torch.is_grad_enabled():
+        for t in tensors:
+            if torch.is_tensor(t) and t.requires_grad:
+                raise _lib.AocHipError(f"aoc_amd.{what} is inference-only (no autograd graph is built): call it under torch.no_grad() "
+                                       "or detach its inputs; training must use the reference's PyTorch modules")
+
+
 def _p(t):
     return ctypes.c_void_p(t.data_ptr()) if t is not None else None
 
@@ -127,6 +138,21 @@ def kmeans_replicate(rows, seg_offsets, seg_k, n_rep, rows_capacity=None):
     k_out = torch.empty(n_rep * n_seg, dtype=torch.int32, device=dev)
     _lib.check(_lib.lib().aoc_kmeans_replicate(_p(rows), _p(seg_offsets), _p(seg_k), n_seg, int(n_rep), cap, _p(rows_out), _p(off_out), _p(k_out),
                                                _stream()), "aoc_kmeans_replicate")
+    return rows_out, off_out, k_out
+
+
+def kmeans_replicate_levels(rows, seg_offsets, n_seg, n_rep, levels, rows_capacity=None):
+    """aoc_kmeans_replicate_levels: n_rep replicas of the segment lists, replica f clustering at K = levels[f % len(levels)] with the
+    sticky rule of AEM:268 applied on the device -> (rows [n_rep*cap], seg_offsets [n_rep*S+1], seg_k [n_rep*S])."""
+    _need_gpu(rows, seg_offsets)
+    cap = int(rows.numel() if rows_capacity is None else rows_capacity)
+    dev = rows.device
+    lv = np.ascontiguousarray(np.asarray(levels, dtype=np.int32))
+    rows_out = rows if n_rep == 1 else torch.empty(n_rep * cap, dtype=torch.int32, device=dev)
+    off_out = torch.empty(n_rep * n_seg + 1, dtype=torch.int32, device=dev)
+    k_out = torch.empty(n_rep * n_seg, dtype=torch.int32, device=dev)
+    _lib.check(_lib.lib().aoc_kmeans_replicate_levels(_p(rows), _p(seg_offsets), int(n_seg), int(n_rep), lv.ctypes.data_as(ctypes.c_void_p), int(lv.size),
+                                                      cap, _p(rows_out), _p(off_out), _p(k_out), _stream()), "aoc_kmeans_replicate_levels")
     return rows_out, off_out, k_out
 
 

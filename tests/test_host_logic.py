@@ -154,3 +154,22 @@ def test_c_abi_rejects_bad_arguments_without_a_gpu():
     assert L.aoc_dense_match_min(p, 100, 100, p, ip, ip, 50, ip, p, 3, p, 1, 100, 1, p, 16, None) == WORKSPACE
     assert L.aoc_split_record_bytes(100) == 448 and L.aoc_split_record_bytes(104) == 0 and L.aoc_split_record_bytes(98) == 0
     assert L.aoc_dense_match_workspace_bytes(0, 5, 3) == 0
+
+
+def test_mirrors_refuse_to_run_under_autograd():
+    """the drop-in names include the reference's training-time ones; they build no autograd graph, so they must raise
+    (instead of silently training nothing) when a gradient is wanted."""
+    import aoc_amd
+    gate = aoc_amd.attention.IA_gate(8, 4)
+    x, head = torch.randn(2, 4, 3, 3), torch.randn(2, 8)
+    with pytest.raises(aoc_amd._lib.AocHipError, match="inference-only"):
+        gate(x, head)                                         # parameters require grad and autograd is on
+    blk = aoc_amd.conditioning_layer.conditioning_block(4, 8, 0.3)
+    with pytest.raises(aoc_amd._lib.AocHipError, match="inference-only"):
+        blk(x, head)
+    q = torch.randn(5, 6, 4, requires_grad=True)
+    with pytest.raises(aoc_amd._lib.AocHipError, match="inference-only"):
+        aoc_amd.matching.global_matching(torch.randn(5, 6, 4), q, torch.ones(5, 6, 2), 1, 0., None, 1, False, 0)
+    with torch.no_grad():                                     # under no_grad the guard passes and the missing GPU is what is reported
+        with pytest.raises(aoc_amd._lib.AocHipError, match="no CPU fallback"):
+            gate(x, head)

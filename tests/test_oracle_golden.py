@@ -180,3 +180,129 @@ def test_shannon_entropy_matches_reference_output(golden):
     # the frame decision with every label seen reduces to the same map
     _, _, unc = oe.frame_decision(torch.from_numpy(g["preds"]), list(range(g["preds"].shape[1])))
     np.testing.assert_array_equal(unc.numpy(), g["uncertainty"][0, 0])
+
+
+# ------------------------------------------------------------------------------------------ round-2 fixtures (make_golden_r2.py)
+def _check_km_calls(g, proxies_per_level):
+    """Every kmeans2 call the reference made, in call order (level-major, objects in order)."""
+    live = [p for lv in proxies_per_level for p in (lv or []) if p is not None]
+    assert len(live) == int(g["km_calls"])
+    for i, p in enumerate(live):
+        assert p["k"] == int(g[f"km{i}_k"]) and len(p["labels"]) == int(g[f"km{i}_n"])
+        assert np.array_equal(p["init_rows"], g[f"km{i}_rows"])
+        assert np.array_equal(p["labels"], g[f"km{i}_labels"])
+        assert np.array_equal(p["centroid"].numpy(), g[f"km{i}_centroid"])
+
+
+@pytest.mark.parametrize("name", ["cluster_K8_R1_O3", "cluster_K32_R2_O4", "cluster_levels_8_16_32_R2_O4", "cluster_levels_small_obj"])
+def test_cluster_levels(golden, name):
+    """cluster_num != 16 (AEM:232) and the multi-level K in {8, 16, 32} configuration (BASELINE.json configs[2])."""
+    g = golden(name)
+    refs, labs = _refs(g)
+    levels = [int(v) for v in g["levels"]]
+    np.random.seed(int(g["seed"]))
+    out, prox = om.global_matching_for_eval_cluster(refs, T(g["in_query"]), labs, 4, T(g["in_bias"]), None, return_proxies=True,
+                                                    cluster_num=levels if len(levels) > 1 else levels[0])
+    assert tuple(out.shape) == g["out"].shape and out.shape[-1] == 2 * len(levels)
+    np.testing.assert_allclose(out.numpy(), g["out"], **TOL)
+    _check_km_calls(g, prox if len(levels) > 1 else [prox])
+    if name == "cluster_levels_small_obj":      # object 1 has 12 pixels: K sticks at 12 from there on for the levels 16 and 32
+        assert [int(g[f"km{i}_k"]) for i in range(int(g["km_calls"]))] == [8, 8, 8, 16, 12, 12, 32, 12, 12]
+
+
+@pytest.mark.parametrize("name,fn", [("cluster_atrous2", "cluster"), ("cluster_atrous2_objpix", "cluster"), ("dense_atrous2", "dense"),
+                                     ("dense_atrous2_objpix", "dense"), ("dense_atrous3_even", "dense")])
+def test_atrous_pool_flattening(golden, name, fn):
+    """AEM:513-579 / 715-787 with atrous_rate > 1, with and without atrous_obj_pixel_num."""
+    g = golden(name)
+    refs, labs = _refs(g)
+    rate, objpix = int(g["atrous_rate"]), int(g["atrous_obj_pixel_num"])
+    np.random.seed(int(g["seed"]))
+    if fn == "cluster":
+        out, prox = om.global_matching_for_eval_cluster(refs, T(g["in_query"]), labs, 4, T(g["in_bias"]), None, rate, False, objpix, return_proxies=True)
+        _check_km_calls(g, [prox])
+    else:
+        out = om.global_matching_for_eval(refs, T(g["in_query"]), labs, 4, T(g["in_bias"]), None, rate, False, objpix)
+    assert tuple(out.shape) == g["out"].shape
+    np.testing.assert_allclose(out.numpy(), g["out"], **TOL)
+
+
+@pytest.mark.parametrize("name", ["dense_train_twin_atrous2", "cluster_train_twin", "cluster_train_twin_atrous2", "cluster_train_twin_unlabelled"])
+def test_training_twins(golden, name):
+    """AEM:616-685 with atrous label masking, and matching.py:1324 global_matching_cluster2 (two-channel early-out)."""
+    g = golden(name)
+    rate, objpix = int(g["atrous_rate"]), int(g["atrous_obj_pixel_num"])
+    np.random.seed(int(g["seed"]))
+    args = (T(g["in_ref"][0]), T(g["in_query"]), T(g["lab_onehot"][0].copy()), 3, T(g["in_bias"]), None, rate, False, objpix)
+    out = om.global_matching(*args) if name.startswith("dense") else om.global_matching_cluster(*args)
+    assert tuple(out.shape) == g["out"].shape
+    np.testing.assert_allclose(out.numpy(), g["out"], **TOL)
+    if name == "cluster_train_twin_unlabelled":
+        assert g["out"].shape[-1] == 2 and np.all(g["out"] == 1.0)          # AEM:455-456
+
+
+@pytest.mark.parametrize("name,mode,relu", [("gct_l2", "l2", False), ("gct_l1", "l1", False), ("gct_l1_relu", "l1", True)])
+def test_gct_vs_reference_class(golden, name, mode, relu):
+    g = golden(name)
+    sh = (1, -1, 1, 1)
+    y = ocal.gct_forward(T(g["in_x"]), T(g["in_alpha"]).view(sh), T(g["in_gamma"]).view(sh), T(g["in_beta"]).view(sh), float(g["eps"]), mode, relu)
+    np.testing.assert_allclose(y.numpy(), g["out"], rtol=1e-6, atol=1e-7)
+
+
+def test_bottleneck_prehead_ia_logit_vs_reference(golden):
+    g = golden("bottleneck_64_128")
+    p = {k[2:].replace("__", "."): T(v) for k, v in g.items() if k.startswith("p_")}
+    y, s1 = ocal.bottleneck(T(g["in_x"]), p)
+    np.testing.assert_allclose(s1.numpy(), g["stage1"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(y.numpy(), g["out"], rtol=1e-5, atol=2e-6)
+    g = golden("dynamic_prehead")
+    y = ocal.dynamic_prehead(T(g["in_x"]), T(g["in_conv_w"]), T(g["in_conv_b"]), T(g["in_gn_w"]), T(g["in_gn_b"]), int(g["groups"]), float(g["eps"]))
+    np.testing.assert_allclose(y.numpy(), g["out"], rtol=1e-5, atol=1e-6)
+    g = golden("ia_logit")
+    y = ocal.ia_logit(T(g["in_x"]), T(g["in_head"]), T(g["in_w"]), T(g["in_b"]))
+    np.testing.assert_allclose(y.numpy(), g["out"], rtol=1e-5, atol=1e-6)
+    aug = ocal.augment_background_logit(y[:, :1], y[:, :1] * 0.5 - 0.1)
+    np.testing.assert_allclose(aug.numpy(), g["aug"], rtol=1e-5, atol=1e-6)
+
+
+def fullsize_inputs(g):
+    """The full-size cfg1 frame pair is regenerated from its seed; the fixture stores the SHA-256 of the inputs."""
+    import hashlib
+    from aoc_amd import synthetic as syn
+    cfg = syn.CONFIGS["cfg1"]
+    d = syn.make_clip(cfg, seed=int(g["clip_seed"]), frames=2)
+    sha = np.frombuffer(hashlib.sha256(d["emb"].tobytes() + d["lab"].tobytes()).digest(), np.uint8)
+    assert np.array_equal(sha, g["in_sha256"]), "synthetic clip generator no longer reproduces the recorded inputs"
+    return cfg, d
+
+
+def check_fullsize(g, key, out, atol_sub, atol_f16=1.5e-3):
+    a = out.reshape(-1, *out.shape[-2:])                               # [hw, O, F]
+    np.testing.assert_allclose(a[::7], g[f"{key}_sub"], rtol=0, atol=atol_sub)                   # exact float32 sub-sample
+    np.testing.assert_allclose(a, g[f"{key}_f16"].reshape(a.shape), rtol=0, atol=atol_f16)       # every pixel, float16-compressed
+    np.testing.assert_allclose(a.astype(np.float64).sum(0), g[f"{key}_sum"], rtol=0, atol=atol_sub * a.shape[0] * 0.05 + 1e-3)
+
+
+def test_fullsize_cfg1_oracle(golden):
+    """one full-size cfg1 frame (121x213, O = 2, K = 16) of the reference: cluster (bit-exact k-means), dense, local."""
+    import os
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
+    with np.load(os.path.join(os.path.dirname(__file__), "golden", "fullsize_cfg1.npz")) as z:
+        g = {k: z[k] for k in z.files}
+    cfg, d = fullsize_inputs(g)
+    e0, e1 = T(d["emb"][0]), T(d["emb"][1])
+    from aoc_amd import synthetic as syn
+    l0 = T(syn.one_hot(d["lab"][0], cfg.n_obj))
+    bias = torch.zeros(cfg.n_obj)
+    np.random.seed(int(g["seed"]))
+    out, prox = om.global_matching_for_eval_cluster([e0], e1, [l0], 4, bias, return_proxies=True)
+    g2 = dict(g)
+    for i in range(int(g["km_calls"])):
+        g2[f"km{i}_labels"] = g[f"km{i}_labels"].astype(np.int32)
+    _check_km_calls(g2, [prox])
+    check_fullsize(g, "cluster", out.numpy()[0], 2e-6)
+    check_fullsize(g, "local", om.local_matching(e0, e1, l0, bias, [2, 4, 6, 8, 10, 12]).numpy()[0], 2e-6)
+    # dense: every 7th query pixel (the [m, n] distance matrix of the full frame is 2.6 GB)
+    q = e1.reshape(-1, cfg.c)[::7]
+    dn = om.proto_transform(om.nearest_neighbor_features_per_object(e0.reshape(-1, cfg.c), q, l0.reshape(-1, cfg.n_obj)).squeeze(-1), bias.view(1, -1))
+    np.testing.assert_allclose(dn.numpy()[:, :, None], g["dense_sub"], rtol=0, atol=2e-6)
