@@ -9,6 +9,7 @@
 #include <stdlib.h>
 
 #include "aoc_common.h"
+#include "correlation_shared.h"
 
 namespace {
 
@@ -121,11 +122,20 @@ __device__ __forceinline__ float aoc_min16_dpp(float v) {     // lane 15 of each
     return v;
 }
 
+// blockIdx.y = frame of a batched launch (frames share m, C and the set structure; pointers differ)
+struct PcFrames {
+    const float *query[AOC_CORR_MAX_FRAMES], *proxies[AOC_CORR_MAX_FRAMES], *sqnorm[AOC_CORR_MAX_FRAMES], *bias[AOC_CORR_MAX_FRAMES];
+    float *out[AOC_CORR_MAX_FRAMES];
+};
 template <int TMAX, bool EXACT>
-__global__ __launch_bounds__(256) void proxy_corr_min_kernel(const float *__restrict__ query, int64_t m, int C,
-                                                              const float *__restrict__ proxies, const float *__restrict__ proxy_sqnorm,
-                                                              ProxyTileTable tiles, const float *__restrict__ set_bias,
-                                                              float *__restrict__ out, int64_t pstride, int transform) {
+__global__ __launch_bounds__(256) void proxy_corr_min_kernel(PcFrames frames, int64_t m, int C, ProxyTileTable tiles, int64_t pstride, int transform,
+                                                              const int32_t *__restrict__ gate) {
+    if (gate && *gate == 0) return;            // the fp16-split kernel of correlation_batched.hip owns this launch
+    const float *__restrict__ query = frames.query[blockIdx.y];
+    const float *__restrict__ proxies = frames.proxies[blockIdx.y];
+    const float *__restrict__ proxy_sqnorm = frames.sqnorm[blockIdx.y];
+    const float *__restrict__ set_bias = frames.bias[blockIdx.y];
+    float *__restrict__ out = frames.out[blockIdx.y];
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int NB4 = (TMAX + 3) / 4;
     const int TP = EXACT ? NB4 * 4 : aoc_tile_tp(C);
@@ -532,71 +542,10 @@ extern "C" {
 int aoc_proxy_corr_min(const float *query, int64_t m, int C, const float *proxies, const float *proxy_sqnorm, int n_proxy,
                        int n_set, const int32_t *set_begin_host, const int32_t *set_size_host, const int64_t *set_out_offset_host,
                        const float *set_bias, float *out, int64_t out_pixel_stride, int transform, aoc_stream_t stream) {
-    if (!query || !proxies || !set_begin_host || !set_size_host || !set_out_offset_host || !out) return AOC_ERR_INVALID_ARG;
-    if (m < 1 || C < 4 || n_set < 1 || n_proxy < 0) return AOC_ERR_INVALID_ARG;
-    if ((C & 3) || C > AOC_MAX_CHANNELS) return AOC_ERR_UNSUPPORTED;
-    for (int s = 0; s < n_set; ++s)
-        if (set_size_host[s] < 0 || set_begin_host[s] < 0 || set_begin_host[s] + set_size_host[s] > n_proxy) return AOC_ERR_INVALID_ARG;
-    hipStream_t st = aoc_hip_stream(stream);
-    const int RS = aoc_tile_row_stride(C);
-    const size_t tile_bytes = (size_t)16 * RS * sizeof(float) + 16 * sizeof(float);
-    int max_tiles = (int)((size_t)130 * 1024 / tile_bytes);   // leaves room for the per-wave transpose buffer
-    if (max_tiles > PC_MAX_TILES) max_tiles = PC_MAX_TILES;
-    if (max_tiles < 4) return AOC_ERR_UNSUPPORTED;
-    const int64_t n_row_tiles = (m + 15) / 16;
-    int grid = (int)((n_row_tiles + 3) / 4);
-    if (grid > 512) grid = 512;        // two blocks per CU (LDS permitting): tiles staged once per block, waves walk the row tiles
-
-    ProxyTileTable tab;
-    tab.n = 0;
-    tab.n_out = 0;
-    bool out_overflow = false;
-    auto add_out = [&](int64_t off, int bias_idx) -> int {
-        if (tab.n_out >= PC_MAX_OUT) { out_overflow = true; return 0; }
-        tab.oc_offset[tab.n_out] = off;
-        tab.oc_bias[tab.n_out] = bias_idx;
-        return tab.n_out++;
-    };
-    auto flush = [&]() -> int {
-        if (tab.n == 0) return AOC_OK;
-        if (out_overflow) tab.n_out = 0;       // too many output columns for the transpose buffer: direct stores
-        const size_t lds = (size_t)tab.n * tile_bytes + (size_t)4 * 16 * (tab.n_out + 1) * sizeof(float);
-#define AOC_PC(TM, EX) hipLaunchKernelGGL((proxy_corr_min_kernel<TM, EX>), dim3(grid), dim3(256), lds, st, query, m, C, proxies, proxy_sqnorm, tab, set_bias, out, out_pixel_stride, transform)
-        if (C == 100) AOC_PC(25, true); else if (C <= 128) AOC_PC(32, false); else AOC_PC(64, false);
-#undef AOC_PC
-        tab.n = 0;
-        tab.n_out = 0;
-        out_overflow = false;
-        return hipGetLastError() == hipSuccess ? AOC_OK : AOC_ERR_LAUNCH;
-    };
-    int s = 0;
-    while (s < n_set) {
-        const int size = set_size_host[s];
-        if (size == 1) {
-            // run of single-proxy sets over consecutive proxies with a constant output step -> one column-wise tile
-            int run = 1;
-            const int64_t step = (s + 1 < n_set) ? set_out_offset_host[s + 1] - set_out_offset_host[s] : 0;
-            while (run < 16 && s + run < n_set && set_size_host[s + run] == 1 && set_begin_host[s + run] == set_begin_host[s] + run &&
-                   set_out_offset_host[s + run] - set_out_offset_host[s + run - 1] == step)
-                ++run;
-            if (tab.n + 1 > max_tiles) { int rc = flush(); if (rc) return rc; }
-            const int oc0 = tab.n_out;
-            for (int c = 0; c < run; ++c) add_out(set_out_offset_host[s + c], s + c);
-            tab.t[tab.n++] = ProxyTile{set_begin_host[s], run, s, 1, set_out_offset_host[s], step, oc0, 0};
-            s += run;
-        } else {
-            const int nt = size == 0 ? 1 : (size + 15) / 16;
-            if (nt > max_tiles) return AOC_ERR_UNSUPPORTED;
-            if (tab.n + nt > max_tiles) { int rc = flush(); if (rc) return rc; }
-            const int oc0 = add_out(set_out_offset_host[s], s);
-            for (int t = 0; t < nt; ++t) {
-                const int cols = size == 0 ? 0 : ((t == nt - 1) ? size - 16 * t : 16);
-                tab.t[tab.n++] = ProxyTile{set_begin_host[s] + 16 * t, cols, s, (t == 0 ? 2 : 0) | (t == nt - 1 ? 4 : 0), set_out_offset_host[s], 0, oc0, 0};
-            }
-            ++s;
-        }
-    }
-    return flush();
+    if (!query || !proxies || !out) return AOC_ERR_INVALID_ARG;
+    const aoc_corr_frame fr = {query, proxies, proxy_sqnorm, set_bias, out};
+    return aoc_corr_fp32_batched(&fr, 1, m, C, n_proxy, n_set, set_begin_host, set_size_host, set_out_offset_host, out_pixel_stride, transform,
+                                 nullptr, stream);
 }
 
 size_t aoc_dense_match_workspace_bytes(int64_t m, int64_t n_fg_capacity, int n_obj) {
@@ -614,6 +563,86 @@ int aoc_dense_match_min(const float *query, int64_t m, int C, const float *pool,
 }
 
 }  // extern "C"
+
+int aoc_corr_fp32_batched(const aoc_corr_frame *frames_host, int n_frames, int64_t m, int C, int n_proxy, int n_set,
+                          const int32_t *set_begin_host, const int32_t *set_size_host, const int64_t *set_out_offset_host,
+                          int64_t out_pixel_stride, int transform, const int32_t *gate, aoc_stream_t stream) {
+    if (!frames_host || !set_begin_host || !set_size_host || !set_out_offset_host) return AOC_ERR_INVALID_ARG;
+    if (n_frames < 1 || m < 1 || C < 4 || n_set < 1 || n_proxy < 0) return AOC_ERR_INVALID_ARG;
+    if ((C & 3) || C > AOC_MAX_CHANNELS) return AOC_ERR_UNSUPPORTED;
+    for (int s = 0; s < n_set; ++s)
+        if (set_size_host[s] < 0 || set_begin_host[s] < 0 || set_begin_host[s] + set_size_host[s] > n_proxy) return AOC_ERR_INVALID_ARG;
+    hipStream_t st = aoc_hip_stream(stream);
+    const int RS = aoc_tile_row_stride(C);
+    const size_t tile_bytes = (size_t)16 * RS * sizeof(float) + 16 * sizeof(float);
+    int max_tiles = (int)((size_t)130 * 1024 / tile_bytes);   // leaves room for the per-wave transpose buffer
+    if (max_tiles > PC_MAX_TILES) max_tiles = PC_MAX_TILES;
+    if (max_tiles < 4) return AOC_ERR_UNSUPPORTED;
+    const int64_t n_row_tiles = (m + 15) / 16;
+    int grid = (int)((n_row_tiles + 3) / 4);
+    if (grid > 512) grid = 512;        // two blocks per CU (LDS permitting): tiles staged once per block, waves walk the row tiles
+    for (int f0 = 0; f0 < n_frames; f0 += AOC_CORR_MAX_FRAMES) {
+        const int nf = n_frames - f0 < AOC_CORR_MAX_FRAMES ? n_frames - f0 : AOC_CORR_MAX_FRAMES;
+        PcFrames fr;
+        for (int f = 0; f < AOC_CORR_MAX_FRAMES; ++f) {
+            const aoc_corr_frame &src = frames_host[f0 + (f < nf ? f : 0)];
+            if (!src.query || !src.proxies || !src.out) return AOC_ERR_INVALID_ARG;
+            fr.query[f] = src.query; fr.proxies[f] = src.proxies; fr.sqnorm[f] = src.proxy_sqnorm; fr.bias[f] = src.set_bias; fr.out[f] = src.out;
+        }
+        ProxyTileTable tab;
+        tab.n = 0;
+        tab.n_out = 0;
+        bool out_overflow = false;
+        auto add_out = [&](int64_t off, int bias_idx) -> int {
+            if (tab.n_out >= PC_MAX_OUT) { out_overflow = true; return 0; }
+            tab.oc_offset[tab.n_out] = off;
+            tab.oc_bias[tab.n_out] = bias_idx;
+            return tab.n_out++;
+        };
+        auto flush = [&]() -> int {
+            if (tab.n == 0) return AOC_OK;
+            if (out_overflow) tab.n_out = 0;       // too many output columns for the transpose buffer: direct stores
+            const size_t lds = (size_t)tab.n * tile_bytes + (size_t)4 * 16 * (tab.n_out + 1) * sizeof(float);
+#define AOC_PC(TM, EX) hipLaunchKernelGGL((proxy_corr_min_kernel<TM, EX>), dim3(grid, nf), dim3(256), lds, st, fr, m, C, tab, out_pixel_stride, transform, gate)
+            if (C == 100) AOC_PC(25, true); else if (C <= 128) AOC_PC(32, false); else AOC_PC(64, false);
+#undef AOC_PC
+            tab.n = 0;
+            tab.n_out = 0;
+            out_overflow = false;
+            return hipGetLastError() == hipSuccess ? AOC_OK : AOC_ERR_LAUNCH;
+        };
+        int s = 0;
+        while (s < n_set) {
+            const int size = set_size_host[s];
+            if (size == 1) {
+                // run of single-proxy sets over consecutive proxies with a constant output step -> one column-wise tile
+                int run = 1;
+                const int64_t step = (s + 1 < n_set) ? set_out_offset_host[s + 1] - set_out_offset_host[s] : 0;
+                while (run < 16 && s + run < n_set && set_size_host[s + run] == 1 && set_begin_host[s + run] == set_begin_host[s] + run &&
+                       set_out_offset_host[s + run] - set_out_offset_host[s + run - 1] == step)
+                    ++run;
+                if (tab.n + 1 > max_tiles) { int rc = flush(); if (rc) return rc; }
+                const int oc0 = tab.n_out;
+                for (int c = 0; c < run; ++c) add_out(set_out_offset_host[s + c], s + c);
+                tab.t[tab.n++] = ProxyTile{set_begin_host[s], run, s, 1, set_out_offset_host[s], step, oc0, 0};
+                s += run;
+            } else {
+                const int nt = size == 0 ? 1 : (size + 15) / 16;
+                if (nt > max_tiles) return AOC_ERR_UNSUPPORTED;
+                if (tab.n + nt > max_tiles) { int rc = flush(); if (rc) return rc; }
+                const int oc0 = add_out(set_out_offset_host[s], s);
+                for (int t = 0; t < nt; ++t) {
+                    const int cols = size == 0 ? 0 : ((t == nt - 1) ? size - 16 * t : 16);
+                    tab.t[tab.n++] = ProxyTile{set_begin_host[s] + 16 * t, cols, s, (t == 0 ? 2 : 0) | (t == nt - 1 ? 4 : 0), set_out_offset_host[s], 0, oc0, 0};
+                }
+                ++s;
+            }
+        }
+        int rc = flush();
+        if (rc) return rc;
+    }
+    return AOC_OK;
+}
 
 static thread_local AocDenseProbe g_dense_probe = {nullptr, nullptr};
 AocDenseProbe aoc_take_dense_probe() {

@@ -105,6 +105,10 @@ def launch_cluster_proxies_batch(cfg, ref_emb, ref_labels, init_rows_list, side_
             # while this stream still reads them
             for t in (ref_emb, ref_labels, *init_rows_list):
                 t.record_stream(side)
+        # the per-frame proxy tables are allocated BEFORE the chain: the caller's stream writes their k = 1 rows as soon as the label
+        # prep is done, so they must not share a block with any temporary of the chain that is still running on this stream
+        tables = [torch.empty(n_ad + O, C, dtype=torch.float32, device=dev) for _ in range(F)]
+        sqns = [torch.empty(n_ad + O, dtype=torch.float32, device=dev) for _ in range(F)]
         pool = ref_emb.reshape(R * hw, C)
         prep = ops.label_prep(ref_labels.reshape(R * hw, O))
         prep_event = torch.cuda.Event()
@@ -118,8 +122,7 @@ def launch_cluster_proxies_batch(cfg, ref_emb, ref_labels, init_rows_list, side_
             out = ClusterProxiesAhead()
             out.R = R
             out.prep, out.prep_event = prep, prep_event
-            out.table = torch.empty(n_ad + O, C, dtype=torch.float32, device=dev)
-            out.sqn = torch.empty(n_ad + O, dtype=torch.float32, device=dev)
+            out.table, out.sqn = tables[f], sqns[f]
             sl = slice(f * L * O, (f + 1) * L * O)
             out.table[:n_ad].copy_(proxies[sl].reshape(-1, C))
             out.sqn[:n_ad].copy_(psq[sl].reshape(-1))
