@@ -170,6 +170,33 @@ int aoc_proxy_corr_min(const float *query, int64_t m, int C,
                        const int64_t *set_out_offset_host, const float *set_bias,
                        float *out, int64_t out_pixel_stride, int transform, aoc_stream_t stream);
 
+/* Batched form: the same correlation for n_frames frames (of one or of several independent sequences) in ONE persistent launch.
+ * One 480p frame is 11.6 MB of traffic: a launch that small is latency-bound by construction ("tiny working sets"), and
+ * the reference runs 2 x O x n_chunks launches per frame (AEM:316-319).  All frames share m, C and the set structure (same number
+ * of objects and proxy levels); their pointers differ.  Outputs are pixel-contiguous planes: element (pixel i, set s) of frame f is
+ * written at frames[f].out[set_out_offset[s] + i].
+ *
+ *  precision AOC_CORR_SPLIT (C = 100 only; other widths run the fp32 kernel): every value x 2^10 is split in registers into hi + lo
+ *            fp16 and q.p = qh.ph + qh.pl + ql.ph (dropped ql.pl term < 2^-22 |q.p|) is accumulated in fp32 by
+ *            v_mfma_f32_32x32x16_f16 as ONE K = 304 dot product that also carries -|p|^2/2; fp32-equivalent (tests pin <= 5e-6 on the
+ *            outputs).  Needs |x| 2^10 <= 65000 and |x|^2 <= 4000 for every query / proxy value; checked on the device, and when it
+ *            fails the exact-fp32 kernel recomputes the launch inside the same call (no host round trip).
+ *  precision AOC_CORR_FP32: exact fp32 MFMA (v_mfma_f32_16x16x4_f32), the arithmetic of aoc_proxy_corr_min.
+ *  workspace: aoc_proxy_corr_min_batched_workspace_bytes() bytes (the device-side flag). */
+typedef struct aoc_corr_frame {
+    const float *query;         /* [m, C] */
+    const float *proxies;       /* [n_proxy, C] */
+    const float *proxy_sqnorm;  /* [n_proxy] (+inf = ignore) or NULL */
+    const float *set_bias;      /* [n_set] or NULL */
+    float *out;
+} aoc_corr_frame;
+enum aoc_corr_precision { AOC_CORR_SPLIT = 0, AOC_CORR_FP32 = 1 };
+size_t aoc_proxy_corr_min_batched_workspace_bytes(void);
+int aoc_proxy_corr_min_batched(const aoc_corr_frame *frames_host, int n_frames, int64_t m, int C, int n_proxy, int n_set,
+                               const int32_t *set_begin_host, const int32_t *set_size_host,
+                               const int64_t *set_out_offset_host, int transform, int precision,
+                               void *workspace, size_t workspace_bytes, aoc_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Dense pixel-level matching: AEM:178-227 + 61-89 without materialising [m, O, n]:
  *   out[i,o] = min_j ( (|q_i|^2 + |r_j|^2) - 2 q_i.r_j + 5e4 * wrong[j,o] ),  j over kept rows,

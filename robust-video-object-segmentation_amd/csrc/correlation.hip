@@ -126,17 +126,21 @@ __device__ __forceinline__ float aoc_min16_dpp(float v) {     // lane 15 of each
 struct PcFrames {
     const float *query[AOC_CORR_MAX_FRAMES], *proxies[AOC_CORR_MAX_FRAMES], *sqnorm[AOC_CORR_MAX_FRAMES], *bias[AOC_CORR_MAX_FRAMES];
     float *out[AOC_CORR_MAX_FRAMES];
+    int32_t n;
 };
 template <int TMAX, bool EXACT>
 __global__ __launch_bounds__(256) void proxy_corr_min_kernel(PcFrames frames, int64_t m, int C, ProxyTileTable tiles, int64_t pstride, int transform,
                                                               const int32_t *__restrict__ gate) {
     if (gate && *gate == 0) return;            // the fp16-split kernel of correlation_batched.hip owns this launch
-    const float *__restrict__ query = frames.query[blockIdx.y];
-    const float *__restrict__ proxies = frames.proxies[blockIdx.y];
-    const float *__restrict__ proxy_sqnorm = frames.sqnorm[blockIdx.y];
-    const float *__restrict__ set_bias = frames.bias[blockIdx.y];
-    float *__restrict__ out = frames.out[blockIdx.y];
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    // frames of the launch: one per blockIdx.y, or (gated take-over launch: a small grid that normally exits at once) all of them in turn
+    for (int fi = blockIdx.y; fi < frames.n; fi += gridDim.y) {
+    if (fi != (int)blockIdx.y) __syncthreads();
+    const float *__restrict__ query = frames.query[fi];
+    const float *__restrict__ proxies = frames.proxies[fi];
+    const float *__restrict__ proxy_sqnorm = frames.sqnorm[fi];
+    const float *__restrict__ set_bias = frames.bias[fi];
+    float *__restrict__ out = frames.out[fi];
     constexpr int NB4 = (TMAX + 3) / 4;
     const int TP = EXACT ? NB4 * 4 : aoc_tile_tp(C);
     const int RS = EXACT ? (4 * NB4 * 4 + 4) : aoc_tile_row_stride(C);
@@ -259,6 +263,7 @@ __global__ __launch_bounds__(256) void proxy_corr_min_kernel(PcFrames frames, in
             }
         }
     }
+    }   // frames
 }
 
 // ------------------------------------------------------------------------------------------
@@ -584,6 +589,7 @@ int aoc_corr_fp32_batched(const aoc_corr_frame *frames_host, int n_frames, int64
     for (int f0 = 0; f0 < n_frames; f0 += AOC_CORR_MAX_FRAMES) {
         const int nf = n_frames - f0 < AOC_CORR_MAX_FRAMES ? n_frames - f0 : AOC_CORR_MAX_FRAMES;
         PcFrames fr;
+        fr.n = nf;
         for (int f = 0; f < AOC_CORR_MAX_FRAMES; ++f) {
             const aoc_corr_frame &src = frames_host[f0 + (f < nf ? f : 0)];
             if (!src.query || !src.proxies || !src.out) return AOC_ERR_INVALID_ARG;
@@ -603,7 +609,7 @@ int aoc_corr_fp32_batched(const aoc_corr_frame *frames_host, int n_frames, int64
             if (tab.n == 0) return AOC_OK;
             if (out_overflow) tab.n_out = 0;       // too many output columns for the transpose buffer: direct stores
             const size_t lds = (size_t)tab.n * tile_bytes + (size_t)4 * 16 * (tab.n_out + 1) * sizeof(float);
-#define AOC_PC(TM, EX) hipLaunchKernelGGL((proxy_corr_min_kernel<TM, EX>), dim3(grid, nf), dim3(256), lds, st, fr, m, C, tab, out_pixel_stride, transform, gate)
+#define AOC_PC(TM, EX) hipLaunchKernelGGL((proxy_corr_min_kernel<TM, EX>), dim3(gate ? (grid < 256 ? grid : 256) : grid, gate ? 1 : nf), dim3(256), lds, st, fr, m, C, tab, out_pixel_stride, transform, gate)
             if (C == 100) AOC_PC(25, true); else if (C <= 128) AOC_PC(32, false); else AOC_PC(64, false);
 #undef AOC_PC
             tab.n = 0;

@@ -29,10 +29,10 @@
 namespace {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int CB_NW = 8;                         // waves per block (one block per CU: the proxy image fills most of the LDS)
-constexpr int CB_NT = CB_NW * 64;
+constexpr int CB_NW = 8;                         // waves per block (one block per CU, two waves per SIMD: image 100 KB + 8 x 6.4 KB transposition buffers)
 constexpr int CB_CH = 50;                        // channels per lane half (C = 100)
 constexpr int CB_PK = CB_CH / 2;                 // packed fp16 pairs per plane
 constexpr int CB_STEPS = 19;                     // k-steps: (3 * 100 + 3 + 1 pad) / 16
@@ -51,29 +51,7 @@ __device__ __forceinline__ uint32_t pack_f16(_Float16 a, _Float16 b) {
     return x.u;
 }
 
-// 50 fp32 channels of one lane half -> hi / lo packed planes, |x|^2 partial and max |x|
-struct SplitHalf {
-    uint32_t hi[CB_PK], lo[CB_PK];
-    float sq, amax;
-};
-__device__ __forceinline__ void split_half(const float (&v)[CB_CH], SplitHalf &o) {
-    float sq = 0.0f, amax = 0.0f;
-#pragma unroll
-    for (int e = 0; e < CB_PK; ++e) {
-        const float x0 = v[2 * e], x1 = v[2 * e + 1];
-        sq = __builtin_fmaf(x0, x0, sq);
-        sq = __builtin_fmaf(x1, x1, sq);
-        amax = __builtin_fmaxf(amax, __builtin_fmaxf(__builtin_fabsf(x0), __builtin_fabsf(x1)));
-        const float s0 = x0 * CB_SCALE, s1 = x1 * CB_SCALE;
-        const _Float16 h0 = (_Float16)s0, h1 = (_Float16)s1;
-        o.hi[e] = pack_f16(h0, h1);
-        o.lo[e] = pack_f16((_Float16)(s0 - (float)h0), (_Float16)(s1 - (float)h1));
-    }
-    o.sq = sq;
-    o.amax = amax;
-}
-
-// the 50 channels of lane half h of one fp32 row: 12 x 16 B at float offset 48 h + 4 t, then 8 B at 96 + 2 h
+// the 50 channels of lane half h of one fp32 row in global memory: 12 x 16 B at float offset 48 h + 4 t, then 8 B at 96 + 2 h
 __device__ __forceinline__ void load_half_row(const float *__restrict__ row, int h, float (&v)[CB_CH]) {
     const float4 *p4 = reinterpret_cast<const float4 *>(row + 48 * h);
 #pragma unroll
@@ -85,24 +63,102 @@ __device__ __forceinline__ void load_half_row(const float *__restrict__ row, int
     v[48] = y.x; v[49] = y.y;
 }
 
-struct CbWork {      // work range of one block: global tile index g = frame * tiles_per_frame + tile
-    int64_t g0, g1;
+struct PixelSeq {            // B operand of one pixel tile: the 76-dword sequence [hi | hi | lo | norm constants] as 19 MFMA operands + |q|^2
+    u32x4 b[CB_STEPS];
+    float q2part;            // this lane half's share of |q|^2
+    float amax;
 };
 
-__global__ __launch_bounds__(CB_NT) void proxy_corr_batched_kernel(AocCorrFrames frames, int64_t m, AocCorrTiles tiles, int transform,
-                                                                    int32_t *__restrict__ gate, int n_blocks_virtual) {
+// the 50 fp32 channels of this lane (pixel j, channel half h) -> packed hi / hi / lo planes of the operand sequence, |q|^2 share, max |x|
+__device__ __forceinline__ void convert_raw(const float (&x)[CB_CH], PixelSeq &o) {
+    float sq = 0.0f, amax = 0.0f;
+#pragma unroll
+    for (int e = 0; e < CB_PK; ++e) {
+        const float x0 = x[2 * e], x1 = x[2 * e + 1];
+        sq = __builtin_fmaf(x0, x0, sq);
+        sq = __builtin_fmaf(x1, x1, sq);
+        amax = __builtin_fmaxf(amax, __builtin_fmaxf(__builtin_fabsf(x0), __builtin_fabsf(x1)));
+        const float s0 = x0 * CB_SCALE, s1 = x1 * CB_SCALE;
+        const _Float16 h0 = (_Float16)s0, h1 = (_Float16)s1;
+        const uint32_t hi = pack_f16(h0, h1);
+        // the second copy of the hi plane is made opaque: otherwise the compiler keeps ONE register for both and re-assembles the four
+        // registers of every MFMA operand with v_mov for each of the proxy tiles (4 x 95 moves per pixel tile instead of 25)
+        uint32_t hi2;
+        asm volatile("v_mov_b32 %0, %1" : "=v"(hi2) : "v"(hi));
+        o.b[e >> 2][e & 3] = hi;
+        o.b[(CB_PK + e) >> 2][(CB_PK + e) & 3] = hi2;
+        o.b[(2 * CB_PK + e) >> 2][(2 * CB_PK + e) & 3] = pack_f16((_Float16)(s0 - (float)h0), (_Float16)(s1 - (float)h1));
+    }
+    o.q2part = sq;
+    o.amax = amax;
+}
+
+// One 32-pixel query tile is 32 x 400 = 12 800 CONTIGUOUS bytes: a wave fetches it with 12.5 fully coalesced 16-byte loads per lane
+// (1 KiB per instruction) and transposes it through its private 6.4 KB LDS buffer in two halves of 16 pixel rows: the lanes that own
+// pixels 0..15 read their (pixel, channel half) piece back after the first half is parked, the others after the second.
+constexpr int CB_FLAT = 13;                      // 16-byte chunks per lane (the 13th only for lanes 0..31)
+constexpr int CB_TILE_BYTES = 32 * 400;
+constexpr int CB_CHUNKS = CB_TILE_BYTES / 16;    // 800
+constexpr int CB_HALF_CHUNKS = CB_CHUNKS / 2;    // 400: chunks of the first 16 pixel rows
+constexpr int CB_WBUF_BYTES = CB_TILE_BYTES / 2;
+
+struct CbSlotDesc {          // epilogue constants of one (proxy tile, lane half), staged per frame: two store slots
+    int32_t off_a, off_b;    // element offset of the slot's output plane in the frame's `out` (-1: no store)
+    float bias_a, bias_b;
+    int32_t valid_a, valid_b;   // the set has at least one proxy (else the constant 5e4, AEM:310-313)
+    int32_t pad0, pad1;
+};
+struct CbColDesc {           // one row of the column-wise tile
+    int32_t off;
+    float bias;
+    int32_t valid, pad;
+};
+
+// (sigmoid(d + bias) - 0.5) * 2 with the hardware exp2 / rcp (about 1e-7 absolute on the output; d + bias is a squared distance plus a
+// small bias, so the exponent argument is accurate where the result is not saturated)
+__device__ __forceinline__ float cb_transform(float d, float bias) {
+    const float e = __builtin_amdgcn_exp2f((d + bias) * -1.44269504088896341f);
+    return 2.0f * __builtin_amdgcn_rcpf(1.0f + e) - 1.0f;
+}
+
+// lanes 0..31 get max over both lane halves of a, lanes 32..63 of b (one v_permlane32_swap: no LDS round trip)
+__device__ __forceinline__ float cb_halfmax2(float a, float b) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __builtin_fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+
+// every lane gets the sum over both lane halves
+__device__ __forceinline__ float cb_halfsum(float a) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(a), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+// NT = proxy tiles of the launch; COL0: tile 0 is the column-wise tile (k = 1 proxies).  Block = NW waves, two per SIMD: while one
+// wave converts its next pixel tile (VALU) or waits for LDS, its partner's MFMA chain keeps the matrix pipe busy.
+template <int NW, int NT, bool COL0>
+__global__ __launch_bounds__(NW * 64) void proxy_corr_batched_kernel(AocCorrFrames frames, int64_t m, AocCorrTiles tiles, int transform,
+                                                                      int32_t *__restrict__ gate, int dbg) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    const int n_rows = tiles.n * 32;
+    constexpr int NTH = NW * 64;
+    constexpr int n_rows = NT * 32;
     uint32_t *limg = lds;                                                     // [n_rows][CB_ROW_DW]
-    int32_t *lsrc = reinterpret_cast<int32_t *>(limg + (size_t)tiles.n * CB_TILE_DW);   // [n_rows] proxy row feeding each image row (-1: none)
+    int32_t *lsrc = reinterpret_cast<int32_t *>(limg + (size_t)NT * CB_TILE_DW);   // [n_rows] proxy row feeding each image row (-1: none)
     float *lnorm = reinterpret_cast<float *>(lsrc + n_rows);                  // [n_rows] |p|^2 of that proxy
     int32_t *lfirst = reinterpret_cast<int32_t *>(lnorm + n_rows);            // [AOC_CORR_MAX_OUT] first valid image row of each output column (-1: absent)
-    float *lbias = reinterpret_cast<float *>(lfirst + AOC_CORR_MAX_OUT);      // [AOC_CORR_MAX_OUT]
+    CbSlotDesc *lslot = reinterpret_cast<CbSlotDesc *>(lfirst + AOC_CORR_MAX_OUT);   // [NT][2]
+    CbColDesc *lcol = reinterpret_cast<CbColDesc *>(lslot + NT * 2);          // [32]
+    uint32_t *wbuf_all = reinterpret_cast<uint32_t *>(lcol + 32);             // [NW][6 400 B]
+    float *dump = reinterpret_cast<float *>(gate) + 16 + (threadIdx.x & 31);  // where masked-off lanes store
 
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);        // wave-uniform: keeps the tile bookkeeping and pointer loads scalar
     const int j = lane & 31, h = lane >> 5;
+    uint32_t *wbuf = wbuf_all + (size_t)wave * (CB_WBUF_BYTES / 4);
+    const uint32_t *wbuf_lane = wbuf + (j & 15) * 100 + h * 48;               // this lane's channels 48 h .. 48 h + 47 of pixel row j % 16
+    const uint32_t *wbuf_tail = wbuf + (j & 15) * 100 + 96 + 2 * h;           // ... and 96 + 2 h, 97 + 2 h
     const int64_t T = (m + 31) >> 5;                                          // 32-pixel tiles per frame
     const int64_t total = T * frames.n;
+    const int64_t frame_chunks = m * 25;                                      // 16-byte chunks of one frame's query
     // XCD-aware virtual block id: workgroups are dealt round-robin to the 8 XCDs; give every XCD a contiguous range of the work list so
     // the blocks that share a frame's proxy table (and write neighbouring output planes) share one L2
     int vb;
@@ -115,36 +171,74 @@ __global__ __launch_bounds__(CB_NT) void proxy_corr_batched_kernel(AocCorrFrames
     if (g0 >= g1) return;
     const int f_beg = (int)(g0 / T), f_end = (int)((g1 - 1) / T) + 1;
 
-    // this wave's tiles: within frame f the tiles [lo_f, hi_f) of the block's range, taken round-robin by the 8 waves
+    // this wave's tiles: within frame f the tiles [lo_f, hi_f) of the block's range, taken round-robin by the NW waves
     auto seg_lo = [&](int f) -> int64_t { return f == f_beg ? g0 - (int64_t)f * T : 0; };
     auto seg_hi = [&](int f) -> int64_t { return f == f_end - 1 ? g1 - (int64_t)f * T : T; };
-    // first tile of this wave at or after frame f (returns frame in nf, tile in nt; nf = f_end when there is none)
-    auto first_tile_from = [&](int f, int &nf, int64_t &nt) {
-        for (; f < f_end; ++f) {
-            const int64_t t = seg_lo(f) + wave;
-            if (t < seg_hi(f)) { nf = f; nt = t; return; }
+    // the tile after (f, t) in this wave's list (f = f_end: none)
+    auto advance = [&](int &f, int64_t &t) {
+        t += NW;
+        while (f < f_end && t >= seg_hi(f)) {
+            ++f;
+            if (f < f_end) t = seg_lo(f) + wave;
         }
-        nf = f_end; nt = 0;
     };
 
-    float raw[CB_CH];
-    auto issue_pixel_loads = [&](int f, int64_t tile) {
-        int64_t pix = tile * 32 + j;
-        if (pix > m - 1) pix = m - 1;
-        load_half_row(frames.f[f].query + pix * 100, h, raw);
+    // ---- the wave's pipeline: tile i in `seq` (MFMA operand), tile i+1 in flight from HBM into `flat`
+    u32x4 flat[CB_FLAT];
+    auto issue_flat = [&](int f_, int64_t tile_) {
+        // wave-uniform by construction; say so, so that the pointer comes from a scalar load instead of queueing behind the stores
+        const int f = __builtin_amdgcn_readfirstlane(f_);
+        const int64_t tile = ((int64_t)__builtin_amdgcn_readfirstlane((int)(tile_ >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)tile_);
+        const u32x4 *q = reinterpret_cast<const u32x4 *>(frames.f[f].query);
+#pragma unroll
+        for (int t = 0; t < CB_FLAT; ++t) {
+            int64_t c = tile * CB_CHUNKS + t * 64 + lane;
+            if (c > frame_chunks - 1) c = frame_chunks - 1;                   // last tile of a frame: re-read valid data, never stored
+            if (t < CB_FLAT - 1 || lane < 32) flat[t] = q[c];
+        }
     };
-
-    int nf;
-    int64_t nt;
-    first_tile_from(f_beg, nf, nt);
-    if (nf < f_end) issue_pixel_loads(nf, nt);          // in flight under the first staging pass
+    const uint32_t nconst = h == 0 ? pack_f16((_Float16)CB_QCONST, (_Float16)CB_QCONST) : pack_f16((_Float16)CB_QCONST, (_Float16)0.0f);
+    PixelSeq seq;
+    // flat -> LDS -> seq, in two halves of 16 pixel rows (chunks [0, 400) and [400, 800)); DS operations of a wave execute in order,
+    // so the second half may overwrite the buffer right behind the first half's reads
+    auto convert_tile = [&]() {
+        float raw[CB_CH];
+        seq.b[CB_STEPS - 1][3] = nconst;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+#pragma unroll
+            for (int t = 0; t < CB_FLAT; ++t) {
+                const int c = t * 64 + lane;                                  // chunk of the tile held in flat[t]
+                const bool mine = half == 0 ? c < CB_HALF_CHUNKS : (c >= CB_HALF_CHUNKS && c < CB_CHUNKS);
+                if ((half == 0 ? t * 64 < CB_HALF_CHUNKS : t * 64 + 63 >= CB_HALF_CHUNKS) && mine)
+                    reinterpret_cast<u32x4 *>(wbuf)[c - half * CB_HALF_CHUNKS] = flat[t];
+            }
+            if ((j >> 4) == half) {                                           // only the LDS reads are predicated; the arithmetic runs once
+#pragma unroll
+                for (int c = 0; c < 12; ++c) {
+                    const float4 v = *reinterpret_cast<const float4 *>(wbuf_lane + 4 * c);
+                    raw[4 * c] = v.x; raw[4 * c + 1] = v.y; raw[4 * c + 2] = v.z; raw[4 * c + 3] = v.w;
+                }
+                const float2 v = *reinterpret_cast<const float2 *>(wbuf_tail);
+                raw[48] = v.x; raw[49] = v.y;
+            }
+        }
+        convert_raw(raw, seq);
+    };
 
     bool bad = false;
+    int fa, fb;                        // frames of tiles i, i+1 of this wave (f_end: none)
+    int64_t ta, tb;
+    fa = f_beg; ta = seg_lo(fa) + wave - NW; advance(fa, ta);
+    fb = fa; tb = ta; if (fa < f_end) advance(fb, tb);
+    if (fa < f_end) issue_flat(fa, ta);                // in flight under the first staging pass
+    bool primed = false;
+
     for (int f = f_beg; f < f_end; ++f) {
         const AocCorrFrame fr = frames.f[f];
         // ---- stage this frame's proxy image -----------------------------------------------------------------
         // phase 1: which proxy feeds each image row, its norm
-        for (int r = threadIdx.x; r < n_rows; r += CB_NT) {
+        for (int r = threadIdx.x; r < n_rows; r += NTH) {
             const AocCorrTile &tl = tiles.t[r >> 5];
             const int rr = r & 31;
             int src = -1;
@@ -160,12 +254,13 @@ __global__ __launch_bounds__(CB_NT) void proxy_corr_batched_kernel(AocCorrFrames
                     nrm = fr.sqnorm[src];
                 } else {
                     const float4 *p = reinterpret_cast<const float4 *>(fr.proxies + (size_t)src * 100);
-                    float s = 0.0f;
+                    float sacc = 0.0f;
                     for (int t = 0; t < 25; ++t) {
                         const float4 x = p[t];
-                        s = __builtin_fmaf(x.x, x.x, s); s = __builtin_fmaf(x.y, x.y, s); s = __builtin_fmaf(x.z, x.z, s); s = __builtin_fmaf(x.w, x.w, s);
+                        sacc = __builtin_fmaf(x.x, x.x, sacc); sacc = __builtin_fmaf(x.y, x.y, sacc);
+                        sacc = __builtin_fmaf(x.z, x.z, sacc); sacc = __builtin_fmaf(x.w, x.w, sacc);
                     }
-                    nrm = s;
+                    nrm = sacc;
                 }
                 if (!(nrm < INFINITY)) src = -1;                              // +inf (or NaN) norm: proxy absent (AEM:271-273, 283-286)
                 else if (nrm > CB_MAX_SQ) bad = true;
@@ -176,146 +271,181 @@ __global__ __launch_bounds__(CB_NT) void proxy_corr_batched_kernel(AocCorrFrames
         __syncthreads();
         // phase 2: per output column the first valid row of its set (pads of the set's row groups are filled with a copy of it:
         // a duplicate never changes a min); columns of a column-wise tile are their own set
-        for (int oc = threadIdx.x; oc < tiles.n_out; oc += CB_NT) {
+        for (int oc = threadIdx.x; oc < tiles.n_out; oc += NTH) {
             const int r0 = tiles.oc_row0[oc], nr = tiles.oc_rows[oc];
             int first = -1;
             for (int r = r0; r < r0 + nr; ++r)
                 if (lsrc[r] >= 0) { first = r; break; }
             lfirst[oc] = first;
-            lbias[oc] = fr.bias ? fr.bias[tiles.oc_bias[oc]] : 0.0f;
         }
         __syncthreads();
-        // phase 3: (row, half) items -> image
-        for (int it = threadIdx.x; it < n_rows * 2; it += CB_NT) {
-            const int r = it >> 1, hh = it & 1;
+        // phase 3: one item per (image row, float4 of the proxy row): consecutive threads read consecutive 16 bytes; the two packed
+        // hi pairs land at dwords e, e+1 of the half's sequence and again at 50 + e (the [hi | lo | hi] layout), the lo pairs at 25 + e
+        for (int it = threadIdx.x; it < n_rows * 25; it += NTH) {
+            const int r = it / 25, t = it - r * 25;
             const AocCorrTile &tl = tiles.t[r >> 5];
             int srow = r;                                                     // image row whose proxy is copied here
-            if (lsrc[r] < 0 && tl.kind == 0) {
-                const int first = lfirst[tl.oc[(r & 31) >> 3]];
-                srow = first;
+            if (lsrc[r] < 0) {
+                const int oc = tl.kind == 0 ? tl.oc[(r & 31) >> 3] : -1;
+                srow = oc >= 0 ? lfirst[oc] : -1;
             }
-            uint32_t *dst = limg + (size_t)r * CB_ROW_DW + hh * CB_HALF_DW;
             const int src = srow >= 0 ? lsrc[srow] : -1;
-            if (src < 0) {
-#pragma unroll
-                for (int s = 0; s < CB_STEPS; ++s) reinterpret_cast<uint4 *>(dst)[s] = make_uint4(0, 0, 0, 0);
-                continue;
+            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (src >= 0) x = reinterpret_cast<const float4 *>(fr.proxies + (size_t)src * 100)[t];
+            const float am = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(x.x), __builtin_fabsf(x.y)), __builtin_fmaxf(__builtin_fabsf(x.z), __builtin_fabsf(x.w)));
+            if (am > CB_MAX_ABS) bad = true;
+            const float s0 = x.x * CB_SCALE, s1 = x.y * CB_SCALE, s2 = x.z * CB_SCALE, s3 = x.w * CB_SCALE;
+            const _Float16 h0 = (_Float16)s0, h1 = (_Float16)s1, h2 = (_Float16)s2, h3 = (_Float16)s3;
+            const uint32_t hi0 = pack_f16(h0, h1), hi1 = pack_f16(h2, h3);
+            const uint32_t lo0 = pack_f16((_Float16)(s0 - (float)h0), (_Float16)(s1 - (float)h1));
+            const uint32_t lo1 = pack_f16((_Float16)(s2 - (float)h2), (_Float16)(s3 - (float)h3));
+            uint32_t *row = limg + (size_t)r * CB_ROW_DW;
+            if (t < 24) {
+                uint32_t *d = row + (t >= 12 ? CB_HALF_DW : 0) + 2 * (t >= 12 ? t - 12 : t);
+                d[0] = hi0; d[1] = hi1;
+                d[CB_PK] = lo0; d[CB_PK + 1] = lo1;
+                d[2 * CB_PK] = hi0; d[2 * CB_PK + 1] = hi1;
+            } else {
+                // channels 96, 97 -> pair 24 of half 0; 98, 99 -> pair 24 of half 1; plus the norm slots and the pad of both halves
+                row[24] = hi0; row[CB_PK + 24] = lo0; row[2 * CB_PK + 24] = hi0;
+                row[CB_HALF_DW + 24] = hi1; row[CB_HALF_DW + CB_PK + 24] = lo1; row[CB_HALF_DW + 2 * CB_PK + 24] = hi1;
+                const float a = src >= 0 ? -16.0f * lnorm[srow] : 0.0f;
+                const _Float16 n0 = (_Float16)a;
+                const _Float16 n1 = (_Float16)(a - (float)n0);
+                const _Float16 n2 = (_Float16)((a - (float)n0) - (float)n1);
+                row[3 * CB_PK] = pack_f16(n0, n1);
+                row[CB_HALF_DW + 3 * CB_PK] = pack_f16(n2, (_Float16)0.0f);
             }
-            float v[CB_CH];
-            load_half_row(fr.proxies + (size_t)src * 100, hh, v);
-            SplitHalf sp;
-            split_half(v, sp);
-            if (sp.amax > CB_MAX_ABS || !(sp.amax == sp.amax)) bad = true;
-            const float a = -16.0f * lnorm[srow];
-            const _Float16 n0 = (_Float16)a;
-            const _Float16 n1 = (_Float16)(a - (float)n0);
-            const _Float16 n2 = (_Float16)((a - (float)n0) - (float)n1);
-            uint32_t seq[CB_HALF_DW];
-#pragma unroll
-            for (int e = 0; e < CB_PK; ++e) { seq[e] = sp.hi[e]; seq[CB_PK + e] = sp.lo[e]; seq[2 * CB_PK + e] = sp.hi[e]; }
-            seq[3 * CB_PK] = hh == 0 ? pack_f16(n0, n1) : pack_f16(n2, (_Float16)0.0f);
-#pragma unroll
-            for (int s = 0; s < CB_STEPS; ++s) reinterpret_cast<uint4 *>(dst)[s] = make_uint4(seq[4 * s], seq[4 * s + 1], seq[4 * s + 2], seq[4 * s + 3]);
+        }
+        // phase 4: epilogue constants per (tile, lane half): which output plane each store slot writes, its bias, whether its set exists.
+        // Slot a of half hh: gs 4 -> the set (half 0 of its last tile only); gs 2 -> set hh; gs 1 -> set 2 hh.  Slot b: gs 1 -> set 2 hh + 1.
+        for (int it = threadIdx.x; it < NT * 2; it += NTH) {
+            const int ti = it >> 1, hh = it & 1;
+            const AocCorrTile &tl = tiles.t[ti];
+            int oca = -1, ocb = -1;
+            if (tl.kind == 0) {
+                if (tl.gs == 4) oca = (tl.last && hh == 0) ? tl.oc[0] : -1;
+                else if (tl.gs == 2) oca = tl.oc[2 * hh];
+                else { oca = tl.oc[2 * hh]; ocb = tl.oc[2 * hh + 1]; }
+            }
+            CbSlotDesc dsc;
+            dsc.off_a = oca >= 0 ? (int32_t)tiles.oc_offset[oca] : -1;
+            dsc.off_b = ocb >= 0 ? (int32_t)tiles.oc_offset[ocb] : -1;
+            dsc.bias_a = (oca >= 0 && fr.bias) ? fr.bias[tiles.oc_bias[oca]] : 0.0f;
+            dsc.bias_b = (ocb >= 0 && fr.bias) ? fr.bias[tiles.oc_bias[ocb]] : 0.0f;
+            dsc.valid_a = oca >= 0 ? (lfirst[oca] >= 0) : 0;
+            dsc.valid_b = ocb >= 0 ? (lfirst[ocb] >= 0) : 0;
+            dsc.pad0 = dsc.pad1 = 0;
+            lslot[it] = dsc;
+        }
+        if (COL0) {
+            for (int row = threadIdx.x; row < 32; row += NTH) {
+                const AocCorrTile &tl = tiles.t[0];
+                CbColDesc c;
+                const bool on = row < tl.cnt[0];
+                const int oc = tl.oc[0] + (on ? row : 0);
+                c.off = on ? (int32_t)tiles.oc_offset[oc] : -1;
+                c.bias = (on && fr.bias) ? fr.bias[tiles.oc_bias[oc]] : 0.0f;
+                c.valid = on ? (lfirst[oc] >= 0) : 0;
+                c.pad = 0;
+                lcol[row] = c;
+            }
         }
         __syncthreads();
 
         // ---- this wave's pixel tiles of frame f ----------------------------------------------------------------
-        const int64_t hi_f = seg_hi(f);
-        for (int64_t tile = seg_lo(f) + wave; tile < hi_f; tile += CB_NW) {
-            // raw holds this tile (issued one tile ago): split it into the B operand sequence
-            SplitHalf sp;
-            split_half(raw, sp);
-            if (sp.amax > CB_MAX_ABS || !(sp.amax == sp.amax)) bad = true;
-            const float q2 = sp.sq + __shfl_xor(sp.sq, 32);
-            if (!(q2 <= CB_MAX_SQ)) bad = true;
-            uint32_t seq[CB_HALF_DW];
-#pragma unroll
-            for (int e = 0; e < CB_PK; ++e) { seq[e] = sp.hi[e]; seq[CB_PK + e] = sp.hi[e]; seq[2 * CB_PK + e] = sp.lo[e]; }
-            seq[3 * CB_PK] = h == 0 ? pack_f16((_Float16)CB_QCONST, (_Float16)CB_QCONST) : pack_f16((_Float16)CB_QCONST, (_Float16)0.0f);
-            // next tile's loads: in flight under this tile's MFMAs
-            if (tile + CB_NW < hi_f) { nf = f; nt = tile + CB_NW; }
-            else first_tile_from(f + 1, nf, nt);
-            if (nf < f_end) issue_pixel_loads(nf, nt);
-
-            const int64_t pix = tile * 32 + j;
+        if (!primed && fa < f_end) {
+            convert_tile();                                                   // tile i: flat -> seq
+            if (fb < f_end) issue_flat(fb, tb);                               // tile i+1 requested
+            primed = true;
+        }
+        while (fa == f) {
+            const int64_t pix = ta * 32 + j;
             const bool live = pix < m;
+            const float q2 = cb_halfsum(seq.q2part);
+            if (!(q2 <= CB_MAX_SQ) || seq.amax > CB_MAX_ABS) bad = true;
+            float *const out_pix = fr.out + pix;
             float carry = -INFINITY;
-            for (int ti = 0; ti < tiles.n; ++ti) {
-                const AocCorrTile tl = tiles.t[ti];
+#pragma unroll
+            for (int ti = 0; ti < NT; ++ti) {
                 const uint4 *arow = reinterpret_cast<const uint4 *>(limg + (size_t)(ti * 32 + j) * CB_ROW_DW + h * CB_HALF_DW);
                 f32x16 acc;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-                f16x8 a0 = __builtin_bit_cast(f16x8, arow[0]);
-                f16x8 a1 = __builtin_bit_cast(f16x8, arow[1]);
+                if (dbg != 1) {
 #pragma unroll
-                for (int s = 0; s < CB_STEPS; ++s) {
-                    f16x8 a2 = a1;
-                    if (s + 2 < CB_STEPS) a2 = __builtin_bit_cast(f16x8, arow[s + 2]);
-                    const f16x8 b = __builtin_bit_cast(f16x8, make_uint4(seq[4 * s], seq[4 * s + 1], seq[4 * s + 2], seq[4 * s + 3]));
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b, acc, 0, 0, 0);
-                    a0 = a1; a1 = a2;
-                }
-                if (tl.kind == 1) {
-                    // column-wise: every row is its own output (k = 1 proxies, no min: AEM:127)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int row = (r >> 2) * 8 + h * 4 + (r & 3);
-                        if (row < tl.cnt[0] && live) {
-                            const int oc = tl.oc[0] + row;
-                            float d = lfirst[oc] >= 0 ? q2 + CB_UNSCALE * acc[r] : AOC_PAD_DISTANCE;
-                            if (transform) d = aoc_proto_transform(d, lbias[oc]);
-                            fr.out[tiles.oc_offset[oc] + pix] = d;
-                        }
+                    for (int s = 0; s < CB_STEPS; ++s) {
+                        const f16x8 a = __builtin_bit_cast(f16x8, arow[s]);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, __builtin_bit_cast(f16x8, seq.b[s]), acc, 0, 0, 0);
                     }
-                } else {
-                    // grouped: group g = rows 8g .. 8g+7 = registers 4g .. 4g+3 of both lane halves
-                    float gm[4];
+                }
+                if (dbg == 3) { asm volatile("" :: "v"(acc[0]), "v"(acc[5]), "v"(acc[10]), "v"(acc[15])); continue; }
+                if (COL0 && ti == 0) {
+                    // column-wise tile: every row is its own output (k = 1 proxies, no min: AEM:127).  Register r of lane half h is
+                    // row (r / 4) * 8 + 4 h + r % 4; row groups beyond the tile's rows are skipped with uniform branches.
+                    const int cnt = tiles.t[0].cnt[0];
 #pragma unroll
-                    for (int g = 0; g < 4; ++g)
-                        gm[g] = __builtin_fmaxf(__builtin_fmaxf(acc[4 * g], acc[4 * g + 1]), __builtin_fmaxf(acc[4 * g + 2], acc[4 * g + 3]));
-                    if (tl.gs == 4) {
-                        float v = __builtin_fmaxf(__builtin_fmaxf(gm[0], gm[1]), __builtin_fmaxf(gm[2], gm[3]));
-                        v = __builtin_fmaxf(v, __shfl_xor(v, 32));
-                        if (!tl.first) v = __builtin_fmaxf(v, carry);
-                        carry = v;
-                        if (tl.last && h == 0 && live) {
-                            const int oc = tl.oc[0];
-                            float d = lfirst[oc] >= 0 ? q2 + CB_UNSCALE * v : AOC_PAD_DISTANCE;
-                            if (transform) d = aoc_proto_transform(d, lbias[oc]);
-                            fr.out[tiles.oc_offset[oc] + pix] = d;
-                        }
-                    } else if (tl.gs == 2) {
-                        float v0 = __builtin_fmaxf(gm[0], gm[1]), v1 = __builtin_fmaxf(gm[2], gm[3]);
-                        v0 = __builtin_fmaxf(v0, __shfl_xor(v0, 32));
-                        v1 = __builtin_fmaxf(v1, __shfl_xor(v1, 32));
-                        const float v = h == 0 ? v0 : v1;                     // lane half h stores set h
-                        const int oc = tl.oc[2 * h];
-                        if (oc >= 0 && live) {
-                            float d = lfirst[oc] >= 0 ? q2 + CB_UNSCALE * v : AOC_PAD_DISTANCE;
-                            if (transform) d = aoc_proto_transform(d, lbias[oc]);
-                            fr.out[tiles.oc_offset[oc] + pix] = d;
-                        }
-                    } else {
+                    for (int g = 0; g < 4; ++g) {
+                        if (8 * g < cnt) {
 #pragma unroll
-                        for (int g = 0; g < 4; ++g) gm[g] = __builtin_fmaxf(gm[g], __shfl_xor(gm[g], 32));
-#pragma unroll
-                        for (int u = 0; u < 2; ++u) {                         // lane half h stores sets 2h, 2h + 1
-                            const float v = h == 0 ? gm[u] : gm[2 + u];
-                            const int oc = tl.oc[2 * h + u];
-                            if (oc >= 0 && live) {
-                                float d = lfirst[oc] >= 0 ? q2 + CB_UNSCALE * v : AOC_PAD_DISTANCE;
-                                if (transform) d = aoc_proto_transform(d, lbias[oc]);
-                                fr.out[tiles.oc_offset[oc] + pix] = d;
+                            for (int u = 0; u < 4; ++u) {
+                                const CbColDesc c = lcol[8 * g + 4 * h + u];
+                                float d = c.valid ? q2 + CB_UNSCALE * acc[4 * g + u] : AOC_PAD_DISTANCE;
+                                const float td = cb_transform(d, c.bias);
+                                d = transform ? td : d;
+                                float *p = (c.off >= 0 && live) ? out_pix + c.off : dump;
+                                *p = d;
                             }
                         }
                     }
+                    continue;
                 }
+                // grouped tile: group g = rows 8g .. 8g+7 = registers 4g .. 4g+3 of both lane halves
+                const CbSlotDesc sd = lslot[ti * 2 + h];
+                const int gs = tiles.t[ti].gs;
+                float gm[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    gm[g] = __builtin_fmaxf(__builtin_fmaxf(acc[4 * g], acc[4 * g + 1]), __builtin_fmaxf(acc[4 * g + 2], acc[4 * g + 3]));
+                float va, vb = 0.0f;
+                if (gs == 4) {                                                // one set spanning the tile (possibly continued from / into neighbours)
+                    float v = __builtin_fmaxf(__builtin_fmaxf(gm[0], gm[1]), __builtin_fmaxf(gm[2], gm[3]));
+                    v = cb_halfmax2(v, v);
+                    if (!tiles.t[ti].first) v = __builtin_fmaxf(v, carry);
+                    carry = v;
+                    va = v;
+                } else if (gs == 2) {                                         // two sets: lane half h ends up with set h
+                    va = cb_halfmax2(__builtin_fmaxf(gm[0], gm[1]), __builtin_fmaxf(gm[2], gm[3]));
+                } else {                                                      // four sets: lane half h ends up with sets 2h (slot a), 2h + 1 (slot b)
+                    va = cb_halfmax2(gm[0], gm[2]);
+                    vb = cb_halfmax2(gm[1], gm[3]);
+                }
+                {
+                    float d = sd.valid_a ? q2 + CB_UNSCALE * va : AOC_PAD_DISTANCE;
+                    const float td = cb_transform(d, sd.bias_a);
+                    d = transform ? td : d;
+                    float *p = (sd.off_a >= 0 && live) ? out_pix + sd.off_a : dump;
+                    *p = d;
+                }
+                if (gs == 1) {
+                    float d = sd.valid_b ? q2 + CB_UNSCALE * vb : AOC_PAD_DISTANCE;
+                    const float td = cb_transform(d, sd.bias_b);
+                    d = transform ? td : d;
+                    float *p = (sd.off_b >= 0 && live) ? out_pix + sd.off_b : dump;
+                    *p = d;
+                }
+            }
+            // next tile: flat -> seq (its loads were issued one tile ago), then request the one after it
+            fa = fb; ta = tb;
+            if (fa < f_end) {
+                if (dbg != 4) convert_tile();
+                advance(fb, tb);
+                if (fb < f_end && dbg != 2) issue_flat(fb, tb);
             }
         }
         __syncthreads();                                                      // every wave is done with this frame's image
     }
-    if (bad) atomicOr(gate, 1);
+    if (bad && dbg == 0) atomicOr(gate, 1);
 }
 
 inline int cb_n_cus() {
@@ -365,7 +495,9 @@ int aoc_proxy_corr_min_batched(const aoc_corr_frame *frames_host, int n_frames, 
 
     // ---- pack the sets into 32-row tiles: single-proxy sets -> column-wise tiles, the others by row-group class
     const size_t tile_bytes = (size_t)CB_TILE_DW * 4 + 32 * 8;
-    int max_tiles = (int)(((size_t)160 * 1024 - AOC_CORR_MAX_OUT * 8 - 64) / tile_bytes);
+    constexpr int NW = CB_NW;
+    const size_t lds_fixed = AOC_CORR_MAX_OUT * 4 + (size_t)AOC_CORR_MAX_TILES * 2 * 32 + 32 * 16 + (size_t)NW * CB_WBUF_BYTES;
+    int max_tiles = (int)(((size_t)160 * 1024 - lds_fixed) / tile_bytes);
     if (max_tiles > AOC_CORR_MAX_TILES) max_tiles = AOC_CORR_MAX_TILES;
     const int n_cu = cb_n_cus();
     const int64_t T = (m + 31) / 32;
@@ -384,12 +516,32 @@ int aoc_proxy_corr_min_batched(const aoc_corr_frame *frames_host, int n_frames, 
         auto reset = [&]() { tab.n = 0; tab.n_out = 0; };
         auto flush = [&]() -> int {
             if (tab.n == 0) return AOC_OK;
-            const size_t lds = (size_t)tab.n * tile_bytes + AOC_CORR_MAX_OUT * 8;
+            const size_t lds = (size_t)tab.n * tile_bytes + lds_fixed;
             int64_t grid = T * fr.n;
             if (grid > n_cu) grid = n_cu;
-            if (hipFuncSetAttribute(reinterpret_cast<const void *>(proxy_corr_batched_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-                return AOC_ERR_LAUNCH;
-            hipLaunchKernelGGL(proxy_corr_batched_kernel, dim3((unsigned)grid), dim3(CB_NT), lds, st, fr, m, tab, transform, gate, 0);
+            static const int dbg = getenv("AOC_CORR_DEBUG") ? atoi(getenv("AOC_CORR_DEBUG")) : 0;
+            const bool col0 = tab.t[0].kind == 1;
+#define AOC_CB(N, COL)                                                                                                                  \
+    do {                                                                                                                                \
+        static const bool lds_ok = hipFuncSetAttribute(reinterpret_cast<const void *>(proxy_corr_batched_kernel<NW, N, COL>),            \
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;            \
+        if (!lds_ok) return AOC_ERR_LAUNCH;                                                                                              \
+        hipLaunchKernelGGL((proxy_corr_batched_kernel<NW, N, COL>), dim3((unsigned)grid), dim3(NW * 64), lds, st, fr, m, tab, transform, gate, dbg); \
+    } while (0)
+            switch (tab.n * 2 + (col0 ? 1 : 0)) {
+                case 2: AOC_CB(1, false); break;
+                case 3: AOC_CB(1, true); break;
+                case 4: AOC_CB(2, false); break;
+                case 5: AOC_CB(2, true); break;
+                case 6: AOC_CB(3, false); break;
+                case 7: AOC_CB(3, true); break;
+                case 8: AOC_CB(4, false); break;
+                case 9: AOC_CB(4, true); break;
+                case 10: AOC_CB(5, false); break;
+                case 11: AOC_CB(5, true); break;
+                default: return AOC_ERR_UNSUPPORTED;
+            }
+#undef AOC_CB
             reset();
             return hipGetLastError() == hipSuccess ? AOC_OK : AOC_ERR_LAUNCH;
         };
@@ -409,10 +561,17 @@ int aoc_proxy_corr_min_batched(const aoc_corr_frame *frames_host, int n_frames, 
                 const int c = size == 1 ? 0 : size <= 8 ? 1 : size <= 16 ? 2 : 3;
                 if (c != cls) continue;
                 if (cls == 0) {
-                    // runs of single-proxy sets over consecutive proxies share a column-wise tile
-                    const bool cont = open_tile >= 0 && tab.t[open_tile].cnt[0] < 32 && set_begin_host[s] == tab.t[open_tile].begin[0] + tab.t[open_tile].cnt[0];
+                    // runs of single-proxy sets over consecutive proxies whose output planes are a constant step apart share a column-wise tile
+                    bool cont = open_tile >= 0 && tab.t[open_tile].cnt[0] < 32 && set_begin_host[s] == tab.t[open_tile].begin[0] + tab.t[open_tile].cnt[0];
+                    if (cont) {
+                        AocCorrTile &tl = tab.t[open_tile];
+                        const int64_t step = set_out_offset_host[s] - tab.oc_offset[tl.oc[0] + tl.cnt[0] - 1];
+                        if (tl.cnt[0] == 1) tl.step = step;
+                        else if (tl.step != step) cont = false;
+                    }
                     if (!cont || tab.n_out + 1 > AOC_CORR_MAX_OUT) {
-                        if (tab.n + 1 > max_tiles || tab.n_out + 1 > AOC_CORR_MAX_OUT) { int rc = flush(); if (rc) return rc; }
+                        // the kernel takes at most one column-wise tile per launch, as tile 0
+                        if (tab.n > 0) { int rc = flush(); if (rc) return rc; }
                         open_tile = tab.n++;
                         AocCorrTile &tl = tab.t[open_tile];
                         tl = AocCorrTile{};

@@ -3,7 +3,7 @@
 #include "aoc_common.h"
 
 constexpr int AOC_CORR_MAX_FRAMES = 32;   // frames per launch (kernel-argument table)
-constexpr int AOC_CORR_MAX_TILES = 7;     // 32-row proxy tiles resident in LDS per launch (7 x 19.5 KB)
+constexpr int AOC_CORR_MAX_TILES = 5;     // 32-row proxy tiles resident in LDS per launch (5 x 19.5 KB next to the waves' pixel-tile buffers)
 constexpr int AOC_CORR_MAX_OUT = 64;      // output columns (sets) per launch
 
 struct AocCorrFrame {
@@ -16,12 +16,14 @@ struct AocCorrFrames {
 };
 // One 32-row tile of the proxy image.  kind 0 (grouped): row group g (rows 8g .. 8g+7) holds cnt[g] proxies starting at begin[g] of the
 // set with output column oc[g] (-1: unused); gs = row groups per set (1, 2 or 4); first / last: position in a multi-tile set (gs = 4).
-// kind 1 (column-wise): cnt[0] single-proxy sets starting at proxy begin[0], output columns oc[0] .. oc[0] + cnt[0] - 1.
+// kind 1 (column-wise): cnt[0] single-proxy sets starting at proxy begin[0], output columns oc[0] .. oc[0] + cnt[0] - 1, whose output
+// planes are `step` elements apart.
 struct AocCorrTile {
     int32_t begin[4];
     int16_t cnt[4];
     int16_t oc[4];
     int32_t kind, gs, first, last;
+    int64_t step;
 };
 struct AocCorrTiles {
     AocCorrTile t[AOC_CORR_MAX_TILES];

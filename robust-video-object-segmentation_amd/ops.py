@@ -196,6 +196,53 @@ def proxy_corr_min(query_flat, proxies, proxy_sqnorm, set_begin, set_size, set_o
     return out
 
 
+class _CorrFrame(ctypes.Structure):
+    """aoc_corr_frame of include/aoc_hip.h."""
+    _fields_ = [("query", ctypes.c_void_p), ("proxies", ctypes.c_void_p), ("proxy_sqnorm", ctypes.c_void_p), ("set_bias", ctypes.c_void_p),
+                ("out", ctypes.c_void_p)]
+
+
+CORR_PRECISION = {"split": 0, "fp32": 1}
+_corr_ws = {}
+
+
+def proxy_corr_min_batched(frames, set_begin, set_size, set_out_offset, transform=True, precision="split"):
+    """aoc_proxy_corr_min_batched: the correlation of several frames (of one or of several sequences) in ONE launch.
+    frames: sequence of (query_flat [m, C], proxies [n_proxy, C], proxy_sqnorm [n_proxy] or None, set_bias [n_set] or None, out) with the same m, C,
+    n_proxy; element (pixel i, set s) of a frame is written at out.data_ptr()[set_out_offset[s] + i] (pixel-contiguous planes)."""
+    q0, p0 = frames[0][0], frames[0][1]
+    m, C = q0.shape
+    n_proxy = p0.shape[0]
+    sb = np.ascontiguousarray(np.asarray(set_begin, dtype=np.int32))
+    ss = np.ascontiguousarray(np.asarray(set_size, dtype=np.int32))
+    so = np.ascontiguousarray(np.asarray(set_out_offset, dtype=np.int64))
+    n_set = sb.size
+    assert ss.size == n_set and so.size == n_set
+    arr = (_CorrFrame * len(frames))()
+    keep = []
+    for i, (q, p, sq, b, out) in enumerate(frames):
+        q, p = _f32c(q), _f32c(p)
+        sq = _f32c(sq) if sq is not None else None
+        b = _f32c(b) if b is not None else None
+        _need_gpu(q, p, sq, b, out)
+        assert q.shape == (m, C) and p.shape == (n_proxy, C) and (b is None or b.numel() == n_set)
+        keep.append((q, p, sq, b))
+        arr[i] = _CorrFrame(q.data_ptr(), p.data_ptr(), sq.data_ptr() if sq is not None else None, b.data_ptr() if b is not None else None,
+                            out.data_ptr())
+    dev = q0.device
+    L = _lib.lib()
+    # the 256-byte flag workspace is only touched by kernels of this call, which are ordered on the call's stream: one per (device, stream)
+    key = (dev.index, _stream().value)
+    ws = _corr_ws.get(key)
+    if ws is None:
+        ws = _corr_ws[key] = _ws(L.aoc_proxy_corr_min_batched_workspace_bytes(), dev)
+    vp = ctypes.c_void_p
+    _lib.check(L.aoc_proxy_corr_min_batched(ctypes.cast(arr, vp), len(frames), m, C, n_proxy, n_set, sb.ctypes.data_as(vp), ss.ctypes.data_as(vp),
+                                            so.ctypes.data_as(vp), int(bool(transform)), CORR_PRECISION[precision], _p(ws), ws.numel(), _stream()),
+               "aoc_proxy_corr_min_batched")
+    return [f[4] for f in frames]
+
+
 def dense_match_min(query_flat, pool, prep, obj_bias, out, out_pixel_stride, out_obj_stride, transform=True):
     query_flat = _f32c(query_flat)
     pool = _f32c(pool)

@@ -1,0 +1,110 @@
+"""aoc_proxy_corr_min_batched (fp16-split matrix pipe, several frames per launch) against the CPU oracle's distances and against the
+exact-fp32 kernel.  Tolerance on the proto-mask outputs: 5e-6, as for every other matching branch."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ATOL = 5e-6
+
+
+@pytest.fixture(scope="module")
+def aoc():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    import aoc_amd
+    aoc_amd._lib.lib()
+    return aoc_amd
+
+
+def _oracle(q, table, sqn, sb, ss, bias, transform=True):
+    """[n_set, m] float64-free restatement with the oracle's own functions (AEM:29-59, 92-128)."""
+    from oracle import matching as om
+    qsq = q.pow(2).sum(1)
+    outs = []
+    for s, (b, n) in enumerate(zip(sb, ss)):
+        live = [i for i in range(b, b + n) if np.isfinite(float(sqn[i]))]
+        if not live:
+            d = torch.full((q.shape[0],), 5e4)
+        else:
+            p = table[live]
+            d = om.flattened_pairwise_distances(p, p.pow(2).sum(1), q, qsq).min(dim=1)[0]
+        outs.append(om.proto_transform(d, bias[s]) if transform else d)
+    return torch.stack(outs)
+
+
+def _case(rng, m, C, sizes, absent=(), n_frames=1, scale=0.3):
+    """sets of the given sizes over one proxy table (kmax-strided like the product's tables), `absent` proxies get norm = +inf"""
+    kmax = max(max(sizes), 1)
+    sb = [i * kmax for i in range(len(sizes))]
+    n_proxy = len(sizes) * kmax
+    frames = []
+    for _ in range(n_frames):
+        q = torch.from_numpy((np.maximum(rng.randn(m, C), 0) * scale).astype(np.float32))
+        t = torch.from_numpy((np.maximum(rng.randn(n_proxy, C), 0) * scale).astype(np.float32))
+        sq = t.pow(2).sum(1)
+        for a in absent:
+            sq[a] = float("inf")
+        bias = torch.from_numpy((rng.rand(len(sizes)).astype(np.float32) - 0.5))
+        frames.append((q, t, sq, bias))
+    return frames, sb, list(sizes)
+
+
+@pytest.mark.parametrize("sizes,absent,m,n_frames", [
+    ([16] * 8 + [1] * 4, (), 25773, 2),                  # cfg2 shape: 4 objects x (centroid, centroid_avg) + 4 k = 1 proxies
+    ([8] * 6 + [16] * 6 + [32] * 6 + [1] * 3, (), 1000, 3),   # multi-level
+    ([64, 64, 5, 12, 1, 1, 20, 40, 0, 3], (), 777, 2),   # multi-tile sets, odd sizes, an empty set
+    ([16, 16, 16, 16, 1, 1], (3, 4, 5, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 65), 333, 1),   # absent proxies / whole absent set / absent k=1
+    ([16] * 8 + [1] * 4, (), 31, 5),                     # fewer pixels than a tile
+])
+def test_batched_split_vs_oracle(aoc, sizes, absent, m, n_frames):
+    rng = np.random.RandomState(len(sizes) * 7 + m)
+    C = 100
+    frames, sb, ss = _case(rng, m, C, sizes, absent, n_frames)
+    n_set = len(sizes)
+    so = [s * m for s in range(n_set)]
+    dev_frames, outs = [], []
+    for q, t, sq, bias in frames:
+        out = torch.full((n_set, m), -7.0, device="cuda")
+        outs.append(out)
+        dev_frames.append((q.cuda(), t.cuda(), sq.cuda(), bias.cuda(), out))
+    aoc.ops.proxy_corr_min_batched(dev_frames, sb, ss, so, True, "split")
+    ref32 = [torch.full((n_set, m), -7.0, device="cuda") for _ in frames]
+    aoc.ops.proxy_corr_min_batched([(f[0], f[1], f[2], f[3], r) for f, r in zip(dev_frames, ref32)], sb, ss, so, True, "fp32")
+    for (q, t, sq, bias), out, r32 in zip(frames, outs, ref32):
+        want = _oracle(q, t, sq, sb, ss, bias)
+        np.testing.assert_allclose(out.cpu().numpy(), want.numpy(), rtol=0, atol=ATOL)
+        np.testing.assert_allclose(r32.cpu().numpy(), want.numpy(), rtol=0, atol=ATOL)
+
+
+def test_batched_raw_distances_and_wide_range(aoc):
+    """transform = 0 (raw squared distances) on data with a wide dynamic range, against float64."""
+    rng = np.random.RandomState(5)
+    m, C = 2000, 100
+    q = (rng.randn(m, C) * np.exp(rng.randn(m, 1))).astype(np.float32) * 0.5
+    t = (rng.randn(40, C) * np.exp(rng.randn(40, 1))).astype(np.float32) * 0.5
+    sb, ss = [0, 16, 32, 33, 34], [16, 16, 1, 1, 6]
+    so = [s * m for s in range(5)]
+    out = torch.empty(5, m, device="cuda")
+    aoc.ops.proxy_corr_min_batched([(torch.from_numpy(q).cuda(), torch.from_numpy(t).cuda(), None, None, out)], sb, ss, so, False, "split")
+    q64, t64 = q.astype(np.float64), t.astype(np.float64)
+    d = (q64 ** 2).sum(1)[:, None] + (t64 ** 2).sum(1)[None] - 2 * q64 @ t64.T
+    want = np.stack([d[:, b:b + n].min(1) for b, n in zip(sb, ss)])
+    scale = (q64 ** 2).sum(1)[None] + (t64 ** 2).sum(1).max()
+    assert float(np.max(np.abs(out.cpu().numpy() - want) / scale)) < 2e-6      # fp32-level relative error of a distance
+
+
+def test_batched_takeover_when_values_do_not_fit(aoc):
+    """|x| * 2^10 > 65000 somewhere: the device-side flag makes the exact-fp32 kernel recompute the launch (no host round trip)."""
+    rng = np.random.RandomState(6)
+    m, C = 500, 100
+    frames, sb, ss = _case(rng, m, C, [16, 16, 1], (), 2)
+    frames[1][0][123, 7] = 80.0                                   # 80 * 1024 > 65000
+    so = [s * m for s in range(3)]
+    dev_frames = [(q.cuda(), t.cuda(), sq.cuda(), b.cuda(), torch.empty(3, m, device="cuda")) for q, t, sq, b in frames]
+    aoc.ops.proxy_corr_min_batched(dev_frames, sb, ss, so, True, "split")
+    ref = [torch.empty(3, m, device="cuda") for _ in frames]
+    aoc.ops.proxy_corr_min_batched([(f[0], f[1], f[2], f[3], r) for f, r in zip(dev_frames, ref)], sb, ss, so, True, "fp32")
+    for f, r in zip(dev_frames, ref):
+        assert torch.equal(f[4], r)                               # bit-identical: it IS the fp32 kernel's result
