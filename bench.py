@@ -5,24 +5,30 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-A "step" is one frame of one synthetic video sequence per stream (--streams, default 1) through the
-whole hot path: label prep, scipy-exact k-means proxies, proxy / dense / local matching, fg->bg,
-the 24-channel proto-mask tensor, then the ten IA gates and four conditioning blocks at the
-decoder's activation shapes.  Workload = BASELINE.json configs[1] (cfg2): 480p -> 121x213 stride-4
-maps, 3 objects + background, K = 16 proxies, 60-frame clips whose reference pool grows by one frame
-every MEM_EVERY = 5 frames (R = 1..12), exactly as the reference's eval loop does
-(eval_manager_mm.py:309-361).  Inputs (feature maps, label maps, k-means initial rows, decoder
+(`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment re-launches itself under torch.distributed.run.)
+
+A "step" is one frame of every in-flight synthetic video sequence (--streams per rank, default 2) through the whole hot path: label
+prep, scipy-exact k-means proxies, proxy / dense / local matching, fg->bg, the proto-mask tensor, then the ten IA gates and four
+conditioning blocks at the decoder's activation shapes.  Workload = BASELINE.json configs[1] (cfg2): 480p -> 121x213 stride-4 maps, 3
+objects + background, K = 16 proxies, 60-frame clips whose reference pool holds one more frame every MEM_EVERY = 5 frames (R = 1..12),
+as in the reference's eval loop (eval_manager_mm.py:309-361).  Inputs (feature maps, label maps, k-means initial rows, decoder
 activations) are synthetic, seeded and resident in HBM before the timed region.
 
-Prints ONE JSON line on rank 0 (contract in the task statement): whole-job frames/s, the roofline of
-the dominant kernel measured with HIP events inside the timed region, and a CPU baseline (the oracle
-timed on the host cores, rank 0, N = 1 only).
+The frames of a clip are visited in GROUPS of MEM_EVERY consecutive frames (one pool state each) and the groups in a fixed interleaved
+order, so that ANY number of steps sees small and large pools in proportion (the line prints the histogram of R actually timed);
+inside a group everything happens as in the sequential loop: the first frame's k-means chain can only start once the pool is final,
+the chains of the others are enqueued ahead.
+
+Prints ONE JSON line on rank 0 (contract in the task statement): whole-job frames/s, roofline objects measured with HIP events inside
+the run, and a CPU baseline (the oracle timed on the host cores, rank 0, N = 1 only).
 """
 import argparse
 import os
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # main + dense + k-means stream per sequence: more than the default 4 hardware queues
 import ctypes
 import json
+import socket
+import subprocess
 import sys
 import time
 
@@ -33,12 +39,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 import aoc_amd  # noqa: E402
-from aoc_amd import hotpath, ops, sharding  # noqa: E402
+from aoc_amd import eval_runner, hotpath, ops, sharding  # noqa: E402
 from aoc_amd import synthetic as syn  # noqa: E402
 
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 PEAK_F16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md: v_mfma_f32_32x32x16_f16, dense
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, dense
+
+CONFIG_LEVELS = {"cfg3": [8, 16, 32]}     # BASELINE.json configs[2]: multi-level proxies
 
 
 class HipEventPairs:
@@ -71,8 +79,9 @@ class HipEventPairs:
 
 
 class OpTimer:
-    """HIP-event timing of every call of selected aoc_amd.ops functions on the stream they are
-    launched on (torch's current stream), inside the timed region."""
+    """HIP-event timing of every call of selected aoc_amd.ops functions on the stream they are launched on (torch's current stream).
+    Recording is switched on for the timed region only; the explicit ordering of the sequences' dense kernels is applied always (warm-up
+    and timed region schedule the same way)."""
 
     def __init__(self, names):
         self.names = names
@@ -91,19 +100,24 @@ class OpTimer:
             self._orig[n] = fn
 
             def wrapped(*a, _fn=fn, _n=n, **k):
-                if not self.enabled:
-                    return _fn(*a, **k)
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                if _n in self.probed and self.dense_done is not None and self.serialize_dense:
-                    # only one dense kernel fits per CU, so the dense kernels of the two sequences run back to back anyway;
-                    # making that order explicit keeps the queueing of one behind the other out of the timed interval
+                dense = _n in self.probed
+                if dense and self.dense_done is not None and self.serialize_dense:
+                    # only one dense kernel fits per CU, so the dense kernels of the sequences run back to back anyway; making that
+                    # order explicit keeps the queueing of one behind the other out of the timed interval
                     torch.cuda.current_stream().wait_event(self.dense_done)
+                if not self.enabled:
+                    out = _fn(*a, **k)
+                    if dense:
+                        self.dense_done = torch.cuda.Event()
+                        self.dense_done.record()
+                    return out
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-                if _n in self.probed:
+                if dense:
                     self.kernel_probe.arm()
                 out = _fn(*a, **k)
                 e1.record()
-                if _n in self.probed:
+                if dense:
                     self.dense_done = e1
                 self.records[_n].append((e0, e1))
                 self.meta[_n].append(meta_fns[_n](*a, **k) if _n in meta_fns else None)
@@ -120,10 +134,25 @@ class OpTimer:
         return out
 
 
-class ClipWorkload:
-    """One synthetic sequence of a config, resident on the GPU, stepped with the reference's memory policy."""
+def group_order(n_groups):
+    """Visiting order of the pool-state groups: smallest, largest, second smallest, second largest, ...: every window of an even
+    number of groups has the clip's mean pool size, so any run length samples R in proportion."""
+    order, lo, hi = [], 0, n_groups - 1
+    while lo <= hi:
+        order.append(lo)
+        if hi != lo:
+            order.append(hi)
+        lo += 1
+        hi -= 1
+    return order
 
-    def __init__(self, cfg, seed, device, mc, overlap=True):
+
+class ClipWorkload:
+    """One synthetic sequence of a config, resident on the GPU.  The pool of frame t is emb[0::MEM_EVERY][:R(t)] with the clip's own
+    (ground-truth) label maps, R(t) = 1 + (t - 1) // MEM_EVERY -- exactly what the sequential loop with the reference's memory policy
+    builds -- so every pool state exists from the start and the frames can be visited group by group in any order."""
+
+    def __init__(self, cfg, seed, device, mc, overlap=True, phase=0):
         self.cfg, self.mc, self.dev = cfg, mc, device
         # the k-means branch (a long chain of small launches) runs on a high-priority side stream,
         # concurrently with the MFMA-bound dense matching on the main stream
@@ -135,93 +164,120 @@ class ClipWorkload:
         self.lab = torch.from_numpy(np.stack([syn.one_hot(l, O) for l in clip["lab"]])).to(device)   # [T,h,w,O]
         self.T = cfg.frames
         self.bias = torch.zeros(O, device=device)
-        rmax = 1 + (self.T - 1) // mc.MEM_EVERY + 1
-        self.pool_emb = torch.empty(rmax, cfg.h, cfg.w, cfg.c, device=device)
-        self.pool_lab = torch.empty(rmax, cfg.h, cfg.w, O, device=device)
-        # per-frame k-means initial rows (inputs): permutation(n_i)[:K_i] with the sticky K rule
+        me = mc.MEM_EVERY
+        self.pool_emb = self.emb[0:self.T - 1:me].contiguous()                               # pool frames 0, 5, 10, ...
+        self.pool_lab = self.lab[0:self.T - 1:me].contiguous()
+        self.rmax = self.pool_emb.shape[0]
+        levels = mc.cluster_levels
+        kmax = max(levels)
+        # per-frame k-means initial rows (inputs): permutation(n_i)[:K_i] with the sticky K rule, per level
         self.init_rows = {}
-        ref_idx = [0]
         for t in range(1, self.T):
-            counts = [int(sum((self.lab_ids[i] == o).sum() for i in ref_idx)) for o in range(O)]
-            rows = syn.kmeans_init_rows(seed * 100003 + t, counts, mc.CLUSTER_NUM)
-            init = np.zeros((O, mc.CLUSTER_NUM), np.int32)
-            for o, r in enumerate(rows):
-                if r is not None:
-                    init[o, :len(r)] = r
-            self.init_rows[t] = (torch.from_numpy(init).to(device), rows)
-            if t % mc.MEM_EVERY == 0:
-                ref_idx.append(t)
-        self.dense_state = {"capacity_frames": rmax}      # fp16 split records of the pool, converted once per appended frame
+            R = self.R_of(t)
+            counts = [int(sum((self.lab_ids[i * me] == o).sum() for i in range(R))) for o in range(O)]
+            init = np.zeros((len(levels) * O, kmax), np.int32)
+            host = []
+            for li, k in enumerate(levels):
+                rows = syn.kmeans_init_rows(seed * 100003 + t * 7 + li, counts, k)
+                host.append(rows)
+                for o, r in enumerate(rows):
+                    if r is not None:
+                        init[li * O + o, :len(r)] = r
+            self.init_rows[t] = (torch.from_numpy(init).to(device), host)
+        # visiting order: groups of MEM_EVERY frames that share a pool, groups interleaved; `phase` rotates it per sequence
+        groups = [list(range(g * me + 1, min(g * me + me, self.T - 1) + 1)) for g in range((self.T - 2) // me + 1)]
+        order = group_order(len(groups))
+        if phase % 2:                                      # odd sequences walk (largest, smallest, ...): two sequences together balance any window
+            order = [g for i in range(0, len(order), 2) for g in reversed(order[i:i + 2])]
+        rot = (phase // 2) * 2 % len(order)
+        order = order[rot:] + order[:rot]
+        self.order = [t for g in order for t in groups[g]]
+        self.group_first = {groups[g][0] for g in range(len(groups))}
+        self.group_of = {t: g for g in range(len(groups)) for t in groups[g]}
+        self.groups = groups
+        self.dense_state = {"capacity_frames": self.rmax}  # fp16 split records of the pool (one conversion per appended frame)
         self.ahead = {}                                    # frame -> adaptive proxies already enqueued on a side stream
-        self.pool_event = None                             # recorded after the last change of the pool
+        self.pool_event = None                             # recorded when the pool of the current group is final
         self.chains = mc.MEM_EVERY                         # k-means chains enqueued ahead (bench --chains)
         self.dense_stream = None                           # CU-masked stream for the dense kernel alone
         self.reuse_proxies = False                         # non-parity mode: one k-means per pool state
         self.cached_ahead = None
+        self.r_hist = {}
+        self.count_r = False
         self.reset()
 
+    def R_of(self, t):
+        return 1 + (t - 1) // self.mc.MEM_EVERY
+
     def reset(self):
-        self.t, self.R = 1, 1
+        self.pos = 0
         self.dense_state["frames"] = 0
         self.dense_state.pop("ref_pool", None)
         self.cached_ahead = None
-        self.pool_emb[0].copy_(self.emb[0])
-        self.pool_lab[0].copy_(self.lab[0])
-        self.pool_event = torch.cuda.Event()
-        self.pool_event.record()
+        self.ahead.clear()
+        self._enter_frame()
+
+    @property
+    def t(self):
+        return self.order[self.pos]
+
+    @property
+    def R(self):
+        return self.R_of(self.t)
+
+    def _enter_frame(self):
+        """Book-keeping when the walk reaches a frame: at the first frame of a group the pool has just received its newest frame
+        (eval_manager_mm.py:309-312): that frame's split records are converted again and nothing that depends on the pool may have
+        been enqueued earlier."""
+        if self.t in self.group_first:
+            self.dense_state["frames"] = min(self.dense_state.get("frames", 0), self.R - 1)
+            self.dense_state.pop("ref_pool", None)
+            self.cached_ahead = None
+            self.ahead.clear()
+            self.pool_event = torch.cuda.Event()
+            self.pool_event.record()
 
     def refs(self):
         return self.pool_emb[:self.R], self.pool_lab[:self.R]
 
+    def next_in_group(self):
+        """Frames after the current one that see the same pool (they follow it directly in the walk)."""
+        g = self.groups[self.group_of[self.t]]
+        return [u for u in g if u > self.t]
+
     def pretouch(self, gates, acts, dense_precision, pipeline):
         """Setup, not a benchmark step: one frame at EVERY pool size the clip will reach, largest first, so that torch's
         caching allocator already owns a block for every request of the timed region (otherwise each pool growth calls
-        hipMalloc, which synchronises the device).  The pool is filled with copies of frame 0 for this; reset() restores it."""
-        rmax = self.pool_emb.shape[0]
-        self.pool_emb[:] = self.emb[0]
-        self.pool_lab[:] = self.lab[0]
-        for R in range(rmax, 0, -1):
-            self.R, self.t = R, self.T - 1
-            self.pool_event = torch.cuda.Event()
-            self.pool_event.record()
-            self.ahead.clear()
+        hipMalloc, which synchronises the device)."""
+        t_of = {self.R_of(t): t for t in range(1, self.T)}
+        for R in range(self.rmax, 0, -1):
+            t = t_of[R]
             self.dense_state["frames"] = 0
             self.dense_state.pop("ref_pool", None)
-            ref_emb, ref_lab = self.refs()
-            counts = [int((self.lab_ids[0] == o).sum()) * R for o in range(self.cfg.n_obj)]
-            rows = syn.kmeans_init_rows(12345, counts, self.mc.CLUSTER_NUM)
-            init = np.zeros((self.cfg.n_obj, self.mc.CLUSTER_NUM), np.int32)
-            for o, r in enumerate(rows):
-                if r is not None:
-                    init[o, :len(r)] = r
-            init = torch.from_numpy(init).to(self.dev)
+            ref_emb, ref_lab = self.pool_emb[:R], self.pool_lab[:R]
+            init = self.init_rows[t][0]
+            ev = torch.cuda.Event()
+            ev.record()
             if self.side is not None and pipeline:
-                ahead = hotpath.launch_cluster_proxies(self.mc, ref_emb, ref_lab, init, self.side, wait_event=self.pool_event)
+                ahead = hotpath.launch_cluster_proxies(self.mc, ref_emb, ref_lab, init, self.side, wait_event=ev)
                 for nb in range(2, self.chains):               # batched chains of every size the run can ask for
-                    hotpath.launch_cluster_proxies_batch(self.mc, ref_emb, ref_lab, [init] * nb, self.side, wait_event=self.pool_event)
-                feat, head, _ = hotpath.proto_mask_features(self.mc, ref_emb, ref_lab, self.emb[1], self.lab[1], self.emb[2], self.bias,
+                    hotpath.launch_cluster_proxies_batch(self.mc, ref_emb, ref_lab, [init] * nb, self.side, wait_event=ev)
+                feat, head, _ = hotpath.proto_mask_features(self.mc, ref_emb, ref_lab, self.emb[t - 1], self.lab[t - 1], self.emb[t], self.bias,
                                                             cluster_ahead=ahead, dense_state=self.dense_state, dense_precision=dense_precision,
                                                             dense_stream=self.dense_stream)
             else:
-                feat, head, _ = hotpath.proto_mask_features(self.mc, ref_emb, ref_lab, self.emb[1], self.lab[1], self.emb[2], self.bias,
+                feat, head, _ = hotpath.proto_mask_features(self.mc, ref_emb, ref_lab, self.emb[t - 1], self.lab[t - 1], self.emb[t], self.bias,
                                                             cluster_state=dict(init_rows=init), side_stream=self.side,
                                                             dense_state=self.dense_state, dense_precision=dense_precision)
             gates(acts, head)
             torch.cuda.synchronize()
-        self.ahead.clear()
         self.reset()
 
     def advance(self):
-        """eval_manager_mm.py:309-312,356-361: append the frame to the pool every MEM_EVERY frames."""
-        if self.t % self.mc.MEM_EVERY == 0:
-            self.pool_emb[self.R].copy_(self.emb[self.t])
-            self.pool_lab[self.R].copy_(self.lab[self.t])
-            self.R += 1
-            self.pool_event = torch.cuda.Event()
-            self.pool_event.record()                       # the next k-means chain must see the appended frame
-        self.t += 1
-        if self.t >= self.T:
-            self.reset()
+        if self.count_r:
+            self.r_hist[self.R] = self.r_hist.get(self.R, 0) + 1
+        self.pos = (self.pos + 1) % len(self.order)
+        self._enter_frame()
 
 
 def make_activations(gates, O, h, w, device, seed):
@@ -229,56 +285,47 @@ def make_activations(gates, O, h, w, device, seed):
     return [torch.randn(O, c, hh, ww, generator=g).to(device) for (_, c, hh, ww, _) in gates.plan(h, w)]
 
 
-def frame_step(wl, gates, acts, dense_precision="split", pipeline=True):
+def launch_chains(wl):
+    """Enqueue the k-means chain of the current frame and of the following frames of its group (they all see the pool as it is now)
+    on the side stream: the current frame alone (it is needed first), the others batched into one chain."""
+    ref_emb, ref_lab = wl.refs()
+    t = wl.t
+    rest = wl.next_in_group()[:max(0, wl.chains - 1)]
+    wl.ahead[t] = hotpath.launch_cluster_proxies(wl.mc, ref_emb, ref_lab, wl.init_rows[t][0], wl.side, wait_event=wl.pool_event)
+    if rest:
+        outs = hotpath.launch_cluster_proxies_batch(wl.mc, ref_emb, ref_lab, [wl.init_rows[f][0] for f in rest], wl.side, wait_event=wl.pool_event)
+        for f, a in zip(rest, outs):
+            wl.ahead[f] = a
+
+
+def frame_step(wl, gates, acts, dense_precision="split", pipeline=True, defer_corr=False):
+    """One frame of one sequence; returns (feat, gate outputs, pending correlation or None)."""
     ref_emb, ref_lab = wl.refs()
     t = wl.t
     if wl.side is not None and pipeline:
-        # the k-means chain of a frame only depends on the pool (which changes every MEM_EVERY frames): the chains of all
-        # frames that will see the same pool are enqueued on side streams right after the pool update and run under the
-        # other work of the frames before them
+        # the k-means chain of a frame only depends on the pool: the chains of all frames of a group are enqueued on the side stream as
+        # soon as the group's pool is final and run under the other work of the frames before them
         if wl.reuse_proxies and wl.cached_ahead is not None and wl.cached_ahead.R == wl.R:
-            # NON-PARITY mode: the adaptive proxies computed for this pool are reused until the pool changes,
-            # instead of re-clustering the unchanged pool with fresh initial rows for every frame like the reference
+            # NON-PARITY mode (SURVEY 8f-3): the adaptive proxies computed for this pool are reused until the pool changes
             ahead = wl.cached_ahead
         else:
             if t not in wl.ahead:
                 launch_chains(wl)
             ahead = wl.ahead.pop(t)
             wl.cached_ahead = ahead if wl.reuse_proxies else None
-        if not wl.reuse_proxies and t % wl.mc.MEM_EVERY != 0 and t + 1 < wl.T and (t + 1) not in wl.ahead:
-            # the next frame sees the same pool: its chain goes onto the side stream now, behind this frame's chain, and
-            # does not wait for anything this frame still has to do on the main stream
-            wl.ahead[t + 1] = hotpath.launch_cluster_proxies(wl.mc, ref_emb, ref_lab, wl.init_rows[t + 1][0], wl.side, wait_event=wl.pool_event)
-        feat, head, _ = hotpath.proto_mask_features(wl.mc, ref_emb, ref_lab, wl.emb[t - 1], wl.lab[t - 1], wl.emb[t], wl.bias,
-                                                    cluster_ahead=ahead, dense_state=wl.dense_state, dense_precision=dense_precision,
-                                                    dense_stream=wl.dense_stream)
+        nxt = wl.next_in_group()
+        if not wl.reuse_proxies and nxt and nxt[0] not in wl.ahead:
+            wl.ahead[nxt[0]] = hotpath.launch_cluster_proxies(wl.mc, ref_emb, ref_lab, wl.init_rows[nxt[0]][0], wl.side, wait_event=wl.pool_event)
+        feat, head, aux = hotpath.proto_mask_features(wl.mc, ref_emb, ref_lab, wl.emb[t - 1], wl.lab[t - 1], wl.emb[t], wl.bias,
+                                                      cluster_ahead=ahead, dense_state=wl.dense_state, dense_precision=dense_precision,
+                                                      dense_stream=wl.dense_stream, defer_correlation=defer_corr)
     else:
-        feat, head, _ = hotpath.proto_mask_features(wl.mc, ref_emb, ref_lab, wl.emb[t - 1], wl.lab[t - 1], wl.emb[t], wl.bias,
-                                                    cluster_state=dict(init_rows=wl.init_rows[t][0]), side_stream=wl.side,
-                                                    dense_state=wl.dense_state, dense_precision=dense_precision)
+        feat, head, aux = hotpath.proto_mask_features(wl.mc, ref_emb, ref_lab, wl.emb[t - 1], wl.lab[t - 1], wl.emb[t], wl.bias,
+                                                      cluster_state=dict(init_rows=wl.init_rows[t][0]), side_stream=wl.side,
+                                                      dense_state=wl.dense_state, dense_precision=dense_precision, defer_correlation=defer_corr)
     outs = gates(acts, head)
-    wl.advance()                                           # pool append / sequence restart happen here (after the frame's outputs)
-    if wl.side is not None and pipeline and wl.t not in wl.ahead and not (wl.reuse_proxies and wl.cached_ahead is not None and wl.cached_ahead.R == wl.R):
-        launch_chains(wl)
-    return feat, outs
-
-
-def launch_chains(wl):
-    """Enqueue the k-means chains of frame wl.t and of the following frames up to the next pool update (they all see the
-    pool as it is now) on the side stream: the first frame alone (it is needed first), the others batched into one chain."""
-    ref_emb, ref_lab = wl.refs()
-    t = wl.t
-    for k in [k for k in wl.ahead if k < t or k >= wl.T]:
-        del wl.ahead[k]
-    frames = [t]
-    while frames[-1] % wl.mc.MEM_EVERY != 0 and frames[-1] + 1 < wl.T and len(frames) < wl.chains:
-        frames.append(frames[-1] + 1)                      # a frame with t % MEM_EVERY == 0 is appended: later ones see another pool
-    wl.ahead[t] = hotpath.launch_cluster_proxies(wl.mc, ref_emb, ref_lab, wl.init_rows[t][0], wl.side, wait_event=wl.pool_event)
-    if len(frames) > 1:
-        rest = hotpath.launch_cluster_proxies_batch(wl.mc, ref_emb, ref_lab, [wl.init_rows[f][0] for f in frames[1:]], wl.side,
-                                                    wait_event=wl.pool_event)
-        for f, a in zip(frames[1:], rest):
-            wl.ahead[f] = a
+    wl.advance()                                           # the walk moves on (a new group = a new pool state starts here)
+    return feat, outs, aux["pending_correlation"]
 
 
 def _block_weights(mod):
@@ -291,45 +338,57 @@ def _block_weights(mod):
 
 
 DENSE_SUBSAMPLE = 16
+CPU_BASELINE_R = 6             # pool frames of the CPU sample: the clip's average is 6.4
 
 
 def cpu_baseline(cfg, mc, seed, gates, acts_cpu):
-    """The oracle (a port of the reference path, proved equal to it on the golden vectors) timed on the
-    host cores for ONE frame of the same workload at R = 1 (the cheapest frame of the clip), bounded to
-    a few tens of seconds: the dense branch (linear in query pixels) runs on every 16th query pixel and
-    is scaled by 16; each distinct calibration gate shape is timed once and multiplied by its count.
-    Returns the per-branch features (for a parity spot check) and the timings."""
+    """The oracle (a port of the reference path, proved equal to it on the golden vectors) timed on the host cores for ONE frame of
+    the same workload at R = 6 pool frames (the clip's average is 6.4), bounded to a few tens of seconds: the dense branch (linear in
+    query pixels) runs on every 16th query pixel and is scaled by 16; each distinct calibration gate shape is timed once and multiplied
+    by its count.  A second, cheap frame at R = 1 provides the per-branch features for the parity spot check."""
     from oracle import calibration as ocal
     from oracle import matching as om
     threads = min(32, os.cpu_count() or 1)
     torch.set_num_threads(threads)
-    clip = syn.make_clip(cfg, seed, frames=2)
+    me = mc.MEM_EVERY
+    clip = syn.make_clip(cfg, seed, frames=(CPU_BASELINE_R - 1) * me + 3)
     O = cfg.n_obj
     emb = torch.from_numpy(clip["emb"])
     lab = torch.from_numpy(np.stack([syn.one_hot(l, O) for l in clip["lab"]]))
-    counts = [int((clip["lab"][0] == o).sum()) for o in range(O)]
-    rows = syn.kmeans_init_rows(seed * 100003 + 1, counts, mc.CLUSTER_NUM)
+    levels = mc.cluster_levels
+    cn = levels if mc.CLUSTER_LEVELS else levels[0]
     bias = torch.zeros(O)
     mld = list(mc.MODEL_MULTI_LOCAL_DISTANCE)
-    tm, feats = {}, {}
+    tm = {}
 
     def timed(key, fn):
         t0 = time.perf_counter()
         out = fn()
-        tm[key] = time.perf_counter() - t0
+        tm[key] = tm.get(key, 0.0) + time.perf_counter() - t0
         return out
 
-    ref_flat, lab_flat = emb[0].reshape(-1, cfg.c), lab[0].reshape(-1, O)
-    q_sub = emb[1].reshape(-1, cfg.c)[::DENSE_SUBSAMPLE]
-    feats["dense_sub"] = timed("dense", lambda: om.proto_transform(om.nearest_neighbor_features_per_object(ref_flat, q_sub, lab_flat).squeeze(-1), bias.view(1, -1)))
+    def rows_for(ref_ids, s):
+        counts = [int(sum((clip["lab"][i] == o).sum() for i in ref_ids)) for o in range(O)]
+        rows = [syn.kmeans_init_rows(seed * 100003 + s + li, counts, k) for li, k in enumerate(levels)]
+        return rows if mc.CLUSTER_LEVELS else rows[0]
+
+    # ---- the timed frame: pool = frames 0, 5, .., 25, previous frame 26, query 27
+    ref_ids = [i * me for i in range(CPU_BASELINE_R)]
+    tq = ref_ids[-1] + 2
+    refs, labs = [emb[i] for i in ref_ids], [lab[i] for i in ref_ids]
+    ref_flat = torch.cat([r.reshape(-1, cfg.c) for r in refs])
+    lab_flat = torch.cat([l.reshape(-1, O) for l in labs])
+    q_sub = emb[tq].reshape(-1, cfg.c)[::DENSE_SUBSAMPLE]
+    timed("dense", lambda: om.proto_transform(om.nearest_neighbor_features_per_object(ref_flat, q_sub, lab_flat).squeeze(-1), bias.view(1, -1)))
     tm["dense"] *= DENSE_SUBSAMPLE
-    feats["cluster"] = timed("cluster", lambda: om.global_matching_for_eval_cluster([emb[0]], emb[1], [lab[0]], 4, bias, init_rows=rows))
-    feats["local"] = timed("local", lambda: om.local_matching(emb[0], emb[1], lab[0], bias, mld))
-    ref_e, ref_l = [emb[0].permute(2, 0, 1).unsqueeze(0)], [lab[0].permute(2, 0, 1).unsqueeze(1)]
+    timed("cluster", lambda: om.global_matching_for_eval_cluster(refs, emb[tq], labs, 4, bias, init_rows=rows_for(ref_ids, 1), cluster_num=cn))
+    timed("local", lambda: om.local_matching(emb[tq - 1], emb[tq], lab[tq - 1], bias, mld))
+    ref_e = [e.permute(2, 0, 1).unsqueeze(0) for e in refs]
+    ref_l = [l.permute(2, 0, 1).unsqueeze(1) for l in labs]
     head, ref_pos, _, prev_pos, _ = timed("pool", lambda: ocal.attention_head_for_eval_p_m(
-        ref_e, ref_l, emb[0].permute(2, 0, 1).unsqueeze(0).expand(O, -1, -1, -1), ref_l[0], mc.MODEL_EPSILON))
-    feats["proxy"] = timed("proxy", lambda: om.global_matching_for_eval_proxy(ref_pos, emb[1], [lab[0]], 4, bias))
-    feats["local_proxy"] = timed("local_proxy", lambda: om.local_matching(torch.matmul(lab[0], prev_pos), emb[1], lab[0], bias, mld))
+        ref_e, ref_l, emb[tq - 1].permute(2, 0, 1).unsqueeze(0).expand(O, -1, -1, -1), lab[tq - 1].permute(2, 0, 1).unsqueeze(1), mc.MODEL_EPSILON))
+    timed("proxy", lambda: om.global_matching_for_eval_proxy(ref_pos, emb[tq], labs, 4, bias))
+    timed("local_proxy", lambda: om.local_matching(torch.matmul(lab[tq - 1], prev_pos), emb[tq], lab[tq - 1], bias, mld))
     t_match = sum(tm.values())
     t_cal, seen = 0.0, {}
     for (name, c, hh, ww, extra), x in zip(gates.plan(cfg.h, cfg.w), acts_cpu):
@@ -348,7 +407,76 @@ def cpu_baseline(cfg, mc, seed, gates, acts_cpu):
                 ocal.ia_gate(x, hd, sd["IA.weight"], sd["IA.bias"])
             seen[key] = time.perf_counter() - t0
         t_cal += seen[key]
-    return feats, rows, tm, t_match, t_cal, threads
+
+    # ---- parity frame (R = 1): per-branch features of the oracle, untimed
+    feats = {}
+    rows1 = rows_for([0], 2)
+    q1_sub = emb[1].reshape(-1, cfg.c)[::DENSE_SUBSAMPLE]
+    feats["dense_sub"] = om.proto_transform(om.nearest_neighbor_features_per_object(emb[0].reshape(-1, cfg.c), q1_sub, lab[0].reshape(-1, O)).squeeze(-1),
+                                            bias.view(1, -1))
+    feats["cluster"] = om.global_matching_for_eval_cluster([emb[0]], emb[1], [lab[0]], 4, bias, init_rows=rows1, cluster_num=cn)
+    feats["local"] = om.local_matching(emb[0], emb[1], lab[0], bias, mld)
+    e0 = emb[0].permute(2, 0, 1).unsqueeze(0)
+    l0 = lab[0].permute(2, 0, 1).unsqueeze(1)
+    _, rp, _, pp, _ = ocal.attention_head_for_eval_p_m([e0], [l0], e0.expand(O, -1, -1, -1), l0, mc.MODEL_EPSILON)
+    feats["proxy"] = om.global_matching_for_eval_proxy(rp, emb[1], [lab[0]], 4, bias)
+    feats["local_proxy"] = om.local_matching(torch.matmul(lab[0], pp), emb[1], lab[0], bias, mld)
+    return feats, rows1, (emb[:2], lab[:2]), tm, t_match, t_cal, threads
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def correlation_roofline(cfg, mc, dev, batches=(1, 4, 16), reps=20):
+    """The correlation kernel by itself: B distinct frames per aoc_proxy_corr_min_batched launch, B in `batches`, each
+    timed with HIP events around `reps` back-to-back launches on an otherwise idle GPU (median)."""
+    O, C, hw = cfg.n_obj, cfg.c, cfg.h * cfg.w
+    levels = mc.cluster_levels
+    L, kmax = len(levels), max(levels)
+    n_ad = L * O * 2 * kmax
+    ch = hotpath.channel_slices(mc)
+    stride = mc.proto_channels * hw
+    sb, ss, so = [], [], []
+    for l, k in enumerate(levels):
+        for o in range(O):
+            for f in range(2):
+                sb.append(((l * O + o) * 2 + f) * kmax)
+                ss.append(k)
+                so.append(o * stride + (ch["cluster"] + 2 * l + f) * hw)
+    for o in range(O):
+        sb.append(n_ad + o)
+        ss.append(1)
+        so.append(o * stride + ch["proxy"] * hw)
+    n_set = len(sb)
+    rng = np.random.RandomState(0)
+    frames = []
+    for _ in range(max(batches)):
+        q = torch.from_numpy(syn.fresh_embedding(rng, cfg.h, cfg.w, C)).to(dev).reshape(hw, C)
+        table = torch.from_numpy((np.maximum(rng.randn(n_ad + O, C), 0) * 0.1).astype(np.float32)).to(dev)
+        frames.append((q, table, table.pow(2).sum(1), torch.zeros(n_set, device=dev), torch.empty(O, mc.proto_channels, cfg.h, cfg.w, device=dev)))
+    algo = hw * C * 4 + (n_ad + O) * C * 4 + 4 * hw * n_set
+    out = []
+    for b in batches:
+        fr = frames[:b]
+        for _ in range(3):
+            ops.proxy_corr_min_batched(fr, sb, ss, so, True, "split")
+        torch.cuda.synchronize()
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
+        evs[0].record()
+        for i in range(reps):
+            ops.proxy_corr_min_batched(fr, sb, ss, so, True, "split")
+            evs[i + 1].record()
+        torch.cuda.synchronize()
+        ms = float(np.median([evs[i].elapsed_time(evs[i + 1]) for i in range(reps)]))
+        gbs = b * algo / (ms * 1e-3) / 1e9
+        out.append(dict(frames_per_launch=b, avg_launch_ms=round(ms, 4), algorithmic_bytes_per_launch=b * algo, achieved=round(gbs, 1),
+                        frac=round(gbs / PEAK_HBM_GBS, 4)))
+    return out
 
 
 def main():
@@ -361,28 +489,40 @@ def main():
     ap.add_argument("--dense", default="split", choices=["split", "fp32"],
                     help="dense-matching arithmetic: fp16-split products with fp32 accumulate (fp32-equivalent) or exact-fp32 MFMA")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--exact-run", action="store_true",
-                    help="add an informational second region: the same K steps with the exact-fp32 dense kernel (reported as exact_fp32_dense_run)")
+    ap.add_argument("--exact-steps", type=int, default=10,
+                    help="steps of the informational second region with the exact-fp32 dense kernel (reported as exact_fp32_dense_run; 0 = skip)")
     ap.add_argument("--cu-reserve", type=int, default=64,
                     help="keep the main streams off this many CUs (HIP CU mask) so the side-stream k-means chain always finds free CUs")
     ap.add_argument("--chains", type=int, default=3,
                     help="frames whose k-means is enqueued right after a pool update (1 = only the next frame; the others are batched into one chain)")
     ap.add_argument("--dense-stream", dest="mask_main", action="store_false",
-                    help="put only the dense kernel under the CU mask (on its own stream) instead of the whole main stream "
-                         "(measured slower: the unmasked light kernels then take the reserved CUs from the k-means chains)")
+                    help="put only the dense kernel under the CU mask (on its own stream) instead of the whole main stream")
     ap.add_argument("--reuse-proxies", action="store_true",
                     help="NON-PARITY mode (SURVEY 8f-3): cluster the pool once per pool update instead of once per frame; the JSON "
                          "line then says so in config.proxy_mode and is not comparable with the default")
+    ap.add_argument("--no-batch-corr", dest="batch_corr", action="store_false",
+                    help="one correlation launch per sequence and frame instead of ONE batched launch for the frames of all in-flight sequences")
     ap.add_argument("--no-dense-order", action="store_true",
                     help="do not order the sequences' dense kernels explicitly (their live timing then includes queueing behind each other)")
     ap.add_argument("--no-pipeline", action="store_true",
-                    help="start a frame's k-means chain with the frame instead of right after the previous frame's pool update")
+                    help="start a frame's k-means chain with the frame instead of as soon as its pool is final")
     ap.add_argument("--no-overlap", action="store_true", help="run the k-means branch on the main stream (no intra-frame stream overlap)")
+    ap.add_argument("--eval-sharded", action="store_true",
+                    help="BASELINE.json configs[4]: run the sequence-sharded evaluation (eval_runner) over the ranks instead of the cfg2 step loop; "
+                         "a fixed sequence set (strong scaling), --eval-scale of the 30 + 507 sequences")
+    ap.add_argument("--eval-scale", type=float, default=0.03)
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # one process per GPU over RCCL: re-launch under torch.distributed.run
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU (or let `python bench.py --gpus N` launch them)")
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -390,29 +530,71 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # RCCL over xGMI
+    n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
+    if args.cu_reserve >= n_cu:
+        args.cu_reserve = 0
     if args.cu_reserve > 0:
-        os.environ.setdefault("AOC_DENSE_CUS", str(256 - args.cu_reserve))   # the dense kernel sizes its grid in whole rounds of CUs
+        os.environ.setdefault("AOC_DENSE_CUS", str(n_cu - args.cu_reserve))   # the dense kernel sizes its grid in whole rounds of CUs
+        os.environ.setdefault("AOC_CORR_CUS", str(n_cu - args.cu_reserve))
     aoc_amd._lib.lib()
 
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+
+    if args.eval_sharded:
+        # ---- BASELINE.json configs[4]: a fixed synthetic sequence set partitioned over the ranks (LPT), one all-reduce at the end
+        specs = eval_runner.make_sequence_set("cfg5", scale=args.eval_scale, seed=0)
+        np.random.seed(1234 + rank)
+        with torch.no_grad():
+            eval_runner.eval_sharded(specs[:1], 0, 1, dev, max_frames=3)          # warm-up: allocator, library load
+            barrier()
+            t0 = time.perf_counter()
+            tot = eval_runner.eval_sharded(specs, rank, world, dev)
+            barrier()
+            elapsed = time.perf_counter() - t0
+        el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        if world > 1:
+            torch.distributed.all_reduce(el, op=torch.distributed.ReduceOp.MAX)
+        if rank == 0:
+            line = {"metric": "frames/sec, AOC-Net matching + read-out + memory policy, sequence-sharded evaluation", "value": round(tot["frames"] / float(el.item()), 3),
+                    "unit": "frames/s", "n_gpus": world, "steps": int(tot["frames"]), "warmup": 3, "ms_per_step": round(float(el.item()) / max(tot["frames"], 1) * 1e3, 4),
+                    "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                    "config": {"workload": f"cfg5: {len(specs)} synthetic sequences ({args.eval_scale:g} of 30 DAVIS-17-val-like 121x213 K=16 + 507 YouTube-VOS-19-like "
+                                           "145x261 K in {8,16,32}), closed loop (matching -> DynamicPreHead -> linear read-out -> soft-max -> memory policy), "
+                                           "reference-API path (one host read-back of the row counts per frame for scipy's initial rows)",
+                               "sharding": "sequences over ranks by LPT on frames x objects, no data-path collective; one all-reduce(SUM) + one all-reduce(MAX) of metric accumulators"},
+                    "eval": {k: tot[k] for k in ("sequences", "ranks", "frames", "objects", "mean_j", "mean_f", "rank_seconds_max", "rank_seconds_mean",
+                                                 "imbalance", "planned_imbalance")},
+                    "roofline": None, "cpu_baseline": None}
+            print(json.dumps(line), flush=True)
+        if world > 1:
+            torch.distributed.barrier()
+            torch.distributed.destroy_process_group()
+        return
+
     cfg = syn.CONFIGS[args.config]
-    mc = hotpath.MatchingConfig(CLUSTER_NUM=cfg.k)
+    levels = CONFIG_LEVELS.get(args.config)
+    mc = hotpath.MatchingConfig(CLUSTER_NUM=cfg.k, CLUSTER_LEVELS=levels)
     torch.manual_seed(0)
     gates = hotpath.CalibrationGates(mc).to(dev)
     n_streams = max(1, args.streams)
     # sequences are sharded over ranks: rank r owns sequences r*n_streams .. (+n_streams)
-    workloads = [ClipWorkload(cfg, seed=1 + rank * n_streams + s, device=dev, mc=mc, overlap=not args.no_overlap) for s in range(n_streams)]
+    workloads = [ClipWorkload(cfg, seed=1 + rank * n_streams + s, device=dev, mc=mc, overlap=not args.no_overlap,
+                              phase=s) for s in range(n_streams)]
     for wl in workloads:
         wl.chains = 1 if args.reuse_proxies else max(1, min(args.chains, mc.MEM_EVERY))
         wl.reuse_proxies = args.reuse_proxies
     acts = make_activations(gates, cfg.n_obj, cfg.h, cfg.w, dev, seed=7)
+
     def make_main_stream():
-        """Main stream of one sequence.  With --cu-reserve N its workgroups are kept off N of the 256 CUs (HIP CU mask), so
+        """Main stream of one sequence.  With --cu-reserve N its workgroups are kept off N of the CUs (HIP CU mask), so
         that the latency-bound k-means chain on the side stream always finds free CUs next to the dense kernel, whose
         blocks fill a CU's register file and do not yield."""
         if args.cu_reserve <= 0:
             return torch.cuda.Stream(device=dev)
         hip = ctypes.CDLL("libamdhip64.so")
-        n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
         words = (n_cu + 31) // 32
         mask = [0] * words
         for cu in range(n_cu - args.cu_reserve):           # contiguous: interleaved masks were observed to be ignored
@@ -424,6 +606,7 @@ def main():
             print(f"bench: hipExtStreamCreateWithCUMask failed ({rc}); running without the CU reservation", file=sys.stderr)
             args.cu_reserve = 0
             os.environ.pop("AOC_DENSE_CUS", None)
+            os.environ.pop("AOC_CORR_CUS", None)
             return torch.cuda.Stream(device=dev)
         return torch.cuda.ExternalStream(handle.value, device=dev)
 
@@ -436,6 +619,7 @@ def main():
         dense_streams = [make_main_stream() if args.cu_reserve > 0 else None for _ in range(n_streams)]
     for wl, ds in zip(workloads, dense_streams):
         wl.dense_stream = ds
+    batch_corr = args.batch_corr and n_streams > 1 and cfg.c == 100
 
     hw, C, O = cfg.h * cfg.w, cfg.c, cfg.n_obj
 
@@ -446,40 +630,57 @@ def main():
     def meta_dense_split(query_flat, query_split, pool, pool_split, prep, *a, **k):
         return meta_dense(query_flat, pool[:prep.n], prep)
 
-    def meta_proxy(query_flat, proxies, *a, **k):
+    def meta_proxy(query_flat, proxies, proxy_sqnorm, set_begin, *a, **k):
         m, npx = query_flat.shape[0], proxies.shape[0]
-        return dict(flops=2.0 * m * npx * C, bytes=m * C * 4 + npx * C * 4 + m * (3 * O) * 4)
+        return dict(flops=2.0 * m * npx * C, bytes=m * C * 4 + npx * C * 4 + m * len(set_begin) * 4)
+
+    def meta_proxy_batched(frames, set_begin, *a, **k):
+        m, npx = frames[0][0].shape[0], frames[0][1].shape[0]
+        return dict(flops=2.0 * m * npx * C * len(frames), bytes=(m * C * 4 + npx * C * 4 + m * len(set_begin) * 4) * len(frames), frames=len(frames))
 
     def meta_kmeans(pool, rows, seg_offsets, seg_k, init_rows, kmax, iters=20, rows_capacity=None):
         n = pool.shape[0]
         return dict(flops=2.0 * iters * n * kmax * C, bytes=float(iters) * n * C * 4 * 2 + n * 4)
 
+    def meta_film(x, *a, **k):
+        return dict(flops=float(x.numel()), bytes=2.0 * x.numel() * 4)          # 2 O c h w s
+
+    def meta_cond(z, *a, **k):
+        return dict(flops=2.0 * z.numel(), bytes=1.0 * z.numel() * 4)           # O C H W s (one read of z)
+
     # HIP-event pairs only around the ops the roofline objects need (an event pair costs ~25 us of host time, and the host
     # enqueues ~60 ops per frame); every kernel's duration is in the rocprofv3 summary under profiles/
-    timer = OpTimer(["dense_match_min", "dense_match_min_split", "proxy_corr_min", "kmeans_segmented", "local_window_match"])
+    timer = OpTimer(["dense_match_min", "dense_match_min_split", "proxy_corr_min", "proxy_corr_min_batched", "kmeans_segmented", "local_window_match",
+                     "film_scale", "cond_gate_pool"])
     timer.serialize_dense = not args.no_dense_order
-    timer.install(dict(dense_match_min=meta_dense, dense_match_min_split=meta_dense_split, proxy_corr_min=meta_proxy, kmeans_segmented=meta_kmeans))
+    timer.install(dict(dense_match_min=meta_dense, dense_match_min_split=meta_dense_split, proxy_corr_min=meta_proxy,
+                       proxy_corr_min_batched=meta_proxy_batched, kmeans_segmented=meta_kmeans, film_scale=meta_film, cond_gate_pool=meta_cond))
+    corr_stream = torch.cuda.Stream(device=dev) if batch_corr else None
 
     def run_steps(n):
         for _ in range(n):
+            pend = []
             for wl, st in zip(workloads, streams):
                 if n_streams > 1 or (args.cu_reserve > 0 and args.mask_main):
                     with torch.cuda.stream(st):
-                        frame_step(wl, gates, acts, args.dense, not args.no_pipeline)
+                        _, _, p = frame_step(wl, gates, acts, args.dense, not args.no_pipeline, batch_corr)
                 else:
-                    frame_step(wl, gates, acts, args.dense, not args.no_pipeline)
-
-    def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            torch.distributed.barrier()
+                    _, _, p = frame_step(wl, gates, acts, args.dense, not args.no_pipeline, batch_corr)
+                pend.append(p)
+            if batch_corr:
+                # ONE correlation launch for the frames of all in-flight sequences; every sequence's stream joins it
+                done = hotpath.launch_correlations(pend, corr_stream)
+                for st in streams:
+                    st.wait_event(done)
 
     with torch.no_grad():
-        for wl, st in zip(workloads, streams):             # allocator pre-touch at the largest pool size (setup)
+        for wl, st in zip(workloads, streams):             # allocator pre-touch at every pool size (setup)
             with torch.cuda.stream(st):
                 wl.pretouch(gates, acts, args.dense, not args.no_pipeline)
         run_steps(args.warmup)
         barrier()
+        for wl in workloads:
+            wl.count_r = True
         timer.enabled = True                 # HIP events around every op, on the stream the op is launched on
         t0 = time.perf_counter()
         if os.environ.get("AOC_BENCH_PROFILE"):
@@ -497,6 +698,8 @@ def main():
         barrier()
         elapsed = time.perf_counter() - t0
         timer.enabled = False
+        for wl in workloads:
+            wl.count_r = False
 
     el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
@@ -504,28 +707,32 @@ def main():
     elapsed_max = float(el.item())
     frames_local = args.steps * n_streams
     metrics = sharding.allreduce_metrics(dict(frames=frames_local, objects=frames_local * (O - 1), gpu_seconds=elapsed), device=dev)
+    r_hist = {}
+    for wl in workloads:
+        for r, c in wl.r_hist.items():
+            r_hist[r] = r_hist.get(r, 0) + c
 
     probe_ms = timer.kernel_probe.elapsed_ms()
 
-    # second, informational region (N = 1 only): the same K steps with the exact-fp32 dense kernel (`--dense fp32`), so that the
-    # line also carries the figure of the all-fp32 arithmetic next to the headline
+    # second, informational region (N = 1 only): a few steps with the exact-fp32 dense kernel (`--dense fp32`), so that the line also
+    # carries the figure of the all-fp32 arithmetic next to the headline
     exact = None
-    if world == 1 and args.dense == "split" and args.exact_run:
+    if world == 1 and args.dense == "split" and args.exact_steps > 0:
         with torch.no_grad():
             for wl in workloads:
                 wl.reset()
-                wl.ahead.clear()
             saved = args.dense
             args.dense = "fp32"
-            run_steps(min(args.warmup, 2))
+            run_steps(2)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            run_steps(args.steps)
+            run_steps(args.exact_steps)
             torch.cuda.synchronize()
             e2 = time.perf_counter() - t1
             args.dense = saved
-        exact = dict(value=round(args.steps * n_streams / e2, 3), unit="frames/s", ms_per_step=round(e2 / args.steps * 1e3, 4),
-                     note="same workload and steps with aoc_dense_match_min (v_mfma_f32_16x16x4_f32) instead of the fp16-split kernel")
+        exact = dict(value=round(args.exact_steps * n_streams / e2, 3), unit="frames/s", steps=args.exact_steps, ms_per_step=round(e2 / args.exact_steps * 1e3, 4),
+                     note="same workload with aoc_dense_match_min (v_mfma_f32_16x16x4_f32) instead of the fp16-split kernel; a shorter region that starts "
+                          "at the beginning of the group walk")
     if rank == 0:
         summ = timer.summary()
         kernels = {}
@@ -564,20 +771,14 @@ def main():
                                 executed_tflops=round(executed, 1), pipe_frac=round(executed / PEAK_F16_MFMA_TFLOPS, 4),
                                 note="fp32-equivalent products from 3 fp16 MFMAs (hi*hi + hi*lo + lo*hi, fp32 accumulate); frac prices the "
                                      "ALGORITHMIC fp32 flops against the dense fp16 peak, pipe_frac the executed ones; avg_launch_ms = hipEvents "
-                                     "recorded by the library immediately around the kernel while the other sequence's stream shares the GPU",
-                                op_avg_ms=k.get("op_avg_ms"), traffic_source=None)
+                                     "recorded by the library immediately around the kernel while the other sequence's stream shares the GPU; traffic "
+                                     "(PMC FETCH/WRITE) is not measurable inside the run: the separate --pmc passes are under profiles/",
+                                op_avg_ms=k.get("op_avg_ms"))
                 if args.cu_reserve > 0:
                     # the kernel is launched on a stream whose CU mask leaves cu_reserve CUs to the k-means chains
-                    cus = 256 - args.cu_reserve
+                    cus = n_cu - args.cu_reserve
                     roofline["cus_available_to_kernel"] = cus
-                    roofline["pipe_frac_of_available_cus"] = round(executed / (PEAK_F16_MFMA_TFLOPS * cus / 256.0), 4)
-                pmc_file = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_dense_split.json")
-                if os.path.exists(pmc_file):
-                    # PMC counters cannot be read from inside the run: separate rocprofv3 --pmc passes of this command, committed
-                    with open(pmc_file) as fh:
-                        pmc = json.load(fh)
-                    roofline["traffic"] = pmc["traffic_bytes_per_launch"]
-                    roofline["traffic_source"] = "profiles/r01_pmc_dense_split.json (FETCH_SIZE x2 + WRITE_SIZE per dispatch, separate --pmc passes)"
+                    roofline["pipe_frac_of_available_cus"] = round(executed / (PEAK_F16_MFMA_TFLOPS * cus / n_cu), 4)
         km = kernels.get("kmeans_segmented")
         km_roof = None
         if km and "gbs" in km:
@@ -585,60 +786,57 @@ def main():
                            achieved=km["gbs"], peak=PEAK_HBM_GBS, unit="GB/s", frac=round(km["gbs"] / PEAK_HBM_GBS, 4),
                            avg_launch_ms=km["avg_ms"], algorithmic_bytes_per_launch=km["avg_bytes"],
                            note="a dependent chain of ~160 launches whose ordered float32 sums are latency-bound by construction")
-        corr = kernels.get("proxy_corr_min")
+
+        def hbm_roof(name, kernel, note):
+            kk = kernels.get(name)
+            if not kk or "gbs" not in kk:
+                return None
+            return dict(kernel=kernel, bound="hbm", achieved=kk["gbs"], peak=PEAK_HBM_GBS, unit="GB/s", frac=round(kk["gbs"] / PEAK_HBM_GBS, 4),
+                        avg_launch_ms=kk["avg_ms"], algorithmic_bytes_per_launch=kk["avg_bytes"], calls=kk["calls"], note=note)
+
+        film_roof = hbm_roof("film_scale", "film_scale_kernel (aoc_film_scale: IA gates and the FiLM of the conditioning blocks)",
+                             "in-run average over the 14 activation shapes of decoding_module.py:22-84; algorithmic bytes 2 O c h w 4 (SURVEY 8d)")
+        cond_roof = hbm_roof("cond_gate_pool", "cond_scores / cond_kth_largest / cond_masked_gap (aoc_cond_gate_pool)",
+                             "in-run average over the 4 conditioning blocks; algorithmic bytes O C H W 4 = ONE read of z (SURVEY 8d); the op reads z twice "
+                             "(scores, masked pooling) around the exact k-th-largest selection")
+        corr_name = "proxy_corr_min_batched" if "proxy_corr_min_batched" in kernels else "proxy_corr_min"
+        corr = kernels.get(corr_name)
         corr_roof = None
         if corr and "gbs" in corr:
-            corr_roof = dict(kernel="proxy_corr_min_kernel", bound="hbm", achieved=corr["gbs"], peak=PEAK_HBM_GBS, unit="GB/s",
+            corr_roof = dict(kernel="proxy_corr_batched_kernel (aoc_proxy_corr_min_batched)" if corr_name.endswith("batched") else "proxy_corr_min_kernel",
+                             bound="hbm", achieved=corr["gbs"], peak=PEAK_HBM_GBS, unit="GB/s",
                              frac=round(corr["gbs"] / PEAK_HBM_GBS, 4), avg_launch_ms=corr["avg_ms"], algorithmic_bytes_per_launch=corr["avg_bytes"],
-                             note="in-run figure: the event pair also spans the time the launch waits behind the other streams' kernels")
-            # the kernel by itself: the same launch (one frame: 132 proxies x 25 773 pixels) 50 times back to back on an idle GPU
-            wl = workloads[0]
-            with torch.no_grad():
-                torch.cuda.synchronize()
-                kmax = mc.CLUSTER_NUM
-                table = torch.randn(O * 2 * kmax + O, C, device=dev) * 0.3
-                sqn = table.pow(2).sum(1)
-                feat = torch.empty(O, mc.proto_channels, cfg.h, cfg.w, device=dev)
-                stride = mc.proto_channels * hw
-                sb = [(o * 2 + f) * kmax for o in range(O) for f in range(2)] + [O * 2 * kmax + o for o in range(O)]
-                ss = [kmax] * (2 * O) + [1] * O
-                so = [o * stride + (1 + f) * hw for o in range(O) for f in range(2)] + [o * stride + 3 * hw for o in range(O)]
-                bias3 = torch.zeros(3 * O, device=dev)
-                q = wl.emb[1].reshape(hw, C)
-                run = lambda: timer._orig["proxy_corr_min"](q, table, sqn, sb, ss, so, bias3, feat, 1, True)
-                for _ in range(5):
-                    run()
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                for _ in range(50):
-                    run()
-                e1.record()
-                torch.cuda.synchronize()
-                iso_ms = e0.elapsed_time(e1) / 50
-            iso_gbs = corr["avg_bytes"] / (iso_ms * 1e-3) / 1e9
-            corr_roof.update(isolated_avg_launch_ms=round(iso_ms, 4), isolated_achieved=round(iso_gbs, 1), isolated_frac=round(iso_gbs / PEAK_HBM_GBS, 4))
+                             frames_per_launch=n_streams if corr_name.endswith("batched") else 1,
+                             note="in-run figure: the event pair also spans the time the launch waits behind the other streams' kernels; "
+                                  "`isolated` = the same kernel with B distinct frames per launch on an idle GPU")
+            if C == 100:
+                with torch.no_grad():
+                    corr_roof["isolated"] = correlation_roofline(cfg, mc, dev)
+                best = max(corr_roof["isolated"], key=lambda r: r["frac"])
+                corr_roof.update(isolated_best_frac=best["frac"], isolated_best_frames_per_launch=best["frames_per_launch"])
 
         cpu = None
         parity = None
         if world == 1 and not args.no_cpu_baseline:
             acts_cpu = [a.cpu() for a in acts]
-            feats, rows, tm, t_match, t_cal, threads = cpu_baseline(cfg, mc, 1, gates, acts_cpu)
+            feats, rows, (emb2, lab2), tm, t_match, t_cal, threads = cpu_baseline(cfg, mc, 1, gates, acts_cpu)
             br = ", ".join(f"{k} {v:.2f}" for k, v in tm.items())
             cpu = dict(value=round(1.0 / (t_match + t_cal), 5), unit="frames/s", cores=threads, kind="port",
-                       sample=f"1 frame of {cfg.name} at R=1 (the cheapest frame; the GPU figure averages R=1..12): matching {t_match:.2f} s "
+                       sample=f"1 frame of {cfg.name} with R={CPU_BASELINE_R} pool frames (the clip's average is 6.4): matching {t_match:.2f} s "
                               f"[{br}; dense timed on every {DENSE_SUBSAMPLE}th query pixel and scaled x{DENSE_SUBSAMPLE}] + calibration gates "
                               f"{t_cal:.2f} s (each distinct gate shape timed once x its count); torch CPU fp32 + C k-means oracle, {threads} threads")
-            # parity spot check of the same frame on the GPU: every branch against the oracle, and a surrogate
+            # parity spot check of a frame (R = 1) on the GPU: every branch against the oracle, and a surrogate
             # mask (argmin over objects of the dense-matching channel) on the sub-sampled pixels
-            wl = workloads[0]
+            e2, l2 = emb2.to(dev), lab2.to(dev)
             with torch.no_grad():
-                fg, _, _ = hotpath.proto_mask_features(mc, wl.emb[:1], wl.lab[:1], wl.emb[0], wl.lab[0], wl.emb[1], wl.bias, init_rows=rows)
+                fg, _, _ = hotpath.proto_mask_features(mc, e2[:1], l2[:1], e2[0], l2[0], e2[1], workloads[0].bias, init_rows=rows)
             fg = fg.cpu()
             chs = hotpath.channel_slices(mc)
             nl = len(mc.MODEL_MULTI_LOCAL_DISTANCE)
+            ncl = 2 * len(mc.cluster_levels)
             diffs = {
                 "dense": float((fg[:, 0].reshape(O, -1)[:, ::DENSE_SUBSAMPLE].t() - feats["dense_sub"]).abs().max()),
-                "cluster": float((fg[:, chs["cluster"]:chs["cluster"] + 2] - feats["cluster"][0].permute(2, 3, 0, 1)).abs().max()),
+                "cluster": float((fg[:, chs["cluster"]:chs["cluster"] + ncl] - feats["cluster"][0].permute(2, 3, 0, 1)).abs().max()),
                 "proxy": float((fg[:, chs["proxy"]:chs["proxy"] + 1] - feats["proxy"][0].permute(2, 3, 0, 1)).abs().max()),
                 "local": float((fg[:, chs["local"]:chs["local"] + nl] - feats["local"][0].permute(2, 3, 0, 1)).abs().max()),
                 "local_proxy": float((fg[:, chs["local_proxy"]:chs["local_proxy"] + nl] - feats["local_proxy"][0].permute(2, 3, 0, 1)).abs().max()),
@@ -649,19 +847,23 @@ def main():
             parity = dict(max_abs_feature_diff=max(diffs.values()), per_branch=diffs, surrogate_mask_mean_iou=iou_sum / iou_n)
 
         value = metrics["frames"] / elapsed_max
+        rs = sorted(r_hist)
         line = {
             "metric": "frames/sec, AOC-Net matching + calibration hot path (480p, 3 objects)",
             "value": round(value, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed_max / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{cfg.name}: {cfg.h}x{cfg.w} stride-4 maps{' (480p)' if (cfg.h, cfg.w) == (121, 213) else ''}, O={O} ({O - 1} objects + background), K={cfg.k} proxies, "
-                                   f"C={C}, {cfg.frames}-frame clips, MEM_EVERY={mc.MEM_EVERY} (R=1..{1 + (cfg.frames - 2) // mc.MEM_EVERY}), "
-                                   "20 Lloyd iterations, local windows [2..12]",
+            "config": {"workload": f"{cfg.name}: {cfg.h}x{cfg.w} stride-4 maps{' (480p)' if (cfg.h, cfg.w) == (121, 213) else ''}, O={O} ({O - 1} objects + background), "
+                                   f"K={'/'.join(str(k) for k in mc.cluster_levels)} proxies, C={C}, {cfg.frames}-frame clips, MEM_EVERY={mc.MEM_EVERY} "
+                                   f"(pool sizes R=1..{workloads[0].rmax}, visited group-wise in an interleaved order), 20 Lloyd iterations, local windows [2..12]",
+                       "R_timed": {"histogram": {str(r): r_hist[r] for r in rs}, "mean": round(sum(r * c for r, c in r_hist.items()) / max(sum(r_hist.values()), 1), 3),
+                                   "clip_mean": round(float(np.mean([workloads[0].R_of(t) for t in range(1, cfg.frames)])), 3)},
                        "sequences_per_gpu": n_streams, "frames_per_step": n_streams, "sharding": "sequences over ranks, no data-path collective",
                        "intra_frame_overlap": ("none" if args.no_overlap else "k-means chain on a side HIP stream" +
-                                               ("" if args.no_pipeline else ", enqueued as soon as the pool it depends on is final "
-                                                "(right after the previous frame's memory update)")),
-                       "cu_reserve": (f"main streams masked off {args.cu_reserve} of 256 CUs (hipExtStreamCreateWithCUMask), left to the side-stream "
+                                               ("" if args.no_pipeline else ", enqueued as soon as the pool it depends on is final")),
+                       "correlation": ("ONE aoc_proxy_corr_min_batched launch per step for the frames of all in-flight sequences" if batch_corr
+                                       else "one aoc_proxy_corr_min launch per sequence and frame"),
+                       "cu_reserve": (f"main streams masked off {args.cu_reserve} of {n_cu} CUs (hipExtStreamCreateWithCUMask), left to the side-stream "
                                       "k-means chains" if args.cu_reserve > 0 else "none"),
                        "proxy_mode": ("NON-PARITY: adaptive proxies reused until the pool changes (one k-means per MEM_EVERY frames)"
                                       if args.reuse_proxies else "reference: the pool is re-clustered for every frame with that frame's initial rows"),
@@ -669,7 +871,8 @@ def main():
                                            "on overflow / soft labels" if args.dense == "split" else "exact fp32 MFMA")},
             "host_enqueue_ms_per_step": round(host_enqueue_s / args.steps * 1e3, 3),
             "exact_fp32_dense_run": exact,
-            "roofline": roofline, "roofline_correlation_kernel": corr_roof, "roofline_kmeans_chain": km_roof, "cpu_baseline": cpu, "parity": parity, "kernels": kernels,
+            "roofline": roofline, "roofline_correlation_kernel": corr_roof, "roofline_kmeans_chain": km_roof, "roofline_film_scale": film_roof,
+            "roofline_cond_gate_pool": cond_roof, "cpu_baseline": cpu, "parity": parity, "kernels": kernels,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

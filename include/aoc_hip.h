@@ -392,6 +392,17 @@ int aoc_confident_labels(const float *probs, int n_ch, int64_t n, uint32_t exist
 int aoc_label_onehot_nearest(const int32_t *label, int H, int W, int h, int w, int n_obj, float *onehot_hwc,
                              aoc_stream_t stream);
 
+/* J (region similarity) and F (boundary measure) of a predicted label map against the ground truth, summed over the foreground
+ * objects 1 .. n_obj-1 and ACCUMULATED on the device: accum[0] += sum_o J_o, accum[1] += sum_o F_o,
+ * accum[2] += n_obj - 1, accum[3] += 1.  The reference scores saved PNGs with the external DAVIS toolkit (README.md:110; its only
+ * in-repo IoU is utils/metric.py:3-34): the definitions here are DAVIS-2017's db_eval_iou and db_eval_boundary (seg2bmap boundaries,
+ * dilation by skimage's disk(bound_pix), bound_pix = ceil(0.008 * hypot(H, W)) chosen by the caller).  pred, gt [H, W] int32 labels;
+ * workspace_is_clean != 0 skips the zeroing of the counters (the call leaves them zeroed).  n_obj <= 16. */
+size_t aoc_mask_jf_workspace_bytes(int H, int W);
+int aoc_mask_jf_accumulate(const int32_t *pred, const int32_t *gt, int H, int W, int n_obj, int bound_pix,
+                           void *workspace, size_t workspace_bytes, int workspace_is_clean, double *accum,
+                           aoc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

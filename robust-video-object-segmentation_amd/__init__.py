@@ -15,5 +15,6 @@ from . import hotpath  # noqa: F401
 from . import sharding  # noqa: F401
 from . import eval_loop  # noqa: F401
 from . import gct  # noqa: F401
+from . import eval_runner  # noqa: F401
 
-__all__ = ["synthetic", "ops", "matching", "attention", "conditioning_layer", "hotpath", "sharding", "eval_loop", "gct"]
+__all__ = ["synthetic", "ops", "matching", "attention", "conditioning_layer", "hotpath", "sharding", "eval_loop", "gct", "eval_runner"]

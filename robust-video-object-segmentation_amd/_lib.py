@@ -31,6 +31,8 @@ SIGNATURES = {
     "aoc_object_logit": (_i, [_vp, _i, _i, _i64, _vp, _i64, _vp, _i64, _vp, _vp]),
     "aoc_confident_labels": (_i, [_vp, _i, _i64, ctypes.c_uint32, _vp, ctypes.c_float, _vp, _vp, _vp, _vp]),
     "aoc_label_onehot_nearest": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "aoc_mask_jf_workspace_bytes": (_sz, [_i, _i]),
+    "aoc_mask_jf_accumulate": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _sz, _i, _vp, _vp]),
     "aoc_kmeans_replicate": (_i, [_vp, _vp, _vp, _i, _i, _i64, _vp, _vp, _vp, _vp]),
     "aoc_kmeans_replicate_levels": (_i, [_vp, _vp, _i, _i, _vp, _i, _i64, _vp, _vp, _vp, _vp]),
     "aoc_build_proxies_workspace_bytes": (_sz, [_i64, _i, _i]),

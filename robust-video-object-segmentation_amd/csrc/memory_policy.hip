@@ -49,9 +49,111 @@ __global__ __launch_bounds__(256) void label_onehot_nearest_kernel(const int32_t
     for (int c = 0; c < n_obj; ++c) o[c] = (l == c) ? 1.0f : 0.0f;
 }
 
+// ---- J (region similarity) and F (boundary measure) of a predicted label map against the ground truth, per foreground object,
+// accumulated on the device so that an evaluation never reads a mask back (the reference saves PNGs and scores them with the external
+// DAVIS toolkit, README.md:110; its only in-repo IoU is utils/metric.py:3-34).  Definitions: DAVIS-2017 db_eval_iou / db_eval_boundary
+// (seg2bmap boundaries, dilation by a disk of bound_pix, F = 2 P R / (P + R)); restated in oracle/metrics.py.
+//
+// bits[y, x]: bit o = pixel is a boundary pixel of the binary mask (label == o), low 16 bits for `pred`, high 16 bits for `gt`.
+__global__ __launch_bounds__(256) void jf_boundary_kernel(const int32_t *__restrict__ pred, const int32_t *__restrict__ gt, int H, int W, int n_obj,
+                                                           uint32_t *__restrict__ bits, int32_t *__restrict__ counts) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= H * W) return;
+    const int x = idx % W, y = idx / W;
+    const bool last_row = y == H - 1, last_col = x == W - 1;
+    uint32_t out = 0;
+    for (int side = 0; side < 2; ++side) {
+        const int32_t *m = side ? gt : pred;
+        const int c = m[idx];
+        const int e = last_col ? c : m[idx + 1];
+        const int s = last_row ? c : m[idx + W];
+        const int se = (last_row || last_col) ? c : m[idx + W + 1];
+        for (int o = 1; o < n_obj; ++o) {
+            const bool mc = c == o;
+            bool b;
+            if (last_row && last_col) b = false;                           // b[-1, -1] = 0
+            else if (last_row) b = mc != (e == o);                          // b[-1, :] = seg ^ e
+            else if (last_col) b = mc != (s == o);                          // b[:, -1] = seg ^ s
+            else b = (mc != (e == o)) || (mc != (s == o)) || (mc != (se == o));
+            if (b) out |= 1u << (o + 16 * side);
+        }
+        // region counts: |pred = o|, |gt = o|, |both|
+        if (c >= 1 && c < n_obj) atomicAdd(&counts[(side ? 1 : 0) * 16 + c], 1);
+    }
+    const int p = pred[idx], g = gt[idx];
+    if (p == g && p >= 1 && p < n_obj) atomicAdd(&counts[2 * 16 + p], 1);
+    bits[idx] = out;
+}
+
+// boundary matches within a disk of radius `r`: counts[3][o] += pred boundary pixels with a gt boundary pixel of o nearby,
+// counts[4][o] the other way round, counts[5][o] / counts[6][o] the boundary pixel totals
+__global__ __launch_bounds__(256) void jf_match_kernel(const uint32_t *__restrict__ bits, int H, int W, int n_obj, int r, int32_t *__restrict__ counts) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= H * W) return;
+    const uint32_t here = bits[idx];
+    if (here == 0) return;
+    const int x = idx % W, y = idx / W;
+    uint32_t near = 0;
+    for (int dy = -r; dy <= r; ++dy) {
+        const int yy = y + dy;
+        if (yy < 0 || yy >= H) continue;
+        for (int dx = -r; dx <= r; ++dx) {
+            const int xx = x + dx;
+            if (xx < 0 || xx >= W || dx * dx + dy * dy > r * r) continue;   // skimage.morphology.disk(r)
+            near |= bits[(size_t)yy * W + xx];
+        }
+    }
+    const uint32_t pb = here & 0xffffu, gb = here >> 16, ngt = near >> 16, npr = near & 0xffffu;
+    for (int o = 1; o < n_obj; ++o) {
+        if ((pb >> o) & 1u) { atomicAdd(&counts[5 * 16 + o], 1); if ((ngt >> o) & 1u) atomicAdd(&counts[3 * 16 + o], 1); }
+        if ((gb >> o) & 1u) { atomicAdd(&counts[6 * 16 + o], 1); if ((npr >> o) & 1u) atomicAdd(&counts[4 * 16 + o], 1); }
+    }
+}
+
+__global__ void jf_finalize_kernel(int32_t *__restrict__ counts, int n_obj, double *__restrict__ accum) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double sj = 0.0, sf = 0.0;
+    for (int o = 1; o < n_obj; ++o) {
+        const double ap = counts[o], ag = counts[16 + o], in = counts[32 + o];
+        const double un = ap + ag - in;
+        sj += un == 0.0 ? 1.0 : in / un;                                   // db_eval_iou: both empty -> 1
+        const double np_ = counts[5 * 16 + o], ng = counts[6 * 16 + o], mp = counts[3 * 16 + o], mg = counts[4 * 16 + o];
+        double prec, rec;
+        if (np_ == 0.0 && ng > 0.0) { prec = 1.0; rec = 0.0; }
+        else if (np_ > 0.0 && ng == 0.0) { prec = 0.0; rec = 1.0; }
+        else if (np_ == 0.0 && ng == 0.0) { prec = 1.0; rec = 1.0; }
+        else { prec = mp / np_; rec = mg / ng; }
+        sf += (prec + rec == 0.0) ? 0.0 : 2.0 * prec * rec / (prec + rec);
+    }
+    accum[0] += sj;
+    accum[1] += sf;
+    accum[2] += (double)(n_obj - 1);
+    accum[3] += 1.0;
+    for (int i = 0; i < 7 * 16; ++i) counts[i] = 0;                         // ready for the next frame
+}
+
 }  // namespace
 
 extern "C" {
+
+size_t aoc_mask_jf_workspace_bytes(int H, int W) { return H < 1 || W < 1 ? 0 : aoc_align_up((size_t)7 * 16 * sizeof(int32_t), 256) + (size_t)H * W * sizeof(uint32_t); }
+
+int aoc_mask_jf_accumulate(const int32_t *pred, const int32_t *gt, int H, int W, int n_obj, int bound_pix, void *workspace, size_t workspace_bytes,
+                           int workspace_is_clean, double *accum, aoc_stream_t stream) {
+    if (!pred || !gt || !workspace || !accum || H < 1 || W < 1 || n_obj < 1 || bound_pix < 0) return AOC_ERR_INVALID_ARG;
+    if (n_obj > 16) return AOC_ERR_UNSUPPORTED;
+    if (workspace_bytes < aoc_mask_jf_workspace_bytes(H, W)) return AOC_ERR_WORKSPACE;
+    hipStream_t st = aoc_hip_stream(stream);
+    int32_t *counts = static_cast<int32_t *>(workspace);
+    uint32_t *bits = reinterpret_cast<uint32_t *>(static_cast<char *>(workspace) + aoc_align_up((size_t)7 * 16 * sizeof(int32_t), 256));
+    if (!workspace_is_clean && hipMemsetAsync(counts, 0, 7 * 16 * sizeof(int32_t), st) != hipSuccess) return AOC_ERR_LAUNCH;
+    const unsigned nb = (unsigned)(((size_t)H * W + 255) / 256);
+    hipLaunchKernelGGL(jf_boundary_kernel, dim3(nb), dim3(256), 0, st, pred, gt, H, W, n_obj, bits, counts);
+    hipLaunchKernelGGL(jf_match_kernel, dim3(nb), dim3(256), 0, st, bits, H, W, n_obj, bound_pix, counts);
+    hipLaunchKernelGGL(jf_finalize_kernel, dim3(1), dim3(64), 0, st, counts, n_obj, accum);
+    AOC_RETURN_IF_LAUNCH_FAILED();
+    return AOC_OK;
+}
 
 int aoc_confident_labels(const float *probs, int n_ch, int64_t n, uint32_t exist_bits, const int32_t *join_label, float unc_ratio,
                          int32_t *labels_out, int32_t *confident_out, float *entropy_out, aoc_stream_t stream) {

@@ -1,0 +1,187 @@
+"""Sequence-sharded evaluation runner: the counterpart of ``Evaluator.evaluating`` (networks/engine/eval_manager_mm.py:160-394) for
+BASELINE.json configs[4] ("DAVIS-17 + YTB-19 full eval, sequences sharded across 8 x MI355X").
+
+The reference evaluates on one GPU: ``for seq in dataset`` (eval_manager_mm.py:172) with all per-sequence state dropped between
+sequences (:376-382).  Sequences are therefore independent units: here they are partitioned over the ranks by longest-processing-time
+first on ``frames x objects`` (sharding.lpt_partition), every rank runs its share with its own library handle and no communication,
+and ONE all-reduce(SUM) of a small float64 vector (RCCL over xGMI with the "nccl" backend) produces the report.  Within a sequence the
+loop is the reference's: frame 0 seeds the pool with its ground truth, every later frame goes through the matching path, the decoder
+(here: DynamicPreHead + a fixed linear read-out standing in for the conv decoder, which is out of scope), soft-max, and the memory
+policy (eval_loop.MemoryPolicy: never-seen labels, arg-max, entropy -> label 125, pool append every MEM_EVERY frames).
+
+No datasets exist in the build environment: ``make_sequence_set`` generates seeded synthetic clips whose counts mirror DAVIS-17 val
+(30 sequences, 480p -> 121x213 maps, <= 3 objects) and YouTube-VOS-19 valid (507 sequences at 6 fps, 145x261 maps, <= 5 objects,
+multi-level proxies K in {8, 16, 32}).  The region similarity J (utils/metric.py:3-34 formula) of the predicted masks against the
+synthetic ground truth, and the boundary measure F, are accumulated on the device (aoc_mask_jf_accumulate: no mask is ever read back).
+"""
+import time
+from dataclasses import dataclass
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import sharding
+from . import synthetic as syn
+
+
+@dataclass(frozen=True)
+class SequenceSpec:
+    name: str
+    h: int
+    w: int
+    n_obj: int                  # objects INCLUDING background
+    frames: int
+    seed: int
+    levels: tuple = (16,)       # cluster_num levels of the adaptive-proxy branch
+    mem_every: int = 5
+
+    @property
+    def cost(self):
+        """frames x objects: the quantity the partition balances."""
+        return self.frames * self.n_obj
+
+    def clip_config(self):
+        return syn.ClipConfig(self.name, self.h, self.w, self.n_obj, max(self.levels), 100, self.frames, self.mem_every)
+
+
+def make_sequence_set(kind="cfg5", scale=1.0, seed=0) -> List[SequenceSpec]:
+    """Synthetic stand-in for the evaluation sets of BASELINE.json configs[4].  ``scale`` < 1 keeps that fraction of each set
+    (at least one sequence of each), so that short runs and CPU tests walk the same code path."""
+    rng = np.random.RandomState(seed)
+    out = []
+    if kind in ("cfg5", "davis17"):
+        n = max(1, int(round(30 * scale)))
+        for i in range(n):          # DAVIS-17 val: 30 sequences, 50..104 frames, 1..3 objects (+ background)
+            out.append(SequenceSpec(f"davis{i:02d}", 121, 213, 2 + int(rng.randint(0, 3)), int(rng.randint(50, 105)), 1000 + i, (16,)))
+    if kind in ("cfg5", "ytb19"):
+        n = max(1, int(round(507 * scale)))
+        for i in range(n):          # YouTube-VOS-19 valid: 507 sequences, 6 fps -> 20..36 frames, 1..5 objects (+ background)
+            out.append(SequenceSpec(f"ytb{i:03d}", 145, 261, 2 + int(rng.randint(0, 5)), int(rng.randint(20, 37)), 5000 + i, (8, 16, 32)))
+    if not out:
+        raise ValueError(f"unknown sequence set {kind!r}")
+    return out
+
+
+class HotPathBackend:
+    """One frame on the MI355X: matching (libaoc_hip.so) -> DynamicPreHead -> read-out -> soft-max.  The read-out weights are
+    seeded, so every rank decodes identically."""
+
+    def __init__(self, device, dense_precision=None):
+        from . import hotpath
+        self.hot = hotpath
+        self.device = device
+        self.dense_precision = dense_precision
+        self._heads = {}
+
+    def _head(self, n_ch):
+        if n_ch not in self._heads:
+            g = torch.Generator().manual_seed(1234 + n_ch)
+            pre = self.hot.DynamicPreHead(in_dim=n_ch, embed_dim=64)
+            with torch.no_grad():
+                pre.conv.weight.copy_(torch.randn(pre.conv.weight.shape, generator=g) * (2.0 / n_ch) ** 0.5)
+                pre.conv.bias.zero_()
+            w = (torch.randn(64, generator=g) * 0.75).to(self.device)
+            self._heads[n_ch] = (pre.to(self.device), w)
+        return self._heads[n_ch]
+
+    def start(self, spec):
+        from .eval_loop import MemoryPolicy
+        self.spec = spec
+        self.mc = self.hot.MatchingConfig(CLUSTER_LEVELS=list(spec.levels) if len(spec.levels) > 1 else None, CLUSTER_NUM=spec.levels[0],
+                                          MEM_EVERY=spec.mem_every)
+        self.policy = MemoryPolicy(mem_every=spec.mem_every, unc_ratio=1.0)
+        self.bias = torch.zeros(spec.n_obj, device=self.device)
+        self.rng = np.random.RandomState(spec.seed)
+
+    def first_frame(self, emb, gt_label):
+        self.policy.start(emb, gt_label)
+
+    @torch.no_grad()
+    def frame(self, emb):
+        """emb [h, w, C] -> predicted label map [H, W] int32 (H = 4 h: the reference's masks live at image resolution)."""
+        spec, h, w = self.spec, self.spec.h, self.spec.w
+        ref_emb, ref_lab, prev_emb, prev_lab = self.policy.reference_pool(h, w, spec.n_obj)
+        feat, _, _ = self.hot.proto_mask_features(self.mc, ref_emb, ref_lab, prev_emb, prev_lab, emb, self.bias, dense_precision=self.dense_precision)
+        pre, wv = self._head(feat.shape[1])
+        y = pre(feat)                                                          # [O, 64, h, w]
+        logit = torch.einsum("ochw,c->ohw", y, wv)
+        logit = torch.nn.functional.interpolate(logit[None], size=(4 * h, 4 * w), mode="bilinear", align_corners=True)[0]
+        label, _, _ = self.policy.update(emb, torch.softmax(logit, dim=0))
+        return label
+
+
+def _gt_fullres(lab_hw):
+    """stride-4 synthetic label map -> image-resolution ground truth (each feature pixel covers a 4x4 block)."""
+    return np.kron(lab_hw, np.ones((4, 4), np.int32)).astype(np.int32)
+
+
+class HostMetric:
+    """J of predicted vs ground-truth label maps on the host (sharding.mask_iou_sums over the foreground objects): for CPU-side runs
+    of the runner (tests with a stub backend).  Same interface as ops.MaskJF."""
+
+    def __init__(self):
+        self.sj, self.n, self.frames = 0.0, 0.0, 0.0
+
+    def add(self, pred, gt, n_obj):
+        s, n = sharding.mask_iou_sums(pred, gt, n_obj)
+        s0 = 1.0 if int(((pred == 0) | (gt == 0)).sum()) == 0 else int(((pred == 0) & (gt == 0)).sum()) / int(((pred == 0) | (gt == 0)).sum())
+        self.sj += s - s0                      # foreground objects only, like the device metric
+        self.n += n - 1
+        self.frames += 1
+
+    def totals(self):
+        return dict(sum_j=self.sj, sum_f=0.0, objects=self.n, frames=self.frames)
+
+
+def run_sequence(spec: SequenceSpec, backend, device, metric=None, max_frames: Optional[int] = None):
+    """The per-sequence loop of eval_manager_mm.py:196-361.  Returns the metric accumulators of sharding.METRIC_FIELDS
+    (sum_iou = sum over frames and foreground objects of J, sum_f of F, iou_count = number of (frame, object) pairs)."""
+    cfg = spec.clip_config()
+    frames = spec.frames if max_frames is None else min(spec.frames, max_frames)
+    clip = syn.make_clip(cfg, spec.seed, frames=frames)
+    emb = torch.from_numpy(clip["emb"]).to(device)
+    if metric is None:
+        if device.type == "cuda":
+            from . import ops
+            metric = ops.MaskJF(device)
+        else:
+            metric = HostMetric()
+    before = metric.totals()
+    backend.start(spec)
+    backend.first_frame(emb[0], torch.from_numpy(_gt_fullres(clip["lab"][0])).to(device))
+    if device.type == "cuda":
+        torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for t in range(1, frames):
+        pred = backend.frame(emb[t])
+        metric.add(pred, torch.from_numpy(_gt_fullres(clip["lab"][t])).to(pred.device), spec.n_obj)
+    if device.type == "cuda":
+        torch.cuda.synchronize(device)
+    dt = time.perf_counter() - t0
+    after = metric.totals()
+    return dict(frames=frames - 1, objects=(frames - 1) * (spec.n_obj - 1), gpu_seconds=dt, sum_iou=after["sum_j"] - before["sum_j"],
+                sum_f=after["sum_f"] - before["sum_f"], iou_count=after["objects"] - before["objects"])
+
+
+def eval_sharded(specs: Sequence[SequenceSpec], rank: int, world: int, device, backend=None, metric=None, max_frames=None):
+    """Partition ``specs`` over ``world`` ranks (LPT on frames x objects), run this rank's share, all-reduce the accumulators.
+    Returns the job totals plus the load-balance figures (max / mean rank time), identical on every rank."""
+    parts = sharding.lpt_partition([s.cost for s in specs], world)
+    mine = parts[rank]
+    if backend is None:
+        backend = HotPathBackend(device)
+    local = {k: 0.0 for k in sharding.METRIC_FIELDS}
+    for i in mine:
+        r = run_sequence(specs[i], backend, device, metric, max_frames)
+        for k in sharding.METRIC_FIELDS:
+            local[k] += r[k]
+    dev = device if device.type == "cuda" else None
+    tot = sharding.allreduce_metrics(local, device=dev)
+    t_max = sharding.allreduce_max(local["gpu_seconds"], device=dev)
+    mean_t = tot["gpu_seconds"] / world
+    costs = [sum(specs[i].cost for i in p) for p in parts]
+    tot.update(sequences=len(specs), ranks=world, rank_seconds_max=t_max, rank_seconds_mean=mean_t, imbalance=t_max / max(mean_t, 1e-12),
+               planned_imbalance=max(costs) / max(sum(costs) / world, 1e-12), mean_j=tot["sum_iou"] / max(tot["iou_count"], 1.0),
+               mean_f=tot["sum_f"] / max(tot["iou_count"], 1.0), sequences_local=len(mine))
+    return tot

@@ -141,9 +141,35 @@ def launch_cluster_proxies(cfg, ref_emb, ref_labels, init_rows_dev, side_stream=
     return launch_cluster_proxies_batch(cfg, ref_emb, ref_labels, [init_rows_dev], side_stream, wait_event)[0]
 
 
+class PendingCorrelation:
+    """The correlation launch of one frame, deferred (proto_mask_features(defer_correlation=True)) so that the frames of several
+    sequences in flight can share ONE batched launch (launch_correlations).  `ready` is recorded on the frame's stream when everything
+    the launch reads (query, proxy table incl. the k = 1 rows) is final."""
+    __slots__ = ("query", "table", "sqn", "set_begin", "set_size", "set_off", "set_bias", "feat", "ready", "stream")
+
+
+def launch_correlations(pending, stream=None, precision="split"):
+    """ONE aoc_proxy_corr_min_batched launch for the deferred correlations of several frames (same configuration: map size, objects,
+    levels).  Runs on `stream` (default: the current stream) after every frame's `ready` event; returns the event that marks the
+    outputs (the cluster / k = 1 proxy channels of every frame's proto-mask tensor) complete -- consumers wait for it."""
+    stream = torch.cuda.current_stream() if stream is None else stream
+    with torch.cuda.stream(stream):
+        for p in pending:
+            if p.stream is not stream:
+                stream.wait_event(p.ready)
+                for t in (p.query, p.table, p.sqn, p.set_bias, p.feat):
+                    t.record_stream(stream)
+        p0 = pending[0]
+        ops.proxy_corr_min_batched([(p.query, p.table, p.sqn, p.set_bias, p.feat) for p in pending], p0.set_begin, p0.set_size, p0.set_off, True,
+                                   precision)
+        done = torch.cuda.Event()
+        done.record(stream)
+    return done
+
+
 def proto_mask_features(cfg, ref_emb, ref_labels, prev_emb, prev_labels, cur_emb, dis_bias, init_rows=None,
                         cluster_state=None, side_stream=None, dense_state=None, dense_precision=None, cluster_ahead=None,
-                        dense_stream=None):
+                        dense_stream=None, defer_correlation=False):
     """All matching branches of one frame -> (features [O, 24, h, w], attention_head [O, 4C], aux).
 
     ref_emb     [R, h, w, C]  reference pool (channel-last)          ref_labels [R, h, w, O] float one-hot
@@ -158,13 +184,17 @@ def proto_mask_features(cfg, ref_emb, ref_labels, prev_emb, prev_labels, cur_emb
     dense_state  optional dict owned by the caller and kept across the frames of ONE sequence: caches the fp16 split
                  records of the reference pool (only frames appended since the last call are converted) and the pooled
                  reference heads, which only depend on the pool (recomputed when the number of pool frames changes).  The pool
-                 must be append-only while the dict lives (the reference's memory policy, eval_manager_mm.py:329-361).
+                 must be append-only while the dict lives (the reference's memory policy, eval_manager_mm.py:329-361): a call may see
+                 any PREFIX of it; the caller sets dense_state["frames"] = 0 when the pool restarts (next sequence).
     dense_precision  "split" (default, ops.DENSE_PRECISION) or "fp32": see ops.dense_match.
     dense_stream  optional stream for the dense matching kernel alone (e.g. one created with a HIP CU mask): the call forks
                  to it for that kernel and joins in front of the background maps, so the light kernels of this frame (and
                  of other sequences) are not queued behind the one kernel that fills every CU it may use.
     cluster_ahead  a ClusterProxiesAhead of this frame's pool (launch_cluster_proxies): the adaptive proxies were
                  enqueued earlier on a side stream; this call only waits for them in front of the correlation launch.
+    defer_correlation  do not launch the correlation kernel: aux["pending_correlation"] carries it for hotpath.launch_correlations, which
+                 batches the frames of several sequences into one launch (the cluster / k = 1 proxy channels of `feat` are complete
+                 only after the event that call returns).
     With several cluster levels (cfg.CLUSTER_LEVELS) the cluster channels are (centroid, centroid_avg) per level, in level order.
     """
     R, h, w, C = ref_emb.shape
@@ -226,7 +256,7 @@ def proto_mask_features(cfg, ref_emb, ref_labels, prev_emb, prev_labels, cur_emb
     if dense_state is not None and (dense_precision or ops.DENSE_PRECISION) == "split" and ops.split_record_bytes(C):
         pool_split = dense_state.get("pool_split")
         done = dense_state.get("frames", 0)
-        if pool_split is None or pool_split.records.shape[0] < R * hw or done > R:
+        if pool_split is None or pool_split.records.shape[0] < R * hw:
             cap = max(R, dense_state.get("capacity_frames", R)) * hw
             pool_split = ops.SplitRows()
             pool_split.records = torch.empty(cap, ops.split_record_bytes(C), dtype=torch.uint8, device=dev)
@@ -236,7 +266,8 @@ def proto_mask_features(cfg, ref_emb, ref_labels, prev_emb, prev_labels, cur_emb
             done = 0
         if done < R:
             ops.split_rows(pool[done * hw:R * hw], out=pool_split, row0=done * hw)
-        dense_state["pool_split"], dense_state["frames"] = pool_split, R
+        # records of pool frames [0, max(done, R)) are valid; a caller that restarts the pool (new sequence) resets "frames" to 0
+        dense_state["pool_split"], dense_state["frames"] = pool_split, max(done, R)
     dense_done = None
     if dense_stream is not None:
         main = torch.cuda.current_stream()
@@ -284,7 +315,16 @@ def proto_mask_features(cfg, ref_emb, ref_labels, prev_emb, prev_labels, cur_emb
     set_bias = torch.cat([set_bias, bias])
     if cluster_ahead is not None:
         torch.cuda.current_stream().wait_event(cluster_ahead.done_event)   # join: the proxy table is complete
-    ops.proxy_corr_min(query_flat, table, sqn, set_begin, set_size, set_off, set_bias, feat, 1, True)
+    pending = None
+    if defer_correlation:
+        pending = PendingCorrelation()
+        pending.query, pending.table, pending.sqn, pending.set_bias, pending.feat = query_flat, table, sqn, set_bias, feat
+        pending.set_begin, pending.set_size, pending.set_off = set_begin, set_size, set_off
+        pending.stream = torch.cuda.current_stream()
+        pending.ready = torch.cuda.Event()
+        pending.ready.record(pending.stream)
+    else:
+        ops.proxy_corr_min(query_flat, table, sqn, set_begin, set_size, set_off, set_bias, feat, 1, True)
 
     # ---- previous-frame mask channel (aocnet.py:356 to_cat_previous_frame)
     feat[:, ch["prev_mask"]].copy_(prev_labels.permute(2, 0, 1))
@@ -300,7 +340,7 @@ def proto_mask_features(cfg, ref_emb, ref_labels, prev_emb, prev_labels, cur_emb
     elif cfg.MODEL_MATCHING_BACKGROUND:
         feat[:, ch["local_bg"]:ch["local_bg"] + nl].copy_(feat[:, ch["local"]:ch["local"] + nl])     # AEM:10-11
         feat[:, ch["global_bg"]].copy_(feat[:, ch["global_fg"]])
-    return feat, attention_head, dict(cluster=cp, prev_pos=prev_pos, ref_pos=ref_pos)
+    return feat, attention_head, dict(cluster=cp, prev_pos=prev_pos, ref_pos=ref_pos, pending_correlation=pending)
 
 
 class DynamicPreHead(nn.Module):

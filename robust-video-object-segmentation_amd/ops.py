@@ -527,6 +527,34 @@ def label_onehot_nearest(label_hw, h, w, n_obj):
     return out
 
 
+class MaskJF:
+    """Device-side accumulator of the DAVIS region similarity J and boundary measure F (aoc_mask_jf_accumulate): add(pred, gt) enqueues
+    three small kernels and never synchronises; totals() reads the four float64 accumulators back once."""
+
+    def __init__(self, device):
+        self.accum = torch.zeros(4, dtype=torch.float64, device=device)
+        self.ws = None
+        self.shape = None
+
+    def add(self, pred, gt, n_obj):
+        _need_gpu(pred, gt)
+        pred, gt = pred.to(torch.int32).contiguous(), gt.to(torch.int32).contiguous()
+        H, W = pred.shape
+        assert gt.shape == (H, W)
+        L = _lib.lib()
+        clean = 1
+        if self.shape != (H, W):
+            self.ws = torch.zeros(int(L.aoc_mask_jf_workspace_bytes(H, W)), dtype=torch.uint8, device=pred.device)
+            self.shape = (H, W)
+        bound_pix = int(np.ceil(0.008 * np.hypot(H, W)))
+        _lib.check(L.aoc_mask_jf_accumulate(_p(pred), _p(gt), H, W, int(n_obj), bound_pix, _p(self.ws), self.ws.numel(), clean, _p(self.accum), _stream()),
+                   "aoc_mask_jf_accumulate")
+
+    def totals(self):
+        sj, sf, n, frames = self.accum.tolist()
+        return dict(sum_j=sj, sum_f=sf, objects=n, frames=frames)
+
+
 # ------------------------------------------------------------------------------------------ decoder-side streams (8f-4)
 def plane_reduce(x, mode):
     """x [N, C, H, W] -> [N, C] plane sums of x (mode 0), x^2 (1) or |x| (2)."""

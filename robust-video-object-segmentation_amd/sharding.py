@@ -10,7 +10,7 @@ from typing import List, Sequence
 import torch
 import torch.distributed as dist
 
-METRIC_FIELDS = ("frames", "objects", "gpu_seconds", "sum_iou", "iou_count")
+METRIC_FIELDS = ("frames", "objects", "gpu_seconds", "sum_iou", "iou_count", "sum_f")
 
 
 def lpt_partition(costs: Sequence[float], n_ranks: int) -> List[List[int]]:
@@ -32,6 +32,14 @@ def allreduce_metrics(local: dict, device=None) -> dict:
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.all_reduce(vec, op=dist.ReduceOp.SUM)
     return dict(zip(METRIC_FIELDS, vec.tolist()))
+
+
+def allreduce_max(value: float, device=None) -> float:
+    """Maximum of a scalar over the ranks (the slowest rank's time: load imbalance)."""
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
 
 
 def mask_iou_sums(pred: torch.Tensor, ref: torch.Tensor, n_obj: int):

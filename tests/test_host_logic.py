@@ -173,3 +173,81 @@ def test_mirrors_refuse_to_run_under_autograd():
     with torch.no_grad():                                     # under no_grad the guard passes and the missing GPU is what is reported
         with pytest.raises(aoc_amd._lib.AocHipError, match="no CPU fallback"):
             gate(x, head)
+
+
+_RUNNER_WORKER = r'''
+import json, os, sys
+sys.path.insert(0, sys.argv[1])
+import torch
+import torch.distributed as dist
+import aoc_amd
+from aoc_amd import eval_runner as er
+
+class StubBackend:
+    """CPU stand-in for the HIP hot path: a deterministic label map from the embedding (the loop, the partition, the metric and the
+    reduction are the product's own)."""
+    def start(self, spec): self.spec = spec
+    def first_frame(self, emb, gt): pass
+    def frame(self, emb):
+        lab = (emb[..., :3].sum(-1) * 40.0).long() % self.spec.n_obj
+        return lab.repeat_interleave(4, 0).repeat_interleave(4, 1).to(torch.int32)
+
+rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+if world > 1:
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+specs = er.make_sequence_set("cfg5", scale=0.012, seed=3)          # 1 DAVIS-like + 6 YTB-like sequences
+tot = er.eval_sharded(specs, rank, world, torch.device("cpu"), backend=StubBackend(), max_frames=4)
+if rank == 0:
+    print("RUNNER " + json.dumps({k: tot[k] for k in ("frames", "objects", "sum_iou", "iou_count", "sequences", "ranks", "planned_imbalance")}))
+if world > 1:
+    dist.destroy_process_group()
+'''
+
+
+def test_eval_runner_sharded_gloo_world2_equals_single_process(tmp_path):
+    """BASELINE.json configs[4] path on CPU: the real runner (sequence set, LPT partition, per-sequence loop, metric accumulators,
+    all-reduce) with a stub backend, world_size 2 over gloo, must give the totals of the single-process run."""
+    script = tmp_path / "runner_worker.py"
+    script.write_text(_RUNNER_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    one = subprocess.run([sys.executable, str(script), ROOT], env=env, capture_output=True, text=True, timeout=300)
+    assert one.returncode == 0, one.stderr[-2000:]
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29541", str(script), ROOT], env=env, capture_output=True, text=True, timeout=300)
+    assert two.returncode == 0, two.stderr[-2000:]
+    import json
+    a = json.loads([l for l in one.stdout.splitlines() if l.startswith("RUNNER ")][0][7:])
+    b = json.loads([l for l in two.stdout.splitlines() if l.startswith("RUNNER ")][0][7:])
+    assert a["ranks"] == 1 and b["ranks"] == 2 and a["sequences"] == b["sequences"] == 7
+    for k in ("frames", "objects", "iou_count"):
+        assert a[k] == b[k]
+    assert abs(a["sum_iou"] - b["sum_iou"]) < 1e-9 and a["sum_iou"] > 0
+    assert 1.0 <= b["planned_imbalance"] < 1.5
+
+
+def test_sequence_set_mirrors_the_evaluation_sets():
+    from aoc_amd import eval_runner as er
+    s = er.make_sequence_set("cfg5")
+    assert len(s) == 537 and sum(x.name.startswith("davis") for x in s) == 30
+    assert all(x.levels == (8, 16, 32) and (x.h, x.w) == (145, 261) and 2 <= x.n_obj <= 6 for x in s if x.name.startswith("ytb"))
+    assert all(x.levels == (16,) and (x.h, x.w) == (121, 213) and 2 <= x.n_obj <= 4 for x in s if x.name.startswith("davis"))
+    parts = aoc_amd.sharding.lpt_partition([x.cost for x in s], 8)
+    loads = [sum(s[i].cost for i in p) for p in parts]
+    assert max(loads) / (sum(loads) / 8) < 1.01                      # LPT balances 537 sequences over 8 ranks to within 1 %
+
+
+def test_oracle_davis_metrics_known_answers():
+    """oracle/metrics.py (restated DAVIS J / F): hand-checkable cases."""
+    from oracle import metrics as om
+    a = np.zeros((20, 30), bool)
+    a[5:15, 5:20] = True
+    assert om.db_eval_iou(a, a) == 1.0 and om.db_eval_boundary(a, a) == 1.0
+    assert om.db_eval_iou(np.zeros_like(a), np.zeros_like(a)) == 1.0 and om.db_eval_boundary(np.zeros_like(a), np.zeros_like(a)) == 1.0
+    b = np.zeros_like(a)
+    b[5:15, 10:25] = True
+    assert abs(om.db_eval_iou(a, b) - (10 * 10) / (10 * 20)) < 1e-12
+    assert om.db_eval_boundary(a, np.zeros_like(a)) == 0.0
+    bm = om.seg2bmap(a)
+    assert bm[4, 10] and bm[14, 10] and not bm[8, 10] and bm[8, 4] and bm[8, 19]
