@@ -325,6 +325,8 @@ def frame_step(wl, gates, acts, dense_precision="split", pipeline=True, defer_co
                                                       dense_state=wl.dense_state, dense_precision=dense_precision, defer_correlation=defer_corr)
     outs = gates(acts, head)
     wl.advance()                                           # the walk moves on (a new group = a new pool state starts here)
+    if wl.side is not None and pipeline and wl.t not in wl.ahead and not (wl.reuse_proxies and wl.cached_ahead is not None and wl.cached_ahead.R == wl.R):
+        launch_chains(wl)                                  # the next frame's pool is final now: its chain starts under the other sequences' work
     return feat, outs, aux["pending_correlation"]
 
 
@@ -500,8 +502,9 @@ def main():
     ap.add_argument("--reuse-proxies", action="store_true",
                     help="NON-PARITY mode (SURVEY 8f-3): cluster the pool once per pool update instead of once per frame; the JSON "
                          "line then says so in config.proxy_mode and is not comparable with the default")
-    ap.add_argument("--no-batch-corr", dest="batch_corr", action="store_false",
-                    help="one correlation launch per sequence and frame instead of ONE batched launch for the frames of all in-flight sequences")
+    ap.add_argument("--batch-corr", action="store_true",
+                    help="ONE batched correlation launch per step for the frames of all in-flight sequences instead of one launch per sequence and "
+                         "frame (measured slower with 2 sequences in flight: the shared launch makes the streams wait for each other every step)")
     ap.add_argument("--no-dense-order", action="store_true",
                     help="do not order the sequences' dense kernels explicitly (their live timing then includes queueing behind each other)")
     ap.add_argument("--no-pipeline", action="store_true",

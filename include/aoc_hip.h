@@ -170,6 +170,16 @@ int aoc_proxy_corr_min(const float *query, int64_t m, int C,
                        const int64_t *set_out_offset_host, const float *set_bias,
                        float *out, int64_t out_pixel_stride, int transform, aoc_stream_t stream);
 
+/* use_float16=True (AEM:388-392 / matching.py:2640-2646: `.half()` operands): same arguments; operands, |q|^2, |p|^2, the dot products and
+ * the distances are rounded to float16 where the reference's float16 tensors round them (sums accumulate in fp32, as torch does);
+ * proxy_sqnorm is only consulted for its +inf "absent" marks.  Outputs are fp32 (the bias is added and the sigmoid taken in fp32, as the
+ * reference's type promotion does). */
+int aoc_proxy_corr_min_f16(const float *query, int64_t m, int C,
+                           const float *proxies, const float *proxy_sqnorm, int n_proxy,
+                           int n_set, const int32_t *set_begin_host, const int32_t *set_size_host,
+                           const int64_t *set_out_offset_host, const float *set_bias,
+                           float *out, int64_t out_pixel_stride, int transform, aoc_stream_t stream);
+
 /* Batched form: the same correlation for n_frames frames (of one or of several independent sequences) in ONE persistent launch.
  * One 480p frame is 11.6 MB of traffic: a launch that small is latency-bound by construction ("tiny working sets"), and
  * the reference runs 2 x O x n_chunks launches per frame (AEM:316-319).  All frames share m, C and the set structure (same number
@@ -213,6 +223,16 @@ int aoc_dense_match_min(const float *query, int64_t m, int C,
                         const float *obj_bias, int n_obj,
                         float *out, int64_t out_pixel_stride, int64_t out_obj_stride,
                         int transform, void *workspace, size_t workspace_bytes, aoc_stream_t stream);
+
+/* use_float16=True (AEM:801-803 `.half()`; AEM:65-66 the wrong-label mask becomes float16 too): same arguments and workspace as
+ * aoc_dense_match_min; operands, norms, dot products, distances, the 5e4 padding (49984 in float16) and its sum are rounded to float16
+ * where the reference's float16 tensors round them (sums accumulate in fp32).  Outputs are fp32. */
+int aoc_dense_match_min_f16(const float *query, int64_t m, int C,
+                            const float *pool, const int32_t *fg_rows, const int32_t *n_fg,
+                            int64_t n_fg_capacity, const uint32_t *wrong_bits,
+                            const float *obj_bias, int n_obj,
+                            float *out, int64_t out_pixel_stride, int64_t out_obj_stride,
+                            int transform, void *workspace, size_t workspace_bytes, aoc_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Dense pixel-level matching on the fp16 matrix pipe with fp32-equivalent products (same reference
@@ -270,9 +290,22 @@ int aoc_local_window_match(const float *query, const float *prev, const uint32_t
                            const float *obj_bias, int n_obj, float *out, int transform,
                            aoc_stream_t stream);
 
-/* Bilinear (align_corners=True) resize of a channel-last map [h,w,C] -> [H,W,C]  (AEM:938-941). */
+/* The same with the two remaining arguments of the reference call (AEM:968-971):
+ *   atrous_rate  window offsets are the multiples of the rate up to pad = max - max % rate (AEM:949-959 unfold with that stride); the
+ *                nested windows are radii / rate rings (AEM:1039);
+ *   float16      use_float16=True (AEM:1002-1005): operands, norms, dot products and distances are rounded to float16 exactly where the
+ *                reference's float16 tensors round them (the sums accumulate in fp32 as torch does); outputs are fp32. */
+int aoc_local_window_match_ex(const float *query, const float *prev, const uint32_t *right_bits,
+                              int H, int W, int C, const int32_t *radii_host, int n_radii,
+                              const float *obj_bias, int n_obj, float *out, int transform,
+                              int atrous_rate, int float16, aoc_stream_t stream);
+
+/* Bilinear (align_corners=True) resize of a channel-last map [h,w,C] -> [H,W,C]  (AEM:938-941).  _ex with float16 != 0: the resize
+ * of a float16 tensor (float16 samples, fp32 arithmetic, float16 result), as F.interpolate does in the use_float16 mode. */
 int aoc_resize_bilinear_hwc(const float *in, int h, int w, int C, float *out, int H, int W,
                             aoc_stream_t stream);
+int aoc_resize_bilinear_hwc_ex(const float *in, int h, int w, int C, float *out, int H, int W,
+                               int float16, aoc_stream_t stream);
 /* Bilinear (align_corners=True) resize of planes [P,h,w]; plane p = (po, pi) = (p / inner_count,
  * p % inner_count); element (p,y,x) is written at
  *   out[po*out_outer_stride + pi*out_plane_stride + (y*W + x)*out_pixel_stride]

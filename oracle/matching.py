@@ -117,8 +117,10 @@ def _as_bias(dis_bias, obj_nums):
 # --------------------------------------------------------------------------- a6
 def nearest_neighbor_features_per_object(ref_flat, query_flat, labels_flat):
     """AEM:178-227 + 61-89 (dense pixel-level matching, de-chunked):
-    out[i,o] = min_j ( d(q_i, r_j) + 5e4 * (label[j,o] < 0.1) )    -> [m, O, 1]"""
-    wrong = (labels_flat < 0.1).permute(1, 0).float()                     # AEM:197-198
+    out[i,o] = min_j ( d(q_i, r_j) + 5e4 * (label[j,o] < 0.1) )    -> [m, O, 1]
+    float16 operands (use_float16=True, AEM:801-803) run the SAME tensor operations on float16 tensors: the wrong-label mask is cast
+    to the operands' dtype (AEM:65-66), so norms, dot products, distances, the padded sum and the min are float16."""
+    wrong = (labels_flat < 0.1).permute(1, 0).to(ref_flat.dtype)          # AEM:197-198, 65-68
     ref_sq = ref_flat.pow(2).sum(1)                                       # AEM:199
     query_sq = query_flat.pow(2).sum(1)                                   # AEM:200
     d = flattened_pairwise_distances(ref_flat, ref_sq, query_flat, query_sq)  # [m, n]
@@ -131,8 +133,8 @@ def nearest_neighbor_features_per_object(ref_flat, query_flat, labels_flat):
 def global_matching_for_eval(all_reference_embeddings, query_embeddings, all_reference_labels,
                              n_chunks=20, dis_bias=0., ori_size=None, atrous_rate=1,
                              use_float16=False, atrous_obj_pixel_num=0):
-    """AEM:688-817 (fp32 path).  -> [1, h, w, O, 1]"""
-    assert not use_float16, "oracle restates the fp32 path (MODEL_FLOAT16_MATCHING=False)"
+    """AEM:688-817.  -> [1, h, w, O, 1].  use_float16: the operands are cast with .half() after the row filter (AEM:801-803); the
+    bias is added and the sigmoid taken in fp32 by type promotion (AEM:808), the result is fp32 (AEM:815-816)."""
     h, w, embedding_dim = query_embeddings.size()
     obj_nums = all_reference_labels[0].size(2)
     ref_flat, labels_flat = _flatten_reference_pool(all_reference_embeddings, all_reference_labels,
@@ -141,8 +143,10 @@ def global_matching_for_eval(all_reference_embeddings, query_embeddings, all_ref
     ref_flat, labels_flat, _ = _keep_foreground_rows(ref_flat, labels_flat)
     if labels_flat.size(0) == 0:
         return torch.ones(1, h, w, obj_nums, 1)                           # AEM:796-797
+    if use_float16:
+        ref_flat, query_flat = ref_flat.half(), query_flat.half()         # AEM:801-803
     nn = nearest_neighbor_features_per_object(ref_flat, query_flat, labels_flat)
-    return _finish(nn, h, w, obj_nums, _as_bias(dis_bias, obj_nums), ori_size)
+    return _finish(nn, h, w, obj_nums, _as_bias(dis_bias, obj_nums), ori_size).float()
 
 
 def _train_twin_labels(reference_labels, h, w, atrous_rate, atrous_obj_pixel_num):
@@ -165,12 +169,11 @@ def _train_twin_labels(reference_labels, h, w, atrous_rate, atrous_obj_pixel_num
 def global_matching(reference_embeddings, query_embeddings, reference_labels,
                     n_chunks=100, dis_bias=0., ori_size=None, atrous_rate=1,
                     use_float16=False, atrous_obj_pixel_num=0):
-    """AEM:616-685 (training twin, single reference frame, fp32)."""
-    assert not use_float16
+    """AEM:616-685 (training twin, single reference frame)."""
     h, w, _ = query_embeddings.size()
     labels = _train_twin_labels(reference_labels, h, w, atrous_rate, atrous_obj_pixel_num)
     return global_matching_for_eval([reference_embeddings], query_embeddings, [labels],
-                                    n_chunks, dis_bias, ori_size, 1, False, 0)
+                                    n_chunks, dis_bias, ori_size, 1, use_float16, 0)
 
 
 # ------------------------------------------------------------------- a2, a3, a4
@@ -281,14 +284,17 @@ def global_matching_for_eval_proxy(all_reference_embeddings, query_embeddings, a
                                    use_float16=False, atrous_obj_pixel_num=0):
     """matching.py:2518-2662 (the runnable copy; AEM:819-873 has undefined names).
     ``all_reference_embeddings`` is the [O, C] tensor of k=1 proxies (aocnet.py:314-315):
-    out[i,o] = d(q_i, proxy_o), no min.  -> [1, h, w, O, 1]"""
-    assert not use_float16
+    out[i,o] = d(q_i, proxy_o), no min.  -> [1, h, w, O, 1]
+    use_float16=True raises UnboundLocalError in BOTH copies of the reference (matching.py:2640-2646 reads a name it never assigns);
+    the oracle restates what the code evidently means -- the query and the proxies cast with .half() -- PARITY UNPINNED for that mode."""
     h, w, embedding_dim = query_embeddings.size()
     obj_nums = all_reference_labels[0].size(2)
     query_flat = query_embeddings.reshape(-1, embedding_dim)
     proxies = all_reference_embeddings
+    if use_float16:
+        query_flat, proxies = query_flat.half(), proxies.half()
     d = flattened_pairwise_distances(proxies, proxies.pow(2).sum(1), query_flat, query_flat.pow(2).sum(1))
-    return _finish(d, h, w, obj_nums, _as_bias(dis_bias, obj_nums), ori_size)
+    return _finish(d, h, w, obj_nums, _as_bias(dis_bias, obj_nums), ori_size).float()
 
 
 def global_matching_proxy(reference_embeddings, query_embeddings, reference_labels,
@@ -342,12 +348,12 @@ def local_pairwise_distances(x, y, max_distance=9, atrous_rate=1, allow_downsamp
     py2 = F.pad(y2, (pad, pad, pad, pad), mode='constant', value=WRONG_LABEL_PADDING_DISTANCE)
     xs = x[0].permute(1, 2, 0)                                            # [H, W, C]
     n_off = 2 * pad // atrous_rate + 1
-    out = torch.empty(height, width, n_off * n_off)
+    out = torch.empty(height, width, n_off * n_off, dtype=x.dtype)
     for oy in range(n_off):
         for ox in range(n_off):
             ys = py[0, :, oy * atrous_rate: oy * atrous_rate + height, ox * atrous_rate: ox * atrous_rate + width]
             ys2 = py2[0, 0, oy * atrous_rate: oy * atrous_rate + height, ox * atrous_rate: ox * atrous_rate + width]
-            dot = (xs * ys.permute(1, 2, 0)).sum(2)
+            dot = (xs.float() * ys.permute(1, 2, 0).float()).sum(2).to(x.dtype)      # matmul: exact products, fp32 accumulation, one rounding
             out[:, :, oy * n_off + ox] = x2 + ys2 - 2. * dot              # AEM:961
     return out
 
@@ -357,9 +363,10 @@ def local_matching(prev_frame_embedding, query_embedding, prev_frame_labels, dis
                    allow_downsample=True, allow_parallel=True):
     """AEM:968-1060 (== local_matching_proxy AEM:1064-1156).  -> [1, h, w, O, len(multi_local_distance)]
     with channel order [max_distance, d_0, d_1, ...] (AEM:1034-1046)."""
-    assert not use_float16
     multi_local_distance = list(multi_local_distance)
     max_distance = multi_local_distance[-1]
+    if use_float16:                                                        # AEM:1002-1005
+        query_embedding, prev_frame_embedding = query_embedding.half(), prev_frame_embedding.half()
     if ori_size is None:
         ori_size = tuple(prev_frame_embedding.size()[:2])
     obj_num = prev_frame_labels.size(2)
@@ -377,7 +384,7 @@ def local_matching(prev_frame_embedding, query_embedding, prev_frame_labels, dis
         for ox in range(n_off):
             sl = pl[:, 0, oy * atrous_rate: oy * atrous_rate + height, ox * atrous_rate: ox * atrous_rate + width]
             masks[:, :, oy * n_off + ox, :] = sl.permute(1, 2, 0) > 0.9   # AEM:1027-1028
-    padv = torch.tensor(WRONG_LABEL_PADDING_DISTANCE)
+    padv = torch.tensor(WRONG_LABEL_PADDING_DISTANCE, dtype=d.dtype)     # AEM:1001-1005 (pad.half() in float16 mode)
     d_masked = torch.where(masks, d.unsqueeze(-1).expand(-1, -1, -1, obj_num), padv)   # AEM:1032
     multi = [d_masked.min(dim=2)[0].permute(2, 0, 1).unsqueeze(1)]
     r = d_masked.reshape(height, width, n_off, n_off, obj_num)
@@ -388,7 +395,7 @@ def local_matching(prev_frame_embedding, query_embedding, prev_frame_labels, dis
         multi.append(sub.min(dim=2)[0].permute(2, 0, 1).unsqueeze(1))
     multi = torch.cat(multi, dim=1)
     bias = _as_bias(dis_bias, obj_num)
-    multi = proto_transform(multi, bias.reshape(-1, 1, 1, 1))             # AEM:1049
+    multi = proto_transform(multi, bias.reshape(-1, 1, 1, 1)).float()     # AEM:1049-1052 (fp32 by type promotion, then .float())
     if (height, width) != tuple(ori_size):
         multi = F.interpolate(multi, size=tuple(ori_size), mode='bilinear', align_corners=True)
     return multi.permute(2, 3, 0, 1).reshape(1, ori_size[0], ori_size[1], obj_num, -1)

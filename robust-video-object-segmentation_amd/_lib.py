@@ -42,6 +42,8 @@ SIGNATURES = {
     "aoc_proxy_corr_min_batched": (_i, [_vp, _i, _i64, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _sz, _vp]),
     "aoc_dense_match_workspace_bytes": (_sz, [_i64, _i64, _i]),
     "aoc_dense_match_min": (_i, [_vp, _i64, _i, _vp, _vp, _vp, _i64, _vp, _vp, _i, _vp, _i64, _i64, _i, _vp, _sz, _vp]),
+    "aoc_dense_match_min_f16": (_i, [_vp, _i64, _i, _vp, _vp, _vp, _i64, _vp, _vp, _i, _vp, _i64, _i64, _i, _vp, _sz, _vp]),
+    "aoc_proxy_corr_min_f16": (_i, [_vp, _i64, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i64, _i, _vp]),
     "aoc_dense_match_set_probe": (_i, [_vp, _vp]),
     "aoc_split_record_bytes": (_sz, [_i]),
     "aoc_split_rows": (_i, [_vp, _i64, _i, _vp, _vp, _vp, _vp]),
@@ -50,6 +52,8 @@ SIGNATURES = {
                                        _vp, _sz, _vp]),
     "aoc_local_window_match": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp]),
     "aoc_resize_bilinear_hwc": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _vp]),
+    "aoc_resize_bilinear_hwc_ex": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _vp]),
+    "aoc_local_window_match_ex": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _vp]),
     "aoc_resize_bilinear_planes": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _i64, _i64, _i64, _vp]),
     "aoc_resize_nearest_bits": (_i, [_vp, _i, _i, _vp, _i, _i, _vp]),
     "aoc_fg2bg_min": (_i, [_vp, _i, _i, _i64, _i64, _vp, _i64, _vp]),

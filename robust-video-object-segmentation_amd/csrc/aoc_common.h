@@ -33,6 +33,13 @@ __device__ __forceinline__ float aoc_fmin_raw(float a, float b) {
 
 __device__ __forceinline__ int aoc_lane() { return threadIdx.x & 63; }
 
+// Round to the nearest float16 and back: the `.half()` matching mode of the reference (AEM:593-595, 801-803, 1002-1005) computes norms,
+// dot products and distances as float16 TENSORS, i.e. every tensor-level result is rounded to float16 (torch accumulates the sums in
+// fp32 and rounds once).  f16 == false: identity.
+__device__ __forceinline__ float aoc_h(float x) { return (float)(_Float16)x; }
+template <bool F16>
+__device__ __forceinline__ float aoc_hr(float x) { return F16 ? (float)(_Float16)x : x; }
+
 // min / sum across the 16 lanes that share (lane >> 4)  (one MFMA 16x16 output row group).
 __device__ __forceinline__ float aoc_min16(float v) {
     v = fminf(v, __shfl_xor(v, 1));
@@ -58,7 +65,7 @@ __host__ __device__ __forceinline__ int aoc_tile_row_stride(int C) { return 4 * 
 int aoc_dense_match_min_gated(const float *query, int64_t m, int C, const float *pool, const int32_t *fg_rows, const int32_t *n_fg,
                               int64_t n_fg_capacity, const uint32_t *wrong_bits, const float *obj_bias, int n_obj, float *out,
                               int64_t out_pixel_stride, int64_t out_obj_stride, int transform, void *workspace, size_t workspace_bytes,
-                              const int32_t *gate, aoc_stream_t stream);
+                              const int32_t *gate, aoc_stream_t stream, int float16 = 0);
 
 // measurement probe of aoc_dense_match_set_probe (thread-local; defined in correlation.hip)
 struct AocDenseProbe { hipEvent_t start, stop; };

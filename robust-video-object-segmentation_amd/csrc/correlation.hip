@@ -36,7 +36,7 @@ struct ProxyTileTable {
 
 // Stage 16-column operand tiles into the k-permuted LDS image.  row_of(c) gives the source row
 // pointer of tile column c (nullptr = zero fill).
-template <typename RowFn>
+template <bool F16, typename RowFn>
 __device__ __forceinline__ void stage_tile_rows(float *__restrict__ lds, int n_rows, int C, int TP, int RS, RowFn row_of) {
     const int c4 = C >> 2;
     const int total = n_rows * c4;
@@ -60,7 +60,7 @@ __device__ __forceinline__ void stage_tile_rows(float *__restrict__ lds, int n_r
         for (int it = 0; it < BATCH; ++it) {
             if (dst[it] >= 0) {
                 float *d = lds + dst[it];
-                d[0] = v[it].x; d[TP] = v[it].y; d[2 * TP] = v[it].z; d[3 * TP] = v[it].w;
+                d[0] = aoc_hr<F16>(v[it].x); d[TP] = aoc_hr<F16>(v[it].y); d[2 * TP] = aoc_hr<F16>(v[it].z); d[3 * TP] = aoc_hr<F16>(v[it].w);
             }
         }
     }
@@ -76,7 +76,8 @@ __device__ __forceinline__ void stage_tile_rows(float *__restrict__ lds, int n_r
 }
 
 // Load the A fragment (16 query rows) and the rows' squared norms.
-template <int TMAX>
+// F16: the reference's `.half()` mode -- the operand is rounded to float16, |q|^2 = h(sum h(q_c^2)) (AEM:200 on a float16 tensor)
+template <int TMAX, bool F16 = false>
 __device__ __forceinline__ void load_a_fragment(const float *__restrict__ query, int64_t m, int C, int64_t row0, float (&a)[TMAX], float &q2) {
     const int lane = aoc_lane();
     const int i = lane & 15, kq = lane >> 4, T = C >> 2;
@@ -86,12 +87,12 @@ __device__ __forceinline__ void load_a_fragment(const float *__restrict__ query,
     float part = 0.0f;
 #pragma unroll
     for (int t = 0; t < TMAX; ++t) {
-        a[t] = (t < T) ? src[4 * t] : 0.0f;
-        part += a[t] * a[t];
+        a[t] = aoc_hr<F16>((t < T) ? src[4 * t] : 0.0f);
+        part += aoc_hr<F16>(a[t] * a[t]);
     }
     part += __shfl_xor(part, 16);
     part += __shfl_xor(part, 32);
-    q2 = part;   // |q_i|^2 on every lane with (lane & 15) == i
+    q2 = aoc_hr<F16>(part);   // |q_i|^2 on every lane with (lane & 15) == i
 }
 
 template <int TMAX>
@@ -128,7 +129,7 @@ struct PcFrames {
     float *out[AOC_CORR_MAX_FRAMES];
     int32_t n;
 };
-template <int TMAX, bool EXACT>
+template <int TMAX, bool EXACT, bool F16>
 __global__ __launch_bounds__(256) void proxy_corr_min_kernel(PcFrames frames, int64_t m, int C, ProxyTileTable tiles, int64_t pstride, int transform,
                                                               const int32_t *__restrict__ gate) {
     if (gate && *gate == 0) return;            // the fp16-split kernel of correlation_batched.hip owns this launch
@@ -148,7 +149,7 @@ __global__ __launch_bounds__(256) void proxy_corr_min_kernel(PcFrames frames, in
     float *lp2 = lds + (size_t)ncols_total * RS;
     float *wbuf_all = lp2 + ncols_total;                      // [4 waves][16 rows][n_out + 1] raw distances
     const int nout = tiles.n_out, wld = nout + 1;
-    stage_tile_rows(lds, ncols_total, C, TP, RS, [&](int c) -> const float * {
+    stage_tile_rows<F16>(lds, ncols_total, C, TP, RS, [&](int c) -> const float * {
         const ProxyTile &pt = tiles.t[c >> 4];
         return ((c & 15) < pt.ncols) ? proxies + (size_t)(pt.proxy_begin + (c & 15)) * C : nullptr;
     });
@@ -157,13 +158,13 @@ __global__ __launch_bounds__(256) void proxy_corr_min_kernel(PcFrames frames, in
         const ProxyTile &pt = tiles.t[c >> 4];
         float v = INFINITY;
         if ((c & 15) < pt.ncols) {
-            if (proxy_sqnorm) {
-                v = proxy_sqnorm[pt.proxy_begin + (c & 15)];
-            } else {   // |p|^2 from the staged image (AEM:150 .pow(2).sum(1); any order)
+            if (proxy_sqnorm) v = proxy_sqnorm[pt.proxy_begin + (c & 15)];
+            if (!proxy_sqnorm || (F16 && v < INFINITY)) {   // |p|^2 from the staged image (AEM:150 .pow(2).sum(1); any order)
                 const float *r = lds + (size_t)c * RS;
                 v = 0.0f;
                 for (int kq = 0; kq < 4; ++kq)
-                    for (int t = 0; t < (C >> 2); ++t) v += r[kq * TP + t] * r[kq * TP + t];
+                    for (int t = 0; t < (C >> 2); ++t) v += aoc_hr<F16>(r[kq * TP + t] * r[kq * TP + t]);
+                v = aoc_hr<F16>(v);
             }
         }
         lp2[c] = v;
@@ -190,7 +191,7 @@ __global__ __launch_bounds__(256) void proxy_corr_min_kernel(PcFrames frames, in
     for (int64_t rt = (int64_t)blockIdx.x * 4 + wave; rt < n_row_tiles; rt += (int64_t)gridDim.x * 4) {
         const int64_t row0 = rt * 16;
         float a[TMAX], q2;
-        load_a_fragment<TMAX>(query, m, C, row0, a, q2);
+        load_a_fragment<TMAX, F16>(query, m, C, row0, a, q2);
         float q2r[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) q2r[r] = __shfl(q2, g * 4 + r);
@@ -208,7 +209,8 @@ __global__ __launch_bounds__(256) void proxy_corr_min_kernel(PcFrames frames, in
             }
             float d[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) d[r] = (q2r[r] + t.p2) - 2.0f * acc[r];   // AEM:43
+            for (int r = 0; r < 4; ++r)   // AEM:43; in float16 mode every tensor-level result is a float16
+                d[r] = F16 ? aoc_h(aoc_h(q2r[r] + t.p2) - 2.0f * aoc_h(acc[r])) : (q2r[r] + t.p2) - 2.0f * acc[r];
             if (pt.flags & 1) {   // column-wise: k = 1 proxies, no min (AEM:127)
                 if (j < pt.ncols) {
                     if (nout > 0) {
@@ -272,6 +274,7 @@ __global__ __launch_bounds__(256) void proxy_corr_min_kernel(PcFrames frames, in
 // accumulators.  Grid = (row blocks, n-splits); partial minima go to the workspace.
 constexpr int DM_NB = 8;
 
+template <bool F16>
 __global__ __launch_bounds__(256) void gather_sqnorm_kernel(const float *__restrict__ pool, int C, const int32_t *__restrict__ fg_rows,
                                                              const int32_t *__restrict__ n_fg, float *__restrict__ r2,
                                                              const int32_t *__restrict__ gate) {
@@ -280,8 +283,11 @@ __global__ __launch_bounds__(256) void gather_sqnorm_kernel(const float *__restr
     if (p >= *n_fg) return;
     const float *x = pool + (size_t)fg_rows[p] * C;
     float s = 0.0f;
-    for (int t = 0; t < C; ++t) s += x[t] * x[t];
-    r2[p] = s;
+    for (int t = 0; t < C; ++t) {
+        const float v = aoc_hr<F16>(x[t]);
+        s += aoc_hr<F16>(v * v);
+    }
+    r2[p] = aoc_hr<F16>(s);
 }
 
 // One B tile (16 reference pixels) held in registers: the lane's k-stream as TP/4 float4, plus the
@@ -297,7 +303,7 @@ struct DenseBTile {
 // waves; the NEXT chunk's row ids and rows are fetched into registers while the current chunk is multiplied
 // (loads stay in flight across the barrier, written to LDS after it), so the matrix pipe only idles for the
 // LDS write pass.
-template <int NA, int OMAX, int TMAX, bool EXACT, int NW>
+template <int NA, int OMAX, int TMAX, bool EXACT, int NW, bool F16>
 __global__ __launch_bounds__(NW * 64, 2) void dense_match_partial_kernel(const float *__restrict__ query, int64_t m, int C,
                                                                           const float *__restrict__ pool, const int32_t *__restrict__ fg_rows,
                                                                           const int32_t *__restrict__ n_fg_ptr, const float *__restrict__ r2_all,
@@ -332,7 +338,7 @@ __global__ __launch_bounds__(NW * 64, 2) void dense_match_partial_kernel(const f
 #pragma unroll
     for (int ia = 0; ia < NA; ++ia) {
         float q2;
-        load_a_fragment<TMAX>(query, m, C, wave_row0 + ia * 16, a[ia], q2);
+        load_a_fragment<TMAX, F16>(query, m, C, wave_row0 + ia * 16, a[ia], q2);
 #pragma unroll
         for (int r = 0; r < 4; ++r) q2r[ia][r] = __shfl(q2, g * 4 + r);
     }
@@ -370,14 +376,15 @@ __global__ __launch_bounds__(NW * 64, 2) void dense_match_partial_kernel(const f
         }
         float padv[OMAX];   // per-column padding of every object (AEM:84-86); objects >= n_obj are never written
 #pragma unroll
-        for (int o = 0; o < OMAX; ++o) padv[o] = ((t.wrong >> o) & 1u) ? AOC_PAD_DISTANCE : 0.0f;
+        for (int o = 0; o < OMAX; ++o) padv[o] = ((t.wrong >> o) & 1u) ? (F16 ? aoc_h(AOC_PAD_DISTANCE) : AOC_PAD_DISTANCE) : 0.0f;
 #pragma unroll
         for (int ia = 0; ia < NA; ++ia)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float d = (q2r[ia][r] + t.r2) - 2.0f * acc[ia][r];   // AEM:43
+                // AEM:43; float16 mode (AEM:65-66, 801-803): dists, the padded sum and the min are float16 tensors
+                const float d = F16 ? aoc_h(aoc_h(q2r[ia][r] + t.r2) - 2.0f * aoc_h(acc[ia][r])) : (q2r[ia][r] + t.r2) - 2.0f * acc[ia][r];
 #pragma unroll
-                for (int o = 0; o < OMAX; ++o) mn[o][ia][r] = aoc_fmin_raw(mn[o][ia][r], d + padv[o]);   // AEM:88
+                for (int o = 0; o < OMAX; ++o) mn[o][ia][r] = aoc_fmin_raw(mn[o][ia][r], F16 ? aoc_h(d + padv[o]) : d + padv[o]);   // AEM:88
             }
     };
 
@@ -426,7 +433,7 @@ __global__ __launch_bounds__(NW * 64, 2) void dense_match_partial_kernel(const f
             if (idx < ROWS * c4) {
                 const int rr = idx / c4, t = idx - rr * c4;
                 float *d = lds + (size_t)rr * RS + t;
-                d[0] = stg.v[it].x; d[TP] = stg.v[it].y; d[2 * TP] = stg.v[it].z; d[3 * TP] = stg.v[it].w;
+                d[0] = aoc_hr<F16>(stg.v[it].x); d[TP] = aoc_hr<F16>(stg.v[it].y); d[2 * TP] = aoc_hr<F16>(stg.v[it].z); d[3 * TP] = aoc_hr<F16>(stg.v[it].w);
             }
         }
 #pragma unroll
@@ -550,7 +557,16 @@ int aoc_proxy_corr_min(const float *query, int64_t m, int C, const float *proxie
     if (!query || !proxies || !out) return AOC_ERR_INVALID_ARG;
     const aoc_corr_frame fr = {query, proxies, proxy_sqnorm, set_bias, out};
     return aoc_corr_fp32_batched(&fr, 1, m, C, n_proxy, n_set, set_begin_host, set_size_host, set_out_offset_host, out_pixel_stride, transform,
-                                 nullptr, stream);
+                                 nullptr, stream, 0);
+}
+
+int aoc_proxy_corr_min_f16(const float *query, int64_t m, int C, const float *proxies, const float *proxy_sqnorm, int n_proxy,
+                           int n_set, const int32_t *set_begin_host, const int32_t *set_size_host, const int64_t *set_out_offset_host,
+                           const float *set_bias, float *out, int64_t out_pixel_stride, int transform, aoc_stream_t stream) {
+    if (!query || !proxies || !out) return AOC_ERR_INVALID_ARG;
+    const aoc_corr_frame fr = {query, proxies, proxy_sqnorm, set_bias, out};
+    return aoc_corr_fp32_batched(&fr, 1, m, C, n_proxy, n_set, set_begin_host, set_size_host, set_out_offset_host, out_pixel_stride, transform,
+                                 nullptr, stream, 1);
 }
 
 size_t aoc_dense_match_workspace_bytes(int64_t m, int64_t n_fg_capacity, int n_obj) {
@@ -564,14 +580,22 @@ int aoc_dense_match_min(const float *query, int64_t m, int C, const float *pool,
                         float *out, int64_t out_pixel_stride, int64_t out_obj_stride, int transform,
                         void *workspace, size_t workspace_bytes, aoc_stream_t stream) {
     return aoc_dense_match_min_gated(query, m, C, pool, fg_rows, n_fg, n_fg_capacity, wrong_bits, obj_bias, n_obj, out, out_pixel_stride,
-                                     out_obj_stride, transform, workspace, workspace_bytes, nullptr, stream);
+                                     out_obj_stride, transform, workspace, workspace_bytes, nullptr, stream, 0);
+}
+
+int aoc_dense_match_min_f16(const float *query, int64_t m, int C, const float *pool, const int32_t *fg_rows, const int32_t *n_fg,
+                            int64_t n_fg_capacity, const uint32_t *wrong_bits, const float *obj_bias, int n_obj,
+                            float *out, int64_t out_pixel_stride, int64_t out_obj_stride, int transform,
+                            void *workspace, size_t workspace_bytes, aoc_stream_t stream) {
+    return aoc_dense_match_min_gated(query, m, C, pool, fg_rows, n_fg, n_fg_capacity, wrong_bits, obj_bias, n_obj, out, out_pixel_stride,
+                                     out_obj_stride, transform, workspace, workspace_bytes, nullptr, stream, 1);
 }
 
 }  // extern "C"
 
 int aoc_corr_fp32_batched(const aoc_corr_frame *frames_host, int n_frames, int64_t m, int C, int n_proxy, int n_set,
                           const int32_t *set_begin_host, const int32_t *set_size_host, const int64_t *set_out_offset_host,
-                          int64_t out_pixel_stride, int transform, const int32_t *gate, aoc_stream_t stream) {
+                          int64_t out_pixel_stride, int transform, const int32_t *gate, aoc_stream_t stream, int float16) {
     if (!frames_host || !set_begin_host || !set_size_host || !set_out_offset_host) return AOC_ERR_INVALID_ARG;
     if (n_frames < 1 || m < 1 || C < 4 || n_set < 1 || n_proxy < 0) return AOC_ERR_INVALID_ARG;
     if ((C & 3) || C > AOC_MAX_CHANNELS) return AOC_ERR_UNSUPPORTED;
@@ -609,8 +633,9 @@ int aoc_corr_fp32_batched(const aoc_corr_frame *frames_host, int n_frames, int64
             if (tab.n == 0) return AOC_OK;
             if (out_overflow) tab.n_out = 0;       // too many output columns for the transpose buffer: direct stores
             const size_t lds = (size_t)tab.n * tile_bytes + (size_t)4 * 16 * (tab.n_out + 1) * sizeof(float);
-#define AOC_PC(TM, EX) hipLaunchKernelGGL((proxy_corr_min_kernel<TM, EX>), dim3(gate ? (grid < 256 ? grid : 256) : grid, gate ? 1 : nf), dim3(256), lds, st, fr, m, C, tab, out_pixel_stride, transform, gate)
-            if (C == 100) AOC_PC(25, true); else if (C <= 128) AOC_PC(32, false); else AOC_PC(64, false);
+#define AOC_PC(TM, EX, F16) hipLaunchKernelGGL((proxy_corr_min_kernel<TM, EX, F16>), dim3(gate ? (grid < 256 ? grid : 256) : grid, gate ? 1 : nf), dim3(256), lds, st, fr, m, C, tab, out_pixel_stride, transform, gate)
+            if (float16) { if (C == 100) AOC_PC(25, true, true); else if (C <= 128) AOC_PC(32, false, true); else AOC_PC(64, false, true); }
+            else if (C == 100) AOC_PC(25, true, false); else if (C <= 128) AOC_PC(32, false, false); else AOC_PC(64, false, false);
 #undef AOC_PC
             tab.n = 0;
             tab.n_out = 0;
@@ -664,7 +689,7 @@ extern "C" int aoc_dense_match_set_probe(void *start_event, void *stop_event) {
 int aoc_dense_match_min_gated(const float *query, int64_t m, int C, const float *pool, const int32_t *fg_rows, const int32_t *n_fg,
                               int64_t n_fg_capacity, const uint32_t *wrong_bits, const float *obj_bias, int n_obj,
                               float *out, int64_t out_pixel_stride, int64_t out_obj_stride, int transform,
-                              void *workspace, size_t workspace_bytes, const int32_t *gate, aoc_stream_t stream) {
+                              void *workspace, size_t workspace_bytes, const int32_t *gate, aoc_stream_t stream, int float16) {
     if (!query || !pool || !fg_rows || !n_fg || !wrong_bits || !out || !workspace) return AOC_ERR_INVALID_ARG;
     if (m < 1 || C < 4 || n_obj < 1 || n_fg_capacity < 1 || n_fg_capacity >= (1ll << 31)) return AOC_ERR_INVALID_ARG;
     if ((C & 3) || C > 128 || n_obj > 16) return AOC_ERR_UNSUPPORTED;
@@ -678,15 +703,22 @@ int aoc_dense_match_min_gated(const float *query, int64_t m, int C, const float 
     const int RS = aoc_tile_row_stride(C);
     const size_t lds = (size_t)DM_NB * 16 * RS * sizeof(float) + DM_NB * 16 * (sizeof(float) + sizeof(uint32_t) + 2 * sizeof(int32_t));
 
-    hipLaunchKernelGGL(gather_sqnorm_kernel, dim3((unsigned)((n_fg_capacity + 255) / 256)), dim3(256), 0, st, pool, C, fg_rows, n_fg, r2, gate);
+    if (float16) hipLaunchKernelGGL(gather_sqnorm_kernel<true>, dim3((unsigned)((n_fg_capacity + 255) / 256)), dim3(256), 0, st, pool, C, fg_rows, n_fg, r2, gate);
+    else hipLaunchKernelGGL(gather_sqnorm_kernel<false>, dim3((unsigned)((n_fg_capacity + 255) / 256)), dim3(256), 0, st, pool, C, fg_rows, n_fg, r2, gate);
     const dim3 grid(row_blocks, ns);
     const AocDenseProbe probe = gate ? AocDenseProbe{nullptr, nullptr} : aoc_take_dense_probe();
     if (probe.start) (void)hipEventRecord(probe.start, st);
-#define AOC_DM(NA, OM, TM, EX) hipLaunchKernelGGL((dense_match_partial_kernel<NA, OM, TM, EX, DM_NW>), grid, dim3(DM_NW * 64), lds, st, query, m, C, pool, fg_rows, n_fg, r2, wrong_bits, n_obj, partial, gate)
-    if (C == 100) {
-        if (n_obj <= 4) AOC_DM(2, 4, 25, true); else if (n_obj <= 8) AOC_DM(1, 8, 25, true); else AOC_DM(1, 16, 25, true);
+#define AOC_DM(NA, OM, TM, EX, F16) hipLaunchKernelGGL((dense_match_partial_kernel<NA, OM, TM, EX, DM_NW, F16>), grid, dim3(DM_NW * 64), lds, st, query, m, C, pool, fg_rows, n_fg, r2, wrong_bits, n_obj, partial, gate)
+    if (float16) {
+        if (C == 100) {
+            if (n_obj <= 4) AOC_DM(2, 4, 25, true, true); else if (n_obj <= 8) AOC_DM(1, 8, 25, true, true); else AOC_DM(1, 16, 25, true, true);
+        } else {
+            if (n_obj <= 4) AOC_DM(2, 4, 32, false, true); else if (n_obj <= 8) AOC_DM(1, 8, 32, false, true); else AOC_DM(1, 16, 32, false, true);
+        }
+    } else if (C == 100) {
+        if (n_obj <= 4) AOC_DM(2, 4, 25, true, false); else if (n_obj <= 8) AOC_DM(1, 8, 25, true, false); else AOC_DM(1, 16, 25, true, false);
     } else {
-        if (n_obj <= 4) AOC_DM(2, 4, 32, false); else if (n_obj <= 8) AOC_DM(1, 8, 32, false); else AOC_DM(1, 16, 32, false);
+        if (n_obj <= 4) AOC_DM(2, 4, 32, false, false); else if (n_obj <= 8) AOC_DM(1, 8, 32, false, false); else AOC_DM(1, 16, 32, false, false);
     }
 #undef AOC_DM
     if (probe.stop) (void)hipEventRecord(probe.stop, st);

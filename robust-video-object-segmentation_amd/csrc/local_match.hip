@@ -25,13 +25,18 @@ struct LocalRadii {
     int32_t n;
 };
 
+// radii are in units of the atrous rate (ring a = max(|dy|, |dx|) / rate; only offsets that are multiples of the rate exist,
+// AEM:949-959 unfold with stride = atrous_rate); R = rate * radii.r[n-1] is the window half-size in pixels.
+// f16 != 0: the reference's `.half()` mode (AEM:1002-1005): operands, norms, dot products and distances rounded to float16.
 template <int TMAX>
 __global__ __launch_bounds__(256) void local_window_kernel(const float *__restrict__ query, const float *__restrict__ prev,
                                                             const uint32_t *__restrict__ right_bits, int H, int W, int C,
                                                             LocalRadii radii, const float *__restrict__ obj_bias, int n_obj,
-                                                            float *__restrict__ out, int transform) {
+                                                            float *__restrict__ out, int transform, int rate, int f16) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int R = radii.r[radii.n - 1];
+    const int RA = radii.r[radii.n - 1];             // window half-size in atrous units
+    const int R = RA * rate;
+    const float padv = f16 ? aoc_h(AOC_PAD_DISTANCE) : AOC_PAD_DISTANCE;
     const int TP = aoc_tile_tp(C), RS = aoc_tile_row_stride(C);
     const int NC = 16 + 2 * R;
     const int NG = (NC + 15) / 16;
@@ -48,8 +53,8 @@ __global__ __launch_bounds__(256) void local_window_kernel(const float *__restri
     const int y0 = blockIdx.y * 4;
     const int y = y0 + wave;
 
-    for (int i = threadIdx.x; i < 4 * acc_per_wave; i += blockDim.x) lacc[i] = AOC_PAD_DISTANCE;   // AEM:1032 pad
-    if (threadIdx.x <= R) {
+    for (int i = threadIdx.x; i < 4 * acc_per_wave; i += blockDim.x) lacc[i] = padv;   // AEM:1032 pad
+    if ((int)threadIdx.x <= RA) {
         int c = 0;
         while (radii.r[c] < (int)threadIdx.x) ++c;
         lcls[threadIdx.x] = c;
@@ -64,11 +69,12 @@ __global__ __launch_bounds__(256) void local_window_kernel(const float *__restri
 #pragma unroll
         for (int t = 0; t < TMAX; ++t) {
             a[t] = (t < T) ? src[4 * t] : 0.0f;
-            part += a[t] * a[t];
+            if (f16) { a[t] = aoc_h(a[t]); part += aoc_h(a[t] * a[t]); }
+            else part += a[t] * a[t];
         }
         part += __shfl_xor(part, 16);
         part += __shfl_xor(part, 32);
-        q2 = part;
+        q2 = f16 ? aoc_h(part) : part;
 #pragma unroll
         for (int r = 0; r < 4; ++r) q2r[r] = __shfl(q2, g * 4 + r);
     }
@@ -84,6 +90,7 @@ __global__ __launch_bounds__(256) void local_window_kernel(const float *__restri
                 const int cx = x0 - R + c;
                 float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (c < NC && cx >= 0 && cx < W) v = reinterpret_cast<const float4 *>(prev + ((size_t)cy * W + cx) * C)[t];
+                if (f16) { v.x = aoc_h(v.x); v.y = aoc_h(v.y); v.z = aoc_h(v.z); v.w = aoc_h(v.w); }
                 float *d = lds + (size_t)c * RS + t;
                 d[0] = v.x; d[TP] = v.y; d[2 * TP] = v.z; d[3 * TP] = v.w;
             }
@@ -104,8 +111,8 @@ __global__ __launch_bounds__(256) void local_window_kernel(const float *__restri
             const float *r = lds + (size_t)c * RS;
             float s = 0.0f;
             for (int kq = 0; kq < 4; ++kq)
-                for (int t = 0; t < (C >> 2); ++t) s += r[kq * TP + t] * r[kq * TP + t];
-            ly2[c] = s;
+                for (int t = 0; t < (C >> 2); ++t) s += f16 ? aoc_h(r[kq * TP + t] * r[kq * TP + t]) : r[kq * TP + t] * r[kq * TP + t];
+            ly2[c] = f16 ? aoc_h(s) : s;
         }
         __syncthreads();
         const int dy = cy - y;
@@ -135,9 +142,9 @@ __global__ __launch_bounds__(256) void local_window_kernel(const float *__restri
                         const int qx = x0 + qi;
                         int dx = cx - qx;
                         dx = dx < 0 ? -dx : dx;
-                        if (dx <= R && qx < W) {
-                            const float d = (q2r[r] + y2) - 2.0f * acc[r];   // AEM:961
-                            const int cls = lcls[max(ady, dx)];
+                        if (dx <= R && qx < W && (rate == 1 || (dx % rate == 0 && ady % rate == 0))) {
+                            const float d = f16 ? aoc_h(aoc_h(q2r[r] + y2) - 2.0f * aoc_h(acc[r])) : (q2r[r] + y2) - 2.0f * acc[r];   // AEM:961
+                            const int cls = lcls[max(ady, dx) / rate];
                             uint32_t b = bits;
                             while (b) {                                     // AEM:1032 where(mask, d, pad)
                                 const int o = __builtin_ctz(b);
@@ -179,10 +186,12 @@ template <int TMAX>
 __global__ __launch_bounds__(256) void local_window_row_kernel(const float *__restrict__ query, const float *__restrict__ prev,
                                                                 const uint32_t *__restrict__ right_bits, int H, int W, int C,
                                                                 LocalRadii radii, const float *__restrict__ obj_bias, int n_obj,
-                                                                float *__restrict__ out, int transform) {
+                                                                float *__restrict__ out, int transform, int rate, int f16) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int TP = (TMAX + 3) / 4 * 4, RS = 4 * TP + 4, NB4 = TP / 4;
-    const int R = radii.r[radii.n - 1];
+    const int RA = radii.r[radii.n - 1];             // window half-size in atrous units
+    const int R = RA * rate;
+    const float padv = f16 ? aoc_h(AOC_PAD_DISTANCE) : AOC_PAD_DISTANCE;
     const int NC = 16 + 2 * R;                          // candidates per row
     const int NG = (NC + 15) / 16;
     const int NCP = NG * 16;
@@ -203,8 +212,8 @@ __global__ __launch_bounds__(256) void local_window_row_kernel(const float *__re
     const int x0 = blockIdx.x * 16;
     const int y = blockIdx.y;
 
-    for (int i = lane; i < acc_per_wave; i += 64) my_acc[i] = AOC_PAD_DISTANCE;      // AEM:1032 pad
-    if (threadIdx.x <= R) {
+    for (int i = lane; i < acc_per_wave; i += 64) my_acc[i] = padv;      // AEM:1032 pad
+    if ((int)threadIdx.x <= RA) {
         int c = 0;
         while (radii.r[c] < (int)threadIdx.x) ++c;
         lcls[threadIdx.x] = c;
@@ -223,10 +232,12 @@ __global__ __launch_bounds__(256) void local_window_row_kernel(const float *__re
 #pragma unroll
         for (int t = 0; t < TMAX; ++t) {
             a[t] = (t < c4) ? src[4 * t] : 0.0f;
-            part += a[t] * a[t];
+            if (f16) { a[t] = aoc_h(a[t]); part += aoc_h(a[t] * a[t]); }
+            else part += a[t] * a[t];
         }
         part += __shfl_xor(part, 16);
         part += __shfl_xor(part, 32);
+        if (f16) part = aoc_h(part);
 #pragma unroll
         for (int r = 0; r < 4; ++r) q2r[r] = __shfl(part, g * 4 + r);
     }
@@ -243,6 +254,7 @@ __global__ __launch_bounds__(256) void local_window_row_kernel(const float *__re
             const int cx = x0 - R + c;
             const bool ok = idx < NCP * c4 && c < NC && cx >= 0 && cx < W;
             pv[i] = ok ? reinterpret_cast<const float4 *>(prev + ((size_t)cy * W + cx) * C)[t] : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (f16) { pv[i].x = aoc_h(pv[i].x); pv[i].y = aoc_h(pv[i].y); pv[i].z = aoc_h(pv[i].z); pv[i].w = aoc_h(pv[i].w); }
         }
         const int cx = x0 - R + lane;
         pbits = (lane < NC && cx >= 0 && cx < W) ? (right_bits[(size_t)cy * W + cx] & ~AOC_ROW_KEPT_BIT) : 0u;   // AEM:1023-1028 (pad 0)
@@ -276,12 +288,19 @@ __global__ __launch_bounds__(256) void local_window_row_kernel(const float *__re
                 const float4 v1 = *reinterpret_cast<const float4 *>(r + TP + 4 * u);
                 const float4 v2 = *reinterpret_cast<const float4 *>(r + 2 * TP + 4 * u);
                 const float4 v3 = *reinterpret_cast<const float4 *>(r + 3 * TP + 4 * u);
-                s0 += v0.x * v0.x + v0.y * v0.y + v0.z * v0.z + v0.w * v0.w;
-                s1 += v1.x * v1.x + v1.y * v1.y + v1.z * v1.z + v1.w * v1.w;
-                s2 += v2.x * v2.x + v2.y * v2.y + v2.z * v2.z + v2.w * v2.w;
-                s3 += v3.x * v3.x + v3.y * v3.y + v3.z * v3.z + v3.w * v3.w;
+                if (f16) {
+                    s0 += aoc_h(v0.x * v0.x) + aoc_h(v0.y * v0.y) + aoc_h(v0.z * v0.z) + aoc_h(v0.w * v0.w);
+                    s1 += aoc_h(v1.x * v1.x) + aoc_h(v1.y * v1.y) + aoc_h(v1.z * v1.z) + aoc_h(v1.w * v1.w);
+                    s2 += aoc_h(v2.x * v2.x) + aoc_h(v2.y * v2.y) + aoc_h(v2.z * v2.z) + aoc_h(v2.w * v2.w);
+                    s3 += aoc_h(v3.x * v3.x) + aoc_h(v3.y * v3.y) + aoc_h(v3.z * v3.z) + aoc_h(v3.w * v3.w);
+                } else {
+                    s0 += v0.x * v0.x + v0.y * v0.y + v0.z * v0.z + v0.w * v0.w;
+                    s1 += v1.x * v1.x + v1.y * v1.y + v1.z * v1.z + v1.w * v1.w;
+                    s2 += v2.x * v2.x + v2.y * v2.y + v2.z * v2.z + v2.w * v2.w;
+                    s3 += v3.x * v3.x + v3.y * v3.y + v3.z * v3.z + v3.w * v3.w;
+                }
             }
-            ly2[lane] = (s0 + s1) + (s2 + s3);
+            ly2[lane] = f16 ? aoc_h((s0 + s1) + (s2 + s3)) : (s0 + s1) + (s2 + s3);
         }
         const int dy = cy - y;
         const int ady = dy < 0 ? -dy : dy;
@@ -307,9 +326,9 @@ __global__ __launch_bounds__(256) void local_window_row_kernel(const float *__re
                     const int qx = x0 + qi;
                     int dx = cx - qx;
                     dx = dx < 0 ? -dx : dx;
-                    if (dx <= R && qx < W) {
-                        const float d = (q2r[r] + y2) - 2.0f * acc[r];   // AEM:961
-                        const int cls = lcls[max(ady, dx)];
+                    if (dx <= R && qx < W && (rate == 1 || (dx % rate == 0 && ady % rate == 0))) {
+                        const float d = f16 ? aoc_h(aoc_h(q2r[r] + y2) - 2.0f * aoc_h(acc[r])) : (q2r[r] + y2) - 2.0f * acc[r];   // AEM:961
+                        const int cls = lcls[max(ady, dx) / rate];
                         uint32_t b = bits;
                         while (b) {                                     // AEM:1032 where(mask, d, pad)
                             const int o = __builtin_ctz(b);
@@ -353,7 +372,7 @@ __device__ __forceinline__ void bilinear_src(int dst, float scale, int in_size, 
 }
 
 __global__ __launch_bounds__(256) void resize_bilinear_hwc_kernel(const float *__restrict__ in, int h, int w, int C,
-                                                                   float *__restrict__ out, int H, int W, float sh, float sw) {
+                                                                   float *__restrict__ out, int H, int W, float sh, float sw, int f16) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t total = (int64_t)H * W * C;
     if (idx >= total) return;
@@ -366,6 +385,10 @@ __global__ __launch_bounds__(256) void resize_bilinear_hwc_kernel(const float *_
     bilinear_src(X, sw, w, x0, x1, wx0, wx1);
     const float v00 = in[((size_t)y0 * w + x0) * C + c], v01 = in[((size_t)y0 * w + x1) * C + c];
     const float v10 = in[((size_t)y1 * w + x0) * C + c], v11 = in[((size_t)y1 * w + x1) * C + c];
+    if (f16) {   // F.interpolate on a float16 tensor: float16 samples, fp32 arithmetic, float16 result
+        out[idx] = aoc_h(hy0 * (wx0 * aoc_h(v00) + wx1 * aoc_h(v01)) + hy1 * (wx0 * aoc_h(v10) + wx1 * aoc_h(v11)));
+        return;
+    }
     out[idx] = hy0 * (wx0 * v00 + wx1 * v01) + hy1 * (wx0 * v10 + wx1 * v11);
 }
 
@@ -406,17 +429,25 @@ extern "C" {
 int aoc_local_window_match(const float *query, const float *prev, const uint32_t *right_bits, int H, int W, int C,
                            const int32_t *radii_host, int n_radii, const float *obj_bias, int n_obj,
                            float *out, int transform, aoc_stream_t stream) {
+    return aoc_local_window_match_ex(query, prev, right_bits, H, W, C, radii_host, n_radii, obj_bias, n_obj, out, transform, 1, 0, stream);
+}
+
+int aoc_local_window_match_ex(const float *query, const float *prev, const uint32_t *right_bits, int H, int W, int C,
+                              const int32_t *radii_host, int n_radii, const float *obj_bias, int n_obj,
+                              float *out, int transform, int atrous_rate, int float16, aoc_stream_t stream) {
     if (!query || !prev || !right_bits || !radii_host || !out) return AOC_ERR_INVALID_ARG;
-    if (H < 1 || W < 1 || C < 4 || n_radii < 1 || n_obj < 1) return AOC_ERR_INVALID_ARG;
+    if (H < 1 || W < 1 || C < 4 || n_radii < 1 || n_obj < 1 || atrous_rate < 1) return AOC_ERR_INVALID_ARG;
     if ((C & 3) || C > 128 || n_radii > LM_MAX_RADII || n_obj > AOC_MAX_OBJECTS) return AOC_ERR_UNSUPPORTED;
     LocalRadii radii;
     radii.n = n_radii;
+    // window radii in units of the atrous rate: AEM:949 pad_max_distance = max - max % rate, AEM:1039 local_dis // rate
     for (int i = 0; i < n_radii; ++i) {
-        radii.r[i] = radii_host[i];
         if (radii_host[i] < 0 || (i > 0 && radii_host[i] <= radii_host[i - 1])) return AOC_ERR_INVALID_ARG;
+        radii.r[i] = radii_host[i] / atrous_rate;
     }
-    for (int i = n_radii; i < LM_MAX_RADII; ++i) radii.r[i] = radii_host[n_radii - 1];
-    const int R = radii_host[n_radii - 1];
+    for (int i = n_radii; i < LM_MAX_RADII; ++i) radii.r[i] = radii.r[n_radii - 1];
+    const int rate = atrous_rate, f16 = float16 ? 1 : 0;
+    const int R = radii.r[n_radii - 1] * atrous_rate;
     if (R > 31) return AOC_ERR_UNSUPPORTED;
     const int RS = aoc_tile_row_stride(C);
     const int NG = (16 + 2 * R + 15) / 16;
@@ -432,18 +463,18 @@ int aoc_local_window_match(const float *query, const float *prev, const uint32_t
         if (use_row && (C == 100 || C == 128) && R <= 16 && lds_row <= 150 * 1024) {
             const dim3 rgrid((W + 15) / 16, H);
             if (C == 100)
-                hipLaunchKernelGGL(local_window_row_kernel<25>, rgrid, dim3(256), lds_row, st, query, prev, right_bits, H, W, C, radii, obj_bias, n_obj, out, transform);
+                hipLaunchKernelGGL(local_window_row_kernel<25>, rgrid, dim3(256), lds_row, st, query, prev, right_bits, H, W, C, radii, obj_bias, n_obj, out, transform, rate, f16);
             else
-                hipLaunchKernelGGL(local_window_row_kernel<32>, rgrid, dim3(256), lds_row, st, query, prev, right_bits, H, W, C, radii, obj_bias, n_obj, out, transform);
+                hipLaunchKernelGGL(local_window_row_kernel<32>, rgrid, dim3(256), lds_row, st, query, prev, right_bits, H, W, C, radii, obj_bias, n_obj, out, transform, rate, f16);
             AOC_RETURN_IF_LAUNCH_FAILED();
             return AOC_OK;
         }
     }
     const dim3 grid((W + 15) / 16, (H + 3) / 4);
     if (C == 100)
-        hipLaunchKernelGGL(local_window_kernel<25>, grid, dim3(256), lds, st, query, prev, right_bits, H, W, C, radii, obj_bias, n_obj, out, transform);
+        hipLaunchKernelGGL(local_window_kernel<25>, grid, dim3(256), lds, st, query, prev, right_bits, H, W, C, radii, obj_bias, n_obj, out, transform, rate, f16);
     else
-        hipLaunchKernelGGL(local_window_kernel<32>, grid, dim3(256), lds, st, query, prev, right_bits, H, W, C, radii, obj_bias, n_obj, out, transform);
+        hipLaunchKernelGGL(local_window_kernel<32>, grid, dim3(256), lds, st, query, prev, right_bits, H, W, C, radii, obj_bias, n_obj, out, transform, rate, f16);
     AOC_RETURN_IF_LAUNCH_FAILED();
     return AOC_OK;
 }
@@ -453,10 +484,14 @@ static inline float align_corners_scale(int in_size, int out_size) {
 }
 
 int aoc_resize_bilinear_hwc(const float *in, int h, int w, int C, float *out, int H, int W, aoc_stream_t stream) {
+    return aoc_resize_bilinear_hwc_ex(in, h, w, C, out, H, W, 0, stream);
+}
+
+int aoc_resize_bilinear_hwc_ex(const float *in, int h, int w, int C, float *out, int H, int W, int float16, aoc_stream_t stream) {
     if (!in || !out || h < 1 || w < 1 || C < 1 || H < 1 || W < 1) return AOC_ERR_INVALID_ARG;
     const int64_t total = (int64_t)H * W * C;
     hipLaunchKernelGGL(resize_bilinear_hwc_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, aoc_hip_stream(stream), in, h, w, C,
-                       out, H, W, align_corners_scale(h, H), align_corners_scale(w, W));
+                       out, H, W, align_corners_scale(h, H), align_corners_scale(w, W), float16 ? 1 : 0);
     AOC_RETURN_IF_LAUNCH_FAILED();
     return AOC_OK;
 }

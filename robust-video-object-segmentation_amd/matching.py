@@ -6,11 +6,11 @@ reference (cited per function); every computation runs in csrc/libaoc_hip.so.  `
 ``allow_parallel`` are accepted and ignored: the fused kernels never materialise the
 [m, O, n] / unfold tensors those flags exist to bound.
 
-Divergences, all documented in DESIGN.md:
-* ``use_float16=True`` -- the cluster path returns the constant the reference degrades to
-  (scipy's kmeans2 rejects float16 -> bare ``except`` -> 5e4 padding, AEM:275-286 -> feature 1.0);
-  the other paths raise NotImplementedError (the model runs with MODEL_FLOAT16_MATCHING=False).
-* atrous_rate > 1 for *local* matching is not implemented (all shipped configs use 1).
+``use_float16=True`` (the default ARGUMENT of every reference function; the model passes MODEL_FLOAT16_MATCHING=False):
+* the cluster path returns the constant the reference degrades to (scipy's kmeans2 rejects float16 -> bare ``except`` -> 5e4
+  padding, AEM:275-286 -> feature 1.0);
+* the dense, k = 1 proxy and local paths run the ``.half()`` arithmetic of the reference on the device (operands, norms, dot
+  products and distances rounded to float16 where its float16 tensors round them; outputs fp32) -- see include/aoc_hip.h.
 """
 import numpy as np
 import torch
@@ -220,8 +220,6 @@ def global_matching_for_eval(all_reference_embeddings, query_embeddings, all_ref
                              n_chunks=20, dis_bias=0., ori_size=None, atrous_rate=1, use_float16=True, atrous_obj_pixel_num=0):
     """AEM:688-817.  -> [1, H, W, O, 1]; ones when nothing is labelled (AEM:796-797).  No host sync."""
     ops.inference_only("global_matching_for_eval", query_embeddings, dis_bias, *all_reference_embeddings)
-    if use_float16:
-        raise NotImplementedError("aoc_amd: float16 matching is not implemented (MODEL_FLOAT16_MATCHING=False in all configs)")
     h, w, embedding_dim = query_embeddings.size()
     obj_nums = all_reference_labels[0].size(2)
     dev = query_embeddings.device
@@ -229,7 +227,7 @@ def global_matching_for_eval(all_reference_embeddings, query_embeddings, all_ref
     prep = ops.label_prep(labels_flat)
     planes = torch.empty(obj_nums, h, w, dtype=torch.float32, device=dev)
     ops.dense_match(query_embeddings.reshape(-1, embedding_dim), pool, prep, _bias_vec(dis_bias, obj_nums, dev),
-                    planes, 1, h * w, True)
+                    planes, 1, h * w, True, precision="f16" if use_float16 else None)     # AEM:801-803
     if ori_size is not None:
         # the all-unlabelled early-out of the reference keeps the map at (h, w) even with ori_size
         if int(prep.counts[obj_nums]) == 0:
@@ -253,8 +251,6 @@ def global_matching_for_eval_proxy(all_reference_embeddings, query_embeddings, a
     """matching.py:2518-2662 (the AEM:819-873 copy references undefined names).  ``all_reference_embeddings``
     is the [O, C] tensor of mean-pooled proxies (aocnet.py:314-315); out[i,o] = d(q_i, proxy_o).  -> [1,H,W,O,1]"""
     ops.inference_only("global_matching_for_eval_proxy", query_embeddings, dis_bias, all_reference_embeddings)
-    if use_float16:
-        raise NotImplementedError("aoc_amd: float16 matching is not implemented")
     h, w, embedding_dim = query_embeddings.size()
     obj_nums = all_reference_labels[0].size(2)
     dev = query_embeddings.device
@@ -263,7 +259,7 @@ def global_matching_for_eval_proxy(all_reference_embeddings, query_embeddings, a
     proxies = all_reference_embeddings.float().contiguous()
     planes = torch.empty(obj_nums, h, w, dtype=torch.float32, device=dev)
     ops.proxy_corr_min(query_embeddings.reshape(-1, embedding_dim), proxies, None, list(range(obj_nums)), [1] * obj_nums,
-                       [o * h * w for o in range(obj_nums)], _bias_vec(dis_bias, obj_nums, dev), planes, 1, True)
+                       [o * h * w for o in range(obj_nums)], _bias_vec(dis_bias, obj_nums, dev), planes, 1, True, float16=bool(use_float16))
     return _emit(planes, h, w, 1, obj_nums, ori_size)
 
 
@@ -285,21 +281,18 @@ def local_matching(prev_frame_embedding, query_embedding, prev_frame_labels, dis
                    ori_size=None, atrous_rate=1, use_float16=True, allow_downsample=True, allow_parallel=True):
     """AEM:968-1060.  -> [1, H, W, O, len(multi_local_distance)], channel order [max, d_0, d_1, ...]."""
     ops.inference_only("local_matching", prev_frame_embedding, query_embedding, dis_bias)
-    if use_float16:
-        raise NotImplementedError("aoc_amd: float16 matching is not implemented")
-    if atrous_rate != 1:
-        raise NotImplementedError("aoc_amd: local matching supports atrous_rate == 1 (TEST/TRAIN_LOCAL_ATROUS_RATE)")
     h, w, _ = prev_frame_embedding.size()
     if ori_size is None:
         ori_size = (h, w)
     obj_num = prev_frame_labels.size(2)
     dev = query_embedding.device
+    f16 = bool(use_float16)                                                # AEM:1002-1005
     radii = [int(r) for r in multi_local_distance]
     right, _ = ops.label_bits(prev_frame_labels.reshape(-1, obj_num), want_wrong=False)
     if allow_downsample:
         H, W = int(h / 2) + 1, int(w / 2) + 1                              # AEM:939
-        q = ops.resize_bilinear_hwc(query_embedding, H, W)
-        p = ops.resize_bilinear_hwc(prev_frame_embedding, H, W)
+        q = ops.resize_bilinear_hwc(query_embedding, H, W, float16=f16)
+        p = ops.resize_bilinear_hwc(prev_frame_embedding, H, W, float16=f16)
     else:
         H, W = h, w
         q, p = query_embedding, prev_frame_embedding
@@ -308,7 +301,8 @@ def local_matching(prev_frame_embedding, query_embedding, prev_frame_labels, dis
         right = ops.resize_nearest_bits(right, h, w, H, W)
     elif (H, W) != (h, w):
         raise ValueError("local_matching: label map and distance map sizes differ")   # reference would fail in unfold too
-    feats = ops.local_window_match(q, p, right, radii, _bias_vec(dis_bias, obj_num, dev), obj_num, True)   # [O, nr, H, W]
+    feats = ops.local_window_match(q, p, right, radii, _bias_vec(dis_bias, obj_num, dev), obj_num, True, atrous_rate=int(atrous_rate),
+                                   float16=f16)                                        # [O, nr, H, W]; AEM:949-959 window stride
     nr = len(radii)
     out = torch.empty(1, ori_size[0], ori_size[1], obj_num, nr, dtype=torch.float32, device=dev)
     ops.resize_bilinear_planes(feats.reshape(obj_num * nr, H, W), int(ori_size[0]), int(ori_size[1]), out, 1, obj_num * nr)

@@ -173,9 +173,10 @@ def build_proxies(pool, fg_rows, seg_offsets, seg_k, labels, centroids):
 
 # ------------------------------------------------------------------------------------------ correlation
 def proxy_corr_min(query_flat, proxies, proxy_sqnorm, set_begin, set_size, set_out_offset, set_bias, out, out_pixel_stride,
-                   transform=True):
+                   transform=True, float16=False):
     """For every pixel i and set s writes f(min over proxies[set_begin[s] : +set_size[s]] of d(q_i, p)) at
-    out.data_ptr()[i*out_pixel_stride + set_out_offset[s]]  (see include/aoc_hip.h)."""
+    out.data_ptr()[i*out_pixel_stride + set_out_offset[s]]  (see include/aoc_hip.h).  float16: the reference's `.half()` mode
+    (aoc_proxy_corr_min_f16)."""
     query_flat = _f32c(query_flat)
     proxies = _f32c(proxies)
     proxy_sqnorm = _f32c(proxy_sqnorm) if proxy_sqnorm is not None else None
@@ -190,9 +191,10 @@ def proxy_corr_min(query_flat, proxies, proxy_sqnorm, set_begin, set_size, set_o
         set_bias = _f32c(set_bias)
         assert set_bias.numel() == n_set
     vp = ctypes.c_void_p
-    _lib.check(_lib.lib().aoc_proxy_corr_min(_p(query_flat), m, C, _p(proxies), _p(proxy_sqnorm), proxies.shape[0], n_set,
-                                             sb.ctypes.data_as(vp), ss.ctypes.data_as(vp), so.ctypes.data_as(vp), _p(set_bias), _p(out),
-                                             int(out_pixel_stride), int(bool(transform)), _stream()), "aoc_proxy_corr_min")
+    fn = _lib.lib().aoc_proxy_corr_min_f16 if float16 else _lib.lib().aoc_proxy_corr_min
+    _lib.check(fn(_p(query_flat), m, C, _p(proxies), _p(proxy_sqnorm), proxies.shape[0], n_set,
+                  sb.ctypes.data_as(vp), ss.ctypes.data_as(vp), so.ctypes.data_as(vp), _p(set_bias), _p(out),
+                  int(out_pixel_stride), int(bool(transform)), _stream()), "aoc_proxy_corr_min_f16" if float16 else "aoc_proxy_corr_min")
     return out
 
 
@@ -243,7 +245,7 @@ def proxy_corr_min_batched(frames, set_begin, set_size, set_out_offset, transfor
     return [f[4] for f in frames]
 
 
-def dense_match_min(query_flat, pool, prep, obj_bias, out, out_pixel_stride, out_obj_stride, transform=True):
+def dense_match_min(query_flat, pool, prep, obj_bias, out, out_pixel_stride, out_obj_stride, transform=True, float16=False):
     query_flat = _f32c(query_flat)
     pool = _f32c(pool)
     _need_gpu(query_flat, pool, out)
@@ -254,9 +256,10 @@ def dense_match_min(query_flat, pool, prep, obj_bias, out, out_pixel_stride, out
     if obj_bias is not None:
         obj_bias = _f32c(obj_bias)
     n_fg = prep.counts[n_obj:n_obj + 1]
-    _lib.check(L.aoc_dense_match_min(_p(query_flat), m, C, _p(pool), _p(prep.fg_rows), _p(n_fg), prep.n, _p(prep.wrong_bits),
-                                     _p(obj_bias), n_obj, _p(out), int(out_pixel_stride), int(out_obj_stride), int(bool(transform)),
-                                     _p(ws), ws.numel(), _stream()), "aoc_dense_match_min")
+    fn = L.aoc_dense_match_min_f16 if float16 else L.aoc_dense_match_min
+    _lib.check(fn(_p(query_flat), m, C, _p(pool), _p(prep.fg_rows), _p(n_fg), prep.n, _p(prep.wrong_bits),
+                  _p(obj_bias), n_obj, _p(out), int(out_pixel_stride), int(out_obj_stride), int(bool(transform)),
+                  _p(ws), ws.numel(), _stream()), "aoc_dense_match_min_f16" if float16 else "aoc_dense_match_min")
     return out
 
 
@@ -328,9 +331,11 @@ def dense_match(query_flat, pool, prep, obj_bias, out, out_pixel_stride, out_obj
     <= 16 objects) and the precision mode allows, else the exact-fp32 one.  `query_split` / `pool_split` are optional
     cached SplitRows (otherwise the rows are converted here)."""
     precision = precision or DENSE_PRECISION
-    if precision not in ("split", "fp32"):
+    if precision not in ("split", "fp32", "f16"):
         raise ValueError(f"unknown dense precision {precision!r}")
     C = query_flat.shape[1]
+    if precision == "f16":            # the reference's use_float16=True arithmetic (AEM:801-803)
+        return dense_match_min(query_flat, pool, prep, obj_bias, out, out_pixel_stride, out_obj_stride, transform, float16=True)
     if precision == "fp32" or split_record_bytes(C) == 0 or prep.n_obj > 16:
         return dense_match_min(query_flat, pool, prep, obj_bias, out, out_pixel_stride, out_obj_stride, transform)
     if pool_split is None:
@@ -341,12 +346,12 @@ def dense_match(query_flat, pool, prep, obj_bias, out, out_pixel_stride, out_obj
 
 
 # ------------------------------------------------------------------------------------------ local matching + resize
-def resize_bilinear_hwc(x, H, W):
+def resize_bilinear_hwc(x, H, W, float16=False):
     x = _f32c(x)
     _need_gpu(x)
     h, w, C = x.shape
     out = torch.empty(H, W, C, dtype=torch.float32, device=x.device)
-    _lib.check(_lib.lib().aoc_resize_bilinear_hwc(_p(x), h, w, C, _p(out), H, W, _stream()), "aoc_resize_bilinear_hwc")
+    _lib.check(_lib.lib().aoc_resize_bilinear_hwc_ex(_p(x), h, w, C, _p(out), H, W, int(bool(float16)), _stream()), "aoc_resize_bilinear_hwc_ex")
     return out
 
 
@@ -368,8 +373,8 @@ def resize_nearest_bits(bits, h, w, H, W):
     return out
 
 
-def local_window_match(query, prev, right_bits, radii, obj_bias, n_obj, transform=True):
-    """query, prev [H,W,C] -> [n_obj, len(radii), H, W] (channel order [max, r_0, ...])."""
+def local_window_match(query, prev, right_bits, radii, obj_bias, n_obj, transform=True, atrous_rate=1, float16=False):
+    """query, prev [H,W,C] -> [n_obj, len(radii), H, W] (channel order [max, r_0, ...]); atrous_rate / float16 as in the reference call."""
     query, prev = _f32c(query), _f32c(prev)
     _need_gpu(query, prev, right_bits)
     H, W, C = query.shape
@@ -377,9 +382,9 @@ def local_window_match(query, prev, right_bits, radii, obj_bias, n_obj, transfor
     out = torch.empty(n_obj, radii.size, H, W, dtype=torch.float32, device=query.device)
     if obj_bias is not None:
         obj_bias = _f32c(obj_bias)
-    _lib.check(_lib.lib().aoc_local_window_match(_p(query), _p(prev), _p(right_bits), H, W, C, radii.ctypes.data_as(ctypes.c_void_p),
-                                                 int(radii.size), _p(obj_bias), n_obj, _p(out), int(bool(transform)), _stream()),
-               "aoc_local_window_match")
+    _lib.check(_lib.lib().aoc_local_window_match_ex(_p(query), _p(prev), _p(right_bits), H, W, C, radii.ctypes.data_as(ctypes.c_void_p),
+                                                    int(radii.size), _p(obj_bias), n_obj, _p(out), int(bool(transform)), int(atrous_rate),
+                                                    int(bool(float16)), _stream()), "aoc_local_window_match_ex")
     return out
 
 

@@ -331,3 +331,48 @@ def test_eval_runner_on_the_gpu(aoc):
     np.random.seed(0)
     again = er.eval_sharded(specs, 0, 1, torch.device("cuda"), max_frames=4)
     assert again["sum_iou"] == tot["sum_iou"] and again["sum_f"] == tot["sum_f"]
+
+
+# ------------------------------------------------------------------------------------------ local atrous, use_float16=True
+@pytest.mark.parametrize("name", ["local_atrous2_down_O3", "local_atrous3_nodown_O3"])
+def test_local_atrous_golden(aoc, golden, name):
+    g = golden(name)
+    out = aoc.matching.local_matching(dev(g["in_prev"]), dev(g["in_query"]), dev(g["lab_onehot"]), dev(g["in_bias"]).view(-1, 1, 1, 1),
+                                      [int(v) for v in g["mld"]], None, int(g["atrous_rate"]), False, bool(g["down"]), True)
+    assert tuple(out.shape) == g["out"].shape
+    np.testing.assert_allclose(out.cpu().numpy(), g["out"], rtol=0, atol=ATOL)
+
+
+def _f16_close(got, want, frac_exact=0.97, atol=1.2e-2):
+    """use_float16 mode: the reference's distances are float16 TENSORS; the device accumulates the same exact products in fp32 in another
+    order, which can move a float16 rounding of a norm / dot product by one float16 ulp of a value of O(1..10) (<= 2^-7), i.e. up to
+    about 4e-3 on an output after the sigmoid's slope <= 1/2.  Stated tolerance: >= 97 % of the outputs equal to 2e-6, all within 1.2e-2."""
+    diff = np.abs(got - want)
+    assert diff.max() <= atol, diff.max()
+    assert np.mean(diff <= 2e-6) >= frac_exact, np.mean(diff <= 2e-6)
+
+
+def test_float16_mode_vs_reference_half_path(aoc, golden):
+    """use_float16=True (the default argument of the reference functions): dense, local (plain and atrous) against the outputs of the
+    reference's own `.half()` code on torch-CPU; the k = 1 proxy path (reference raises UnboundLocalError) against the oracle."""
+    from oracle import matching as om
+    g = golden("dense_fp16_R2_O3")
+    refs, labs = _refs(g)
+    out = aoc.matching.global_matching_for_eval(refs, dev(g["in_query"]), labs, 4, dev(g["in_bias"]).view(-1, 1, 1, 1))     # use_float16 defaults to True
+    assert out.dtype == torch.float32 and tuple(out.shape) == g["out"].shape
+    _f16_close(out.cpu().numpy(), g["out"])
+    for name in ("local_fp16_down_O3", "local_atrous2_fp16_down_O3"):
+        g = golden(name)
+        out = aoc.matching.local_matching(dev(g["in_prev"]), dev(g["in_query"]), dev(g["lab_onehot"]), dev(g["in_bias"]).view(-1, 1, 1, 1),
+                                          [int(v) for v in g["mld"]], None, int(g.get("atrous_rate", 1)), True, bool(g["down"]), True)
+        _f16_close(out.cpu().numpy(), g["out"])
+    g = golden("proxy_eval_O3")
+    lab = g["lab_onehot"][0]
+    want = om.global_matching_for_eval_proxy(torch.from_numpy(g["in_proxies"]), torch.from_numpy(g["in_query"]), [torch.from_numpy(lab.copy())], 4,
+                                             torch.from_numpy(g["in_bias"]), None, 1, True, 0)
+    out = aoc.matching.global_matching_for_eval_proxy(dev(g["in_proxies"]), dev(g["in_query"]), [dev(lab)], 4, dev(g["in_bias"]).view(-1, 1, 1, 1))
+    _f16_close(out.cpu().numpy(), want.numpy())
+    g = golden("cluster_fp16_R2_O3")
+    refs, labs = _refs(g)
+    out = aoc.matching.global_matching_for_eval_cluster(refs, dev(g["in_query"]), labs, 4, dev(g["in_bias"]).view(-1, 1, 1, 1))
+    assert np.array_equal(out.cpu().numpy(), g["out"])                    # exactly 1.0 everywhere, two channels

@@ -306,3 +306,38 @@ def test_fullsize_cfg1_oracle(golden):
     q = e1.reshape(-1, cfg.c)[::7]
     dn = om.proto_transform(om.nearest_neighbor_features_per_object(e0.reshape(-1, cfg.c), q, l0.reshape(-1, cfg.n_obj)).squeeze(-1), bias.view(1, -1))
     np.testing.assert_allclose(dn.numpy()[:, :, None], g["dense_sub"], rtol=0, atol=2e-6)
+
+
+# ------------------------------------------------------------------------------------------ use_float16=True (reference .half() paths)
+def _f16_close(got, want, frac_exact=0.97, atol=1.2e-2):
+    """float16-mode outputs: distances are float16 TENSORS in the reference, so a different fp32 summation order inside a dot product
+    or a norm can move a result by one float16 ulp of a distance of O(1..10) (up to 2^-7 = 0.0078, less than 1.2e-2 on the output after
+    the sigmoid's slope <= 1/2 ... bounded here generously).  Almost all elements agree to fp32 rounding."""
+    diff = np.abs(got - want)
+    assert diff.max() <= atol, diff.max()
+    assert np.mean(diff <= 2e-6) >= frac_exact, np.mean(diff <= 2e-6)
+
+
+def test_float16_dense_and_local_vs_reference_half_path(golden):
+    g = golden("dense_fp16_R2_O3")
+    refs, labs = _refs(g)
+    out = om.global_matching_for_eval(refs, T(g["in_query"]), labs, 4, T(g["in_bias"]), None, 1, True, 0)
+    assert out.dtype == torch.float32 and tuple(out.shape) == g["out"].shape
+    _f16_close(out.numpy(), g["out"])
+    g = golden("local_fp16_down_O3")
+    out = om.local_matching(T(g["in_prev"]), T(g["in_query"]), T(g["lab_onehot"].copy()), T(g["in_bias"]), [int(v) for v in g["mld"]], None, 1, True,
+                            bool(g["down"]))
+    assert out.dtype == torch.float32
+    _f16_close(out.numpy(), g["out"])
+    g = golden("cluster_fp16_R2_O3")                    # scipy rejects float16 -> bare except -> 5e4 -> exactly 1.0 (AEM:275-286)
+    assert g["out"].shape[-1] == 2 and np.all(g["out"] == 1.0) and int(g["km_calls"]) == 0
+
+
+@pytest.mark.parametrize("name", ["local_atrous2_down_O3", "local_atrous3_nodown_O3", "local_atrous2_fp16_down_O3"])
+def test_local_atrous(golden, name):
+    """AEM:949-959 (window offsets are multiples of atrous_rate up to max - max % rate), AEM:1039 (nested radii // rate)."""
+    g = golden(name)
+    out = om.local_matching(T(g["in_prev"]), T(g["in_query"]), T(g["lab_onehot"].copy()), T(g["in_bias"]), [int(v) for v in g["mld"]], None,
+                            int(g["atrous_rate"]), bool(g["float16"]), bool(g["down"]))
+    assert tuple(out.shape) == g["out"].shape
+    np.testing.assert_allclose(out.numpy(), g["out"], **TOL)
