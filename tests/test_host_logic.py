@@ -63,7 +63,7 @@ def test_no_cpu_fallback():
         aoc_amd.matching.foreground2background(torch.zeros(3, 1, 4, 4), 3)
     with pytest.raises(aoc_amd._lib.AocHipError):
         aoc_amd.attention.IA_gate(4, 2)(torch.zeros(1, 2, 3, 3), torch.zeros(1, 4))
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(aoc_amd._lib.AocHipError, match="no CPU fallback"):      # float16 mode is implemented (round 2): only the missing GPU is reported
         aoc_amd.matching.local_matching(torch.zeros(4, 4, 8), torch.zeros(4, 4, 8), torch.zeros(4, 4, 2), use_float16=True)
 
 
