@@ -366,6 +366,13 @@ int aoc_cond_gate_pool(const float *z, int N, int C, int64_t hw, const float *ph
                        const float *phi_b, int k_rank, float *gap, float *scores, float *threshold,
                        void *workspace, size_t workspace_bytes, aoc_stream_t stream);
 
+/* The same, also emitting plane_mean [N, C] = mean over HW of z[n,c,:] (CLB:68 avg_pool2d, the input of conditioning_block's inter-object
+ * code) from the SAME pass that computes the scores: a conditioning block then reads its activation three times (scores + plane sums,
+ * masked pooling, FiLM scale) instead of four.  plane_mean may be NULL. */
+int aoc_cond_gate_pool_ex(const float *z, int N, int C, int64_t hw, const float *phi_w,
+                          const float *phi_b, int k_rank, float *gap, float *plane_mean, float *scores,
+                          float *threshold, void *workspace, size_t workspace_bytes, aoc_stream_t stream);
+
 /* Small dense layer used by the conditioning MLPs (CL:46, CLB:81): y[n,:] = x[n,:] W^T + b. */
 int aoc_linear(const float *x, const float *weight, const float *bias, int N, int in_dim,
                int out_dim, float *y, aoc_stream_t stream);

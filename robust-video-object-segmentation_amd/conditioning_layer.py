@@ -50,11 +50,12 @@ class conditioning_block(nn.Module):
 
     def forward(self, x, proxy_IA_head):
         ops.inference_only("conditioning_block", x, proxy_IA_head, *self.parameters())
-        px1 = ops.plane_mean(x)                                              # CLB:68
         beta_rank = int(self.CL_1.beta_percentage * x.size()[-1] * x.size()[-2])       # CL:32
         if beta_rank < 1:
             raise IndexError("conditioning_layer: beta_rank == 0 (the reference fails at beta_val[..., -1])")
-        gap = ops.cond_gate_pool(x, self.CL_1.phi_layer.weight.detach().reshape(-1), self.CL_1.phi_layer.bias.detach(), beta_rank)   # CLB:72 / CL:28-45
+        # CLB:68 (plane means of x) and CLB:72 / CL:28-45 (gate + masked pooling): the plane sums come out of the pass that computes the scores
+        gap, px1 = ops.cond_gate_pool(x, self.CL_1.phi_layer.weight.detach().reshape(-1), self.CL_1.phi_layer.bias.detach(), beta_rank,
+                                      want_plane_mean=True)
         # CLB:69 (inter-object delta), the three mlp_layer products (CLB:72-78, CL:46) and the concatenation (CLB:80) in one launch
         code = ops.cond_codes(gap, px1, proxy_IA_head,
                               self.CL_1.mlp_layer.weight.detach(), self.CL_1.mlp_layer.bias.detach(),

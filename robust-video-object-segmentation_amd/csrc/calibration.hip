@@ -348,6 +348,209 @@ __global__ __launch_bounds__(256) void cond_masked_gap_kernel(const float *__res
     if (threadIdx.x == 0) gap[(size_t)n * C + c] = (wsum[0] + wsum[1] + wsum[2] + wsum[3]) / (float)hw;
 }
 
+// ---- fused conditioning-layer streams (round 2) --------------------------------------------------------------------------
+// One pass over z produces the phi scores (CL:27), the per-plane sums that conditioning_block needs for its inter-object code
+// (CLB:68 avg_pool2d) and the first radix histogram of the k-th-largest selection (CL:33): a conditioning block reads its activation
+// three times (this pass, the masked pooling, the FiLM scale) instead of four.  The selection itself is spread over the whole GPU:
+// one small kernel per remaining radix digit instead of one 1024-thread block per sample walking its scores four times.
+constexpr int CS_PIX = 256;                     // pixels per block of the fused scores pass and of the radix passes
+struct CondSel { uint32_t prefix, k; };
+
+__device__ __forceinline__ float wave_sum_dpp(float v) {      // lane 63 gets the sum of the wave (row scans + two row broadcasts)
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xf, 0xf, false));   // row_shr:1
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x112, 0xf, 0xf, false));   // row_shr:2
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x114, 0xf, 0xf, false));   // row_shr:4
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x118, 0xf, 0xf, false));   // row_shr:8
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xa, 0xf, false));   // row_bcast:15 -> rows 1, 3
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x143, 0xc, 0xf, false));   // row_bcast:31 -> rows 2, 3
+    return v;
+}
+
+// histogram one digit of up to 4 keys per thread into the block's LDS bins: the lanes of a wave that hit the same bin are counted
+// with a ballot first (scores of one map share their leading bits, so plain LDS atomics would serialise 64 ways)
+__device__ __forceinline__ void hist_add(uint32_t *hist, uint32_t bin, bool act) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int round = 0; round < 2; ++round) {
+        const unsigned long long mm = __ballot(act);
+        if (mm == 0ull) break;
+        const int leader = __builtin_ctzll(mm);
+        const uint32_t lb = __shfl(bin, leader);
+        const unsigned long long same = __ballot(act && bin == lb);
+        if (lane == leader) atomicAdd(&hist[lb], (uint32_t)__popcll(same));
+        act = act && bin != lb;
+    }
+    if (act) atomicAdd(&hist[bin], 1u);
+}
+
+// the bin (from the top) in which the `need`-th largest key of a 256-bin histogram falls, and how many of the keys of that bin
+// are still to be skipped; one wave, every lane returns the result
+__device__ __forceinline__ void select_bin(const uint32_t *__restrict__ hist, uint32_t need, uint32_t &bin, uint32_t &left) {
+    const int lane = threadIdx.x & 63;
+    // lane l owns bins 255 - 4l .. 252 - 4l (descending)
+    uint32_t h[4], tot = 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { h[u] = hist[255 - (4 * lane + u)]; tot += h[u]; }
+    uint32_t inc = tot;                                       // inclusive scan over lanes = keys in this lane's bins and all higher ones
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(inc, o);
+        if (lane >= o) inc += t;
+    }
+    const uint32_t before = inc - tot;
+    const bool mine = before < need && need <= inc;
+    uint32_t b = 0, l = 0;
+    if (mine) {
+        uint32_t acc = before;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (acc < need && need <= acc + h[u]) { b = 255 - (4 * lane + u); l = need - acc; }
+            acc += h[u];
+        }
+    }
+    const unsigned long long mm = __ballot(mine);
+    const int src = mm ? __builtin_ctzll(mm) : 0;
+    bin = __shfl(b, src);
+    left = __shfl(l, src);
+}
+
+// First pass over z, work item = (tile of CS_TILE pixels, chunk of CS_CH channels, sample): partial scores of the chunk
+// (sum_c w[c] z[n,c,p], channels in order) and the tile's share of the chunk's plane sums.  A thread owns CS_PPT pixels, so the
+// cross-lane reduction of a plane sum (6 DPP adds) is paid once per CS_PPT values; every wave-wide load is a 256-byte run.
+// part_scores [n_chunks][N][hw]; plane_partial [n_tiles][N][C]
+constexpr int CS_PPT = 8, CS_TILE = 256 * CS_PPT, CS_CH = 32;
+__global__ __launch_bounds__(256) void cond_scores_part_kernel(const float *__restrict__ z, int C, int64_t hw, const float *__restrict__ phi_w,
+                                                                float *__restrict__ part_scores, float *__restrict__ plane_partial) {
+    __shared__ float lps[4][CS_CH];
+    const int n = blockIdx.z, chunk = blockIdx.y, N = gridDim.z;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t p0 = (int64_t)blockIdx.x * CS_TILE + threadIdx.x;
+    const int c0 = chunk * CS_CH, c1 = min(C, c0 + CS_CH);
+    const float *zn = z + ((size_t)n * C + c0) * hw;
+    float s[CS_PPT];
+#pragma unroll
+    for (int u = 0; u < CS_PPT; ++u) s[u] = 0.0f;
+    for (int c = c0; c < c1; ++c) {
+        float v[CS_PPT];
+#pragma unroll
+        for (int u = 0; u < CS_PPT; ++u) {
+            const int64_t p = p0 + 256 * u;
+            v[u] = p < hw ? zn[(size_t)(c - c0) * hw + p] : 0.0f;
+        }
+        const float w = phi_w[c];
+        float t = 0.0f;
+#pragma unroll
+        for (int u = 0; u < CS_PPT; ++u) { s[u] += w * v[u]; t += v[u]; }
+        t = wave_sum_dpp(t);
+        if (lane == 63) lps[wave][c - c0] = t;
+    }
+#pragma unroll
+    for (int u = 0; u < CS_PPT; ++u) {
+        const int64_t p = p0 + 256 * u;
+        if (p < hw) part_scores[((size_t)chunk * N + n) * hw + p] = s[u];
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < c1 - c0)
+        plane_partial[((size_t)blockIdx.x * N + n) * C + c0 + threadIdx.x] =
+            (lps[0][threadIdx.x] + lps[1][threadIdx.x]) + (lps[2][threadIdx.x] + lps[3][threadIdx.x]);
+}
+
+// scores[n,p] = sum over the channel chunks (in order) of the partial scores + b   (CL:27), and the radix histogram of their top byte.
+// grid (ceil(hw / CS_PIX), N); hist [N][4][256] (zeroed by the caller)
+__global__ __launch_bounds__(CS_PIX) void cond_scores_reduce_kernel(const float *__restrict__ part_scores, int n_chunks, int64_t hw,
+                                                                     const float *__restrict__ phi_b, float *__restrict__ scores,
+                                                                     uint32_t *__restrict__ hist) {
+    __shared__ uint32_t lh[256];
+    const int n = blockIdx.y, N = gridDim.y;
+    const int64_t p = (int64_t)blockIdx.x * CS_PIX + threadIdx.x;
+    lh[threadIdx.x] = 0;
+    const bool ok = p < hw;
+    float s = 0.0f;
+    if (ok)
+        for (int k = 0; k < n_chunks; ++k) s += part_scores[((size_t)k * N + n) * hw + p];
+    const float sc = s + phi_b[0];
+    if (ok) scores[(size_t)n * hw + p] = sc;
+    __syncthreads();
+    hist_add(lh, float_order_key(sc) >> 24, ok);
+    __syncthreads();
+    if (lh[threadIdx.x]) atomicAdd(&hist[((size_t)n * 4 + 0) * 256 + threadIdx.x], lh[threadIdx.x]);
+}
+
+// radix digit `pass` (1..3) of the k-th-largest selection: every block first resolves digit pass-1 from its complete histogram
+// (block x = 0 records it in sel[n][pass-1]), then counts digit `pass` of the keys that still match.   grid (ceil(hw / 1024), N)
+__global__ __launch_bounds__(256) void cond_select_pass_kernel(const float *__restrict__ scores, int64_t hw, int k_rank, int pass,
+                                                                uint32_t *__restrict__ hist, CondSel *__restrict__ sel) {
+    __shared__ uint32_t lh[256];
+    __shared__ CondSel cur;
+    const int n = blockIdx.y;
+    lh[threadIdx.x] = 0;
+    if (threadIdx.x < 64) {
+        const CondSel prev = pass == 1 ? CondSel{0u, (uint32_t)k_rank} : sel[(size_t)n * 4 + pass - 2];
+        uint32_t bin, left;
+        select_bin(hist + ((size_t)n * 4 + pass - 1) * 256, prev.k, bin, left);
+        if (threadIdx.x == 0) {
+            cur = CondSel{prev.prefix | (bin << (8 * (4 - pass))), left};
+            if (blockIdx.x == 0) sel[(size_t)n * 4 + pass - 1] = cur;
+        }
+    }
+    __syncthreads();
+    const uint32_t prefix = cur.prefix, mask = 0xffffffffu << (8 * (4 - pass)), shift = 8 * (3 - pass);
+    {
+        const int64_t p = (int64_t)blockIdx.x * CS_PIX + threadIdx.x;
+        uint32_t key = 0;
+        bool act = false;
+        if (p < hw) {
+            key = float_order_key(scores[(size_t)n * hw + p]);
+            act = (key & mask) == prefix;
+        }
+        hist_add(lh, (key >> shift) & 255u, act);
+    }
+    __syncthreads();
+    if (lh[threadIdx.x]) atomicAdd(&hist[((size_t)n * 4 + pass) * 256 + threadIdx.x], lh[threadIdx.x]);
+}
+
+// gap[n,c] = (1/HW) * sum_p z[n,c,p] * (scores[n,p] > threshold[n])    (CL:36-43), threshold = the k-th largest score (last radix digit
+// resolved here); also plane_mean[n,c] from the block partials of the fused pass.  One block per plane.
+__global__ __launch_bounds__(256) void cond_masked_gap_fused_kernel(const float *__restrict__ z, int C, int64_t hw, const float *__restrict__ scores,
+                                                                     const uint32_t *__restrict__ hist, const CondSel *__restrict__ sel,
+                                                                     const float *__restrict__ plane_partial, int n_part,
+                                                                     float *__restrict__ threshold, float *__restrict__ gap, float *__restrict__ plane_mean) {
+    __shared__ float wsum[4];
+    __shared__ float lthr;
+    const int c = blockIdx.x, n = blockIdx.y, N = gridDim.y;
+    if (threadIdx.x < 64) {
+        const CondSel prev = sel[(size_t)n * 4 + 2];
+        uint32_t bin, left;
+        select_bin(hist + ((size_t)n * 4 + 3) * 256, prev.k, bin, left);
+        if (threadIdx.x == 0) {
+            lthr = key_to_float(prev.prefix | bin);
+            if (c == 0 && threshold) threshold[n] = lthr;
+        }
+    }
+    if (threadIdx.x == 64 && plane_mean) {                    // fixed-order sum of the block partials: run-to-run reproducible
+        float t = 0.0f;
+        for (int b = 0; b < n_part; ++b) t += plane_partial[((size_t)b * N + n) * C + c];
+        plane_mean[(size_t)n * C + c] = t / (float)hw;
+    }
+    __syncthreads();
+    const float thr = lthr;
+    const float *zp = z + ((size_t)n * C + c) * hw;
+    const float *sp = scores + (size_t)n * hw;
+    float acc = 0.0f;
+    int64_t p = threadIdx.x;
+    for (; p + 3 * (int64_t)blockDim.x < hw; p += 4 * (int64_t)blockDim.x) {
+        float zv[4], sv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { zv[u] = zp[p + u * blockDim.x]; sv[u] = sp[p + u * blockDim.x]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc += (sv[u] > thr) ? zv[u] : 0.0f;
+    }
+    for (; p < hw; p += blockDim.x) acc += (sp[p] > thr) ? zp[p] : 0.0f;
+    acc = aoc_wave_sum(acc);
+    if (aoc_lane() == 0) wsum[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) gap[(size_t)n * C + c] = (wsum[0] + wsum[1] + wsum[2] + wsum[3]) / (float)hw;
+}
+
 // out[p, :] = sum_o lab[p, o] * rows[o, :]   (aocnet.py:325: matmul(prev label, prev_head_pos))
 __global__ __launch_bounds__(256) void label_mix_kernel(const float *__restrict__ lab, const float *__restrict__ rows, int64_t n, int n_obj, int C,
                                                          float *__restrict__ out) {
@@ -656,24 +859,59 @@ int aoc_film_scale(const float *x, const float *head, const float *weight, const
     return AOC_OK;
 }
 
+struct CondWs {
+    float *scores, *threshold, *partial, *part_scores;
+    uint32_t *hist;
+    CondSel *sel;
+    int n_part, n_chunks;
+    size_t zero_bytes, total;
+};
+static inline CondWs cond_carve(void *base, int N, int C, int64_t hw) {
+    CondWs w;
+    char *p = static_cast<char *>(base);
+    size_t off = 0;
+    auto take = [&](size_t bytes) { char *r = p ? p + off : nullptr; off += aoc_align_up(bytes, 256); return r; };
+    w.n_part = (int)((hw + CS_TILE - 1) / CS_TILE);
+    w.n_chunks = (C + CS_CH - 1) / CS_CH;
+    w.hist = reinterpret_cast<uint32_t *>(take((size_t)N * 4 * 256 * sizeof(uint32_t)));       // zeroed per call
+    w.zero_bytes = off;
+    w.sel = reinterpret_cast<CondSel *>(take((size_t)N * 4 * sizeof(CondSel)));
+    w.scores = reinterpret_cast<float *>(take((size_t)N * hw * sizeof(float)));
+    w.threshold = reinterpret_cast<float *>(take((size_t)N * sizeof(float)));
+    w.partial = reinterpret_cast<float *>(take((size_t)w.n_part * N * C * sizeof(float)));
+    w.part_scores = reinterpret_cast<float *>(take((size_t)w.n_chunks * N * hw * sizeof(float)));
+    w.total = off;
+    return w;
+}
+
 size_t aoc_cond_gate_pool_workspace_bytes(int N, int C, int64_t hw) {
-    (void)C;
-    if (N < 1 || hw < 1) return 0;
-    return aoc_align_up((size_t)N * hw * sizeof(float), 256) + aoc_align_up((size_t)N * sizeof(float), 256);
+    if (N < 1 || C < 1 || hw < 1) return 0;
+    return cond_carve(nullptr, N, C, hw).total;
 }
 
 int aoc_cond_gate_pool(const float *z, int N, int C, int64_t hw, const float *phi_w, const float *phi_b, int k_rank,
                        float *gap, float *scores, float *threshold, void *workspace, size_t workspace_bytes, aoc_stream_t stream) {
+    return aoc_cond_gate_pool_ex(z, N, C, hw, phi_w, phi_b, k_rank, gap, nullptr, scores, threshold, workspace, workspace_bytes, stream);
+}
+
+int aoc_cond_gate_pool_ex(const float *z, int N, int C, int64_t hw, const float *phi_w, const float *phi_b, int k_rank,
+                          float *gap, float *plane_mean, float *scores, float *threshold, void *workspace, size_t workspace_bytes,
+                          aoc_stream_t stream) {
     if (!z || !phi_w || !phi_b || !gap || !workspace) return AOC_ERR_INVALID_ARG;
     if (N < 1 || C < 1 || hw < 1 || k_rank < 1 || k_rank > hw) return AOC_ERR_INVALID_ARG;
-    if (N > 65535 || C > 65535) return AOC_ERR_UNSUPPORTED;
+    if (N > 65535 || C > 65535 * CS_CH) return AOC_ERR_UNSUPPORTED;
     if (workspace_bytes < aoc_cond_gate_pool_workspace_bytes(N, C, hw)) return AOC_ERR_WORKSPACE;
     hipStream_t st = aoc_hip_stream(stream);
-    float *sc = scores ? scores : static_cast<float *>(workspace);
-    float *th = threshold ? threshold : reinterpret_cast<float *>(static_cast<char *>(workspace) + aoc_align_up((size_t)N * hw * sizeof(float), 256));
-    hipLaunchKernelGGL(cond_scores_kernel, dim3((unsigned)((hw + 255) / 256), N), dim3(256), 0, st, z, C, hw, phi_w, phi_b, sc);
-    hipLaunchKernelGGL(cond_kth_largest_kernel, dim3(N), dim3(1024), 0, st, sc, hw, k_rank, th);
-    hipLaunchKernelGGL(cond_masked_gap_kernel, dim3(C, N), dim3(256), 0, st, z, C, hw, sc, th, gap);
+    const CondWs w = cond_carve(workspace, N, C, hw);
+    float *sc = scores ? scores : w.scores;
+    if (hipMemsetAsync(w.hist, 0, w.zero_bytes, st) != hipSuccess) return AOC_ERR_LAUNCH;
+    const dim3 pgrid((unsigned)((hw + CS_PIX - 1) / CS_PIX), N);
+    hipLaunchKernelGGL(cond_scores_part_kernel, dim3((unsigned)w.n_part, (unsigned)w.n_chunks, N), dim3(256), 0, st, z, C, hw, phi_w, w.part_scores, w.partial);
+    hipLaunchKernelGGL(cond_scores_reduce_kernel, pgrid, dim3(CS_PIX), 0, st, w.part_scores, w.n_chunks, hw, phi_b, sc, w.hist);
+    for (int pass = 1; pass <= 3; ++pass)
+        hipLaunchKernelGGL(cond_select_pass_kernel, pgrid, dim3(256), 0, st, sc, hw, k_rank, pass, w.hist, w.sel);
+    hipLaunchKernelGGL(cond_masked_gap_fused_kernel, dim3(C, N), dim3(256), 0, st, z, C, hw, sc, w.hist, w.sel, w.partial, w.n_part, threshold, gap,
+                       plane_mean);
     AOC_RETURN_IF_LAUNCH_FAILED();
     return AOC_OK;
 }

@@ -308,7 +308,8 @@ __global__ __launch_bounds__(NW * 64, 2) void dense_match_partial_kernel(const f
                                                                           const float *__restrict__ pool, const int32_t *__restrict__ fg_rows,
                                                                           const int32_t *__restrict__ n_fg_ptr, const float *__restrict__ r2_all,
                                                                           const uint32_t *__restrict__ wrong_bits, int n_obj,
-                                                                          float *__restrict__ partial, const int32_t *__restrict__ gate) {
+                                                                          float *__restrict__ partial, const int32_t *__restrict__ gate, int obj_base) {
+    // objects [obj_base, obj_base + OMAX) of the n_obj: more than 16 objects take a second launch over the same pixels
     if (gate && *gate == 0) return;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int NT = NW * 64;
@@ -376,7 +377,7 @@ __global__ __launch_bounds__(NW * 64, 2) void dense_match_partial_kernel(const f
         }
         float padv[OMAX];   // per-column padding of every object (AEM:84-86); objects >= n_obj are never written
 #pragma unroll
-        for (int o = 0; o < OMAX; ++o) padv[o] = ((t.wrong >> o) & 1u) ? (F16 ? aoc_h(AOC_PAD_DISTANCE) : AOC_PAD_DISTANCE) : 0.0f;
+        for (int o = 0; o < OMAX; ++o) padv[o] = ((t.wrong >> (o + obj_base)) & 1u) ? (F16 ? aoc_h(AOC_PAD_DISTANCE) : AOC_PAD_DISTANCE) : 0.0f;
 #pragma unroll
         for (int ia = 0; ia < NA; ++ia)
 #pragma unroll
@@ -489,7 +490,7 @@ __global__ __launch_bounds__(NW * 64, 2) void dense_match_partial_kernel(const f
     // reduce over the 16 columns a lane group holds and write this split's partial minima
 #pragma unroll
     for (int o = 0; o < OMAX; ++o) {
-        if (o < n_obj) {
+        if (o + obj_base < n_obj) {
 #pragma unroll
             for (int ia = 0; ia < NA; ++ia) {
                 float v = 0.0f;
@@ -499,7 +500,7 @@ __global__ __launch_bounds__(NW * 64, 2) void dense_match_partial_kernel(const f
                     if (j == r) v = mr;
                 }
                 const int64_t row = wave_row0 + ia * 16 + g * 4 + j;
-                if (j < 4 && row < m) partial[((int64_t)blockIdx.y * m + row) * n_obj + o] = v;
+                if (j < 4 && row < m) partial[((int64_t)blockIdx.y * m + row) * n_obj + obj_base + o] = v;
             }
         }
     }
@@ -692,7 +693,7 @@ int aoc_dense_match_min_gated(const float *query, int64_t m, int C, const float 
                               void *workspace, size_t workspace_bytes, const int32_t *gate, aoc_stream_t stream, int float16) {
     if (!query || !pool || !fg_rows || !n_fg || !wrong_bits || !out || !workspace) return AOC_ERR_INVALID_ARG;
     if (m < 1 || C < 4 || n_obj < 1 || n_fg_capacity < 1 || n_fg_capacity >= (1ll << 31)) return AOC_ERR_INVALID_ARG;
-    if ((C & 3) || C > 128 || n_obj > 16) return AOC_ERR_UNSUPPORTED;
+    if ((C & 3) || C > 128 || n_obj > AOC_MAX_OBJECTS) return AOC_ERR_UNSUPPORTED;
     if (workspace_bytes < aoc_dense_match_workspace_bytes(m, n_fg_capacity, n_obj)) return AOC_ERR_WORKSPACE;
     hipStream_t st = aoc_hip_stream(stream);
     float *r2 = static_cast<float *>(workspace);
@@ -708,19 +709,22 @@ int aoc_dense_match_min_gated(const float *query, int64_t m, int C, const float 
     const dim3 grid(row_blocks, ns);
     const AocDenseProbe probe = gate ? AocDenseProbe{nullptr, nullptr} : aoc_take_dense_probe();
     if (probe.start) (void)hipEventRecord(probe.start, st);
-#define AOC_DM(NA, OM, TM, EX, F16) hipLaunchKernelGGL((dense_match_partial_kernel<NA, OM, TM, EX, DM_NW, F16>), grid, dim3(DM_NW * 64), lds, st, query, m, C, pool, fg_rows, n_fg, r2, wrong_bits, n_obj, partial, gate)
+    for (int obj_base = 0; obj_base < n_obj; obj_base += 16) {
+    const int n_here = n_obj - obj_base;
+#define AOC_DM(NA, OM, TM, EX, F16) hipLaunchKernelGGL((dense_match_partial_kernel<NA, OM, TM, EX, DM_NW, F16>), grid, dim3(DM_NW * 64), lds, st, query, m, C, pool, fg_rows, n_fg, r2, wrong_bits, n_obj, partial, gate, obj_base)
     if (float16) {
         if (C == 100) {
-            if (n_obj <= 4) AOC_DM(2, 4, 25, true, true); else if (n_obj <= 8) AOC_DM(1, 8, 25, true, true); else AOC_DM(1, 16, 25, true, true);
+            if (n_obj <= 4 && obj_base == 0) AOC_DM(2, 4, 25, true, true); else if (n_here <= 8) AOC_DM(1, 8, 25, true, true); else AOC_DM(1, 16, 25, true, true);
         } else {
-            if (n_obj <= 4) AOC_DM(2, 4, 32, false, true); else if (n_obj <= 8) AOC_DM(1, 8, 32, false, true); else AOC_DM(1, 16, 32, false, true);
+            if (n_obj <= 4 && obj_base == 0) AOC_DM(2, 4, 32, false, true); else if (n_here <= 8) AOC_DM(1, 8, 32, false, true); else AOC_DM(1, 16, 32, false, true);
         }
     } else if (C == 100) {
-        if (n_obj <= 4) AOC_DM(2, 4, 25, true, false); else if (n_obj <= 8) AOC_DM(1, 8, 25, true, false); else AOC_DM(1, 16, 25, true, false);
+        if (n_obj <= 4 && obj_base == 0) AOC_DM(2, 4, 25, true, false); else if (n_here <= 8) AOC_DM(1, 8, 25, true, false); else AOC_DM(1, 16, 25, true, false);
     } else {
-        if (n_obj <= 4) AOC_DM(2, 4, 32, false, false); else if (n_obj <= 8) AOC_DM(1, 8, 32, false, false); else AOC_DM(1, 16, 32, false, false);
+        if (n_obj <= 4 && obj_base == 0) AOC_DM(2, 4, 32, false, false); else if (n_here <= 8) AOC_DM(1, 8, 32, false, false); else AOC_DM(1, 16, 32, false, false);
     }
 #undef AOC_DM
+    }
     if (probe.stop) (void)hipEventRecord(probe.stop, st);
     const int64_t total = m * n_obj;
     hipLaunchKernelGGL(dense_match_finalize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, partial, ns, m, n_obj, n_fg,

@@ -466,20 +466,25 @@ def film_scale(x, head, weight, bias, out=None):
     return y
 
 
-def cond_gate_pool(z, phi_w, phi_b, k_rank, want_debug=False):
-    """CL:23-43 -> gap [N, C] (optionally also scores [N,HW] and threshold [N])."""
+def cond_gate_pool(z, phi_w, phi_b, k_rank, want_debug=False, want_plane_mean=False):
+    """CL:23-43 -> gap [N, C] (optionally also scores [N,HW] and threshold [N]; with want_plane_mean also the plane means [N, C] of z,
+    CLB:68, from the same pass that computes the scores)."""
     z, phi_w, phi_b = _f32c(z), _f32c(phi_w).reshape(-1), _f32c(phi_b).reshape(-1)
     _need_gpu(z, phi_w, phi_b)
     N, C = z.shape[0], z.shape[1]
     hw = z.numel() // (N * C)
     L = _lib.lib()
     gap = torch.empty(N, C, dtype=torch.float32, device=z.device)
+    pm = torch.empty(N, C, dtype=torch.float32, device=z.device) if want_plane_mean else None
     scores = torch.empty(N, hw, dtype=torch.float32, device=z.device) if want_debug else None
     thr = torch.empty(N, dtype=torch.float32, device=z.device) if want_debug else None
     ws = _ws(L.aoc_cond_gate_pool_workspace_bytes(N, C, hw), z.device)
-    _lib.check(L.aoc_cond_gate_pool(_p(z), N, C, hw, _p(phi_w), _p(phi_b), int(k_rank), _p(gap), _p(scores), _p(thr), _p(ws), ws.numel(),
-                                    _stream()), "aoc_cond_gate_pool")
-    return (gap, scores, thr) if want_debug else gap
+    _lib.check(L.aoc_cond_gate_pool_ex(_p(z), N, C, hw, _p(phi_w), _p(phi_b), int(k_rank), _p(gap), _p(pm), _p(scores), _p(thr), _p(ws), ws.numel(),
+                                       _stream()), "aoc_cond_gate_pool_ex")
+    out = (gap, scores, thr) if want_debug else gap
+    if want_plane_mean:
+        return (out + (pm,)) if want_debug else (gap, pm)
+    return out
 
 
 def linear(x, weight, bias):

@@ -376,3 +376,18 @@ def test_float16_mode_vs_reference_half_path(aoc, golden):
     refs, labs = _refs(g)
     out = aoc.matching.global_matching_for_eval_cluster(refs, dev(g["in_query"]), labs, 4, dev(g["in_bias"]).view(-1, 1, 1, 1))
     assert np.array_equal(out.cpu().numpy(), g["out"])                    # exactly 1.0 everywhere, two channels
+
+
+def test_dense_more_than_16_objects(aoc):
+    """O = 21 objects (general float labels): the split kernel covers <= 16, the exact kernel walks the objects 16 at a time."""
+    from oracle import matching as om
+    rng = np.random.RandomState(9)
+    h, w, c, o = 19, 27, 100, 21
+    ref = (np.maximum(rng.randn(2, h, w, c), 0) * 0.3).astype(np.float32)
+    q = (np.maximum(rng.randn(h, w, c), 0) * 0.3).astype(np.float32)
+    ids = rng.randint(0, o, size=(2, h, w))
+    lab = (ids[..., None] == np.arange(o)).astype(np.float32)
+    bias = (rng.rand(o).astype(np.float32) - 0.5)
+    want = om.global_matching_for_eval([torch.from_numpy(r) for r in ref], torch.from_numpy(q), [torch.from_numpy(l) for l in lab], 4, torch.from_numpy(bias))
+    got = aoc.matching.global_matching_for_eval([dev(r) for r in ref], dev(q), [dev(l) for l in lab], 4, dev(bias), None, 1, False, 0)
+    np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), rtol=0, atol=ATOL)
