@@ -192,7 +192,9 @@ int aoc_proxy_corr_min_f16(const float *query, int64_t m, int C,
  *            outputs).  Needs |x| 2^10 <= 65000 and |x|^2 <= 4000 for every query / proxy value; checked on the device, and when it
  *            fails the exact-fp32 kernel recomputes the launch inside the same call (no host round trip).
  *  precision AOC_CORR_FP32: exact fp32 MFMA (v_mfma_f32_16x16x4_f32), the arithmetic of aoc_proxy_corr_min.
- *  workspace: aoc_proxy_corr_min_batched_workspace_bytes() bytes (the device-side flag). */
+ *  workspace: aoc_proxy_corr_min_batched_workspace_bytes() bytes (the device-side take-over flag: the kernel stores the call's sequence
+ *            number there when a precondition fails and the gated fp32 kernel runs iff it finds it).  Zero it once after allocation and
+ *            use it from one stream at a time; the calls themselves never reset it. */
 typedef struct aoc_corr_frame {
     const float *query;         /* [m, C] */
     const float *proxies;       /* [n_proxy, C] */

@@ -131,8 +131,8 @@ struct PcFrames {
 };
 template <int TMAX, bool EXACT, bool F16>
 __global__ __launch_bounds__(256) void proxy_corr_min_kernel(PcFrames frames, int64_t m, int C, ProxyTileTable tiles, int64_t pstride, int transform,
-                                                              const int32_t *__restrict__ gate) {
-    if (gate && *gate == 0) return;            // the fp16-split kernel of correlation_batched.hip owns this launch
+                                                              const int32_t *__restrict__ gate, int32_t gate_value) {
+    if (gate && *gate != gate_value) return;   // the fp16-split kernel of correlation_batched.hip owns this launch
     extern __shared__ __attribute__((aligned(16))) float lds[];
     // frames of the launch: one per blockIdx.y, or (gated take-over launch: a small grid that normally exits at once) all of them in turn
     for (int fi = blockIdx.y; fi < frames.n; fi += gridDim.y) {
@@ -596,7 +596,7 @@ int aoc_dense_match_min_f16(const float *query, int64_t m, int C, const float *p
 
 int aoc_corr_fp32_batched(const aoc_corr_frame *frames_host, int n_frames, int64_t m, int C, int n_proxy, int n_set,
                           const int32_t *set_begin_host, const int32_t *set_size_host, const int64_t *set_out_offset_host,
-                          int64_t out_pixel_stride, int transform, const int32_t *gate, aoc_stream_t stream, int float16) {
+                          int64_t out_pixel_stride, int transform, const int32_t *gate, aoc_stream_t stream, int float16, int32_t gate_value) {
     if (!frames_host || !set_begin_host || !set_size_host || !set_out_offset_host) return AOC_ERR_INVALID_ARG;
     if (n_frames < 1 || m < 1 || C < 4 || n_set < 1 || n_proxy < 0) return AOC_ERR_INVALID_ARG;
     if ((C & 3) || C > AOC_MAX_CHANNELS) return AOC_ERR_UNSUPPORTED;
@@ -634,7 +634,7 @@ int aoc_corr_fp32_batched(const aoc_corr_frame *frames_host, int n_frames, int64
             if (tab.n == 0) return AOC_OK;
             if (out_overflow) tab.n_out = 0;       // too many output columns for the transpose buffer: direct stores
             const size_t lds = (size_t)tab.n * tile_bytes + (size_t)4 * 16 * (tab.n_out + 1) * sizeof(float);
-#define AOC_PC(TM, EX, F16) hipLaunchKernelGGL((proxy_corr_min_kernel<TM, EX, F16>), dim3(gate ? (grid < 256 ? grid : 256) : grid, gate ? 1 : nf), dim3(256), lds, st, fr, m, C, tab, out_pixel_stride, transform, gate)
+#define AOC_PC(TM, EX, F16) hipLaunchKernelGGL((proxy_corr_min_kernel<TM, EX, F16>), dim3(gate ? (grid < 256 ? grid : 256) : grid, gate ? 1 : nf), dim3(256), lds, st, fr, m, C, tab, out_pixel_stride, transform, gate, gate_value)
             if (float16) { if (C == 100) AOC_PC(25, true, true); else if (C <= 128) AOC_PC(32, false, true); else AOC_PC(64, false, true); }
             else if (C == 100) AOC_PC(25, true, false); else if (C <= 128) AOC_PC(32, false, false); else AOC_PC(64, false, false);
 #undef AOC_PC

@@ -5,9 +5,10 @@
 // MFMA makes the arithmetic (0.68 GF) slower than the HBM stream.  Here ONE persistent launch walks the 32-pixel tiles of up to 32
 // frames; every fp32 value (scaled by 2^10) is split once into hi + lo fp16 in registers and
 //     q.p = qh.ph + qh.pl + ql.ph          (the dropped ql.pl term is < 2^-22 |q.p|)
-// is ONE K = 304 dot product per (pixel, proxy): 3 x 100 product slots + 3 slots that carry -|p|^2 / 2, i.e. 19 k-steps of
-// v_mfma_f32_32x32x16_f16 instead of 3 x 7.  The accumulator holds 2^20 (q.p - |p|^2 / 2), so the min over a set's proxies is a
-// max over raw accumulator registers and  d = |q|^2 - 2^-19 max.
+// is three chained products of K = 112 each (100 channels + 3 slots that carry -|p|^2 / 2 + padding): 21 k-steps of
+// v_mfma_f32_32x32x16_f16 on ONE accumulator, the hi plane of each side serving two products from the same registers / LDS bytes.
+// The accumulator holds 2^20 (q.p - |p|^2 / 2), so the min over a set's proxies is a max over raw accumulator registers and
+// d = |q|^2 - 2^-19 max.
 //
 // Operand roles: A = proxies (rows i of the 32x32 tile, read from an LDS image staged once per block and frame), B = query pixels
 // (columns j; built in registers from coalescing-friendly 16-byte global loads).  D register r of lane l is row (r/4)*8 + (l/32)*4 + r%4,
@@ -15,13 +16,14 @@
 // and the 32 lanes of a half then store 32 consecutive pixels of the set's output plane (128-byte runs).
 //
 // The k dimension may be permuted freely as long as both operands agree.  Lane half h (= lane / 32) owns channels 48h .. 48h+47 and
-// 96+2h, 97+2h (twelve 16-byte loads + one 8-byte load per pixel row, all naturally aligned) and supplies, per k-step s, the dwords
-// [4s, 4s+4) of the 76-dword sequence  [ hi(50 ch) | hi(50 ch) | lo(50 ch) | norm-slot constants ]  (query side)  against
-// [ hi | lo | hi | pieces of -16 |p|^2 ]  (proxy side, LDS image, 624-byte rows: conflict-free ds_read_b128).
+// 96+2h, 97+2h and holds two 28-dword planes  hi(50 ch) + norm slots + pad | lo(50 ch) + pad  (query side: 56 registers; proxy side:
+// LDS image, 464-byte rows: conflict-free ds_read_b128).
 //
 // Preconditions of the split arithmetic (|x| 2^10 <= 65000, |x|^2 <= 4000) are checked on the device for every value the kernel
 // touches; a violation raises a flag and the exact-fp32 kernel of correlation.hip, gated on that flag, recomputes the launch.
 #include <stdlib.h>
+
+#include <atomic>
 
 #include "aoc_common.h"
 #include "correlation_shared.h"
@@ -32,12 +34,13 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int CB_NW = 8;                         // waves per block (one block per CU, two waves per SIMD: image 100 KB + 8 x 6.4 KB transposition buffers)
+constexpr int CB_NW = 8;                         // waves per block (one block per CU, two waves per SIMD; 12 waves fit the LDS but spill registers: measured slower)
 constexpr int CB_CH = 50;                        // channels per lane half (C = 100)
 constexpr int CB_PK = CB_CH / 2;                 // packed fp16 pairs per plane
-constexpr int CB_STEPS = 19;                     // k-steps: (3 * 100 + 3 + 1 pad) / 16
-constexpr int CB_HALF_DW = CB_STEPS * 4;         // 76 dwords per (row, lane half)
-constexpr int CB_ROW_DW = 2 * CB_HALF_DW + 4;    // 156 dwords = 624 B: 16 consecutive rows start on distinct 4-bank groups
+constexpr int CB_SEG_STEPS = 7;                  // k-steps per plane: 56 fp16 slots = 50 channels + norm slots + pad
+constexpr int CB_SEG_DW = CB_SEG_STEPS * 4;      // 28 dwords per plane
+constexpr int CB_HALF_DW = 2 * CB_SEG_DW;        // [hi | lo] planes of one (row, lane half): 56 dwords
+constexpr int CB_ROW_DW = 2 * CB_HALF_DW + 4;    // 116 dwords = 464 B: 16 consecutive rows start on distinct 4-bank groups
 constexpr int CB_TILE_DW = 32 * CB_ROW_DW;
 constexpr float CB_SCALE = 1024.0f;              // 2^10
 constexpr float CB_QCONST = 32768.0f;            // query-side value of the norm slots: 2^15 * (-16 |p|^2) = -2^19 |p|^2
@@ -63,8 +66,8 @@ __device__ __forceinline__ void load_half_row(const float *__restrict__ row, int
     v[48] = y.x; v[49] = y.y;
 }
 
-struct PixelSeq {            // B operand of one pixel tile: the 76-dword sequence [hi | hi | lo | norm constants] as 19 MFMA operands + |q|^2
-    u32x4 b[CB_STEPS];
+struct PixelSeq {            // B operands of one pixel tile: hi plane (7 MFMA operands; dword 25 = norm-slot constants) and lo plane + |q|^2
+    u32x4 bh[CB_SEG_STEPS], bl[CB_SEG_STEPS];
     float q2part;            // this lane half's share of |q|^2
     float amax;
 };
@@ -80,15 +83,11 @@ __device__ __forceinline__ void convert_raw(const float (&x)[CB_CH], PixelSeq &o
         amax = __builtin_fmaxf(amax, __builtin_fmaxf(__builtin_fabsf(x0), __builtin_fabsf(x1)));
         const float s0 = x0 * CB_SCALE, s1 = x1 * CB_SCALE;
         const _Float16 h0 = (_Float16)s0, h1 = (_Float16)s1;
-        const uint32_t hi = pack_f16(h0, h1);
-        // the second copy of the hi plane is made opaque: otherwise the compiler keeps ONE register for both and re-assembles the four
-        // registers of every MFMA operand with v_mov for each of the proxy tiles (4 x 95 moves per pixel tile instead of 25)
-        uint32_t hi2;
-        asm volatile("v_mov_b32 %0, %1" : "=v"(hi2) : "v"(hi));
-        o.b[e >> 2][e & 3] = hi;
-        o.b[(CB_PK + e) >> 2][(CB_PK + e) & 3] = hi2;
-        o.b[(2 * CB_PK + e) >> 2][(2 * CB_PK + e) & 3] = pack_f16((_Float16)(s0 - (float)h0), (_Float16)(s1 - (float)h1));
+        o.bh[e >> 2][e & 3] = pack_f16(h0, h1);
+        o.bl[e >> 2][e & 3] = pack_f16((_Float16)(s0 - (float)h0), (_Float16)(s1 - (float)h1));
     }
+    o.bh[6][2] = 0u; o.bh[6][3] = 0u;                                      // dwords 26, 27: padding (dword 25 holds the norm-slot constants)
+    o.bl[6][1] = 0u; o.bl[6][2] = 0u; o.bl[6][3] = 0u;
     o.q2part = sq;
     o.amax = amax;
 }
@@ -137,7 +136,7 @@ __device__ __forceinline__ float cb_halfsum(float a) {
 // wave converts its next pixel tile (VALU) or waits for LDS, its partner's MFMA chain keeps the matrix pipe busy.
 template <int NW, int NT, bool COL0>
 __global__ __launch_bounds__(NW * 64) void proxy_corr_batched_kernel(AocCorrFrames frames, int64_t m, AocCorrTiles tiles, int transform,
-                                                                      int32_t *__restrict__ gate, int dbg) {
+                                                                      int32_t *__restrict__ gate, int dbg, int call_seq) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     constexpr int NTH = NW * 64;
     constexpr int n_rows = NT * 32;
@@ -203,7 +202,7 @@ __global__ __launch_bounds__(NW * 64) void proxy_corr_batched_kernel(AocCorrFram
     // so the second half may overwrite the buffer right behind the first half's reads
     auto convert_tile = [&]() {
         float raw[CB_CH];
-        seq.b[CB_STEPS - 1][3] = nconst;
+        seq.bh[6][1] = nconst;
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
 #pragma unroll
@@ -280,41 +279,60 @@ __global__ __launch_bounds__(NW * 64) void proxy_corr_batched_kernel(AocCorrFram
         }
         __syncthreads();
         // phase 3: one item per (image row, float4 of the proxy row): consecutive threads read consecutive 16 bytes; the two packed
-        // hi pairs land at dwords e, e+1 of the half's sequence and again at 50 + e (the [hi | lo | hi] layout), the lo pairs at 25 + e
-        for (int it = threadIdx.x; it < n_rows * 25; it += NTH) {
-            const int r = it / 25, t = it - r * 25;
-            const AocCorrTile &tl = tiles.t[r >> 5];
-            int srow = r;                                                     // image row whose proxy is copied here
-            if (lsrc[r] < 0) {
-                const int oc = tl.kind == 0 ? tl.oc[(r & 31) >> 3] : -1;
-                srow = oc >= 0 ? lfirst[oc] : -1;
+        // hi pairs land at dwords e, e+1 of the half's hi plane, the lo pairs at the same place of its lo plane
+        for (int it0 = threadIdx.x; it0 < n_rows * 25; it0 += 4 * NTH) {
+            // four items per trip: their global loads are all in flight before the first is converted
+            float4 xs[4];
+            int srcs[4], srows[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int it = it0 + u * NTH;
+                xs[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                srcs[u] = -1; srows[u] = -1;
+                if (it < n_rows * 25) {
+                    const int r = it / 25, t = it - r * 25;
+                    const AocCorrTile &tl = tiles.t[r >> 5];
+                    int srow = r;                                             // image row whose proxy is copied here
+                    if (lsrc[r] < 0) {
+                        const int oc = tl.kind == 0 ? tl.oc[(r & 31) >> 3] : -1;
+                        srow = oc >= 0 ? lfirst[oc] : -1;
+                    }
+                    srows[u] = srow;
+                    srcs[u] = srow >= 0 ? lsrc[srow] : -1;
+                    if (srcs[u] >= 0) xs[u] = reinterpret_cast<const float4 *>(fr.proxies + (size_t)srcs[u] * 100)[t];
+                }
             }
-            const int src = srow >= 0 ? lsrc[srow] : -1;
-            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (src >= 0) x = reinterpret_cast<const float4 *>(fr.proxies + (size_t)src * 100)[t];
-            const float am = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(x.x), __builtin_fabsf(x.y)), __builtin_fmaxf(__builtin_fabsf(x.z), __builtin_fabsf(x.w)));
-            if (am > CB_MAX_ABS) bad = true;
-            const float s0 = x.x * CB_SCALE, s1 = x.y * CB_SCALE, s2 = x.z * CB_SCALE, s3 = x.w * CB_SCALE;
-            const _Float16 h0 = (_Float16)s0, h1 = (_Float16)s1, h2 = (_Float16)s2, h3 = (_Float16)s3;
-            const uint32_t hi0 = pack_f16(h0, h1), hi1 = pack_f16(h2, h3);
-            const uint32_t lo0 = pack_f16((_Float16)(s0 - (float)h0), (_Float16)(s1 - (float)h1));
-            const uint32_t lo1 = pack_f16((_Float16)(s2 - (float)h2), (_Float16)(s3 - (float)h3));
-            uint32_t *row = limg + (size_t)r * CB_ROW_DW;
-            if (t < 24) {
-                uint32_t *d = row + (t >= 12 ? CB_HALF_DW : 0) + 2 * (t >= 12 ? t - 12 : t);
-                d[0] = hi0; d[1] = hi1;
-                d[CB_PK] = lo0; d[CB_PK + 1] = lo1;
-                d[2 * CB_PK] = hi0; d[2 * CB_PK + 1] = hi1;
-            } else {
-                // channels 96, 97 -> pair 24 of half 0; 98, 99 -> pair 24 of half 1; plus the norm slots and the pad of both halves
-                row[24] = hi0; row[CB_PK + 24] = lo0; row[2 * CB_PK + 24] = hi0;
-                row[CB_HALF_DW + 24] = hi1; row[CB_HALF_DW + CB_PK + 24] = lo1; row[CB_HALF_DW + 2 * CB_PK + 24] = hi1;
-                const float a = src >= 0 ? -16.0f * lnorm[srow] : 0.0f;
-                const _Float16 n0 = (_Float16)a;
-                const _Float16 n1 = (_Float16)(a - (float)n0);
-                const _Float16 n2 = (_Float16)((a - (float)n0) - (float)n1);
-                row[3 * CB_PK] = pack_f16(n0, n1);
-                row[CB_HALF_DW + 3 * CB_PK] = pack_f16(n2, (_Float16)0.0f);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int it = it0 + u * NTH;
+                if (it >= n_rows * 25) continue;
+                const int r = it / 25, t = it - r * 25;
+                const float4 x = xs[u];
+                const int src = srcs[u], srow = srows[u];
+                const float am = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(x.x), __builtin_fabsf(x.y)), __builtin_fmaxf(__builtin_fabsf(x.z), __builtin_fabsf(x.w)));
+                if (am > CB_MAX_ABS) bad = true;
+                const float s0 = x.x * CB_SCALE, s1 = x.y * CB_SCALE, s2 = x.z * CB_SCALE, s3 = x.w * CB_SCALE;
+                const _Float16 h0 = (_Float16)s0, h1 = (_Float16)s1, h2 = (_Float16)s2, h3 = (_Float16)s3;
+                const uint32_t hi0 = pack_f16(h0, h1), hi1 = pack_f16(h2, h3);
+                const uint32_t lo0 = pack_f16((_Float16)(s0 - (float)h0), (_Float16)(s1 - (float)h1));
+                const uint32_t lo1 = pack_f16((_Float16)(s2 - (float)h2), (_Float16)(s3 - (float)h3));
+                uint32_t *row = limg + (size_t)r * CB_ROW_DW;
+                if (t < 24) {
+                    uint32_t *d = row + (t >= 12 ? CB_HALF_DW : 0) + 2 * (t >= 12 ? t - 12 : t);
+                    d[0] = hi0; d[1] = hi1;
+                    d[CB_SEG_DW] = lo0; d[CB_SEG_DW + 1] = lo1;
+                } else {
+                    // channels 96, 97 -> pair 24 of half 0; 98, 99 -> pair 24 of half 1; then the norm slots (hi plane, dword 25) and the padding
+                    const float a = src >= 0 ? -16.0f * lnorm[srow] : 0.0f;
+                    const _Float16 n0 = (_Float16)a;
+                    const _Float16 n1 = (_Float16)(a - (float)n0);
+                    const _Float16 n2 = (_Float16)((a - (float)n0) - (float)n1);
+                    uint32_t *d0 = row, *d1 = row + CB_HALF_DW;
+                    d0[24] = hi0; d0[25] = pack_f16(n0, n1); d0[26] = 0u; d0[27] = 0u;
+                    d0[CB_SEG_DW + 24] = lo0; d0[CB_SEG_DW + 25] = 0u; d0[CB_SEG_DW + 26] = 0u; d0[CB_SEG_DW + 27] = 0u;
+                    d1[24] = hi1; d1[25] = pack_f16(n2, (_Float16)0.0f); d1[26] = 0u; d1[27] = 0u;
+                    d1[CB_SEG_DW + 24] = lo1; d1[CB_SEG_DW + 25] = 0u; d1[CB_SEG_DW + 26] = 0u; d1[CB_SEG_DW + 27] = 0u;
+                }
             }
         }
         // phase 4: epilogue constants per (tile, lane half): which output plane each store slot writes, its bias, whether its set exists.
@@ -374,9 +392,13 @@ __global__ __launch_bounds__(NW * 64) void proxy_corr_batched_kernel(AocCorrFram
                 for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
                 if (dbg != 1) {
 #pragma unroll
-                    for (int s = 0; s < CB_STEPS; ++s) {
-                        const f16x8 a = __builtin_bit_cast(f16x8, arow[s]);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, __builtin_bit_cast(f16x8, seq.b[s]), acc, 0, 0, 0);
+                    for (int s = 0; s < CB_SEG_STEPS; ++s) {          // q.p = qh.ph + qh.pl + ql.ph (the norm slots ride in the hi x hi product)
+                        const f16x8 ah = __builtin_bit_cast(f16x8, arow[s]);
+                        const f16x8 al = __builtin_bit_cast(f16x8, arow[CB_SEG_STEPS + s]);
+                        const f16x8 bh = __builtin_bit_cast(f16x8, seq.bh[s]);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, __builtin_bit_cast(f16x8, seq.bl[s]), acc, 0, 0, 0);
                     }
                 }
                 if (dbg == 3) { asm volatile("" :: "v"(acc[0]), "v"(acc[5]), "v"(acc[10]), "v"(acc[15])); continue; }
@@ -445,7 +467,7 @@ __global__ __launch_bounds__(NW * 64) void proxy_corr_batched_kernel(AocCorrFram
         }
         __syncthreads();                                                      // every wave is done with this frame's image
     }
-    if (bad && dbg == 0) atomicOr(gate, 1);
+    if (bad && dbg == 0) atomicExch(gate, call_seq);      // raised for THIS call only: no memset between calls
 }
 
 inline int cb_n_cus() {
@@ -490,8 +512,12 @@ int aoc_proxy_corr_min_batched(const aoc_corr_frame *frames_host, int n_frames, 
                                      nullptr, stream);
     }
 
+    // take-over flag: the kernel stores this call's sequence number in it when a precondition fails and the gated fp32 kernel runs
+    // iff it finds that number there; a workspace is used by one stream at a time, so no reset is needed between calls
     int32_t *gate = static_cast<int32_t *>(workspace);
-    if (hipMemsetAsync(gate, 0, 16, st) != hipSuccess) return AOC_ERR_LAUNCH;
+    static std::atomic<int32_t> g_seq{0};
+    int32_t call_seq = g_seq.fetch_add(1) + 1;
+    if (call_seq <= 0) { g_seq.store(1); call_seq = 1; }
 
     // ---- pack the sets into 32-row tiles: single-proxy sets -> column-wise tiles, the others by row-group class
     const size_t tile_bytes = (size_t)CB_TILE_DW * 4 + 32 * 8;
@@ -526,7 +552,7 @@ int aoc_proxy_corr_min_batched(const aoc_corr_frame *frames_host, int n_frames, 
         static const bool lds_ok = hipFuncSetAttribute(reinterpret_cast<const void *>(proxy_corr_batched_kernel<NW, N, COL>),            \
                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;            \
         if (!lds_ok) return AOC_ERR_LAUNCH;                                                                                              \
-        hipLaunchKernelGGL((proxy_corr_batched_kernel<NW, N, COL>), dim3((unsigned)grid), dim3(NW * 64), lds, st, fr, m, tab, transform, gate, dbg); \
+        hipLaunchKernelGGL((proxy_corr_batched_kernel<NW, N, COL>), dim3((unsigned)grid), dim3(NW * 64), lds, st, fr, m, tab, transform, gate, dbg, call_seq); \
     } while (0)
             switch (tab.n * 2 + (col0 ? 1 : 0)) {
                 case 2: AOC_CB(1, false); break;
@@ -628,7 +654,7 @@ int aoc_proxy_corr_min_batched(const aoc_corr_frame *frames_host, int n_frames, 
     }
     // exact-fp32 kernel: runs only when a precondition of the split arithmetic failed somewhere in the launch
     return aoc_corr_fp32_batched(frames_host, n_frames, m, C, n_proxy, n_set, set_begin_host, set_size_host, set_out_offset_host, 1, transform,
-                                 gate, stream);
+                                 gate, stream, 0, call_seq);
 }
 
 }  // extern "C"

@@ -34,7 +34,7 @@ struct AocCorrTiles {
     int32_t n, n_out;
 };
 
-// exact-fp32 batched correlation (correlation.hip).  gate != NULL: every kernel returns at once unless *gate != 0.
+// exact-fp32 batched correlation (correlation.hip).  gate != NULL: every kernel returns at once unless *gate == gate_value.
 int aoc_corr_fp32_batched(const aoc_corr_frame *frames_host, int n_frames, int64_t m, int C, int n_proxy, int n_set,
                           const int32_t *set_begin_host, const int32_t *set_size_host, const int64_t *set_out_offset_host,
-                          int64_t out_pixel_stride, int transform, const int32_t *gate, aoc_stream_t stream, int float16 = 0);
+                          int64_t out_pixel_stride, int transform, const int32_t *gate, aoc_stream_t stream, int float16 = 0, int32_t gate_value = 1);

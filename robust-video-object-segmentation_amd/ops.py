@@ -237,7 +237,7 @@ def proxy_corr_min_batched(frames, set_begin, set_size, set_out_offset, transfor
     key = (dev.index, _stream().value)
     ws = _corr_ws.get(key)
     if ws is None:
-        ws = _corr_ws[key] = _ws(L.aoc_proxy_corr_min_batched_workspace_bytes(), dev)
+        ws = _corr_ws[key] = torch.zeros(int(L.aoc_proxy_corr_min_batched_workspace_bytes()), dtype=torch.uint8, device=dev)
     vp = ctypes.c_void_p
     _lib.check(L.aoc_proxy_corr_min_batched(ctypes.cast(arr, vp), len(frames), m, C, n_proxy, n_set, sb.ctypes.data_as(vp), ss.ctypes.data_as(vp),
                                             so.ctypes.data_as(vp), int(bool(transform)), CORR_PRECISION[precision], _p(ws), ws.numel(), _stream()),
