@@ -201,6 +201,7 @@ class ClipWorkload:
         self.chains = mc.MEM_EVERY                         # k-means chains enqueued ahead (bench --chains)
         self.dense_stream = None                           # CU-masked stream for the dense kernel alone
         self.reuse_proxies = False                         # non-parity mode: one k-means per pool state
+        self.bank = None                                   # non-parity mode: hotpath.IncrementalProxyBank (one clustering per pool FRAME)
         self.cached_ahead = None
         self.r_hist = {}
         self.count_r = False
@@ -225,6 +226,24 @@ class ClipWorkload:
     def R(self):
         return self.R_of(self.t)
 
+    def enable_incremental(self):
+        """NON-PARITY mode: every pool frame is clustered once, on its own rows; frames match against the union of the
+        per-frame code books.  All pool frames are clustered here (setup); the walk re-clusters a group's newest pool frame when it
+        enters the group, which is what the sequential loop pays per pool update."""
+        self.bank = hotpath.IncrementalProxyBank(self.mc, self.cfg.n_obj, self.cfg.c, self.rmax, self.dev)
+        for r in range(self.rmax):
+            self.bank.append(self.pool_emb[r], self.pool_lab[r], self._bank_init(r), self.side)
+
+    def _bank_init(self, r):
+        O, K = self.cfg.n_obj, self.mc.cluster_levels[0]
+        counts = [int((self.lab_ids[r * self.mc.MEM_EVERY] == o).sum()) for o in range(O)]
+        rows = syn.kmeans_init_rows(777 + r, counts, K)
+        init = np.zeros((O, K), np.int32)
+        for o, rr in enumerate(rows):
+            if rr is not None:
+                init[o, :len(rr)] = rr
+        return torch.from_numpy(init).to(self.dev)
+
     def _enter_frame(self):
         """Book-keeping when the walk reaches a frame: at the first frame of a group the pool has just received its newest frame
         (eval_manager_mm.py:309-312): that frame's split records are converted again and nothing that depends on the pool may have
@@ -236,6 +255,11 @@ class ClipWorkload:
             self.ahead.clear()
             self.pool_event = torch.cuda.Event()
             self.pool_event.record()
+            if self.bank is not None:                      # the newest pool frame joins the bank: ONE single-frame clustering per pool update
+                r = self.R - 1
+                if not hasattr(self, "_bank_inits"):
+                    self._bank_inits = [self._bank_init(i) for i in range(self.rmax)]
+                self.bank.append(self.pool_emb[r], self.pool_lab[r], self._bank_inits[r], self.side, wait_event=self.pool_event, slot=r)
 
     def refs(self):
         return self.pool_emb[:self.R], self.pool_lab[:self.R]
@@ -302,7 +326,11 @@ def frame_step(wl, gates, acts, dense_precision="split", pipeline=True, defer_co
     """One frame of one sequence; returns (feat, gate outputs, pending correlation or None)."""
     ref_emb, ref_lab = wl.refs()
     t = wl.t
-    if wl.side is not None and pipeline:
+    if wl.bank is not None:
+        feat, head, aux = hotpath.proto_mask_features(wl.mc, ref_emb, ref_lab, wl.emb[t - 1], wl.lab[t - 1], wl.emb[t], wl.bias,
+                                                      cluster_ahead=wl.bank.handle(ref_lab), dense_state=wl.dense_state, dense_precision=dense_precision,
+                                                      dense_stream=wl.dense_stream, defer_correlation=defer_corr)
+    elif wl.side is not None and pipeline:
         # the k-means chain of a frame only depends on the pool: the chains of all frames of a group are enqueued on the side stream as
         # soon as the group's pool is final and run under the other work of the frames before them
         if wl.reuse_proxies and wl.cached_ahead is not None and wl.cached_ahead.R == wl.R:
@@ -325,7 +353,7 @@ def frame_step(wl, gates, acts, dense_precision="split", pipeline=True, defer_co
                                                       dense_state=wl.dense_state, dense_precision=dense_precision, defer_correlation=defer_corr)
     outs = gates(acts, head)
     wl.advance()                                           # the walk moves on (a new group = a new pool state starts here)
-    if wl.side is not None and pipeline and wl.t not in wl.ahead and not (wl.reuse_proxies and wl.cached_ahead is not None and wl.cached_ahead.R == wl.R):
+    if wl.bank is None and wl.side is not None and pipeline and wl.t not in wl.ahead and not (wl.reuse_proxies and wl.cached_ahead is not None and wl.cached_ahead.R == wl.R):
         launch_chains(wl)                                  # the next frame's pool is final now: its chain starts under the other sequences' work
     return feat, outs, aux["pending_correlation"]
 
@@ -502,6 +530,9 @@ def main():
     ap.add_argument("--reuse-proxies", action="store_true",
                     help="NON-PARITY mode (SURVEY 8f-3): cluster the pool once per pool update instead of once per frame; the JSON "
                          "line then says so in config.proxy_mode and is not comparable with the default")
+    ap.add_argument("--incremental-proxies", action="store_true",
+                    help="NON-PARITY mode (SURVEY 8f-3, hotpath.IncrementalProxyBank): cluster every reference frame once, when it joins the pool, and match "
+                         "against the union of the per-frame code books; config.proxy_mode says so and the line is not comparable with the default")
     ap.add_argument("--batch-corr", action="store_true",
                     help="ONE batched correlation launch per step for the frames of all in-flight sequences instead of one launch per sequence and "
                          "frame (measured slower with 2 sequences in flight: the shared launch makes the streams wait for each other every step)")
@@ -589,6 +620,8 @@ def main():
     for wl in workloads:
         wl.chains = 1 if args.reuse_proxies else max(1, min(args.chains, mc.MEM_EVERY))
         wl.reuse_proxies = args.reuse_proxies
+        if args.incremental_proxies:
+            wl.enable_incremental()
     acts = make_activations(gates, cfg.n_obj, cfg.h, cfg.w, dev, seed=7)
 
     def make_main_stream():
@@ -868,7 +901,9 @@ def main():
                                        else "one aoc_proxy_corr_min launch per sequence and frame"),
                        "cu_reserve": (f"main streams masked off {args.cu_reserve} of {n_cu} CUs (hipExtStreamCreateWithCUMask), left to the side-stream "
                                       "k-means chains" if args.cu_reserve > 0 else "none"),
-                       "proxy_mode": ("NON-PARITY: adaptive proxies reused until the pool changes (one k-means per MEM_EVERY frames)"
+                       "proxy_mode": ("NON-PARITY: every reference frame clustered once when it joins the pool, frames matched against the union of the "
+                                      "per-frame code books (hotpath.IncrementalProxyBank)" if args.incremental_proxies else
+                                      "NON-PARITY: adaptive proxies reused until the pool changes (one k-means per MEM_EVERY frames)"
                                       if args.reuse_proxies else "reference: the pool is re-clustered for every frame with that frame's initial rows"),
                        "dense_precision": ("fp16-split products (hi*hi + hi*lo + lo*hi), fp32 accumulate: fp32-equivalent; exact-fp32 take-over "
                                            "on overflow / soft labels" if args.dense == "split" else "exact fp32 MFMA")},

@@ -64,7 +64,7 @@ class ClusterProxiesAhead:
     """Adaptive proxies of ONE frame computed ahead of time on a side stream (launch_cluster_proxies): the k-means
     chain only depends on the reference pool, its labels and the initial rows -- not on the frame before -- so while the
     pool is unchanged (4 of 5 frames with MEM_EVERY = 5) the chain of frame t+1 can run under frame t's other work."""
-    __slots__ = ("prep", "table", "sqn", "prep_event", "done_event", "aux", "R")
+    __slots__ = ("prep", "table", "sqn", "prep_event", "done_event", "aux", "R", "cluster_sets")
 
 
 def proxy_table_rows(cfg, n_obj):
@@ -121,6 +121,7 @@ def launch_cluster_proxies_batch(cfg, ref_emb, ref_labels, init_rows_list, side_
         for f in range(F):
             out = ClusterProxiesAhead()
             out.R = R
+            out.cluster_sets = None
             out.prep, out.prep_event = prep, prep_event
             out.table, out.sqn = tables[f], sqns[f]
             sl = slice(f * L * O, (f + 1) * L * O)
@@ -139,6 +140,68 @@ def launch_cluster_proxies_batch(cfg, ref_emb, ref_labels, init_rows_list, side_
 def launch_cluster_proxies(cfg, ref_emb, ref_labels, init_rows_dev, side_stream=None, wait_event=None):
     """launch_cluster_proxies_batch for one frame."""
     return launch_cluster_proxies_batch(cfg, ref_emb, ref_labels, [init_rows_dev], side_stream, wait_event)[0]
+
+
+class IncrementalProxyBank:
+    """NON-PARITY mode: the reference re-clusters the WHOLE reference pool for every frame (AEM:263-279), although the pool
+    only grows by one frame every MEM_EVERY frames.  The bank clusters each reference frame ONCE, when it joins the pool (the same exact
+    k-means chain and the same proxy construction, on that frame's rows only), and matches every later frame against the union of the
+    per-frame code books: the min over an object's proxies then runs over R x K proxies instead of K.  k-means work per sequence drops
+    from (frames x pool size) to (pool frames x 1) frame-clusterings.  Results differ from the reference's by construction -- as two runs
+    of the reference with different numpy seeds differ from each other (tests/test_gpu_round2.py::test_incremental_proxies_accuracy).
+    Single cluster level only."""
+
+    def __init__(self, cfg, n_obj, C, capacity_frames, device):
+        if cfg.CLUSTER_LEVELS and len(cfg.CLUSTER_LEVELS) > 1:
+            raise NotImplementedError("IncrementalProxyBank: one cluster level")
+        self.cfg, self.O, self.C, self.cap, self.dev = cfg, n_obj, C, int(capacity_frames), device
+        self.K = cfg.cluster_levels[0]
+        n_ad = n_obj * 2 * self.cap * self.K
+        # layout [object][centroid | centroid_avg][pool frame][K]: the proxies of one set are contiguous
+        self.table = torch.zeros(n_ad + n_obj, C, dtype=torch.float32, device=device)
+        self.sqn = torch.full((n_ad + n_obj,), float("inf"), dtype=torch.float32, device=device)
+        self.R = 0
+        self.done_event = None
+
+    def reset(self):
+        self.R = 0
+        self.sqn.fill_(float("inf"))
+
+    def append(self, frame_emb, frame_labels, init_rows_dev, side_stream=None, wait_event=None, slot=None):
+        """Cluster the frame that has just joined the pool (frame_emb [h, w, C], frame_labels [h, w, O], init rows [O, K] segment-local).
+        slot: write pool frame `slot` again instead of appending (a benchmark that revisits pool states pays the clustering each time)."""
+        r = self.R if slot is None else int(slot)
+        assert r < self.cap and r <= self.R, "IncrementalProxyBank: capacity exhausted / slot beyond the pool"
+        a = launch_cluster_proxies(self.cfg, frame_emb[None], frame_labels[None], init_rows_dev, side_stream, wait_event)
+        main = torch.cuda.current_stream()
+        side = main if side_stream is None else side_stream
+        O, K, cap = self.O, self.K, self.cap
+        with torch.cuda.stream(side):
+            n_ad = O * 2 * cap * K
+            self.table[:n_ad].view(O, 2, cap, K, self.C)[:, :, r].copy_(a.table[:O * 2 * K].view(O, 2, K, self.C))
+            self.sqn[:n_ad].view(O, 2, cap, K)[:, :, r].copy_(a.sqn[:O * 2 * K].view(O, 2, K))
+            self.done_event = torch.cuda.Event()
+            self.done_event.record(side)
+        if r == self.R:
+            self.R += 1
+
+    def handle(self, ref_labels):
+        """A ClusterProxiesAhead for proto_mask_features(cluster_ahead=...) over the pool's first R frames (ref_labels [R, h, w, O],
+        R <= the number of frames in the bank)."""
+        R = ref_labels.shape[0]
+        assert 1 <= R <= self.R, "the bank holds fewer pool frames"
+        out = ClusterProxiesAhead()
+        out.R = R
+        out.prep = ops.label_prep(ref_labels.reshape(-1, self.O))
+        out.prep_event = torch.cuda.Event()
+        out.prep_event.record()
+        out.done_event = self.done_event
+        out.table, out.sqn = self.table, self.sqn
+        out.aux = None
+        # set (object, centroid | centroid_avg) = the K proxies of each of the R pool frames: contiguous rows of the table
+        out.cluster_sets = ([(o * 2 + f) * self.cap * self.K for o in range(self.O) for f in range(2)], [R * self.K] * (2 * self.O),
+                            self.O * 2 * self.cap * self.K)
+        return out
 
 
 class PendingCorrelation:
@@ -214,6 +277,8 @@ def proto_mask_features(cfg, ref_emb, ref_labels, prev_emb, prev_labels, cur_emb
     levels = cfg.cluster_levels
     L, kmax = len(levels), max(levels)
     n_ad = L * O * 2 * kmax
+    if cluster_ahead is not None and cluster_ahead.cluster_sets is not None:
+        n_ad = cluster_ahead.cluster_sets[2]             # IncrementalProxyBank: its own table layout
 
     # ---- adaptive proxies (k-means, AEM:252-286) + k = 1 proxies (ATT:155-189) in ONE proxy table
     main = torch.cuda.current_stream()
@@ -299,13 +364,20 @@ def proto_mask_features(cfg, ref_emb, ref_labels, prev_emb, prev_labels, cur_emb
 
     # ---- one correlation launch: cluster (2 sets / object / level) + k = 1 proxy (1 set / object), AEM:316-319 + matching.py:2653
     set_begin, set_size, set_off, set_obj = [], [], [], []
-    for l, k in enumerate(levels):
+    if cluster_ahead is not None and cluster_ahead.cluster_sets is not None:
+        set_begin, set_size = list(cluster_ahead.cluster_sets[0]), list(cluster_ahead.cluster_sets[1])
         for o in range(O):
             for f in range(2):
-                set_begin.append(((l * O + o) * 2 + f) * kmax)
-                set_size.append(k)                      # slots >= the sticky K carry norm = +inf and are ignored
-                set_off.append(o * obj_stride + (ch["cluster"] + 2 * l + f) * hw)
+                set_off.append(o * obj_stride + (ch["cluster"] + f) * hw)
                 set_obj.append(o)
+    else:
+        for l, k in enumerate(levels):
+            for o in range(O):
+                for f in range(2):
+                    set_begin.append(((l * O + o) * 2 + f) * kmax)
+                    set_size.append(k)                      # slots >= the sticky K carry norm = +inf and are ignored
+                    set_off.append(o * obj_stride + (ch["cluster"] + 2 * l + f) * hw)
+                    set_obj.append(o)
     for o in range(O):
         set_begin.append(n_ad + o)
         set_size.append(1)

@@ -391,3 +391,57 @@ def test_dense_more_than_16_objects(aoc):
     want = om.global_matching_for_eval([torch.from_numpy(r) for r in ref], torch.from_numpy(q), [torch.from_numpy(l) for l in lab], 4, torch.from_numpy(bias))
     got = aoc.matching.global_matching_for_eval([dev(r) for r in ref], dev(q), [dev(l) for l in lab], 4, dev(bias), None, 1, False, 0)
     np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), rtol=0, atol=ATOL)
+
+
+def test_incremental_proxies_accuracy(aoc):
+    """NON-PARITY mode as a library option: hotpath.IncrementalProxyBank clusters every reference frame once, when it joins
+    the pool, and matches against the union of the per-frame code books.  Every channel but the two cluster channels is identical to the
+    reference mode; the cluster channels disagree with a fresh whole-pool clustering no more than two fresh clusterings with different
+    initial rows disagree with each other (object decision from the nearest-proxy channel; mean absolute feature difference within 2x)."""
+    syn, hot = aoc.synthetic, aoc.hotpath
+    cfg = syn.CONFIGS["cfg1"]
+    clip = syn.make_clip(cfg, 9, frames=8)
+    O = cfg.n_obj
+    emb = torch.from_numpy(clip["emb"]).cuda()
+    lab = torch.from_numpy(np.stack([syn.one_hot(l, O) for l in clip["lab"]])).cuda()
+    mc = hot.MatchingConfig()
+    bias = torch.zeros(O, device="cuda")
+    side = torch.cuda.Stream()
+    ch = hot.channel_slices(mc)
+    pool_ids = [0, 2, 4]
+    ref_emb, ref_lab = emb[pool_ids].contiguous(), lab[pool_ids].contiguous()
+
+    def init_for(seed, ids):
+        counts = [int(sum((clip["lab"][i] == o).sum() for i in ids)) for o in range(O)]
+        rows = syn.kmeans_init_rows(seed, counts, 16)
+        init = np.zeros((O, 16), np.int32)
+        for o, r in enumerate(rows):
+            if r is not None:
+                init[o, :len(r)] = r
+        return torch.from_numpy(init).cuda()
+
+    bank = hot.IncrementalProxyBank(mc, O, cfg.c, capacity_frames=4, device=emb.device)
+    for n, i in enumerate(pool_ids):
+        bank.append(emb[i], lab[i], init_for(100 + n, [i]), side)
+    assert bank.R == 3
+    c0 = ch["cluster"]
+    dec = lambda f: f[:, c0].argmin(0)
+    agree_inc, agree_fresh, diff_inc, diff_fresh = [], [], [], []
+    for t in (5, 6, 7):
+        feats = []
+        for seed in (10 + t, 20 + t):
+            a = hot.launch_cluster_proxies(mc, ref_emb, ref_lab, init_for(seed, pool_ids), side)
+            f, _, _ = hot.proto_mask_features(mc, ref_emb, ref_lab, emb[t - 1], lab[t - 1], emb[t], bias, cluster_ahead=a)
+            feats.append(f)
+        f_i, _, _ = hot.proto_mask_features(mc, ref_emb, ref_lab, emb[t - 1], lab[t - 1], emb[t], bias, cluster_ahead=bank.handle(ref_lab))
+        torch.cuda.synchronize()
+        f_a, f_b = feats
+        other = [i for i in range(f_a.shape[1]) if i not in (c0, c0 + 1)]
+        assert torch.equal(f_a[:, other], f_i[:, other])
+        agree_fresh.append(float((dec(f_a) == dec(f_b)).float().mean()))
+        agree_inc.append(float((dec(f_a) == dec(f_i)).float().mean()))
+        diff_fresh.append(float((f_a[:, c0:c0 + 2] - f_b[:, c0:c0 + 2]).abs().mean()))
+        diff_inc.append(float((f_a[:, c0:c0 + 2] - f_i[:, c0:c0 + 2]).abs().mean()))
+    assert np.mean(agree_inc) >= np.mean(agree_fresh) - 0.03, (agree_inc, agree_fresh)
+    # 3 x 16 proxies per object sit closer to the query pixels than 16: the features move, but by less than the features themselves vary
+    assert np.mean(diff_inc) <= max(3.0 * np.mean(diff_fresh), 0.05), (diff_inc, diff_fresh)
