@@ -93,6 +93,7 @@ class HotPathBackend:
         self.policy = MemoryPolicy(mem_every=spec.mem_every, unc_ratio=1.0)
         self.bias = torch.zeros(spec.n_obj, device=self.device)
         self.rng = np.random.RandomState(spec.seed)
+        self.dense_state = {}                   # per sequence: split records of the (append-only) pool, pooled reference heads
 
     def first_frame(self, emb, gt_label):
         self.policy.start(emb, gt_label)
@@ -102,7 +103,8 @@ class HotPathBackend:
         """emb [h, w, C] -> predicted label map [H, W] int32 (H = 4 h: the reference's masks live at image resolution)."""
         spec, h, w = self.spec, self.spec.h, self.spec.w
         ref_emb, ref_lab, prev_emb, prev_lab = self.policy.reference_pool(h, w, spec.n_obj)
-        feat, _, _ = self.hot.proto_mask_features(self.mc, ref_emb, ref_lab, prev_emb, prev_lab, emb, self.bias, dense_precision=self.dense_precision)
+        feat, _, _ = self.hot.proto_mask_features(self.mc, ref_emb, ref_lab, prev_emb, prev_lab, emb, self.bias, dense_precision=self.dense_precision,
+                                                  dense_state=self.dense_state, rng=self.rng)
         pre, wv = self._head(feat.shape[1])
         y = pre(feat)                                                          # [O, 64, h, w]
         logit = torch.einsum("ochw,c->ohw", y, wv)
@@ -134,13 +136,23 @@ class HostMetric:
         return dict(sum_j=self.sj, sum_f=0.0, objects=self.n, frames=self.frames)
 
 
-def run_sequence(spec: SequenceSpec, backend, device, metric=None, max_frames: Optional[int] = None):
-    """The per-sequence loop of eval_manager_mm.py:196-361.  Returns the metric accumulators of sharding.METRIC_FIELDS
-    (sum_iou = sum over frames and foreground objects of J, sum_f of F, iou_count = number of (frame, object) pairs)."""
+def load_sequence(spec: SequenceSpec, device, max_frames: Optional[int] = None):
+    """Synthesise one sequence and make it resident on the device: (embeddings [T, h, w, C], image-resolution ground truth [T, H, W] int32).
+    Untimed set-up (the stand-in for the dataset loader + backbone, which are out of scope)."""
     cfg = spec.clip_config()
     frames = spec.frames if max_frames is None else min(spec.frames, max_frames)
     clip = syn.make_clip(cfg, spec.seed, frames=frames)
     emb = torch.from_numpy(clip["emb"]).to(device)
+    gt = torch.from_numpy(np.stack([_gt_fullres(l) for l in clip["lab"]])).to(device)
+    return emb, gt
+
+
+def run_sequence(spec: SequenceSpec, backend, device, metric=None, max_frames: Optional[int] = None, data=None):
+    """The per-sequence loop of eval_manager_mm.py:196-361.  Returns the metric accumulators of sharding.METRIC_FIELDS
+    (sum_iou = sum over frames and foreground objects of J, sum_f of F, iou_count = number of (frame, object) pairs).
+    data: the (embeddings, ground truth) pair of load_sequence when the caller made it resident beforehand."""
+    emb, gt = data if data is not None else load_sequence(spec, device, max_frames)
+    frames = emb.shape[0]
     if metric is None:
         if device.type == "cuda":
             from . import ops
@@ -149,13 +161,13 @@ def run_sequence(spec: SequenceSpec, backend, device, metric=None, max_frames: O
             metric = HostMetric()
     before = metric.totals()
     backend.start(spec)
-    backend.first_frame(emb[0], torch.from_numpy(_gt_fullres(clip["lab"][0])).to(device))
+    backend.first_frame(emb[0], gt[0])
     if device.type == "cuda":
         torch.cuda.synchronize(device)
     t0 = time.perf_counter()
     for t in range(1, frames):
         pred = backend.frame(emb[t])
-        metric.add(pred, torch.from_numpy(_gt_fullres(clip["lab"][t])).to(pred.device), spec.n_obj)
+        metric.add(pred, gt[t].to(pred.device), spec.n_obj)
     if device.type == "cuda":
         torch.cuda.synchronize(device)
     dt = time.perf_counter() - t0
@@ -164,18 +176,24 @@ def run_sequence(spec: SequenceSpec, backend, device, metric=None, max_frames: O
                 sum_f=after["sum_f"] - before["sum_f"], iou_count=after["objects"] - before["objects"])
 
 
-def eval_sharded(specs: Sequence[SequenceSpec], rank: int, world: int, device, backend=None, metric=None, max_frames=None):
-    """Partition ``specs`` over ``world`` ranks (LPT on frames x objects), run this rank's share, all-reduce the accumulators.
-    Returns the job totals plus the load-balance figures (max / mean rank time), identical on every rank."""
+def eval_sharded(specs: Sequence[SequenceSpec], rank: int, world: int, device, backend=None, metric=None, max_frames=None, barrier=None):
+    """Partition ``specs`` over ``world`` ranks (LPT on frames x objects), make this rank's sequences resident on the device, then (after
+    ``barrier()`` when given) run them and all-reduce the accumulators.  Returns the job totals plus the load-balance figures (max / mean
+    rank time) and ``loop_seconds_max`` = the slowest rank's time for its share, inputs resident; identical on every rank."""
     parts = sharding.lpt_partition([s.cost for s in specs], world)
     mine = parts[rank]
     if backend is None:
         backend = HotPathBackend(device)
+    data = {i: load_sequence(specs[i], device, max_frames) for i in mine}
+    if barrier is not None:
+        barrier()
     local = {k: 0.0 for k in sharding.METRIC_FIELDS}
+    t0 = time.perf_counter()
     for i in mine:
-        r = run_sequence(specs[i], backend, device, metric, max_frames)
+        r = run_sequence(specs[i], backend, device, metric, max_frames, data=data.pop(i))
         for k in sharding.METRIC_FIELDS:
             local[k] += r[k]
+    loop = time.perf_counter() - t0
     dev = device if device.type == "cuda" else None
     tot = sharding.allreduce_metrics(local, device=dev)
     t_max = sharding.allreduce_max(local["gpu_seconds"], device=dev)
@@ -183,5 +201,5 @@ def eval_sharded(specs: Sequence[SequenceSpec], rank: int, world: int, device, b
     costs = [sum(specs[i].cost for i in p) for p in parts]
     tot.update(sequences=len(specs), ranks=world, rank_seconds_max=t_max, rank_seconds_mean=mean_t, imbalance=t_max / max(mean_t, 1e-12),
                planned_imbalance=max(costs) / max(sum(costs) / world, 1e-12), mean_j=tot["sum_iou"] / max(tot["iou_count"], 1.0),
-               mean_f=tot["sum_f"] / max(tot["iou_count"], 1.0), sequences_local=len(mine))
+               mean_f=tot["sum_f"] / max(tot["iou_count"], 1.0), sequences_local=len(mine), loop_seconds_max=sharding.allreduce_max(loop, device=dev))
     return tot

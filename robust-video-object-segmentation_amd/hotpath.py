@@ -232,14 +232,14 @@ def launch_correlations(pending, stream=None, precision="split"):
 
 def proto_mask_features(cfg, ref_emb, ref_labels, prev_emb, prev_labels, cur_emb, dis_bias, init_rows=None,
                         cluster_state=None, side_stream=None, dense_state=None, dense_precision=None, cluster_ahead=None,
-                        dense_stream=None, defer_correlation=False):
+                        dense_stream=None, defer_correlation=False, rng=None):
     """All matching branches of one frame -> (features [O, 24, h, w], attention_head [O, 4C], aux).
 
     ref_emb     [R, h, w, C]  reference pool (channel-last)          ref_labels [R, h, w, O] float one-hot
     prev_emb    [h, w, C]     previous frame embedding               prev_labels [h, w, O]
     cur_emb     [h, w, C]     current (query) frame embedding        dis_bias   [O] or [O,1,1,1]
     init_rows   optional explicit k-means initial rows per object (per level then per object with several cluster levels);
-                else drawn like scipy from np.random
+                else drawn like scipy from np.random (or from `rng`, a numpy RandomState)
     cluster_state  optional dict with a device tensor ``init_rows`` [levels * O, kmax] for the host-sync-free pipeline
     side_stream  optional torch.cuda.Stream: the adaptive-proxy branch (k-means: a long chain of small,
                  latency-bound launches) runs there, concurrently with the MFMA-bound dense matching on the
@@ -294,7 +294,7 @@ def proto_mask_features(cfg, ref_emb, ref_labels, prev_emb, prev_labels, cur_emb
     else:
         table = torch.empty(n_ad + O, C, dtype=torch.float32, device=dev)
         sqn = torch.empty(n_ad + O, dtype=torch.float32, device=dev)
-        cp = cluster_proxies(pool, labels_flat, levels if cfg.CLUSTER_LEVELS else levels[0], init_rows)
+        cp = cluster_proxies(pool, labels_flat, levels if cfg.CLUSTER_LEVELS else levels[0], init_rows, rng)
         prep = cp["prep"] if cp is not None else ops.label_prep(labels_flat)
         if cp is not None:
             table[:n_ad].copy_(cp["proxies"].reshape(-1, C))
