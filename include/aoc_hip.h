@@ -417,6 +417,15 @@ int aoc_gct_gate(const float *plane_sums, const float *alpha, const float *gamma
 int aoc_object_logit(const float *x, int N, int C, int64_t hw, const float *weight, int64_t weight_stride,
                      const float *bias, int64_t bias_stride, float *out, aoc_stream_t stream);
 
+/* GroupNorm (+ residual) + ReLU of the decoder's Bottleneck (networks/layers/gct.py:69-90: bn1/bn2 followed by relu, bn3 followed by
+ * `out += residual; relu`): y = [relu]( GroupNorm_groups(x) * gamma + beta [+ residual] ), x [N, C, hw], biased variance over each
+ * group's channels x hw as torch.nn.GroupNorm.  Two streams over x (statistics, apply) and one write instead of the separate
+ * normalisation / add / ReLU passes.  gamma, beta [C] or NULL; residual [N, C, hw] or NULL; y may alias x. */
+size_t aoc_groupnorm_relu_workspace_bytes(int N, int groups);
+int aoc_groupnorm_relu(const float *x, int N, int C, int64_t hw, int groups, const float *gamma, const float *beta,
+                       float eps, const float *residual, int relu, float *y, void *workspace,
+                       size_t workspace_bytes, aoc_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Eval-loop memory policy (the caller of the matching path).
  *

@@ -65,6 +65,8 @@ SIGNATURES = {
     "aoc_cond_gate_pool_workspace_bytes": (_sz, [_i, _i, _i64]),
     "aoc_cond_gate_pool": (_i, [_vp, _i, _i, _i64, _vp, _vp, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     "aoc_cond_gate_pool_ex": (_i, [_vp, _i, _i, _i64, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "aoc_groupnorm_relu_workspace_bytes": (_sz, [_i, _i]),
+    "aoc_groupnorm_relu": (_i, [_vp, _i, _i, _i64, _i, _vp, _vp, _f, _vp, _i, _vp, _vp, _sz, _vp]),
     "aoc_linear": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "aoc_label_mix": (_i, [_vp, _vp, _i64, _i, _i, _vp, _vp]),
     "aoc_plane_mean": (_i, [_vp, _i64, _i64, _vp, _vp]),

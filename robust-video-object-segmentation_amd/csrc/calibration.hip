@@ -551,6 +551,62 @@ __global__ __launch_bounds__(256) void cond_masked_gap_fused_kernel(const float 
     if (threadIdx.x == 0) gap[(size_t)n * C + c] = (wsum[0] + wsum[1] + wsum[2] + wsum[3]) / (float)hw;
 }
 
+// ---- GroupNorm (+ residual) + ReLU in two streams (the decoder Bottleneck, gct.py:69-90) ---------------------------
+// GroupNorm as torch computes it (biased variance over the group's channels x HW), then y = relu(gn(x) [+ residual]).  PyTorch runs the
+// normalisation, the residual add and the ReLU as separate passes; here x is read twice (statistics, apply) and y written once.
+// Statistics: per (sample, group) block, per-thread fp32 partial sums of x and x^2 folded in fp64 (fixed order: reproducible).
+__global__ __launch_bounds__(256) void gn_stats_kernel(const float *__restrict__ x, int group_channels, int64_t hw, float eps,
+                                                        float *__restrict__ stats /* [N * groups][2] mean, rstd */) {
+    __shared__ double sh[2][4];
+    const float *xp = x + (size_t)blockIdx.x * group_channels * hw;
+    const int64_t n = (int64_t)group_channels * hw;
+    double s = 0.0, q = 0.0;
+    int64_t i = threadIdx.x;
+    for (; i + 7 * 256 < n; i += 8 * 256) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = xp[i + u * 256];
+        float ps = 0.f, pq = 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { ps += v[u]; pq += v[u] * v[u]; }
+        s += ps; q += pq;
+    }
+    for (; i < n; i += 256) { const float v = xp[i]; s += v; q += (double)v * v; }
+    for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o); q += __shfl_xor(q, o); }
+    if (aoc_lane() == 0) { sh[0][threadIdx.x >> 6] = s; sh[1][threadIdx.x >> 6] = q; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double ts = (sh[0][0] + sh[0][1]) + (sh[0][2] + sh[0][3]), tq = (sh[1][0] + sh[1][1]) + (sh[1][2] + sh[1][3]);
+        const double mean = ts / (double)n;
+        double var = tq / (double)n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        stats[2 * blockIdx.x] = (float)mean;
+        stats[2 * blockIdx.x + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+}
+
+// grid (ceil(hw / 1024), N * C): y = [relu]( (x - mean) * rstd * gamma[c] + beta[c] [+ residual] )
+__global__ __launch_bounds__(256) void gn_apply_kernel(const float *__restrict__ x, int C, int group_channels, int64_t hw, const float *__restrict__ stats,
+                                                        const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                        const float *__restrict__ residual, int relu, float *__restrict__ y) {
+    const int plane = blockIdx.y, c = plane % C, n = plane / C;
+    const int g = n * (C / group_channels) + c / group_channels;
+    const float mean = stats[2 * g], rstd = stats[2 * g + 1];
+    const float a = rstd * (gamma ? gamma[c] : 1.0f), b = (beta ? beta[c] : 0.0f) - mean * a;
+    const float *xp = x + (size_t)plane * hw;
+    const float *rp = residual ? residual + (size_t)plane * hw : nullptr;
+    float *yp = y + (size_t)plane * hw;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int64_t p = (int64_t)blockIdx.x * 1024 + u * 256 + threadIdx.x;
+        if (p < hw) {
+            float v = xp[p] * a + b;
+            if (rp) v += rp[p];
+            yp[p] = relu ? fmaxf(v, 0.0f) : v;
+        }
+    }
+}
+
 // out[p, :] = sum_o lab[p, o] * rows[o, :]   (aocnet.py:325: matmul(prev label, prev_head_pos))
 __global__ __launch_bounds__(256) void label_mix_kernel(const float *__restrict__ lab, const float *__restrict__ rows, int64_t n, int n_obj, int C,
                                                          float *__restrict__ out) {
@@ -912,6 +968,23 @@ int aoc_cond_gate_pool_ex(const float *z, int N, int C, int64_t hw, const float 
         hipLaunchKernelGGL(cond_select_pass_kernel, pgrid, dim3(256), 0, st, sc, hw, k_rank, pass, w.hist, w.sel);
     hipLaunchKernelGGL(cond_masked_gap_fused_kernel, dim3(C, N), dim3(256), 0, st, z, C, hw, sc, w.hist, w.sel, w.partial, w.n_part, threshold, gap,
                        plane_mean);
+    AOC_RETURN_IF_LAUNCH_FAILED();
+    return AOC_OK;
+}
+
+size_t aoc_groupnorm_relu_workspace_bytes(int N, int groups) { return N < 1 || groups < 1 ? 0 : aoc_align_up((size_t)N * groups * 2 * sizeof(float), 256); }
+
+int aoc_groupnorm_relu(const float *x, int N, int C, int64_t hw, int groups, const float *gamma, const float *beta, float eps,
+                       const float *residual, int relu, float *y, void *workspace, size_t workspace_bytes, aoc_stream_t stream) {
+    if (!x || !y || !workspace || N < 1 || C < 1 || hw < 1 || groups < 1) return AOC_ERR_INVALID_ARG;
+    if (C % groups) return AOC_ERR_INVALID_ARG;
+    if ((int64_t)N * C > 65535ll * 16) return AOC_ERR_UNSUPPORTED;
+    if (workspace_bytes < aoc_groupnorm_relu_workspace_bytes(N, groups)) return AOC_ERR_WORKSPACE;
+    hipStream_t st = aoc_hip_stream(stream);
+    float *stats = static_cast<float *>(workspace);
+    hipLaunchKernelGGL(gn_stats_kernel, dim3((unsigned)(N * groups)), dim3(256), 0, st, x, C / groups, hw, eps, stats);
+    hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)((hw + 1023) / 1024), (unsigned)(N * C)), dim3(256), 0, st, x, C, C / groups, hw, stats, gamma, beta,
+                       residual, relu, y);
     AOC_RETURN_IF_LAUNCH_FAILED();
     return AOC_OK;
 }

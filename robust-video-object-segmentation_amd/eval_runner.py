@@ -64,8 +64,10 @@ def make_sequence_set(kind="cfg5", scale=1.0, seed=0) -> List[SequenceSpec]:
 
 
 class HotPathBackend:
-    """One frame on the MI355X: matching (libaoc_hip.so) -> DynamicPreHead -> read-out -> soft-max.  The read-out weights are
-    seeded, so every rank decodes identically."""
+    """One frame on the MI355X: matching (libaoc_hip.so) -> DynamicPreHead -> stand-in read-out -> soft-max.  The conv decoder is out of
+    scope; its stand-in ranks the objects by their matching evidence (logit = -12 x the mean of the dense-matching and the widest
+    local-window proto-mask channels, i.e. nearest-neighbour label propagation) plus a small seeded linear read-out of the pre-head output,
+    which is computed because the real decoder consumes it.  Seeded, so every rank decodes identically."""
 
     def __init__(self, device, dense_precision=None):
         from . import hotpath
@@ -81,7 +83,7 @@ class HotPathBackend:
             with torch.no_grad():
                 pre.conv.weight.copy_(torch.randn(pre.conv.weight.shape, generator=g) * (2.0 / n_ch) ** 0.5)
                 pre.conv.bias.zero_()
-            w = (torch.randn(64, generator=g) * 0.75).to(self.device)
+            w = (torch.randn(64, generator=g) * 0.02).to(self.device)
             self._heads[n_ch] = (pre.to(self.device), w)
         return self._heads[n_ch]
 
@@ -107,7 +109,8 @@ class HotPathBackend:
                                                   dense_state=self.dense_state, rng=self.rng)
         pre, wv = self._head(feat.shape[1])
         y = pre(feat)                                                          # [O, 64, h, w]
-        logit = torch.einsum("ochw,c->ohw", y, wv)
+        ch = self.hot.channel_slices(self.mc)
+        logit = -12.0 * 0.5 * (feat[:, ch["global_fg"]] + feat[:, ch["local"]]) + torch.einsum("ochw,c->ohw", y, wv)
         logit = torch.nn.functional.interpolate(logit[None], size=(4 * h, 4 * w), mode="bilinear", align_corners=True)[0]
         label, _, _ = self.policy.update(emb, torch.softmax(logit, dim=0))
         return label

@@ -577,6 +577,21 @@ def plane_reduce(x, mode):
     return out
 
 
+def groupnorm_relu(x, groups, gamma, beta, eps=1e-5, residual=None, relu=True, out=None):
+    """aoc_groupnorm_relu: [relu](GroupNorm(x) [+ residual]) in two streams over x (gct.py:69-90)."""
+    x = _f32c(x)
+    residual = _f32c(residual) if residual is not None else None
+    _need_gpu(x, gamma, beta, residual)
+    N, C = x.shape[0], x.shape[1]
+    hw = x.numel() // (N * C)
+    L = _lib.lib()
+    y = torch.empty_like(x) if out is None else out
+    ws = _ws(L.aoc_groupnorm_relu_workspace_bytes(N, int(groups)), x.device)
+    _lib.check(L.aoc_groupnorm_relu(_p(x), N, C, hw, int(groups), _p(_f32c(gamma)) if gamma is not None else None, _p(_f32c(beta)) if beta is not None else None,
+                                    float(eps), _p(residual), int(bool(relu)), _p(y), _p(ws), ws.numel(), _stream()), "aoc_groupnorm_relu")
+    return y
+
+
 def gct_gate(plane_sums, alpha, gamma, beta, eps, l1_mode=False):
     plane_sums = _f32c(plane_sums)
     _need_gpu(plane_sums, alpha, gamma, beta)

@@ -445,3 +445,26 @@ def test_incremental_proxies_accuracy(aoc):
     assert np.mean(agree_inc) >= np.mean(agree_fresh) - 0.03, (agree_inc, agree_fresh)
     # 3 x 16 proxies per object sit closer to the query pixels than 16: the features move, but by less than the features themselves vary
     assert np.mean(diff_inc) <= max(3.0 * np.mean(diff_fresh), 0.05), (diff_inc, diff_fresh)
+
+
+def test_bottleneck_golden(aoc, golden):
+    """The decoder's residual block (gct.py:38-90) with the GCT gate and the GroupNorm + ReLU (+ residual) streams on the HIP library,
+    against the output of the reference class."""
+    g = golden("bottleneck_64_128")
+    blk = aoc.gct.Bottleneck(64, 128).cuda()
+    sd = {k[2:].replace("__", "."): torch.from_numpy(v) for k, v in g.items() if k.startswith("p_")}
+    blk.load_state_dict(sd)
+    y = blk(dev(g["in_x"]))
+    np.testing.assert_allclose(y.cpu().numpy(), g["out"], rtol=2e-5, atol=2e-5)
+    t1 = blk._gn(blk.bn1, blk.conv1(blk.GCT1(dev(g["in_x"]))))
+    np.testing.assert_allclose(t1.cpu().numpy(), g["stage1"], rtol=2e-5, atol=5e-6)
+    # the fused GroupNorm + residual + ReLU stream by itself against torch
+    x = torch.randn(3, 64, 17, 23, device="cuda")
+    r = torch.randn_like(x)
+    gn = torch.nn.GroupNorm(32, 64).cuda()
+    with torch.no_grad():
+        gn.weight.uniform_(0.5, 1.5)
+        gn.bias.normal_()
+    want = torch.relu(gn(x) + r)
+    got = aoc.ops.groupnorm_relu(x, 32, gn.weight, gn.bias, gn.eps, r, True)
+    np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=1e-5, atol=2e-6)
