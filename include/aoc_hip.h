@@ -239,9 +239,10 @@ int aoc_dense_match_min_f16(const float *query, int64_t m, int C,
 /* ------------------------------------------------------------------------------------------
  * Dense pixel-level matching on the fp16 matrix pipe with fp32-equivalent products (same reference
  * lines as aoc_dense_match_min).  Each embedding row is converted ONCE into a "split record":
- * x * 2^10 = hi + lo with hi, lo fp16 (|error| <= 2^-24 |x|), plus the three fp16 pieces of -16 |x|^2 in
+ * x * 2^10 = hi + lo with hi, lo fp16 (two 11-bit significands: |error| <= 2^-22 |x|, typically 2^-23), plus the three fp16 pieces of -16 |x|^2 in
  * spare k-slots.  q.r is then qh.rh + qh.rl + ql.rh accumulated in fp32 by v_mfma_f32_32x32x16_f16
- * (the dropped ql.rl term is < 2^-24 |q.r|): deviations from the fp32 reference stay at the level of the
+ * (the dropped ql.rl term is < 2^-22 |q| |r|): a product carries up to about 4x the rounding error of an fp32 product, and the deviations
+ * of the min-distances from the fp32 reference stay within a small multiple of the
  * reference's own fp32 rounding (a few 1e-7 on distances of O(1); tests pin <= 5e-6 on the outputs).
  *
  * The fast kernels need (a) every |x| * 2^10 <= 65000 and |x|^2 <= 4000 and (b) every kept pool row right

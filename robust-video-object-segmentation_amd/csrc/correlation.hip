@@ -634,7 +634,7 @@ int aoc_corr_fp32_batched(const aoc_corr_frame *frames_host, int n_frames, int64
             if (tab.n == 0) return AOC_OK;
             if (out_overflow) tab.n_out = 0;       // too many output columns for the transpose buffer: direct stores
             const size_t lds = (size_t)tab.n * tile_bytes + (size_t)4 * 16 * (tab.n_out + 1) * sizeof(float);
-#define AOC_PC(TM, EX, F16) hipLaunchKernelGGL((proxy_corr_min_kernel<TM, EX, F16>), dim3(gate ? (grid < 256 ? grid : 256) : grid, gate ? 1 : nf), dim3(256), lds, st, fr, m, C, tab, out_pixel_stride, transform, gate, gate_value)
+#define AOC_PC(TM, EX, F16) hipLaunchKernelGGL((proxy_corr_min_kernel<TM, EX, F16>), dim3(gate ? (grid < 32 ? grid : 32) : grid, gate ? 1 : nf), dim3(256), lds, st, fr, m, C, tab, out_pixel_stride, transform, gate, gate_value)
             if (float16) { if (C == 100) AOC_PC(25, true, true); else if (C <= 128) AOC_PC(32, false, true); else AOC_PC(64, false, true); }
             else if (C == 100) AOC_PC(25, true, false); else if (C <= 128) AOC_PC(32, false, false); else AOC_PC(64, false, false);
 #undef AOC_PC

@@ -1,7 +1,8 @@
 // Dense pixel-level matching (AEM:61-89, 178-227) on the fp16 matrix pipe with fp32-equivalent products.
 //
 // Every fp32 value x (scaled by 2^10) is split into hi = fp16(x') and lo = fp16(x' - hi): hi + lo represents x'
-// to 2^-24 relative, and q.r = qh.rh + qh.rl + ql.rh (+ a ql.rl term < 2^-24 |q.r| that is dropped) accumulates in
+// to 2^-22 relative (two 11-bit significands; typically 2^-23), and q.r = qh.rh + qh.rl + ql.rh (+ a ql.rl term < 2^-22 |q||r| that is
+// dropped) accumulates in
 // fp32 inside v_mfma_f32_32x32x16_f16 -- three matrix instructions at 16x the fp32 MFMA rate.  The reference
 // pixel's -|r|^2/2 rides along in three spare k-slots (K = 100 pads to 112 anyway), so one accumulator holds
 // 2^20 * (q.r - |r|^2/2) and the min over reference pixels becomes a max over raw accumulators: the epilogue

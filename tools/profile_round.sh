@@ -30,3 +30,34 @@ PY
   fi
 done
 ls -la "$out"
+
+# ---- round 2: the correlation kernel and the calibration streams by themselves (tools/bench_corr.py, tools/bench_calib.py)
+python $GRAFT_REPO_ROOT/tools/bench_corr.py --config cfg2 --batches 1,4,16,32 --check > "$out/corr_cfg2.jsonl" 2>/dev/null
+python $GRAFT_REPO_ROOT/tools/bench_corr.py --config cfg4 --batches 1,4,8 --check > "$out/corr_cfg4.jsonl" 2>/dev/null
+python $GRAFT_REPO_ROOT/tools/bench_corr.py --config cfg3 --batches 1,4,16 --check > "$out/corr_cfg3.jsonl" 2>/dev/null
+python $GRAFT_REPO_ROOT/tools/bench_calib.py --config cfg2 > "$out/calib_cfg2.jsonl" 2>/dev/null
+python $GRAFT_REPO_ROOT/tools/bench_calib.py --config cfg4 > "$out/calib_cfg4.jsonl" 2>/dev/null
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_corr -- python $GRAFT_REPO_ROOT/tools/bench_corr.py --config cfg2 --batches 16 --reps 20 > /dev/null 2>&1
+f=$(find /tmp/prof_corr -name "*kernel_stats.csv" | head -1)
+if [ -n "$f" ]; then cp "$f" "$out/kernel_stats_corr_B16.csv"; fi
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_calib -- python $GRAFT_REPO_ROOT/tools/bench_calib.py --config cfg2 > /dev/null 2>&1
+f=$(find /tmp/prof_calib -name "*kernel_stats.csv" | head -1)
+if [ -n "$f" ]; then cp "$f" "$out/kernel_stats_calib_cfg2.csv"; fi
+for cfgb in "cfg2 16" "cfg4 4"; do
+  set -- $cfgb
+  for ctr in FETCH_SIZE WRITE_SIZE; do
+    rm -rf /tmp/prof_c_$ctr
+    timeout 600 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d /tmp/prof_c_$ctr -- python $GRAFT_REPO_ROOT/tools/bench_corr.py --config $1 --batches $2 --reps 5 > /dev/null 2>&1
+    f=$(find /tmp/prof_c_$ctr -name "*counter_collection.csv" | head -1)
+    if [ -n "$f" ]; then
+      python - "$f" "$ctr" >> "$out/pmc_corr_$1_B$2.txt" <<'PY'
+import csv, sys
+v = [float(r["Counter_Value"]) for r in csv.DictReader(open(sys.argv[1])) if r.get("Counter_Name") == sys.argv[2] and "proxy_corr_batched" in r["Kernel_Name"]]
+print(f"{sys.argv[2]} proxy_corr_batched_kernel dispatches {len(v)} per-dispatch {sum(v) / max(len(v), 1):.1f} (KB)")
+PY
+    fi
+  done
+done
+$GRAFT_REPO_ROOT/tools/pmc_corr.sh SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES > "$out/pmc_sq_corr_B16.txt" 2>&1
+$GRAFT_REPO_ROOT/tools/pmc_corr.sh SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAIT_INST_LDS >> "$out/pmc_sq_corr_B16.txt" 2>&1
+ls -la "$out"
