@@ -272,6 +272,11 @@ int aoc_dense_match_min_split(const float *query, const void *query_rec, const f
                               float *out, int64_t out_pixel_stride, int64_t out_obj_stride,
                               int transform, void *workspace, size_t workspace_bytes, aoc_stream_t stream);
 
+/* Developer counters of the coarse-then-rescore kernel behind aoc_dense_match_min_split, summed over all launches of the process
+ * since the last reset (synchronises the device): out4[0] (reference tile, query tile) pairs tested with one fp16 product,
+ * out4[1] pairs rescored with all three products, out4[2] reference tiles with at least one rescoring, out4[3] reference tiles. */
+int aoc_dense_prune_stats(uint64_t *out4, int reset);
+
 /* Measurement probe: the NEXT aoc_dense_match_min / aoc_dense_match_min_split call made by the calling thread records
  * `start` immediately before and `stop` immediately after its matrix kernel (dense_match_partial_kernel /
  * dense_split_kernel) on the call's stream, then the probe is cleared.  Both are hipEvent_t created by the caller

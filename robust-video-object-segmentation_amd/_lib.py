@@ -48,6 +48,7 @@ SIGNATURES = {
     "aoc_split_record_bytes": (_sz, [_i]),
     "aoc_split_rows": (_i, [_vp, _i64, _i, _vp, _vp, _vp, _vp]),
     "aoc_dense_match_split_workspace_bytes": (_sz, [_i64, _i64, _i]),
+    "aoc_dense_prune_stats": (_i, [_vp, _i]),
     "aoc_dense_match_min_split": (_i, [_vp, _vp, _vp, _i64, _i, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i64, _i64, _i,
                                        _vp, _sz, _vp]),
     "aoc_local_window_match": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp]),

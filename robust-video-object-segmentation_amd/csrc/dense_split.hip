@@ -21,14 +21,14 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int SP_KS = 7;                       // k-steps of 16 halves: 112 slots = 100 channels + 3 norm slots + pad
 constexpr int SP_K = SP_KS * 16;
-constexpr int SP_REC = SP_KS * 4;              // 16-byte chunks per record: per k-step [hi k0-7][hi k8-15][lo k0-7][lo k8-15]
-constexpr int SP_LDS_ROW = SP_REC + 1;         // +16 B: rows land on distinct bank quads for ds_read_b128
+constexpr int SP_HALF = SP_KS * 2;             // 16-byte chunks per plane: per k-step [k0-7][k8-15]
+constexpr int SP_REC = 2 * SP_HALF;            // 16-byte chunks per record: the hi plane (14 chunks), then the lo plane
 constexpr int SP_NORM_SLOT = 100;              // slots 100..102 of the hi plane: the three fp16 pieces of -16 |r|^2
 constexpr float SP_SCALE = 1024.0f;            // 2^10
 constexpr float SP_QCONST = 32768.0f;          // query-side value of the norm slots: 2^15 * (-16 |r|^2) = -2^19 |r|^2
 constexpr float SP_UNSCALE = -1.0f / 524288.0f;   // d - |q|^2 = -2^-19 * acc
 constexpr int SP_TILE = 32;                    // reference pixels per MFMA tile
-constexpr int SP_NB = 2;                       // tiles per staged chunk
+constexpr int SP_NB = 4;                       // tiles per staged chunk
 constexpr int SP_NW = 8;                       // waves per block
 constexpr int SP_NQ = 2;                       // 32-pixel query tiles per wave (stationary B operands in registers)
 constexpr int SP_ROWS_PER_BLOCK = SP_NW * SP_NQ * 32;
@@ -71,9 +71,11 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float *__restrict
     union { _Float16 h[32]; uint4 q[4]; } u;
 #pragma unroll
     for (int e = 0; e < 16; ++e) { u.h[e] = hi[e]; u.h[16 + e] = lo[e]; }
-    uint4 *dst = rec + (size_t)row * SP_REC + ks * 4;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) dst[c] = u.q[c];
+    uint4 *dst = rec + (size_t)row * SP_REC + ks * 2;
+    dst[0] = u.q[0];
+    dst[1] = u.q[1];
+    dst[SP_HALF] = u.q[2];
+    dst[SP_HALF + 1] = u.q[3];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -82,18 +84,28 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float *__restrict
 __global__ __launch_bounds__(256) void split_plan_kernel(const int32_t *__restrict__ obj_rows, const int32_t *__restrict__ counts,
                                                           const int32_t *__restrict__ obj_offsets, int n_obj, int64_t n,
                                                           const uint32_t *__restrict__ right_bits, const uint32_t *__restrict__ wrong_bits,
-                                                          const int32_t *__restrict__ overflow, int64_t tile_capacity,
-                                                          int32_t *__restrict__ tile_rows, int32_t *__restrict__ tile_obj,
-                                                          int32_t *__restrict__ n_tiles, int32_t *__restrict__ gate) {
+                                                          const int32_t *__restrict__ overflow, const uint4 *__restrict__ prec,
+                                                          int64_t tile_capacity, int32_t *__restrict__ tile_rows,
+                                                          int32_t *__restrict__ tile_obj, int32_t *__restrict__ n_tiles,
+                                                          int32_t *__restrict__ gate, uint32_t *__restrict__ pmax_bits) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    float sq = 0.0f;
     if (e < n) {
         const uint32_t mask = (n_obj >= 32) ? 0xffffffffu : ((1u << n_obj) - 1u);
         const uint32_t right = right_bits[e];
         if (right & AOC_ROW_KEPT_BIT) {
             const uint32_t r = right & mask, nw = ~wrong_bits[e] & mask;
             if (__popc(r) != 1 || nw != r) atomicOr(gate, 1);
+            // |r|^2 back from the record's norm slots (three fp16 pieces of -16 |r|^2)
+            union { uint4 q; _Float16 hh[8]; } u;
+            u.q = prec[(size_t)e * SP_REC + (SP_KS - 1) * 2];
+            sq = -((float)u.hh[SP_NORM_SLOT % 16] + (float)u.hh[SP_NORM_SLOT % 16 + 1] + (float)u.hh[SP_NORM_SLOT % 16 + 2]) * 0.0625f;
         }
     }
+    // largest squared norm among the kept reference pixels (non-negative floats order like their bit patterns)
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) sq = __builtin_fmaxf(sq, __shfl_xor(sq, d));
+    if (aoc_lane() == 0 && sq > 0.0f) atomicMax(pmax_bits, __float_as_uint(sq));
     if (e == 0 && overflow && *overflow) atomicOr(gate, 1);
     const int64_t t = e / SP_TILE;
     const int i = (int)(e - t * SP_TILE);
@@ -106,10 +118,11 @@ __global__ __launch_bounds__(256) void split_plan_kernel(const int32_t *__restri
         base += nt;
     }
     if (e == 0) *n_tiles = (int32_t)base;
+    // a partial last tile is filled up with copies of its first row (a duplicate cannot change a maximum): no padding values anywhere
     int32_t id = -1;
     if (obj >= 0) {
         const int pos = local * SP_TILE + i;
-        if (pos < counts[obj]) id = obj_rows[obj_offsets[obj] + pos];
+        id = obj_rows[obj_offsets[obj] + (pos < counts[obj] ? pos : local * SP_TILE)];
     }
     tile_rows[e] = id;
     if (i == 0) tile_obj[t] = obj;
@@ -127,21 +140,72 @@ __device__ __forceinline__ float max16(const f32x16 &a) {
     return __builtin_fmaxf(m0, m3);
 }
 
-// Block = 8 waves x 2 query tiles (512 query pixels, B operands, resident in registers); the object-sorted
-// reference tiles stream through a double-buffered LDS chunk (A operands).  Grid = (query blocks, tile splits).
-// partial[split][pixel][object] = max over the split's tiles of that object of 2^20 (q.r - |r|^2/2); a split
-// that holds no tile of an object writes nothing there (the finalize kernel knows the tile ranges).
-__global__ __launch_bounds__(SP_NW * 64, 1) void dense_split_kernel(const uint4 *__restrict__ qrec, int64_t m, const uint4 *__restrict__ prec,
-                                                                     const int32_t *__restrict__ tile_rows, const int32_t *__restrict__ tile_obj,
-                                                                     const int32_t *__restrict__ n_tiles_ptr, const int32_t *__restrict__ gate,
-                                                                     int n_obj, float *__restrict__ partial) {
+// float <-> unsigned with the same order (atomicMax on the encoding = max on the floats); every encoded finite value or infinity
+// is > 0, so a zeroed word means "nothing yet"
+__device__ __forceinline__ uint32_t ord_enc(float f) {
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord_dec(uint32_t u) {
+    if (u == 0u) return -INFINITY;
+    return __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
+}
+__device__ __forceinline__ uint32_t load_relaxed(const uint32_t *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ unsigned long long g_prune_stats[4];    // (tile, query tile) pairs tested / rescored, tiles with any rescoring, tiles
+
+// LDS-DMA: 64 lanes x 16 bytes (or 4 bytes) from per-lane global addresses to the LDS bytes [lds_dst + 16 lane, +16).  Written in asm so
+// that hipcc neither counts nor drains it: completion is the kernel's own vmcnt arithmetic (see the step loop).
+__device__ __forceinline__ void glds16(const void *gsrc, uint32_t lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void glds4(const void *gsrc, uint32_t lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+
+constexpr int SP_NBUF = 2;                                        // chunk buffers in LDS
+constexpr int SP_CHUNK_BYTES = SP_NB * SP_TILE * SP_REC * 16;     // 57344: four tiles x 32 rows x 448 B, rows unpadded
+constexpr int SP_DMA_PER_WAVE = SP_CHUNK_BYTES / 1024 / SP_NW;    // 7 wave-wide 1 KiB transfers per wave and chunk
+constexpr int SP_RING_BYTES = SP_NBUF * SP_CHUNK_BYTES;
+constexpr int SP_IDS_OFF = SP_RING_BYTES;                         // 2 slots x 128 row ids
+constexpr int SP_OBJ_OFF = SP_IDS_OFF + 2 * 512;                  // 4 slots x 64 tile objects (4 used)
+constexpr int SP_BND_OFF = SP_OBJ_OFF + 4 * 256;                  // per (wave, query tile): 64 published bounds
+constexpr int SP_LDS_BYTES = SP_BND_OFF + SP_NW * SP_NQ * 256;
+constexpr int SP_TILE_SLACK = 2;                                  // the plan always holds an empty tile after the last one
+
+// Coarse-then-rescore.  Block = 8 waves x 2 query tiles (512 query pixels; both planes of their records are the stationary B
+// operands, 112 VGPR); the object-sorted reference tiles stream through two LDS chunk buffers (4 tiles each, both planes, A
+// operands).  Grid = (query blocks, tile splits).  Per (reference tile, query tile) ONE pass of 7 MFMAs gives
+// coarse = 2^20 (qh.rh - |r|^2/2); the exact three-product value differs from it by the qh.rl + ql.rh terms, bounded by
+// eps(q) = 2^10 |q| max|r| (1 + margins): a pair whose coarse value plus eps is below the best EXACT value already known for that
+// (query pixel, object) cannot hold the maximum and is skipped; any other pair gets the 14 MFMAs of the two cross terms added onto the
+// same accumulators (everything is on chip: no memory latency on that path), which is then exactly the three-product value.  The best
+// exact values live in gbest[pixel][object] (atomicMax on an order-preserving encoding) and are shared by all splits and by the
+// workgroups of later rounds, so the bound tightens after the first few tiles anywhere on the chip.  The true maximum always survives
+// (coarse + eps >= exact >= every bound) and its value does not depend on what else was evaluated: the result is deterministic
+// although the set of rescored tiles is not.
+//
+// Data movement: the chunk of step s + 1 is fetched by LDS-DMA while step s computes (no staging registers, no ds_write pass); its row
+// ids (and the tiles' objects) were themselves DMA'd one step earlier, and the bounds other workgroups published come in the same
+// way.  LDS rows are unpadded (448 B); chunk c of row r sits at position c ^ ((r >> 3) & 3), which makes every ds_read_b128 of an A
+// fragment conflict-free -- the swizzle is applied on the SOURCE address of the DMA, whose destination is lane-linear.  The transfers
+// are asm statements that hipcc neither counts nor drains; one vmcnt(0) + barrier per step (4 tiles) publishes them.
+__global__ __launch_bounds__(SP_NW * 64, 1) void dense_prune_kernel(const uint4 *__restrict__ qrec, const float *__restrict__ q2, int64_t m,
+                                                                     const uint4 *__restrict__ prec, const int32_t *__restrict__ tile_rows,
+                                                                     const int32_t *__restrict__ tile_obj, const int32_t *__restrict__ n_tiles_ptr,
+                                                                     const int32_t *__restrict__ gate, const uint32_t *__restrict__ pmax_bits,
+                                                                     int n_obj, uint32_t *__restrict__ gbest, int dbg) {
     if (*gate) return;
     extern __shared__ __attribute__((aligned(16))) uint4 lds4[];
-    constexpr int NT = SP_NW * 64;
-    constexpr int ROWS = SP_NB * SP_TILE;
-    constexpr int CHUNKS = ROWS * SP_REC;                       // 16-byte pieces per staged chunk
-    constexpr int ITERS = (CHUNKS + NT - 1) / NT;
-    int32_t *lobj = reinterpret_cast<int32_t *>(lds4 + 2 * ROWS * SP_LDS_ROW);   // [2][SP_NB]
+    static_assert(SP_NB == 4 && SP_NQ == 2 && SP_NW == 8 && SP_DMA_PER_WAVE == 7, "the step structure below is written for 4 tiles x 2 query tiles x 8 waves");
+    const uint32_t lds_base = (uint32_t)reinterpret_cast<uintptr_t>(lds4);
+    const char *lds_bytes = reinterpret_cast<const char *>(lds4);
 
     // XCD-aware block -> (query block, tile split) map: workgroups are dealt round-robin to the 8 XCDs, each with its own
     // L2; give every XCD a contiguous range of the (split-major) work list so that the ~gridDim.x blocks that stream the
@@ -154,27 +218,32 @@ __global__ __launch_bounds__(SP_NW * 64, 1) void dense_split_kernel(const uint4 
         by = v / gridDim.x;
         bx = v - by * gridDim.x;
     }
+    // split `by` owns the tiles by, by + ns, by + 2 ns, ...: every split sees the same mix of objects (small objects rescore far more often
+    // than the background; contiguous ranges would leave all of that work to the last splits, i.e. to one XCD)
     const int n_tiles = *n_tiles_ptr;
-    const int tps = (n_tiles + gridDim.y - 1) / gridDim.y;
-    const int tile_beg = by * tps;
-    const int tile_end = min(n_tiles, tile_beg + tps);
-    if (tile_beg >= tile_end) return;
+    const int ns = gridDim.y;
+    if (by >= n_tiles) return;
+    const int n_mine = (n_tiles - by + ns - 1) / ns;
+    const int n_chunks = (n_mine + SP_NB - 1) / SP_NB;
 
-    const int lane = aoc_lane(), wave = threadIdx.x >> 6;
+    const int lane = aoc_lane(), wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int col = lane & 31, h = lane >> 5;
     const int64_t wave_row0 = (int64_t)bx * SP_ROWS_PER_BLOCK + (int64_t)wave * (SP_NQ * 32);
 
-    // ---- stationary query operands
+    // ---- stationary query operands (both planes) and the per-pixel rescoring margin
+    const float pmax = sqrtf(__uint_as_float(*pmax_bits)) * 1.001f;
     f16x8 bh[SP_NQ][SP_KS], bl[SP_NQ][SP_KS];
+    float eps[SP_NQ];
+    bool valid[SP_NQ];
 #pragma unroll
     for (int iq = 0; iq < SP_NQ; ++iq) {
         const int64_t row = wave_row0 + iq * 32 + col;
-        const bool valid = row < m;
-        const uint4 *r = qrec + (size_t)(valid ? row : 0) * SP_REC;
+        valid[iq] = row < m;
+        const uint4 *r = qrec + (size_t)(valid[iq] ? row : 0) * SP_REC;
 #pragma unroll
         for (int ks = 0; ks < SP_KS; ++ks) {
-            uint4 u = r[ks * 4 + h], v = r[ks * 4 + 2 + h];
-            if (!valid) { u = make_uint4(0, 0, 0, 0); v = make_uint4(0, 0, 0, 0); }
+            uint4 u = r[ks * 2 + h], v = r[SP_HALF + ks * 2 + h];
+            if (!valid[iq]) { u = make_uint4(0, 0, 0, 0); v = make_uint4(0, 0, 0, 0); }
             bh[iq][ks] = __builtin_bit_cast(f16x8, u);
             bl[iq][ks] = __builtin_bit_cast(f16x8, v);
         }
@@ -185,148 +254,207 @@ __global__ __launch_bounds__(SP_NW * 64, 1) void dense_split_kernel(const uint4 
             bh[iq][SP_KS - 1][SP_NORM_SLOT % 16 + 1] = (_Float16)SP_QCONST;
             bh[iq][SP_KS - 1][SP_NORM_SLOT % 16 + 2] = (_Float16)SP_QCONST;
         }
+        // |exact - coarse| <= 2^-10 |qh||rh| (1 + 2^-11)^3 (each lo is at most 2^-11 of its hi) + the roundings of 14 more accumulations
+        const float qn = valid[iq] ? sqrtf(q2[row]) : 0.0f;
+        eps[iq] = 1048.0f * qn * pmax + 8.0f * pmax * pmax + 8.0f;
     }
 
-    // ---- staging pipeline (registers -> the other LDS buffer)
-    uint4 sv[ITERS];
-    int32_t ids[ITERS];
-    int32_t obj_next = -1, obj_commit = -1;
-    // padding rows: all-zero channels and the most negative norm pieces, so they never win the max
-    const _Float16 NEG = (_Float16)(-65504.0f);
-    union { _Float16 hh[8]; uint4 q; } padu;
+    // ---- DMA plan of this wave: transfer k of a chunk fills the LDS slots [64 (7 wave + k), +64); slot j holds row j / 28, position j % 28.
+    // Packed per transfer: row of the chunk (0..127) in the high half, source byte offset of that position's chunk in the low half.
+    uint32_t dma_plan[SP_DMA_PER_WAVE];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) padu.hh[e] = (_Float16)0.0f;
-    padu.hh[SP_NORM_SLOT % 16] = NEG; padu.hh[SP_NORM_SLOT % 16 + 1] = NEG; padu.hh[SP_NORM_SLOT % 16 + 2] = NEG;
-    const uint4 pad_chunk = padu.q;
-
-    auto load_ids = [&](int t0) {
-#pragma unroll
-        for (int it = 0; it < ITERS; ++it) {
-            const int idx = it * NT + threadIdx.x;
-            const int rr = idx / SP_REC;
-            ids[it] = (idx < CHUNKS && t0 + rr / SP_TILE < tile_end) ? tile_rows[(size_t)t0 * SP_TILE + rr] : -1;
+    for (int k = 0; k < SP_DMA_PER_WAVE; ++k) {
+        const int j = (wave * SP_DMA_PER_WAVE + k) * 64 + lane;
+        const int r = j / SP_REC, pos = j - r * SP_REC;
+        dma_plan[k] = ((uint32_t)r << 16) | (uint32_t)((pos ^ ((r >> 3) & 3)) * 16);
+    }
+    const char *prec_bytes = reinterpret_cast<const char *>(prec);
+    auto dma_meta = [&](int chunk) {            // row ids (waves 4 and 6) and tile objects (wave 5) of a chunk -> their rings
+        // tile i of the split is tile by + i ns of the plan; past the end everything reads the (always present) empty tile n_tiles
+        const int i0 = chunk * SP_NB;
+        if (wave == 4 || wave == 6) {
+            const int i = i0 + (wave == 6 ? 2 : 0) + (lane >> 5);
+            const int t = min(by + i * ns, n_tiles);
+            glds4(tile_rows + (size_t)t * SP_TILE + (lane & 31), lds_base + SP_IDS_OFF + (chunk & 1) * 512 + (wave == 6 ? 256 : 0));
         }
-        obj_next = (threadIdx.x < SP_NB && t0 + (int)threadIdx.x < tile_end) ? tile_obj[t0 + threadIdx.x] : -1;
+        if (wave == 5) glds4(tile_obj + min(by + (i0 + (lane & 3)) * ns, n_tiles), lds_base + SP_OBJ_OFF + (chunk & 3) * 256);
     };
-    auto issue_rows = [&]() {
+    auto dma_rows = [&](int chunk) {            // the chunk's records -> buffer chunk % 2 (its ids must have landed and been published)
+        const int32_t *ids = reinterpret_cast<const int32_t *>(lds_bytes + SP_IDS_OFF + (chunk & 1) * 512);
+        const uint32_t dst = lds_base + (uint32_t)(chunk % SP_NBUF) * SP_CHUNK_BYTES + (uint32_t)(wave * SP_DMA_PER_WAVE) * 1024u;
+        int id[SP_DMA_PER_WAVE];
 #pragma unroll
-        for (int it = 0; it < ITERS; ++it) {
-            const int idx = it * NT + threadIdx.x;
-            const int rr = idx / SP_REC, c = idx - rr * SP_REC;
-            const int id = ids[it];
-            if (id >= 0) sv[it] = prec[(size_t)id * SP_REC + c];
-            else sv[it] = (c == (SP_KS - 1) * 4) ? pad_chunk : make_uint4(0, 0, 0, 0);
-        }
-        obj_commit = obj_next;
-    };
-    auto commit_rows = [&](int buf) {
+        for (int k = 0; k < SP_DMA_PER_WAVE; ++k) id[k] = ids[dma_plan[k] >> 16];      // all LDS reads before the first (ordering) asm statement
 #pragma unroll
-        for (int it = 0; it < ITERS; ++it) {
-            const int idx = it * NT + threadIdx.x;
-            if (idx < CHUNKS) {
-                const int rr = idx / SP_REC, c = idx - rr * SP_REC;
-                lds4[(size_t)(buf * ROWS + rr) * SP_LDS_ROW + c] = sv[it];
-            }
-        }
-        if (threadIdx.x < SP_NB) lobj[buf * SP_NB + threadIdx.x] = obj_commit;
+        for (int k = 0; k < SP_DMA_PER_WAVE; ++k)
+            glds16(prec_bytes + (size_t)(uint32_t)max(id[k], 0) * (SP_REC * 16) + (dma_plan[k] & 0xffffu), dst + (uint32_t)k * 1024u);
     };
 
-    float best[SP_NQ];
+    // best[iq]: best exact value this lane has produced for the current object; shared[iq]: the best anybody has published
+    float best[SP_NQ], shared[SP_NQ];
+    uint32_t grow[SP_NQ];                          // grow: word index of (pixel, object 0) in gbest (pixel 0 for rows past the end)
 #pragma unroll
-    for (int iq = 0; iq < SP_NQ; ++iq) best[iq] = -INFINITY;
+    for (int iq = 0; iq < SP_NQ; ++iq) {
+        grow[iq] = valid[iq] ? (uint32_t)(wave_row0 + iq * 32 + col) * (uint32_t)n_obj : 0u;
+        best[iq] = INFINITY;
+        shared[iq] = INFINITY;
+    }
     int cur = -1;
-    auto flush = [&]() {
-        if (cur < 0) return;
+    unsigned n_rescored = 0, n_any = 0, n_seen = 0;
+    // what the other workgroups have published for the current object: one 4-byte transfer per query tile into this wave's own LDS
+    // words, read back one step later (device-scope load: the values come from L2, not from this CU's vector cache)
+    auto dma_bound = [&]() {
 #pragma unroll
         for (int iq = 0; iq < SP_NQ; ++iq) {
-            const float v = __builtin_fmaxf(best[iq], __shfl_xor(best[iq], 32));
-            const int64_t row = wave_row0 + iq * 32 + col;
-            if (h == 0 && row < m) partial[((size_t)by * m + row) * n_obj + cur] = v;
-            best[iq] = -INFINITY;
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off sc1\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(gbest + grow[iq] + max(cur, 0)), "s"(lds_base + SP_BND_OFF + (uint32_t)(wave * SP_NQ + iq) * 256u) : "memory");
+        }
+    };
+    auto switch_object = [&](int o) {
+        cur = o;
+        uint32_t u[SP_NQ];
+#pragma unroll
+        for (int iq = 0; iq < SP_NQ; ++iq) u[iq] = load_relaxed(gbest + grow[iq] + cur);
+#pragma unroll
+        for (int iq = 0; iq < SP_NQ; ++iq) {
+            best[iq] = valid[iq] ? -INFINITY : INFINITY;         // rows past the end never ask for a rescoring
+            shared[iq] = valid[iq] ? ord_dec(u[iq]) : INFINITY;
         }
     };
 
-    load_ids(tile_beg);
-    issue_rows();
-    load_ids(tile_beg + SP_NB);
-    commit_rows(0);
-    __syncthreads();
+    // ---- prologue: meta of chunks 0 and 1, rows of chunk 0 (drained: once per workgroup)
+    dma_meta(0);
+    dma_meta(1);
+    __builtin_amdgcn_s_waitcnt(0x0f70);                           // vmcnt(0)
+    __builtin_amdgcn_s_barrier();
+    dma_rows(0);
+    __builtin_amdgcn_s_waitcnt(0x0f70);
+    __builtin_amdgcn_s_barrier();
 
-    int p = 0;
-    for (int t0 = tile_beg; t0 < tile_end; t0 += SP_NB) {
-        const bool more = t0 + SP_NB < tile_end;
-        if (more) {
-            issue_rows();                      // chunk t0 + NB: in flight under this chunk's MFMAs
-            load_ids(t0 + 2 * SP_NB);
-        }
+    // A fragment addressing: chunk index e + h (e even, compile time) of row (tile, col) sits at position (e & ~3) + (((e & 2) + h) ^ x),
+    // x = (col >> 3) & 3: two per-lane byte offsets cover it
+    const int xs = (col >> 3) & 3;
+    const uint32_t row_off = (uint32_t)col * (SP_REC * 16);
+    const uint32_t sw0 = row_off + (uint32_t)((h ^ xs) * 16), sw2 = row_off + (uint32_t)(((2 + h) ^ xs) * 16);
+    auto frag = [&](const char *tile_base, int e) -> f16x8 {       // e: even chunk index (2 ks for the hi plane, 14 + 2 ks for the lo plane)
+        const uint32_t off = ((e & 2) ? sw2 : sw0) + (uint32_t)((e & ~3) * 16);
+        return __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4 *>(tile_base + off));
+    };
+    auto ks_of = [&](int kk) { return (kk + SP_KS - 1) % SP_KS; };  // norm slots first: partial sums stay small
+
+    for (int s = 0; s < n_chunks; ++s) {
+        // (a) prefetches for the next step: published bounds of the current object, meta of chunk s + 2, rows of chunk s + 1 (whose ids
+        // the barrier that ended step s - 1 published)
+        const int4 objs = *reinterpret_cast<const int4 *>(lds_bytes + SP_OBJ_OFF + (s & 3) * 256);
+        const int bound_obj = (dbg & 32) ? -3 : cur;
+        if (!(dbg & 32)) dma_bound();
+        dma_meta(s + 2);
+        if (!(dbg & 4)) dma_rows(s + 1);
+
+        // (b) the four tiles of chunk s
+        const char *chunk_base = lds_bytes + (s % SP_NBUF) * SP_CHUNK_BYTES;
+        const int n_here = min(SP_NB, n_mine - s * SP_NB);
+#pragma unroll 1
+        for (int t = 0; t < n_here; ++t) {
+            const char *tile_base = chunk_base + t * (SP_TILE * SP_REC * 16);
+            const int o = __builtin_amdgcn_readfirstlane(t == 0 ? objs.x : t == 1 ? objs.y : t == 2 ? objs.z : objs.w);
+            if (o != cur) switch_object(o);
+            // coarse pass: 7 k-steps x 2 query tiles, A fragments two k-steps ahead through a ring of three
+            f32x16 acc[SP_NQ];
 #pragma unroll
-        for (int ti = 0; ti < SP_NB; ++ti) {
-            if (t0 + ti < tile_end) {
-                const int o = lobj[p * SP_NB + ti];
-                if (o != cur) { flush(); cur = o; }
-                const uint4 *arow = lds4 + (size_t)(p * ROWS + ti * SP_TILE + col) * SP_LDS_ROW;
-                f32x16 acc[SP_NQ];
+            for (int iq = 0; iq < SP_NQ; ++iq)
 #pragma unroll
-                for (int iq = 0; iq < SP_NQ; ++iq)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[iq][r] = 0.0f;
-                // A fragments one k-step ahead of the MFMAs that consume them (norm slots first: partial sums stay small)
-                f16x8 ah = __builtin_bit_cast(f16x8, arow[(SP_KS - 1) * 4 + h]);
-                f16x8 al = __builtin_bit_cast(f16x8, arow[(SP_KS - 1) * 4 + 2 + h]);
+                for (int r = 0; r < 16; ++r) acc[iq][r] = 0.0f;
+            {
+                f16x8 af[3];
+                af[0] = frag(tile_base, 2 * ks_of(0));
+                af[1] = frag(tile_base, 2 * ks_of(1));
 #pragma unroll
                 for (int kk = 0; kk < SP_KS; ++kk) {
-                    const int ks = (kk == 0) ? SP_KS - 1 : kk - 1;
-                    f16x8 nh = ah, nl = al;
-                    if (kk + 1 < SP_KS) {
-                        nh = __builtin_bit_cast(f16x8, arow[kk * 4 + h]);          // k-step kk (the next one in this order)
-                        nl = __builtin_bit_cast(f16x8, arow[kk * 4 + 2 + h]);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);                             // keep the reads ahead of this k-step's MFMAs
+                    if (kk + 2 < SP_KS) af[(kk + 2) % 3] = frag(tile_base, 2 * ks_of(kk + 2));
 #pragma unroll
-                    for (int iq = 0; iq < SP_NQ; ++iq) acc[iq] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[iq][ks], acc[iq], 0, 0, 0);
-#pragma unroll
-                    for (int iq = 0; iq < SP_NQ; ++iq) acc[iq] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[iq][ks], acc[iq], 0, 0, 0);
-#pragma unroll
-                    for (int iq = 0; iq < SP_NQ; ++iq) acc[iq] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[iq][ks], acc[iq], 0, 0, 0);
-                    ah = nh; al = nl;
+                    for (int iq = 0; iq < SP_NQ; ++iq)
+                        acc[iq] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[kk % 3], bh[iq][ks_of(kk)], acc[iq], 0, 0, 0);
                 }
+            }
+            // which query tiles may hold a new maximum (wave-uniform)
+            bool want[SP_NQ];
 #pragma unroll
-                for (int iq = 0; iq < SP_NQ; ++iq) best[iq] = __builtin_fmaxf(best[iq], max16(acc[iq]));
+            for (int iq = 0; iq < SP_NQ; ++iq) {
+                const float cm = max16(acc[iq]);
+                want[iq] = __builtin_amdgcn_ballot_w64(cm + eps[iq] >= __builtin_fmaxf(best[iq], shared[iq])) != 0ull;
+            }
+            n_seen += 1;
+            if ((want[0] || want[1]) && !(dbg & 2)) {
+                n_any += 1;
+#pragma unroll
+                for (int iq = 0; iq < SP_NQ; ++iq) {
+                    if (want[iq]) {
+                        // cross terms: acc += rh.ql + rl.qh (one chain of 14 MFMAs), then the exact maximum
+                        n_rescored += 1;
+                        f16x8 ah[3], al[3];
+#pragma unroll
+                        for (int kk = 0; kk < 2; ++kk) {
+                            ah[kk] = frag(tile_base, 2 * ks_of(kk));
+                            al[kk] = frag(tile_base, 2 * SP_KS + 2 * ks_of(kk));
+                        }
+#pragma unroll
+                        for (int kk = 0; kk < SP_KS; ++kk) {
+                            if (kk + 2 < SP_KS) {
+                                ah[(kk + 2) % 3] = frag(tile_base, 2 * ks_of(kk + 2));
+                                al[(kk + 2) % 3] = frag(tile_base, 2 * SP_KS + 2 * ks_of(kk + 2));
+                            }
+                            acc[iq] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[kk % 3], bl[iq][ks_of(kk)], acc[iq], 0, 0, 0);
+                            acc[iq] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[kk % 3], bh[iq][ks_of(kk)], acc[iq], 0, 0, 0);
+                        }
+                        const float ex = max16(acc[iq]);
+                        if (ex > best[iq]) {
+                            best[iq] = ex;
+                            if (ex > shared[iq] && !(dbg & 1)) atomicMax(gbest + grow[iq] + cur, ord_enc(ex));      // fire and forget
+                        }
+                    }
+                }
             }
         }
-        if (more) commit_rows(p ^ 1);
-        __syncthreads();
-        p ^= 1;
+
+        // (c) this step's transfers have landed (they had four tiles of time); publish them
+        __builtin_amdgcn_s_waitcnt(0x0f70);          // vmcnt(0)
+        __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0)
+        if (!(dbg & 8)) __builtin_amdgcn_s_barrier();
+        if (bound_obj == cur && cur >= 0) {          // the bounds fetched at the start of this step (this wave's own transfers)
+#pragma unroll
+            for (int iq = 0; iq < SP_NQ; ++iq) {
+                const uint32_t u = *reinterpret_cast<const uint32_t *>(lds_bytes + SP_BND_OFF + (wave * SP_NQ + iq) * 256 + lane * 4);
+                if (valid[iq]) shared[iq] = __builtin_fmaxf(shared[iq], ord_dec(u));
+            }
+        }
     }
-    flush();
+    if (lane == 0) {
+        atomicAdd(&g_prune_stats[0], (unsigned long long)n_seen * SP_NQ);
+        atomicAdd(&g_prune_stats[1], (unsigned long long)n_rescored);
+        atomicAdd(&g_prune_stats[2], (unsigned long long)n_any);
+        atomicAdd(&g_prune_stats[3], (unsigned long long)n_seen);
+    }
 }
 
 // out[i,o] = f( min(own_o, 5e4 + min_{o' != o} own_o') ), own_o = |q_i|^2 - 2^-19 max-accumulator (+inf: no pixel of o)
-__global__ __launch_bounds__(256) void dense_split_finalize_kernel(const float *__restrict__ partial, int n_split, int64_t m, int n_obj,
+__global__ __launch_bounds__(256) void dense_split_finalize_kernel(const uint32_t *__restrict__ gbest, int64_t m, int n_obj,
                                                                     const int32_t *__restrict__ counts, const int32_t *__restrict__ gate,
                                                                     const float *__restrict__ q2, const float *__restrict__ obj_bias,
                                                                     float *__restrict__ out, int64_t pstride, int64_t ostride, int transform) {
     if (*gate) return;
     const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (row >= m) return;
-    int n_tiles = 0;
-    for (int o = 0; o < n_obj; ++o) n_tiles += (counts[o] + SP_TILE - 1) / SP_TILE;
-    const int tps = (n_tiles + n_split - 1) / max(n_split, 1);
     const float qq = q2[row];
     float own[16];
-    int base = 0;
+    int n_kept = 0;
 #pragma unroll
     for (int o = 0; o < 16; ++o) {
         own[o] = INFINITY;
-        if (o < n_obj) {
-            const int nt = (counts[o] + SP_TILE - 1) / SP_TILE;
-            if (nt > 0) {
-                float v = -INFINITY;
-                const int s0 = base / tps, s1 = (base + nt - 1) / tps;
-                for (int s = s0; s <= s1; ++s) v = __builtin_fmaxf(v, partial[((size_t)s * m + row) * n_obj + o]);
-                own[o] = qq + SP_UNSCALE * v;
-            }
-            base += nt;
+        if (o < n_obj && counts[o] > 0) {
+            own[o] = qq + SP_UNSCALE * ord_dec(gbest[(size_t)row * n_obj + o]);
+            n_kept += counts[o];
         }
     }
 #pragma unroll
@@ -337,7 +465,7 @@ __global__ __launch_bounds__(256) void dense_split_finalize_kernel(const float *
             for (int o2 = 0; o2 < 16; ++o2)
                 if (o2 != o && o2 < n_obj) others = fminf(others, own[o2]);
             float v = fminf(own[o], others + AOC_PAD_DISTANCE);
-            if (n_tiles == 0) v = transform ? 1.0f : INFINITY;            // AEM:796-797
+            if (n_kept == 0) v = transform ? 1.0f : INFINITY;            // AEM:796-797
             else if (transform) v = aoc_proto_transform(v, obj_bias ? obj_bias[o] : 0.0f);
             out[row * pstride + o * ostride] = v;
         }
@@ -365,7 +493,7 @@ inline int split_nsplit(int64_t m) {
 
 struct SplitWs {
     int32_t *gate, *n_tiles, *tile_rows, *tile_obj;
-    float *partial;
+    uint32_t *pmax, *gbest;
     void *fp32_ws;
     size_t fp32_bytes, total;
     int64_t tile_capacity;
@@ -375,12 +503,13 @@ inline SplitWs split_carve(void *base, int64_t m, int64_t n, int n_obj) {
     char *p = static_cast<char *>(base);
     size_t off = 0;
     auto take = [&](size_t bytes) { char *r = p ? p + off : nullptr; off += aoc_align_up(bytes, 256); return r; };
-    w.tile_capacity = (n + SP_TILE - 1) / SP_TILE + n_obj + 2 * SP_NB;
+    w.tile_capacity = (n + SP_TILE - 1) / SP_TILE + n_obj + SP_TILE_SLACK;
     w.gate = reinterpret_cast<int32_t *>(take(16));
     w.n_tiles = w.gate ? w.gate + 2 : nullptr;
+    w.pmax = w.gate ? reinterpret_cast<uint32_t *>(w.gate + 3) : nullptr;
     w.tile_rows = reinterpret_cast<int32_t *>(take((size_t)w.tile_capacity * SP_TILE * sizeof(int32_t)));
     w.tile_obj = reinterpret_cast<int32_t *>(take((size_t)w.tile_capacity * sizeof(int32_t)));
-    w.partial = reinterpret_cast<float *>(take((size_t)split_nsplit(m) * m * n_obj * sizeof(float)));
+    w.gbest = reinterpret_cast<uint32_t *>(take((size_t)m * n_obj * sizeof(uint32_t)));
     w.fp32_bytes = aoc_dense_match_workspace_bytes(m, n, n_obj);
     w.fp32_ws = take(w.fp32_bytes);
     w.total = off;
@@ -423,23 +552,42 @@ int aoc_dense_match_min_split(const float *query, const void *query_rec, const f
     hipStream_t st = aoc_hip_stream(stream);
     const SplitWs w = split_carve(workspace, m, n, n_obj);
     if (hipMemsetAsync(w.gate, 0, 16, st) != hipSuccess) return AOC_ERR_LAUNCH;
+    if (hipMemsetAsync(w.gbest, 0, (size_t)m * n_obj * sizeof(uint32_t), st) != hipSuccess) return AOC_ERR_LAUNCH;
     const int64_t plan_threads = w.tile_capacity * SP_TILE > n ? w.tile_capacity * SP_TILE : n;
     hipLaunchKernelGGL(split_plan_kernel, dim3((unsigned)((plan_threads + 255) / 256)), dim3(256), 0, st, obj_rows, counts, obj_offsets, n_obj, n,
-                       right_bits, wrong_bits, overflow_flag, w.tile_capacity, w.tile_rows, w.tile_obj, w.n_tiles, w.gate);
+                       right_bits, wrong_bits, overflow_flag, static_cast<const uint4 *>(pool_rec), w.tile_capacity, w.tile_rows, w.tile_obj,
+                       w.n_tiles, w.gate, w.pmax);
     const int ns = split_nsplit(m);
     const dim3 grid((unsigned)((m + SP_ROWS_PER_BLOCK - 1) / SP_ROWS_PER_BLOCK), ns);
-    const size_t lds = (size_t)2 * SP_NB * SP_TILE * SP_LDS_ROW * 16 + 2 * SP_NB * sizeof(int32_t);
+    const size_t lds = SP_LDS_BYTES;
+    static const bool lds_ok = hipFuncSetAttribute(reinterpret_cast<const void *>(dense_prune_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
+    if (!lds_ok) return AOC_ERR_LAUNCH;
     const AocDenseProbe probe = aoc_take_dense_probe();
+    static const int dbg = getenv("AOC_DENSE_DEBUG") ? atoi(getenv("AOC_DENSE_DEBUG")) : 0;       // developer switch: timing experiments only
     if (probe.start) (void)hipEventRecord(probe.start, st);
-    hipLaunchKernelGGL(dense_split_kernel, grid, dim3(SP_NW * 64), lds, st, static_cast<const uint4 *>(query_rec), m,
-                       static_cast<const uint4 *>(pool_rec), w.tile_rows, w.tile_obj, w.n_tiles, w.gate, n_obj, w.partial);
+    hipLaunchKernelGGL(dense_prune_kernel, grid, dim3(SP_NW * 64), lds, st, static_cast<const uint4 *>(query_rec), query_sqnorm, m,
+                       static_cast<const uint4 *>(pool_rec), w.tile_rows, w.tile_obj, w.n_tiles, w.gate, w.pmax, n_obj, w.gbest, dbg);
     if (probe.stop) (void)hipEventRecord(probe.stop, st);
-    hipLaunchKernelGGL(dense_split_finalize_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, w.partial, ns, m, n_obj, counts, w.gate,
+    hipLaunchKernelGGL(dense_split_finalize_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, w.gbest, m, n_obj, counts, w.gate,
                        query_sqnorm, obj_bias, out, out_pixel_stride, out_obj_stride, transform);
     AOC_RETURN_IF_LAUNCH_FAILED();
     // exact-fp32 kernels: run only when the gate is set
     return aoc_dense_match_min_gated(query, m, C, pool, fg_rows, counts + n_obj, n, wrong_bits, obj_bias, n_obj, out, out_pixel_stride,
                                      out_obj_stride, transform, w.fp32_ws, w.fp32_bytes, w.gate, stream);
+}
+
+// Developer counters of the coarse-then-rescore kernel, summed over all launches since the last reset:
+// out[0] (reference tile, query tile) pairs tested, out[1] pairs rescored, out[2] reference tiles with a rescoring, out[3] reference tiles.
+int aoc_dense_prune_stats(uint64_t *out4, int reset) {
+    if (!out4) return AOC_ERR_INVALID_ARG;
+    unsigned long long v[4] = {0, 0, 0, 0};
+    if (hipMemcpyFromSymbol(v, HIP_SYMBOL(g_prune_stats), sizeof(v)) != hipSuccess) return AOC_ERR_LAUNCH;
+    for (int i = 0; i < 4; ++i) out4[i] = v[i];
+    if (reset) {
+        const unsigned long long z[4] = {0, 0, 0, 0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_prune_stats), z, sizeof(z)) != hipSuccess) return AOC_ERR_LAUNCH;
+    }
+    return AOC_OK;
 }
 
 }  // extern "C"

@@ -7,7 +7,7 @@ import aoc_amd
 from aoc_amd import ops, synthetic as syn
 
 R = int(sys.argv[1]) if len(sys.argv) > 1 else 4
-cfg = syn.CONFIGS["cfg2"]
+cfg = syn.CONFIGS[sys.argv[2] if len(sys.argv) > 2 else "cfg2"]
 clip = syn.make_clip(cfg, 0, frames=R + 1)
 emb = torch.from_numpy(clip["emb"]).cuda()
 lab = torch.from_numpy(np.stack([syn.one_hot(l, cfg.n_obj) for l in clip["lab"]])).cuda()
@@ -36,6 +36,10 @@ for mode in ("fp32", "split"):
     ms = e0.elapsed_time(e1) / n
     print(f"{mode}: R={R} {ms:.3f} ms/call  {flops / ms / 1e9:.1f} fp32-equivalent TFLOP/s", flush=True)
     res = out.clone()
+    if mode == "split":
+        st = ops.dense_prune_stats()
+        print("  rescored %.3f of the (reference tile, query tile) pairs; %.3f of the reference tiles had a rescoring" %
+              (st["rescored"] / max(st["tested"], 1), st["tiles_rescored"] / max(st["tiles"], 1)), flush=True)
     if mode == "fp32":
         ref = res
 print("max |split - fp32| =", float((res - ref).abs().max()))
