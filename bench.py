@@ -711,6 +711,7 @@ def main():
                 wl.pretouch(gates, acts, args.dense, not args.no_pipeline)
         run_steps(args.warmup)
         barrier()
+        ops.dense_prune_stats(reset=True)     # counters of the coarse-then-rescore dense kernel over the timed region (reads synchronise: outside it)
         for wl in workloads:
             wl.count_r = True
         timer.enabled = True                 # HIP events around every op, on the stream the op is launched on
@@ -745,6 +746,7 @@ def main():
             r_hist[r] = r_hist.get(r, 0) + c
 
     probe_ms = timer.kernel_probe.elapsed_ms()
+    prune = ops.dense_prune_stats(reset=True)
 
     # second, informational region (N = 1 only): a few steps with the exact-fp32 dense kernel (`--dense fp32`), so that the line also
     # carries the figure of the all-fp32 arithmetic next to the headline
@@ -780,7 +782,7 @@ def main():
         roofline = None
         dense_ops = [n for n in ("dense_match_min_split", "dense_match_min") if n in kernels]
         if dense_ops:
-            # the single kernel with the largest share of GPU time (profiles/: dense_split_kernel); the k-means op is a chain of
+            # the single kernel with the largest share of GPU time (profiles/: dense_prune_kernel); the k-means op is a chain of
             # ~160 small launches per call and is reported as its own object below
             dom = max(dense_ops, key=lambda n: kernels[n]["total_ms"])
             k = dict(kernels[dom])
@@ -794,17 +796,21 @@ def main():
                                 peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s", frac=round(k["tflops"] / PEAK_FP32_MFMA_TFLOPS, 4), traffic=None,
                                 avg_launch_ms=k["avg_ms"], algorithmic_flops_per_launch=k["avg_flops"])
             else:
-                # algorithmic flops (2 m n C) against the fp16 pipe the kernel runs on; the instruction stream
-                # executes 3 split products on K padded 100 -> 112, i.e. 3.36x the algorithmic flops
-                executed = k["tflops"] * 3.0 * 112.0 / C
-                roofline = dict(kernel="dense_split_kernel (aoc_dense_match_min_split)", bound="mfma", achieved=k["tflops"],
+                # algorithmic flops (2 m n C) against the fp16 pipe the kernel runs on; the instruction stream executes ONE
+                # fp16 product (K padded 100 -> 112) for every (reference tile, query tile) pair and the two cross products only for the
+                # pairs that could hold a maximum (counted by the kernel over the timed region)
+                rescored = prune["rescored"] / max(prune["tested"], 1)
+                executed = k["tflops"] * (1.0 + 2.0 * rescored) * 112.0 / C
+                roofline = dict(kernel="dense_prune_kernel (aoc_dense_match_min_split)", bound="mfma", achieved=k["tflops"],
                                 peak=PEAK_F16_MFMA_TFLOPS, unit="TFLOP/s", frac=round(k["tflops"] / PEAK_F16_MFMA_TFLOPS, 4), traffic=None,
                                 avg_launch_ms=k["avg_ms"], algorithmic_flops_per_launch=k["avg_flops"],
                                 executed_tflops=round(executed, 1), pipe_frac=round(executed / PEAK_F16_MFMA_TFLOPS, 4),
-                                note="fp32-equivalent products from 3 fp16 MFMAs (hi*hi + hi*lo + lo*hi, fp32 accumulate); frac prices the "
-                                     "ALGORITHMIC fp32 flops against the dense fp16 peak, pipe_frac the executed ones; avg_launch_ms = hipEvents "
-                                     "recorded by the library immediately around the kernel while the other sequence's stream shares the GPU; traffic "
-                                     "(PMC FETCH/WRITE) is not measurable inside the run: the separate --pmc passes are under profiles/",
+                                rescored_pair_fraction=round(rescored, 4),
+                                note="fp32-equivalent distances from fp16 MFMAs: one hi*hi product prunes, the pairs that survive get hi*lo + lo*hi "
+                                     "added on chip (exactly the three-product value; same result as evaluating everything); frac prices the "
+                                     "ALGORITHMIC fp32 flops (2 m n C) against the dense fp16 peak, pipe_frac the executed ones; avg_launch_ms = "
+                                     "hipEvents recorded by the library immediately around the kernel while the other sequence's stream shares the "
+                                     "GPU; traffic (PMC FETCH/WRITE) is not measurable inside the run: the separate --pmc passes are under profiles/",
                                 op_avg_ms=k.get("op_avg_ms"))
                 if args.cu_reserve > 0:
                     # the kernel is launched on a stream whose CU mask leaves cu_reserve CUs to the k-means chains

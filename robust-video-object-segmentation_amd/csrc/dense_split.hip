@@ -33,7 +33,7 @@ constexpr int SP_NW = 8;                       // waves per block
 constexpr int SP_NQ = 2;                       // 32-pixel query tiles per wave (stationary B operands in registers)
 constexpr int SP_ROWS_PER_BLOCK = SP_NW * SP_NQ * 32;
 
-static_assert(SP_NORM_SLOT + 3 <= SP_K && SP_NORM_SLOT / 16 == SP_KS - 1 && (SP_NORM_SLOT % 16) + 3 <= 8, "norm slots live in the low half of the last k-step");
+static_assert(SP_NORM_SLOT + 4 <= SP_K && SP_NORM_SLOT / 16 == SP_KS - 1 && (SP_NORM_SLOT % 16) + 4 <= 8, "norm slots live in the low half of the last k-step");
 
 // ------------------------------------------------------------------------------------------
 // fp32 rows -> split records (+ |x|^2).  One thread per (row, k-step).
@@ -55,8 +55,13 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float *__restrict
         lo[e] = (_Float16)(v - (float)hi[e]);
     }
     if (ks == SP_KS - 1) {
-        float s = 0.0f;
-        for (int t = 0; t < C; ++t) s += xr[t] * xr[t];
+        float s = 0.0f, sl = 0.0f;
+        for (int t = 0; t < C; ++t) {
+            s += xr[t] * xr[t];
+            const float v = xr[t] * SP_SCALE;
+            const float l = (float)(_Float16)(v - (float)(_Float16)v);      // the lo value of channel t, as its own thread stores it
+            sl += l * l;
+        }
         if (sqnorm) sqnorm[row] = s;
         bad |= !(s <= 4000.0f);
         const float p = -16.0f * s;
@@ -66,6 +71,9 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float *__restrict
         hi[SP_NORM_SLOT % 16] = p1;
         hi[SP_NORM_SLOT % 16 + 1] = p2;
         hi[SP_NORM_SLOT % 16 + 2] = p3;
+        // slot 103: an upper bound of the Euclidean norm of the row's lo plane (the rescoring margin of the dense kernel); the
+        // query side multiplies it by zero
+        hi[SP_NORM_SLOT % 16 + 3] = (_Float16)(sqrtf(sl) * 1.002f + 1e-6f);
     }
     if (bad) atomicOr(overflow, 1);
     union { _Float16 h[32]; uint4 q[4]; } u;
@@ -89,7 +97,7 @@ __global__ __launch_bounds__(256) void split_plan_kernel(const int32_t *__restri
                                                           int32_t *__restrict__ tile_obj, int32_t *__restrict__ n_tiles,
                                                           int32_t *__restrict__ gate, uint32_t *__restrict__ pmax_bits) {
     const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    float sq = 0.0f;
+    float sq = 0.0f, ln = 0.0f;
     if (e < n) {
         const uint32_t mask = (n_obj >= 32) ? 0xffffffffu : ((1u << n_obj) - 1u);
         const uint32_t right = right_bits[e];
@@ -100,12 +108,17 @@ __global__ __launch_bounds__(256) void split_plan_kernel(const int32_t *__restri
             union { uint4 q; _Float16 hh[8]; } u;
             u.q = prec[(size_t)e * SP_REC + (SP_KS - 1) * 2];
             sq = -((float)u.hh[SP_NORM_SLOT % 16] + (float)u.hh[SP_NORM_SLOT % 16 + 1] + (float)u.hh[SP_NORM_SLOT % 16 + 2]) * 0.0625f;
+            ln = (float)u.hh[SP_NORM_SLOT % 16 + 3];
         }
     }
     // largest squared norm among the kept reference pixels (non-negative floats order like their bit patterns)
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) sq = __builtin_fmaxf(sq, __shfl_xor(sq, d));
+    for (int d = 32; d >= 1; d >>= 1) {
+        sq = __builtin_fmaxf(sq, __shfl_xor(sq, d));
+        ln = __builtin_fmaxf(ln, __shfl_xor(ln, d));
+    }
     if (aoc_lane() == 0 && sq > 0.0f) atomicMax(pmax_bits, __float_as_uint(sq));
+    if (aoc_lane() == 0 && ln > 0.0f) atomicMax(pmax_bits - 2, __float_as_uint(ln));      // gate[1]: largest lo-plane norm
     if (e == 0 && overflow && *overflow) atomicOr(gate, 1);
     const int64_t t = e / SP_TILE;
     const int i = (int)(e - t * SP_TILE);
@@ -232,6 +245,7 @@ __global__ __launch_bounds__(SP_NW * 64, 1) void dense_prune_kernel(const uint4 
 
     // ---- stationary query operands (both planes) and the per-pixel rescoring margin
     const float pmax = sqrtf(__uint_as_float(*pmax_bits)) * 1.001f;
+    const float plmax = __uint_as_float(*(pmax_bits - 2));
     f16x8 bh[SP_NQ][SP_KS], bl[SP_NQ][SP_KS];
     float eps[SP_NQ];
     bool valid[SP_NQ];
@@ -249,14 +263,19 @@ __global__ __launch_bounds__(SP_NW * 64, 1) void dense_prune_kernel(const uint4 
         }
         // norm slots: the query side holds the constant 2^15 (its own norm pieces sit in the record for when the
         // frame later joins the pool); everything else past the channels is zero on both planes
+        const float ql_own = (float)bh[iq][SP_KS - 1][SP_NORM_SLOT % 16 + 3];      // lanes h == 0: the norm of the query pixel's own lo plane
         if (h == 0) {
+            bh[iq][SP_KS - 1][SP_NORM_SLOT % 16 + 3] = (_Float16)0.0f;
             bh[iq][SP_KS - 1][SP_NORM_SLOT % 16] = (_Float16)SP_QCONST;
             bh[iq][SP_KS - 1][SP_NORM_SLOT % 16 + 1] = (_Float16)SP_QCONST;
             bh[iq][SP_KS - 1][SP_NORM_SLOT % 16 + 2] = (_Float16)SP_QCONST;
         }
-        // |exact - coarse| <= 2^-10 |qh||rh| (1 + 2^-11)^3 (each lo is at most 2^-11 of its hi) + the roundings of 14 more accumulations
+        // |exact - coarse| = |qh.rl + ql.rh| <= |qh| |rl| + |ql| |rh| (Euclidean norms of the planes, Cauchy-Schwarz) with |qh| <= 2^10 |q|
+        // (1 + 2^-11), the lo norms as the records carry them (rounded up) and the maxima over the kept reference pixels, plus the
+        // roundings of 14 more accumulations
         const float qn = valid[iq] ? sqrtf(q2[row]) : 0.0f;
-        eps[iq] = 1048.0f * qn * pmax + 8.0f * pmax * pmax + 8.0f;
+        const float ql = valid[iq] ? __shfl(ql_own, col) : 0.0f;
+        eps[iq] = (1026.0f * (qn * plmax + ql * pmax) + 8.0f * pmax * pmax + 8.0f) * ((dbg & 64) ? 0.4f : 1.0f);
     }
 
     // ---- DMA plan of this wave: transfer k of a chunk fills the LDS slots [64 (7 wave + k), +64); slot j holds row j / 28, position j % 28.

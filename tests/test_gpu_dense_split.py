@@ -234,3 +234,34 @@ def test_reused_proxies_accuracy(aoc):
         diff_cached.append(float((f_a[:, c0:c0 + 2] - f_c[:, c0:c0 + 2]).abs().mean()))
     assert np.mean(agree_cached) >= np.mean(agree_fresh) - 0.03, (agree_cached, agree_fresh)
     assert np.mean(diff_cached) <= 1.25 * np.mean(diff_fresh) + 1e-4, (diff_cached, diff_fresh)
+
+
+def test_pruning_with_ties_duplicates_and_mixed_norms(aoc):
+    """The coarse-then-rescore kernel may skip a (reference tile, query tile) pair only when no pixel of it can hold the minimum.
+    Adversarial pool: many exact duplicates of the query pixels (ties at distance 0), near-duplicates a few fp16-lo units apart, and
+    reference pixels whose norms span two orders of magnitude (the margin is priced with the LARGEST norm).  The raw distances must
+    equal the exact-fp32 kernel's within rounding, run after run (the set of rescored tiles depends on timing; the result must not)."""
+    rng = np.random.RandomState(11)
+    m, c, o = 1500, 100, 3
+    q = (np.maximum(rng.randn(m, c), 0) * 0.3).astype(np.float32)
+    dup = q[rng.randint(0, m, 6000)]                                           # exact copies of query pixels
+    near = dup[:3000] * np.float32(1.0 + 2.0 ** -13) + np.float32(2.0 ** -15)  # differ from a copy only in the lo plane
+    big = (np.maximum(rng.randn(4000, c), 0) * 3.0).astype(np.float32)         # norms ~ 10x
+    tiny = (np.maximum(rng.randn(3000, c), 0) * 0.003).astype(np.float32)      # norms ~ 1/100
+    pool = np.concatenate([dup, near, big, tiny, q[::-1].copy()]).astype(np.float32)
+    rng.shuffle(pool)
+    ids = rng.randint(0, o, pool.shape[0])
+    lab = torch.from_numpy((ids[:, None] == np.arange(o)).astype(np.float32))
+    q, pool = torch.from_numpy(q), torch.from_numpy(pool)
+    raw_f = _dense(aoc, q, pool, lab, None, "fp32", transform=False)
+    first = None
+    for _ in range(4):
+        raw_s = _dense(aoc, q, pool, lab, None, "split", transform=False)
+        assert float((raw_s - raw_f).abs().max()) < 2e-4                       # distances up to ~1e3 here: 2e-4 is a few fp32 ulps of them
+        small = raw_f < 1.0                                                     # where the minimum is a (near-)duplicate: plain ATOL_RAW
+        assert float((raw_s - raw_f)[small].abs().max()) < ATOL_RAW
+        if first is None:
+            first = raw_s
+        assert torch.equal(raw_s, first)                                        # deterministic although the pruning pattern is not
+    st = aoc.ops.dense_prune_stats()
+    assert 0 < st["rescored"] <= st["tested"]

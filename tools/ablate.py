@@ -28,18 +28,9 @@ if "local" in what:
 if "corr" in what:
     ops.proxy_corr_min = lambda *a, **k: None
 if "kmeans" in what:
-    _lib = aoc._lib
-    real = _lib.lib().aoc_kmeans_segmented_ex
     # keep the launch structure but run a single Lloyd iteration
-    real_km = ops.kmeans_segmented
-
-    def fake_km(*a, **k):
-        k["iters"] = 1
-        return real_km(*a, **k)
-    if "iters" in real_km.__code__.co_varnames:
-        ops.kmeans_segmented = fake_km
-    else:
-        print("ablate: kmeans_segmented has no iters argument", file=sys.stderr)
+    hotpath.KMEANS_ITERS = 1
+    aoc.matching.KMEANS_ITERS = 1 if hasattr(aoc.matching, "KMEANS_ITERS") else None
 if "gates" in what:
     orig = bench.frame_step
 

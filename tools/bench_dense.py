@@ -8,13 +8,16 @@ from aoc_amd import ops, synthetic as syn
 
 R = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 cfg = syn.CONFIGS[sys.argv[2] if len(sys.argv) > 2 else "cfg2"]
-clip = syn.make_clip(cfg, 0, frames=R + 1)
+import os
+STRIDE = int(os.environ.get("POOL_STRIDE", "1"))          # pool = frames 0, STRIDE, 2 STRIDE, ... (the bench's memory policy: 5)
+QOFF = int(os.environ.get("QUERY_OFFSET", "1"))           # query = last pool frame + QOFF
+clip = syn.make_clip(cfg, 0, frames=(R - 1) * STRIDE + QOFF + 1)
 emb = torch.from_numpy(clip["emb"]).cuda()
 lab = torch.from_numpy(np.stack([syn.one_hot(l, cfg.n_obj) for l in clip["lab"]])).cuda()
 hw, C, O = cfg.h * cfg.w, cfg.c, cfg.n_obj
-pool = emb[:R].reshape(-1, C)
-q = emb[R].reshape(-1, C)
-prep = ops.label_prep(lab[:R].reshape(-1, O))
+pool = emb[0:(R - 1) * STRIDE + 1:STRIDE].reshape(-1, C).contiguous()
+q = emb[(R - 1) * STRIDE + QOFF].reshape(-1, C)
+prep = ops.label_prep(lab[0:(R - 1) * STRIDE + 1:STRIDE].reshape(-1, O).contiguous())
 out = torch.empty(O, hw, device="cuda")
 bias = torch.zeros(O, device="cuda")
 ps = ops.split_rows(pool)
