@@ -240,10 +240,16 @@ int aoc_dense_match_min_f16(const float *query, int64_t m, int C,
  * Dense pixel-level matching on the fp16 matrix pipe with fp32-equivalent products (same reference
  * lines as aoc_dense_match_min).  Each embedding row is converted ONCE into a "split record":
  * x * 2^10 = hi + lo with hi, lo fp16 (two 11-bit significands: |error| <= 2^-22 |x|, typically 2^-23), plus the three fp16 pieces of -16 |x|^2 in
- * spare k-slots.  q.r is then qh.rh + qh.rl + ql.rh accumulated in fp32 by v_mfma_f32_32x32x16_f16
- * (the dropped ql.rl term is < 2^-22 |q| |r|): a product carries up to about 4x the rounding error of an fp32 product, and the deviations
- * of the min-distances from the fp32 reference stay within a small multiple of the
- * reference's own fp32 rounding (a few 1e-7 on distances of O(1); tests pin <= 5e-6 on the outputs).
+ * spare k-slots (and, in a fourth one, an upper bound of the norm of the row's lo plane).  q.r is then qh.rh + qh.rl + ql.rh
+ * accumulated in fp32 by v_mfma_f32_32x32x16_f16 (the dropped ql.rl term is < 2^-22 |q| |r|): a product carries up to about 4x the
+ * rounding error of an fp32 product, and the deviations of the min-distances from the fp32 reference stay within a small multiple
+ * of the reference's own fp32 rounding (a few 1e-7 on distances of O(1); tests pin <= 5e-6 on the outputs).
+ *
+ * The kernel evaluates the qh.rh product for every (32 reference pixels x 32 query pixels) pair and the two cross products only for
+ * the pairs that can hold a minimum: |qh.rl + ql.rh| <= |qh||rl| + |ql||rh| (plane norms from the records), so a pair whose one-product
+ * value lies further than that margin from the best three-product value already known for its (query pixel, object) is skipped.  The
+ * minimum always survives and its value does not depend on what else was evaluated: same result as evaluating all three products
+ * everywhere, run after run (tests/test_gpu_dense_split.py), at about 40 % of the matrix instructions.
  *
  * The fast kernels need (a) every |x| * 2^10 <= 65000 and |x|^2 <= 4000 and (b) every kept pool row right
  * for exactly one object (one-hot labels, as in the reference's eval loop).  Both are checked on the
@@ -279,7 +285,7 @@ int aoc_dense_prune_stats(uint64_t *out4, int reset);
 
 /* Measurement probe: the NEXT aoc_dense_match_min / aoc_dense_match_min_split call made by the calling thread records
  * `start` immediately before and `stop` immediately after its matrix kernel (dense_match_partial_kernel /
- * dense_split_kernel) on the call's stream, then the probe is cleared.  Both are hipEvent_t created by the caller
+ * dense_prune_kernel) on the call's stream, then the probe is cleared.  Both are hipEvent_t created by the caller
  * (bench.py uses it to time that one kernel live, next to the rocprofv3 figure).  NULL, NULL disarms. */
 int aoc_dense_match_set_probe(void *start_event, void *stop_event);
 

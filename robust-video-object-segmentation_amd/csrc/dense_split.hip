@@ -1,13 +1,14 @@
 // Dense pixel-level matching (AEM:61-89, 178-227) on the fp16 matrix pipe with fp32-equivalent products.
 //
-// Every fp32 value x (scaled by 2^10) is split into hi = fp16(x') and lo = fp16(x' - hi): hi + lo represents x'
-// to 2^-22 relative (two 11-bit significands; typically 2^-23), and q.r = qh.rh + qh.rl + ql.rh (+ a ql.rl term < 2^-22 |q||r| that is
-// dropped) accumulates in
-// fp32 inside v_mfma_f32_32x32x16_f16 -- three matrix instructions at 16x the fp32 MFMA rate.  The reference
-// pixel's -|r|^2/2 rides along in three spare k-slots (K = 100 pads to 112 anyway), so one accumulator holds
-// 2^20 * (q.r - |r|^2/2) and the min over reference pixels becomes a max over raw accumulators: the epilogue
-// is one v_max3 per two outputs.  |q|^2 and the 5e4 wrong-label padding (AEM:84-88) are applied per query
-// pixel at the end: with one-hot labels min_j(d_j + 5e4 wrong[j,o]) = min(own_o, 5e4 + min_{o' != o} own_o').
+// Every fp32 value x (scaled by 2^10) is split into hi = fp16(x') and lo = fp16(x' - hi): hi + lo represents x' to 2^-22 relative
+// (two 11-bit significands; typically 2^-23), and q.r = qh.rh + qh.rl + ql.rh (+ a ql.rl term < 2^-22 |q||r| that is dropped)
+// accumulates in fp32 inside v_mfma_f32_32x32x16_f16.  The reference pixel's -|r|^2/2 rides along in three spare k-slots of the hi
+// plane (K = 100 pads to 112 anyway), so one accumulator holds 2^20 * (q.r - |r|^2/2) and the min over reference pixels becomes a max
+// over raw accumulators.  |q|^2 and the 5e4 wrong-label padding (AEM:84-88) are applied per query pixel at the end: with one-hot
+// labels min_j(d_j + 5e4 wrong[j,o]) = min(own_o, 5e4 + min_{o' != o} own_o').
+//
+// dense_prune_kernel evaluates the qh.rh product everywhere and the two cross products only where they can matter (see its header):
+// about 40 % of the matrix instructions of evaluating all three everywhere, for the same result.
 //
 // This kernel only runs when (a) every scaled value fits fp16 and (b) every kept reference pixel is right for
 // exactly one object; both facts are device flags, and the exact-fp32 kernels of correlation.hip take over on
@@ -36,7 +37,8 @@ constexpr int SP_ROWS_PER_BLOCK = SP_NW * SP_NQ * 32;
 static_assert(SP_NORM_SLOT + 4 <= SP_K && SP_NORM_SLOT / 16 == SP_KS - 1 && (SP_NORM_SLOT % 16) + 4 <= 8, "norm slots live in the low half of the last k-step");
 
 // ------------------------------------------------------------------------------------------
-// fp32 rows -> split records (+ |x|^2).  One thread per (row, k-step).
+// fp32 rows -> split records (+ |x|^2).  One thread per (row, k-step).  Record = hi plane (14 x 16 B: per k-step [k0-7][k8-15]), then the
+// lo plane in the same order; hi-plane slots 100..102 = the three fp16 pieces of -16 |x|^2, slot 103 = an upper bound of the lo plane's norm.
 __global__ __launch_bounds__(256) void split_rows_kernel(const float *__restrict__ x, int64_t n, int C, uint4 *__restrict__ rec,
                                                           float *__restrict__ sqnorm, int32_t *__restrict__ overflow) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -29,7 +29,6 @@ for k, (n, v) in sorted(acc.items(), key=lambda kv: -kv[1][1])[:25]:
 PY
   fi
 done
-ls -la "$out"
 
 # ---- round 2: the correlation kernel and the calibration streams by themselves (tools/bench_corr.py, tools/bench_calib.py)
 python $GRAFT_REPO_ROOT/tools/bench_corr.py --config cfg2 --batches 1,4,16,32 --check > "$out/corr_cfg2.jsonl" 2>/dev/null
@@ -60,4 +59,18 @@ PY
 done
 $GRAFT_REPO_ROOT/tools/pmc_corr.sh SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES > "$out/pmc_sq_corr_B16.txt" 2>&1
 $GRAFT_REPO_ROOT/tools/pmc_corr.sh SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAIT_INST_LDS >> "$out/pmc_sq_corr_B16.txt" 2>&1
+
+# ---- the dense kernel by itself: pools as the bench's memory policy builds them (every 5th frame), stand-alone time, share of
+# rescored pairs, PMC traffic and SQ counters of dense_prune_kernel
+cd $GRAFT_REPO_ROOT
+for R in 1 3 6 12; do
+  POOL_STRIDE=5 QUERY_OFFSET=3 timeout 200 python tools/bench_dense.py $R 2>/dev/null | grep -v "^fp32\|split_rows" >> "$out/dense_standalone.txt"
+done
+POOL_STRIDE=5 QUERY_OFFSET=3 tools/kstats.sh 6 python $GRAFT_REPO_ROOT/tools/bench_dense.py 6 > "$out/kernel_stats_dense_R6.txt" 2>&1
+for ctr in FETCH_SIZE WRITE_SIZE; do
+  POOL_STRIDE=5 QUERY_OFFSET=3 tools/pmc_kernel.sh dense_prune "$ctr" python $GRAFT_REPO_ROOT/tools/bench_dense.py 6 >> "$out/pmc_dense_R6.txt" 2>&1
+done
+POOL_STRIDE=5 QUERY_OFFSET=3 tools/pmc_kernel.sh dense_prune "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" python $GRAFT_REPO_ROOT/tools/bench_dense.py 6 >> "$out/pmc_dense_R6.txt" 2>&1
+POOL_STRIDE=5 QUERY_OFFSET=3 tools/pmc_kernel.sh dense_prune "SQ_INSTS_MFMA SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD" python $GRAFT_REPO_ROOT/tools/bench_dense.py 6 >> "$out/pmc_dense_R6.txt" 2>&1
+tools/probe/mfma_probe > "$out/mfma_probe.txt" 2>&1
 ls -la "$out"
