@@ -199,6 +199,7 @@ class ClipWorkload:
         self.ahead = {}                                    # frame -> adaptive proxies already enqueued on a side stream
         self.pool_event = None                             # recorded when the pool of the current group is final
         self.chains = mc.MEM_EVERY                         # k-means chains enqueued ahead (bench --chains)
+        self.chain_plan = None                             # batch sizes of a group's chains, e.g. [1, 2, 2] (bench --chain-plan)
         self.dense_stream = None                           # CU-masked stream for the dense kernel alone
         self.reuse_proxies = False                         # non-parity mode: one k-means per pool state
         self.bank = None                                   # non-parity mode: hotpath.IncrementalProxyBank (one clustering per pool FRAME)
@@ -284,7 +285,7 @@ class ClipWorkload:
             ev.record()
             if self.side is not None and pipeline:
                 ahead = hotpath.launch_cluster_proxies(self.mc, ref_emb, ref_lab, init, self.side, wait_event=ev)
-                for nb in range(2, self.chains):               # batched chains of every size the run can ask for
+                for nb in (sorted({b for b in self.chain_plan if b > 1}) if self.chain_plan else range(2, self.chains)):   # batched chains of every size the run can ask for
                     hotpath.launch_cluster_proxies_batch(self.mc, ref_emb, ref_lab, [init] * nb, self.side, wait_event=ev)
                 feat, head, _ = hotpath.proto_mask_features(self.mc, ref_emb, ref_lab, self.emb[t - 1], self.lab[t - 1], self.emb[t], self.bias,
                                                             cluster_ahead=ahead, dense_state=self.dense_state, dense_precision=dense_precision,
@@ -309,17 +310,41 @@ def make_activations(gates, O, h, w, device, seed):
     return [torch.randn(O, c, hh, ww, generator=g).to(device) for (_, c, hh, ww, _) in gates.plan(h, w)]
 
 
-def launch_chains(wl):
-    """Enqueue the k-means chain of the current frame and of the following frames of its group (they all see the pool as it is now)
-    on the side stream: the current frame alone (it is needed first), the others batched into one chain."""
+def _launch_batch(wl, frames):
     ref_emb, ref_lab = wl.refs()
-    t = wl.t
-    rest = wl.next_in_group()[:max(0, wl.chains - 1)]
-    wl.ahead[t] = hotpath.launch_cluster_proxies(wl.mc, ref_emb, ref_lab, wl.init_rows[t][0], wl.side, wait_event=wl.pool_event)
-    if rest:
-        outs = hotpath.launch_cluster_proxies_batch(wl.mc, ref_emb, ref_lab, [wl.init_rows[f][0] for f in rest], wl.side, wait_event=wl.pool_event)
-        for f, a in zip(rest, outs):
+    if len(frames) == 1:
+        wl.ahead[frames[0]] = hotpath.launch_cluster_proxies(wl.mc, ref_emb, ref_lab, wl.init_rows[frames[0]][0], wl.side, wait_event=wl.pool_event)
+    else:
+        outs = hotpath.launch_cluster_proxies_batch(wl.mc, ref_emb, ref_lab, [wl.init_rows[f][0] for f in frames], wl.side, wait_event=wl.pool_event)
+        for f, a in zip(frames, outs):
             wl.ahead[f] = a
+
+
+def launch_chains(wl, done=None):
+    """Enqueue the k-means chain of the current frame and of the following frames of its group (they all see the pool as it is now)
+    on the side stream.  With a plan (--chain-plan, e.g. 1,2,2): the group's frames are cut into batches of those sizes, one chain per
+    batch; the batch of the current frame and the one after it are enqueued (one batch of lead).  Without: the current frame alone
+    (it is needed first), the next --chains - 1 frames batched into one chain."""
+    t = wl.t
+    if wl.chain_plan:
+        g = wl.groups[wl.group_of[t]]
+        cuts, i = [], 0
+        for b in wl.chain_plan:
+            if i < len(g):
+                cuts.append(g[i:i + b])
+                i += b
+        if i < len(g):
+            cuts.append(g[i:])
+        k = next(j for j, c in enumerate(cuts) if t in c)
+        for c in cuts[k:k + 2]:
+            todo = [f for f in c if f >= t and f != done and f not in wl.ahead]
+            if todo:
+                _launch_batch(wl, todo)
+        return
+    rest = wl.next_in_group()[:max(0, wl.chains - 1)]
+    _launch_batch(wl, [t])
+    if rest:
+        _launch_batch(wl, rest)
 
 
 def frame_step(wl, gates, acts, dense_precision="split", pipeline=True, defer_corr=False):
@@ -342,7 +367,10 @@ def frame_step(wl, gates, acts, dense_precision="split", pipeline=True, defer_co
             ahead = wl.ahead.pop(t)
             wl.cached_ahead = ahead if wl.reuse_proxies else None
         nxt = wl.next_in_group()
-        if not wl.reuse_proxies and nxt and nxt[0] not in wl.ahead:
+        if wl.chain_plan:
+            if not wl.reuse_proxies and nxt:
+                launch_chains(wl, done=t)                   # keeps one batch of lead (no-op when it is already enqueued)
+        elif not wl.reuse_proxies and nxt and nxt[0] not in wl.ahead:
             wl.ahead[nxt[0]] = hotpath.launch_cluster_proxies(wl.mc, ref_emb, ref_lab, wl.init_rows[nxt[0]][0], wl.side, wait_event=wl.pool_event)
         feat, head, aux = hotpath.proto_mask_features(wl.mc, ref_emb, ref_lab, wl.emb[t - 1], wl.lab[t - 1], wl.emb[t], wl.bias,
                                                       cluster_ahead=ahead, dense_state=wl.dense_state, dense_precision=dense_precision,
@@ -525,6 +553,8 @@ def main():
                     help="keep the main streams off this many CUs (HIP CU mask) so the side-stream k-means chain always finds free CUs")
     ap.add_argument("--chains", type=int, default=3,
                     help="frames whose k-means is enqueued right after a pool update (1 = only the next frame; the others are batched into one chain)")
+    ap.add_argument("--chain-plan", default="",
+                    help="batch sizes of the k-means chains of a group of MEM_EVERY frames, e.g. 1,2,2 (overrides --chains)")
     ap.add_argument("--dense-stream", dest="mask_main", action="store_false",
                     help="put only the dense kernel under the CU mask (on its own stream) instead of the whole main stream")
     ap.add_argument("--reuse-proxies", action="store_true",
@@ -615,6 +645,7 @@ def main():
                               phase=s) for s in range(n_streams)]
     for wl in workloads:
         wl.chains = 1 if args.reuse_proxies else max(1, min(args.chains, mc.MEM_EVERY))
+        wl.chain_plan = [int(x) for x in args.chain_plan.split(",")] if (args.chain_plan and not args.reuse_proxies) else None
         wl.reuse_proxies = args.reuse_proxies
         if args.incremental_proxies:
             wl.enable_incremental()

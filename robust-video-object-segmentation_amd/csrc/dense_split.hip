@@ -376,6 +376,8 @@ __global__ __launch_bounds__(SP_NW * 64, 1) void dense_prune_kernel(const uint4 
         // (b) the four tiles of chunk s
         const char *chunk_base = lds_bytes + (s % SP_NBUF) * SP_CHUNK_BYTES;
         const int n_here = min(SP_NB, n_mine - s * SP_NB);
+        // the first two A fragments of a tile are requested while the previous tile's epilogue runs
+        f16x8 pre0 = frag(chunk_base, 2 * ks_of(0)), pre1 = frag(chunk_base, 2 * ks_of(1));
 #pragma unroll 1
         for (int t = 0; t < n_here; ++t) {
             const char *tile_base = chunk_base + t * (SP_TILE * SP_REC * 16);
@@ -389,14 +391,18 @@ __global__ __launch_bounds__(SP_NW * 64, 1) void dense_prune_kernel(const uint4 
                 for (int r = 0; r < 16; ++r) acc[iq][r] = 0.0f;
             {
                 f16x8 af[3];
-                af[0] = frag(tile_base, 2 * ks_of(0));
-                af[1] = frag(tile_base, 2 * ks_of(1));
+                af[0] = pre0;
+                af[1] = pre1;
 #pragma unroll
                 for (int kk = 0; kk < SP_KS; ++kk) {
                     if (kk + 2 < SP_KS) af[(kk + 2) % 3] = frag(tile_base, 2 * ks_of(kk + 2));
 #pragma unroll
                     for (int iq = 0; iq < SP_NQ; ++iq)
                         acc[iq] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[kk % 3], bh[iq][ks_of(kk)], acc[iq], 0, 0, 0);
+                }
+                if (t + 1 < n_here) {
+                    pre0 = frag(tile_base + SP_TILE * SP_REC * 16, 2 * ks_of(0));
+                    pre1 = frag(tile_base + SP_TILE * SP_REC * 16, 2 * ks_of(1));
                 }
             }
             // which query tiles may hold a new maximum (wave-uniform)
