@@ -265,3 +265,20 @@ def test_pruning_with_ties_duplicates_and_mixed_norms(aoc):
         assert torch.equal(raw_s, first)                                        # deterministic although the pruning pattern is not
     st = aoc.ops.dense_prune_stats()
     assert 0 < st["rescored"] <= st["tested"]
+
+
+@pytest.mark.parametrize("name,R", [("cfg4", 2), ("cfg3", 3)])
+def test_full_size_configs_against_exact_fp32(aoc, name, R):
+    """BASELINE configs[3] / [2] at full map size (181x321 with 9 objects, 145x261 with 6): the coarse-then-rescore kernel against the
+    exact-fp32 kernel on a synthetic clip whose pool is built as the memory policy builds it (every 5th frame)."""
+    syn = aoc.synthetic
+    cfg = syn.CONFIGS[name]
+    clip = syn.make_clip(cfg, 3, frames=(R - 1) * 5 + 3)
+    pool = torch.from_numpy(clip["emb"][0:(R - 1) * 5 + 1:5].reshape(-1, cfg.c).copy())
+    lab = torch.from_numpy(np.concatenate([syn.one_hot(clip["lab"][i], cfg.n_obj).reshape(-1, cfg.n_obj) for i in range(0, (R - 1) * 5 + 1, 5)]))
+    q = torch.from_numpy(clip["emb"][(R - 1) * 5 + 2].reshape(-1, cfg.c).copy())
+    bias = torch.linspace(-0.2, 0.2, cfg.n_obj)
+    got = _dense(aoc, q, pool, lab, bias, "split")
+    want = _dense(aoc, q, pool, lab, bias, "fp32")
+    assert got.shape == (cfg.n_obj, cfg.h * cfg.w)
+    assert float((got - want).abs().max()) < ATOL

@@ -1,0 +1,43 @@
+"""Developer micro-benchmark: the 20-iteration k-means chain alone (aoc_kmeans_segmented via hotpath.launch_cluster_proxies_batch) at cfg2 size.
+Usage: python tools/bench_kmeans.py <pool frames R> <frames per chain F>"""
+import sys, time
+import numpy as np
+import torch
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
+import aoc_amd
+from aoc_amd import hotpath, synthetic as syn
+
+R = int(sys.argv[1]) if len(sys.argv) > 1 else 6
+F = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+cfg = syn.CONFIGS["cfg2"]
+clip = syn.make_clip(cfg, 0, frames=(R - 1) * 5 + 1)
+O, C = cfg.n_obj, cfg.c
+emb = torch.from_numpy(clip["emb"][0::5][:R].copy()).cuda()
+lab_ids = clip["lab"][0::5][:R]
+lab = torch.from_numpy(np.stack([syn.one_hot(l, O) for l in lab_ids])).cuda()
+mc = hotpath.MatchingConfig()
+counts = [int((lab_ids == o).sum()) for o in range(O)]
+inits = []
+for f in range(F):
+    rows = syn.kmeans_init_rows(100 + f, counts, mc.CLUSTER_NUM)
+    init = np.zeros((O, mc.CLUSTER_NUM), np.int32)
+    for o, r in enumerate(rows):
+        if r is not None:
+            init[o, :len(r)] = r
+    inits.append(torch.from_numpy(init).cuda())
+side = torch.cuda.Stream()
+def run():
+    if F == 1:
+        return hotpath.launch_cluster_proxies(mc, emb, lab, inits[0], side)
+    return hotpath.launch_cluster_proxies_batch(mc, emb, lab, inits, side)
+for _ in range(3):
+    run()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+n = 10
+for _ in range(n):
+    run()
+torch.cuda.synchronize()
+ms = (time.perf_counter() - t0) / n * 1e3
+rows = sum(counts)
+print(f"k-means chain R={R} F={F}: {ms:.3f} ms per chain ({ms / F:.3f} per frame), {rows} rows x {F} replicas", flush=True)
