@@ -916,7 +916,8 @@ __global__ __launch_bounds__(1024) void km_blockscan_kernel(const int32_t *__res
                                                              const int32_t *__restrict__ hist, int32_t *__restrict__ blockoff, int nb_max,
                                                              int kmax, int32_t *__restrict__ counts, int32_t *__restrict__ cbase,
                                                              int32_t *__restrict__ cchunk, int32_t *__restrict__ owner_cluster,
-                                                             int32_t *__restrict__ owner_local, int nch_cap) {
+                                                             int32_t *__restrict__ owner_local, int nch_cap,
+                                                             uint32_t *__restrict__ cflag) {
     __shared__ int32_t ltot[AOC_MAX_CLUSTERS];
     __shared__ int32_t lchunk[AOC_MAX_CLUSTERS + 1];
     const int s = blockIdx.x;
@@ -969,6 +970,10 @@ __global__ __launch_bounds__(1024) void km_blockscan_kernel(const int32_t *__res
             }
             owner_cluster[cb + i] = oc;
             owner_local[cb + i] = ol;
+            if (cflag) {
+#pragma unroll
+                for (int g = 0; g < 8; ++g) cflag[(size_t)(cb + i) * 8 + g] = 0u;      // nothing published yet in this pass
+            }
         }
     }
 }
@@ -1255,6 +1260,182 @@ __global__ __launch_bounds__(256) void km_chunk_fold_kernel(const float *__restr
             const int t = ks_wave_sum(k[i].acc);
             if (lane == 0) {
                 if (k[i].bad) cexp[(size_t)chunk * C + f] = (int8_t)KC_UNSAFE;
+                cinc0[(size_t)chunk * C + f] = t + k[i].bump0;
+                cinc1[(size_t)chunk * C + f] = t + k[i].bump1;
+            }
+        }
+    }
+}
+
+// P0 + P1 + P2 in one pass over the rows ("scan-fold").  Same grid and roles as km_chunk_fold_kernel, but the workgroup keeps all
+// KS_T member blocks of its chunk (its feature group's columns) in LDS and
+//   1. sums them in any order and PUBLISHES the chunk's local sums (csum + a flag per (chunk, feature group)),
+//   2. adds up the local sums of the cluster's earlier tail chunks (lanes = predecessor chunks; a chunk id is dispatched after every
+//      smaller one, so the flags it waits for belong to workgroups that are running or done) on top of the exact head sum: the
+//      any-order prefix the binade prediction needs,
+//   3. predicts the binade exactly as km_chunk_predict_kernel does and folds the staged rows in it.
+// A flag that does not arrive within the polling budget only makes the wave mark its features KC_UNSAFE: the stitch then folds that
+// chunk from its rows -- time, never exactness (and no dependence on the dispatch order for progress).
+constexpr int KC_POLL_BUDGET = 1 << 16;
+__global__ __launch_bounds__(256) void km_chunk_scanfold_kernel(const float *__restrict__ pool, int C, const int32_t *__restrict__ seg_off,
+                                                                 const int32_t *__restrict__ counts, const int32_t *__restrict__ cbase,
+                                                                 const uint32_t *__restrict__ moff, int kmax,
+                                                                 const int32_t *__restrict__ owner_cluster, const int32_t *__restrict__ owner_local,
+                                                                 const int32_t *__restrict__ cchunk, const float *__restrict__ head_state,
+                                                                 float *__restrict__ csum, uint32_t *__restrict__ cflag,
+                                                                 int8_t *__restrict__ cexp, int32_t *__restrict__ cinc0, int32_t *__restrict__ cinc1,
+                                                                 int start_chunk) {
+    __shared__ float tile[2][64 * KC_G_LD];
+    __shared__ uint32_t loffs[KS_CHUNK];
+    const int chunk = blockIdx.x, grp = blockIdx.y;
+    const int oc = owner_cluster[chunk];
+    if (oc < 0) return;
+    const int ol = owner_local[chunk];
+    if (ol < start_chunk) return;
+    const int f0 = grp * KC_FG;
+    const int s = oc / kmax;
+    const int cnt = counts[oc];
+    const uint32_t *list = moff + seg_off[s] + cbase[oc];
+    const int first = ol * KS_CHUNK;
+    const int lane = aoc_lane(), wave = threadIdx.x >> 6;
+    const int members = min(KS_CHUNK, cnt - first);
+    const int nblk = (members + 63) / 64;
+
+    for (int i = threadIdx.x; i < KS_CHUNK; i += blockDim.x) loffs[i] = (i < members) ? list[first + i] : 0u;
+    __syncthreads();
+    // staging of one member block: 64 rows x (KC_FG / 4) float4 = 320 pieces, thread t takes pieces t and t + 256 (branch-free: every
+    // lane loads from a valid address and selects afterwards).  The chunk is streamed twice through a double-buffered tile: once for
+    // the local sums, once for the folds (the second pass hits L2); keeping all KS_T blocks in LDS instead costs occupancy (45 KB).
+    const int npiece = KC_FG / 4;
+    auto issue = [&](int blk, float4 (&v)[2]) {
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int idx = it * 256 + threadIdx.x;
+            const int mloc = idx / npiece, piece = idx - mloc * npiece;
+            const int m = blk * 64 + mloc;
+            const bool in = idx < 64 * npiece && m < members && f0 + piece * 4 < C;
+            const float4 x = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(pool) + loffs[in ? m : 0] + (in ? (f0 + piece * 4) * 4 : 0));
+            v[it].x = in ? x.x : 0.f; v[it].y = in ? x.y : 0.f; v[it].z = in ? x.z : 0.f; v[it].w = in ? x.w : 0.f;
+        }
+    };
+    auto commit = [&](int buf, const float4 (&v)[2]) {
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int idx = it * 256 + threadIdx.x;
+            if (idx < 64 * npiece) {
+                const int mloc = idx / npiece, piece = idx - mloc * npiece;
+                float *d = tile[buf] + mloc * KC_G_LD + piece * 4;
+                d[0] = v[it].x; d[1] = v[it].y; d[2] = v[it].z; d[3] = v[it].w;
+            }
+        }
+    };
+    float4 v[2];
+    float local[KC_FW];
+#pragma unroll
+    for (int i = 0; i < KC_FW; ++i) local[i] = 0.0f;
+    issue(0, v);
+    commit(0, v);
+    for (int b = 0; b < nblk; ++b) {
+        if (b + 1 < nblk) issue(b + 1, v);
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < KC_FW; ++i) local[i] += tile[b & 1][lane * KC_G_LD + wave * KC_FW + i];
+        if (b + 1 < nblk) commit((b + 1) & 1, v);
+    }
+    issue(0, v);                                       // first block of the second pass: in flight under the publication and the look-back
+
+    // ---- 1. local any-order sums (wave = KC_FW features, lanes = members), published for the later chunks of the cluster
+#pragma unroll
+    for (int i = 0; i < KC_FW; ++i) {
+        local[i] = aoc_wave_sum(local[i]);
+        const int f = f0 + wave * KC_FW + i;
+        if (lane == 0 && f < C) __hip_atomic_store(csum + (size_t)chunk * C + f, local[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // (device-scope stores go through to the memory all XCDs see; the wave waits for theirs to be acknowledged, then the flag -- no
+    // release / acquire fences: across XCDs those write back and invalidate whole L2s)
+    __builtin_amdgcn_s_waitcnt(0x0f70);                  // vmcnt(0)
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(cflag + (size_t)chunk * 8 + grp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+
+    // ---- 2. any-order prefix: exact head sum + the local sums of the earlier tail chunks (chunk ids of a cluster are contiguous)
+    const int cc = cchunk[oc];
+    const int npred = ol - start_chunk;
+    float pre[KC_FW];
+#pragma unroll
+    for (int i = 0; i < KC_FW; ++i) {
+        const int f = f0 + wave * KC_FW + i;
+        pre[i] = (start_chunk > 0 && f < C) ? head_state[(size_t)oc * C + f] : 0.0f;
+    }
+    bool late = false;
+    for (int p0 = 0; p0 < npred; p0 += 64) {
+        const int pc = cc + start_chunk + p0 + lane;
+        const bool have = p0 + lane < npred;
+        if (have) {
+            int polls = 0;
+            while (__hip_atomic_load(cflag + (size_t)pc * 8 + grp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+                if (++polls > KC_POLL_BUDGET) { late = true; break; }
+                __builtin_amdgcn_s_sleep(2);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < KC_FW; ++i) {
+            const int f = f0 + wave * KC_FW + i;
+            float x = 0.0f;
+            if (have && f < C) x = __hip_atomic_load(csum + (size_t)pc * C + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            pre[i] += aoc_wave_sum(x);
+        }
+    }
+    late = __builtin_amdgcn_ballot_w64(late) != 0ull;
+
+    // ---- 3. binade prediction (the same test as km_chunk_predict_kernel) and the integer folds of the staged rows
+    KcFold k[KC_FW];
+    float inv_u[KC_FW];
+    int ebin[KC_FW];
+    bool live[KC_FW];
+    bool any_live = false;
+#pragma unroll
+    for (int i = 0; i < KC_FW; ++i) {
+        const int f = f0 + wave * KC_FW + i;
+        const float end = pre[i] + local[i];
+        int e = KC_UNSAFE;
+        if (!late && f < C && pre[i] > 1e-30f && end < 1e30f && end >= pre[i]) {
+            const int e_lo = (int)((__float_as_uint(pre[i] * 0.9995f) >> 23) & 0xff) - 127;
+            const int e_hi = (int)((__float_as_uint(end * 1.0005f) >> 23) & 0xff) - 127;
+            if (e_lo == e_hi && e_lo >= -100 && e_lo <= 100) e = e_lo;
+        }
+        live[i] = e != KC_UNSAFE;
+        if (lane == 0 && f < C && !live[i]) cexp[(size_t)chunk * C + f] = (int8_t)KC_UNSAFE;
+        inv_u[i] = __uint_as_float((uint32_t)(23 - (live[i] ? e : 0) + 127) << 23);
+        k[i].acc = 0; k[i].par0 = 0; k[i].par1 = 1; k[i].bump0 = 0; k[i].bump1 = 0; k[i].bad = 0;
+        any_live |= live[i];
+        ebin[i] = e;
+    }
+    // does any wave of the workgroup fold anything?  (uniform per workgroup: the second pass has barriers)
+    __shared__ int lany;
+    __syncthreads();                                   // every wave is done with the tile of the first pass
+    if (threadIdx.x == 0) lany = 0;
+    __syncthreads();
+    if (any_live && lane == 0) lany = 1;
+    __syncthreads();
+    if (!lany) return;
+    commit(0, v);
+    for (int b = 0; b < nblk; ++b) {
+        if (b + 1 < nblk) issue(b + 1, v);
+        __syncthreads();
+        if (any_live) {
+#pragma unroll
+            for (int i = 0; i < KC_FW; ++i)
+                if (live[i]) kc_fold_block2(tile[b & 1][lane * KC_G_LD + wave * KC_FW + i], inv_u[i], k[i]);
+        }
+        if (b + 1 < nblk) commit((b + 1) & 1, v);
+    }
+#pragma unroll
+    for (int i = 0; i < KC_FW; ++i) {
+        if (live[i]) {
+            const int f = f0 + wave * KC_FW + i;
+            const int t = ks_wave_sum(k[i].acc);
+            if (lane == 0) {
+                cexp[(size_t)chunk * C + f] = k[i].bad ? (int8_t)KC_UNSAFE : (int8_t)ebin[i];
                 cinc0[(size_t)chunk * C + f] = t + k[i].bump0;
                 cinc1[(size_t)chunk * C + f] = t + k[i].bump1;
             }
@@ -1740,6 +1921,7 @@ struct KsWorkspace {
     int32_t *cchunk, *owner_cluster, *owner_local, *cinc0, *cinc1;
     float *csum, *head;
     int8_t *cexp;
+    uint32_t *cflag;          // per (chunk, feature group): local sums published (km_chunk_scanfold_kernel)
 };
 inline int ks_chunk_capacity(int64_t cap, int n_seg, int kmax) { return (int)(cap / KS_CHUNK) + n_seg * (kmax + 1) + 2; }
 inline size_t ks_workspace_bytes(int64_t cap, int n_seg, int kmax) {
@@ -1748,7 +1930,7 @@ inline size_t ks_workspace_bytes(int64_t cap, int n_seg, int kmax) {
     return aoc_align_up((size_t)cap * 4, 256) + aoc_align_up((size_t)cap * 2, 256) + 2 * aoc_align_up((size_t)n_seg * nb * kmax * 4, 256) +
            3 * aoc_align_up((size_t)n_seg * kmax * 4, 256) + aoc_align_up(((size_t)cap + 64) * 4, 256) + 2 * aoc_align_up(nch * 4, 256) +
            3 * aoc_align_up(nch * AOC_MAX_CHANNELS / 2 * 4, 256) + aoc_align_up(nch * AOC_MAX_CHANNELS / 2, 256) +
-           aoc_align_up((size_t)n_seg * kmax * (AOC_MAX_CHANNELS / 2) * 4, 256);
+           aoc_align_up((size_t)n_seg * kmax * (AOC_MAX_CHANNELS / 2) * 4, 256) + aoc_align_up(nch * 8 * 4, 256);
 }
 inline KsWorkspace ks_carve(void *workspace, int64_t cap, int n_seg, int kmax, int64_t seg_bound = 0) {
     KsWorkspace w;
@@ -1771,7 +1953,8 @@ inline KsWorkspace ks_carve(void *workspace, int64_t cap, int n_seg, int kmax, i
     w.cinc0 = reinterpret_cast<int32_t *>(p); p += aoc_align_up(nch * AOC_MAX_CHANNELS / 2 * 4, 256);
     w.cinc1 = reinterpret_cast<int32_t *>(p); p += aoc_align_up(nch * AOC_MAX_CHANNELS / 2 * 4, 256);
     w.cexp = reinterpret_cast<int8_t *>(p); p += aoc_align_up(nch * AOC_MAX_CHANNELS / 2, 256);
-    w.head = reinterpret_cast<float *>(p);
+    w.head = reinterpret_cast<float *>(p); p += aoc_align_up((size_t)n_seg * kmax * (AOC_MAX_CHANNELS / 2) * 4, 256);
+    w.cflag = reinterpret_cast<uint32_t *>(p);
     return w;
 }
 
@@ -1801,11 +1984,21 @@ inline void ks_launch_sums(hipStream_t st, const float *pool, uint32_t pool_byte
                            seg_k, counts, ws.cbase, ws.moff, kmax, dst, cap, ws.head);
         if (mode == 1) return;
     }
-    hipLaunchKernelGGL(km_chunk_sum_kernel, dim3(ws.nch_cap), dim3(256), 0, st, pool, C, seg_offsets, counts, ws.cbase, ws.moff, kmax, ws.owner_cluster,
-                       ws.owner_local, ws.csum, start);
-    hipLaunchKernelGGL(km_chunk_predict_kernel, dim3(kmax, n_seg), dim3(128), 0, st, seg_k, counts, ws.cchunk, ws.csum, kmax, C, ws.cexp, start, ws.head);
-    hipLaunchKernelGGL(km_chunk_fold_kernel, dim3(ws.nch_cap, (C + KC_FG - 1) / KC_FG), dim3(256), 0, st, pool, C, seg_offsets, counts, ws.cbase, ws.moff,
-                       kmax, ws.owner_cluster, ws.owner_local, ws.cexp, ws.cinc0, ws.cinc1, start);
+    // developer switch AOC_KM_FUSED=1: km_chunk_scanfold_kernel instead of chunk sum -> predict -> fold.  Bit-identical (all k-means tests
+    // pass in both modes); measured 3.5 vs 3.9 ms per 20-iteration chain at R = 6 with one frame per chain, but 6.6 vs 6.4 ms with three
+    // frames per chain and 5.7 vs 5.6 at R = 12: workgroups that wait for their predecessors' sums hold CU slots, so the default stays
+    // the three-kernel tail.
+    static const bool fused = getenv("AOC_KM_FUSED") && atoi(getenv("AOC_KM_FUSED")) == 1;
+    if (fused && C <= KC_FG * 8) {
+        hipLaunchKernelGGL(km_chunk_scanfold_kernel, dim3(ws.nch_cap, (C + KC_FG - 1) / KC_FG), dim3(256), 0, st, pool, C, seg_offsets, counts, ws.cbase,
+                           ws.moff, kmax, ws.owner_cluster, ws.owner_local, ws.cchunk, ws.head, ws.csum, ws.cflag, ws.cexp, ws.cinc0, ws.cinc1, start);
+    } else {
+        hipLaunchKernelGGL(km_chunk_sum_kernel, dim3(ws.nch_cap), dim3(256), 0, st, pool, C, seg_offsets, counts, ws.cbase, ws.moff, kmax, ws.owner_cluster,
+                           ws.owner_local, ws.csum, start);
+        hipLaunchKernelGGL(km_chunk_predict_kernel, dim3(kmax, n_seg), dim3(128), 0, st, seg_k, counts, ws.cchunk, ws.csum, kmax, C, ws.cexp, start, ws.head);
+        hipLaunchKernelGGL(km_chunk_fold_kernel, dim3(ws.nch_cap, (C + KC_FG - 1) / KC_FG), dim3(256), 0, st, pool, C, seg_offsets, counts, ws.cbase, ws.moff,
+                           kmax, ws.owner_cluster, ws.owner_local, ws.cexp, ws.cinc0, ws.cinc1, start);
+    }
     static const int nf = getenv("AOC_KS_NF") ? atoi(getenv("AOC_KS_NF")) : 1;       // features per stitch wave (developer switch)
 #define AOC_KSS(NF) hipLaunchKernelGGL((km_sum_scan_kernel<MODE, NF>), dim3(C / NF, kmax, n_seg), dim3(64), 0, st, pool, pool_bytes, C, seg_offsets, seg_k, \
                                        counts, ws.cbase, ws.moff, kmax, dst, ws.cchunk, ws.cexp, ws.cinc0, ws.cinc1, start, ws.head)
@@ -1921,7 +2114,7 @@ int aoc_kmeans_segmented_ex(const float *pool, int64_t pool_rows, int C, const i
         }
         if (fast) {
             hipLaunchKernelGGL(km_blockscan_kernel, dim3(n_seg), dim3(1024), 0, st, seg_offsets, seg_k, ws.hist, ws.blockoff, ws.nb_max, kmax,
-                               cluster_counts, ws.cbase, ws.cchunk, ws.owner_cluster, ws.owner_local, ws.nch_cap);
+                               cluster_counts, ws.cbase, ws.cchunk, ws.owner_cluster, ws.owner_local, ws.nch_cap, ws.cflag);
             hipLaunchKernelGGL(km_scatter_kernel, agrid, dim3(256), 0, st, rows, (const int32_t *)nullptr, seg_offsets, seg_k, labels, ws.rank16,
                                ws.blockoff, ws.cbase, ws.nb_max, kmax, (uint32_t)C * 4u, ws.moff);
             ks_launch_sums<0>(st, pool, pool_bytes, C, seg_offsets, seg_k, cluster_counts, ws, kmax, n_seg, centroids);
@@ -1994,7 +2187,7 @@ int aoc_build_proxies(const float *pool, int64_t pool_rows, int C, const int32_t
         const dim3 agrid((unsigned)((seg_bound + 255) / 256), (unsigned)n_seg);
         hipLaunchKernelGGL(km_rank_only_kernel, agrid, dim3(256), 0, st, seg_offsets, seg_k, labels, kmax, ws.rank16, ws.hist, ws.nb_max);
         hipLaunchKernelGGL(km_blockscan_kernel, dim3(n_seg), dim3(1024), 0, st, seg_offsets, seg_k, ws.hist, ws.blockoff, ws.nb_max, kmax, ws.counts, ws.cbase,
-                           ws.cchunk, ws.owner_cluster, ws.owner_local, ws.nch_cap);
+                           ws.cchunk, ws.owner_cluster, ws.owner_local, ws.nch_cap, ws.cflag);
         hipLaunchKernelGGL(km_scatter_kernel, agrid, dim3(256), 0, st, (const int32_t *)nullptr, fg_rows, seg_offsets, seg_k, labels, ws.rank16,
                            ws.blockoff, ws.cbase, ws.nb_max, kmax, (uint32_t)C * 4u, ws.moff);
         ks_launch_sums<1>(st, pool, (uint32_t)((uint64_t)pool_rows * C * 4), C, seg_offsets, seg_k, ws.counts, ws, kmax, n_seg, proxies);
