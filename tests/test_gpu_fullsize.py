@@ -221,3 +221,16 @@ def test_cfg4_full_size_kmeans_and_dense(aoc):
     mc = hotpath.MatchingConfig(CLUSTER_NUM=K)
     feat, head, _ = hotpath.proto_mask_features(mc, emb[:1].cuda(), lab[:1].cuda(), emb[1].cuda(), lab[1].cuda(), emb[2].cuda(), bias.cuda(), init_rows=rows)
     assert tuple(feat.shape) == (O, 24, cfg.h, cfg.w) and bool(torch.isfinite(feat).all())
+
+
+def test_kmeans_bit_exact_with_the_single_pass_tail():
+    """AOC_KM_FUSED=1 (km_chunk_scanfold_kernel: chunk sums, look-back and folds in one launch) is read once per process, so the bit-exactness
+    tests of the k-means pipeline are re-run in a child process with the switch set."""
+    import os, subprocess, sys
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, AOC_KM_FUSED="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.join(here, "test_gpu_fullsize.py"), os.path.join(here, "test_gpu_parity.py"),
+                        "-k", "kmeans and not single_pass"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
