@@ -445,16 +445,20 @@ __global__ __launch_bounds__(SP_NW * 64, 1) void dense_prune_kernel(const uint4 
             }
         }
 
-        // (c) this step's transfers have landed (they had four tiles of time); publish them
+        // (c) this step's transfers have landed (they had four tiles of time).  The wave reads back its own bound words right away (its
+        // own vmcnt(0) covers them) so that the lgkmcnt(0) below also retires those reads before the next step's transfer can overwrite
+        // the words; then the barrier publishes the chunk and the row ids to the other waves.
         __builtin_amdgcn_s_waitcnt(0x0f70);          // vmcnt(0)
+        uint32_t seen[SP_NQ];
+#pragma unroll
+        for (int iq = 0; iq < SP_NQ; ++iq)
+            seen[iq] = *reinterpret_cast<const volatile uint32_t *>(lds_bytes + SP_BND_OFF + (wave * SP_NQ + iq) * 256 + lane * 4);
         __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0)
         if (!(dbg & 8)) __builtin_amdgcn_s_barrier();
-        if (bound_obj == cur && cur >= 0) {          // the bounds fetched at the start of this step (this wave's own transfers)
+        if (bound_obj == cur && cur >= 0) {
 #pragma unroll
-            for (int iq = 0; iq < SP_NQ; ++iq) {
-                const uint32_t u = *reinterpret_cast<const uint32_t *>(lds_bytes + SP_BND_OFF + (wave * SP_NQ + iq) * 256 + lane * 4);
-                if (valid[iq]) shared[iq] = __builtin_fmaxf(shared[iq], ord_dec(u));
-            }
+            for (int iq = 0; iq < SP_NQ; ++iq)
+                if (valid[iq]) shared[iq] = __builtin_fmaxf(shared[iq], ord_dec(seen[iq]));
         }
     }
     if (lane == 0) {
