@@ -588,12 +588,20 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU (or let `python bench.py --gpus N` launch them)")
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # AOC_DIST_BACKEND=gloo (developer switch): several ranks on ONE GPU with host-side reductions, to exercise the multi-rank code path
+    # where no multi-GPU node is at hand; the default is RCCL ("nccl"), one rank per GPU
+    backend = os.environ.get("AOC_DIST_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    red_dev = dev if backend == "nccl" else None          # where the few reduced scalars live
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # RCCL over xGMI
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # RCCL over xGMI
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
     if args.cu_reserve >= n_cu:
         args.cu_reserve = 0
@@ -616,7 +624,7 @@ def main():
             # the rank's sequences are synthesised and made resident first; the timed region starts at the barrier inside
             tot = eval_runner.eval_sharded(specs, rank, world, dev, barrier=barrier)
             barrier()
-        el = torch.tensor([tot["loop_seconds_max"]], dtype=torch.float64, device=dev)
+        el = torch.tensor([tot["loop_seconds_max"]], dtype=torch.float64)
         if rank == 0:
             line = {"metric": "frames/sec, AOC-Net matching + read-out + memory policy, sequence-sharded evaluation", "value": round(tot["frames"] / float(el.item()), 3),
                     "unit": "frames/s", "n_gpus": world, "steps": int(tot["frames"]), "warmup": 3, "ms_per_step": round(float(el.item()) / max(tot["frames"], 1) * 1e3, 4),
@@ -765,12 +773,12 @@ def main():
         for wl in workloads:
             wl.count_r = False
 
-    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    el = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
     if world > 1:
         torch.distributed.all_reduce(el, op=torch.distributed.ReduceOp.MAX)
     elapsed_max = float(el.item())
     frames_local = args.steps * n_streams
-    metrics = sharding.allreduce_metrics(dict(frames=frames_local, objects=frames_local * (O - 1), gpu_seconds=elapsed), device=dev)
+    metrics = sharding.allreduce_metrics(dict(frames=frames_local, objects=frames_local * (O - 1), gpu_seconds=elapsed), device=red_dev)
     r_hist = {}
     for wl in workloads:
         for r, c in wl.r_hist.items():

@@ -26,9 +26,16 @@ def lpt_partition(costs: Sequence[float], n_ranks: int) -> List[List[int]]:
     return parts
 
 
+def _reduce_device(device):
+    """RCCL reduces device tensors; the gloo backend (CPU tests, several ranks on one GPU) reduces on the host."""
+    if dist.is_available() and dist.is_initialized() and dist.get_backend() != "nccl":
+        return None
+    return device
+
+
 def allreduce_metrics(local: dict, device=None) -> dict:
     """Sum the metric accumulators over all ranks (no-op without an initialised process group)."""
-    vec = torch.tensor([float(local.get(k, 0.0)) for k in METRIC_FIELDS], dtype=torch.float64, device=device)
+    vec = torch.tensor([float(local.get(k, 0.0)) for k in METRIC_FIELDS], dtype=torch.float64, device=_reduce_device(device))
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.all_reduce(vec, op=dist.ReduceOp.SUM)
     return dict(zip(METRIC_FIELDS, vec.tolist()))
@@ -36,7 +43,7 @@ def allreduce_metrics(local: dict, device=None) -> dict:
 
 def allreduce_max(value: float, device=None) -> float:
     """Maximum of a scalar over the ranks (the slowest rank's time: load imbalance)."""
-    t = torch.tensor([float(value)], dtype=torch.float64, device=device)
+    t = torch.tensor([float(value)], dtype=torch.float64, device=_reduce_device(device))
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())

@@ -162,3 +162,21 @@ def test_dynamic_prehead_vs_torch(aoc, O, h, w):
     assert tuple(cat.shape) == (O, 164, h, w)
     assert torch.equal(cat[:, 100:], got)
     assert torch.equal(cat[:, :100], emb.permute(2, 0, 1).unsqueeze(0).expand(O, -1, -1, -1))
+
+
+def test_bench_two_ranks_on_one_gpu_over_gloo():
+    """The multi-rank path of bench.py (rank set-up, barriers, max-over-ranks timing, all-reduce of the counters, rank-0 report) with two
+    ranks sharing the one GPU of the test box: AOC_DIST_BACKEND=gloo is the developer switch for exactly this; RCCL needs one GPU per rank."""
+    import json, os, subprocess, sys
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, AOC_DIST_BACKEND="gloo")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--exact-steps", "0"],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line, from rank 0"
+    line = lines[0]
+    assert line["n_gpus"] == 2 and line["steps"] == 4 and line["scaling"] == "weak"
+    assert line["value"] > 0 and abs(line["value"] - 2 * line["config"]["frames_per_step"] * 1e3 / line["ms_per_step"]) < 0.05 * line["value"]
