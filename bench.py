@@ -93,8 +93,28 @@ class OpTimer:
         self.dense_done = None
         self.serialize_dense = True
         self.probed = ("dense_match_min_split", "dense_match_min")
+        # raw hipEvent_t from a pre-created pool, recorded on the raw current stream: a torch.cuda.Event costs ~10 us of host time per
+        # record (object construction + current-stream lookup), i.e. ~2 ms per step of this bench's own instrumentation
+        self.hip = self.kernel_probe.hip
+        self.hip.hipEventRecord.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        self.hip.hipStreamWaitEvent.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint]
+        self._pool = []
+
+    def _event(self):
+        if not self._pool:
+            for _ in range(16384):
+                e = ctypes.c_void_p()
+                assert self.hip.hipEventCreate(ctypes.byref(e)) == 0
+                self._pool.append(e)
+        return self._pool.pop()
+
+    def _record(self):
+        e = self._event()
+        assert self.hip.hipEventRecord(e, ops._stream()) == 0
+        return e
 
     def install(self, meta_fns):
+        self._pool.append(self._event())                     # fills the pool (setup)
         for n in self.names:
             fn = getattr(ops, n)
             self._orig[n] = fn
@@ -104,19 +124,17 @@ class OpTimer:
                 if dense and self.dense_done is not None and self.serialize_dense:
                     # only one dense kernel fits per CU, so the dense kernels of the sequences run back to back anyway; making that
                     # order explicit keeps the queueing of one behind the other out of the timed interval
-                    torch.cuda.current_stream().wait_event(self.dense_done)
+                    assert self.hip.hipStreamWaitEvent(ops._stream(), self.dense_done, 0) == 0
                 if not self.enabled:
                     out = _fn(*a, **k)
                     if dense:
-                        self.dense_done = torch.cuda.Event()
-                        self.dense_done.record()
+                        self.dense_done = self._record()
                     return out
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
+                e0 = self._record()
                 if dense:
                     self.kernel_probe.arm()
                 out = _fn(*a, **k)
-                e1.record()
+                e1 = self._record()
                 if dense:
                     self.dense_done = e1
                 self.records[_n].append((e0, e1))
@@ -128,7 +146,11 @@ class OpTimer:
     def summary(self):
         out = {}
         for n in self.names:
-            ms = [a.elapsed_time(b) for a, b in self.records[n]]
+            ms = []
+            for a, b in self.records[n]:
+                v = ctypes.c_float()
+                if self.hip.hipEventElapsedTime(ctypes.byref(v), a, b) == 0:
+                    ms.append(v.value)
             if ms:
                 out[n] = dict(calls=len(ms), total_ms=float(np.sum(ms)), avg_ms=float(np.mean(ms)), meta=self.meta[n])
         return out
