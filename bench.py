@@ -99,6 +99,20 @@ class OpTimer:
         self.hip.hipEventRecord.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         self.hip.hipStreamWaitEvent.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint]
         self._pool = []
+        self.streams = {}
+
+    def timeline(self):
+        """[(op, stream, start_ms, end_ms)] of every timed call, relative to the first recorded event (developer output: --dump-timeline)."""
+        allrec = [(n, st, a, b) for n in self.names for (a, b), st in zip(self.records[n], self.streams.get(n, []))]
+        if not allrec:
+            return []
+        base = allrec[0][2]
+        out = []
+        for n, st, a, b in allrec:
+            va, vb = ctypes.c_float(), ctypes.c_float()
+            if self.hip.hipEventElapsedTime(ctypes.byref(va), base, a) == 0 and self.hip.hipEventElapsedTime(ctypes.byref(vb), base, b) == 0:
+                out.append((n, st, va.value, vb.value))
+        return sorted(out, key=lambda r: r[2])
 
     def _event(self):
         if not self._pool:
@@ -138,6 +152,7 @@ class OpTimer:
                 if dense:
                     self.dense_done = e1
                 self.records[_n].append((e0, e1))
+                self.streams.setdefault(_n, []).append(ops._stream().value)
                 self.meta[_n].append(meta_fns[_n](*a, **k) if _n in meta_fns else None)
                 return out
 
@@ -179,6 +194,8 @@ class ClipWorkload:
         # the k-means branch (a long chain of small launches) runs on a high-priority side stream,
         # concurrently with the MFMA-bound dense matching on the main stream
         self.side = torch.cuda.Stream(device=device, priority=-1) if overlap else None
+        self.sides = [self.side]                           # bench --chain-streams: the chains of a group's batches alternate between these
+        self.next_side = 0
         clip = syn.make_clip(cfg, seed)
         O = cfg.n_obj
         self.emb = torch.from_numpy(clip["emb"]).to(device)                                   # [T,h,w,C]
@@ -334,10 +351,12 @@ def make_activations(gates, O, h, w, device, seed):
 
 def _launch_batch(wl, frames):
     ref_emb, ref_lab = wl.refs()
+    side = wl.sides[wl.next_side % len(wl.sides)]          # independent chains (same pool, different initial rows) may run side by side
+    wl.next_side += 1
     if len(frames) == 1:
-        wl.ahead[frames[0]] = hotpath.launch_cluster_proxies(wl.mc, ref_emb, ref_lab, wl.init_rows[frames[0]][0], wl.side, wait_event=wl.pool_event)
+        wl.ahead[frames[0]] = hotpath.launch_cluster_proxies(wl.mc, ref_emb, ref_lab, wl.init_rows[frames[0]][0], side, wait_event=wl.pool_event)
     else:
-        outs = hotpath.launch_cluster_proxies_batch(wl.mc, ref_emb, ref_lab, [wl.init_rows[f][0] for f in frames], wl.side, wait_event=wl.pool_event)
+        outs = hotpath.launch_cluster_proxies_batch(wl.mc, ref_emb, ref_lab, [wl.init_rows[f][0] for f in frames], side, wait_event=wl.pool_event)
         for f, a in zip(frames, outs):
             wl.ahead[f] = a
 
@@ -358,7 +377,7 @@ def launch_chains(wl, done=None):
         if i < len(g):
             cuts.append(g[i:])
         k = next(j for j, c in enumerate(cuts) if t in c)
-        for c in cuts[k:k + 2]:
+        for c in cuts[k:k + 1 + len(wl.sides)]:
             todo = [f for f in c if f >= t and f != done and f not in wl.ahead]
             if todo:
                 _launch_batch(wl, todo)
@@ -577,6 +596,8 @@ def main():
                     help="frames whose k-means is enqueued right after a pool update (1 = only the next frame; the others are batched into one chain)")
     ap.add_argument("--chain-plan", default="",
                     help="batch sizes of the k-means chains of a group of MEM_EVERY frames, e.g. 1,2,2 (overrides --chains)")
+    ap.add_argument("--dump-timeline", default="", help="developer output: write the timed ops' (name, stream, start, end) to this JSON file")
+    ap.add_argument("--chain-streams", type=int, default=1, help="side streams per sequence for its k-means chains (with --chain-plan: the batches of a group run side by side)")
     ap.add_argument("--dense-stream", dest="mask_main", action="store_false",
                     help="put only the dense kernel under the CU mask (on its own stream) instead of the whole main stream")
     ap.add_argument("--reuse-proxies", action="store_true",
@@ -676,6 +697,8 @@ def main():
     for wl in workloads:
         wl.chains = 1 if args.reuse_proxies else max(1, min(args.chains, mc.MEM_EVERY))
         wl.chain_plan = [int(x) for x in args.chain_plan.split(",")] if (args.chain_plan and not args.reuse_proxies) else None
+        if wl.side is not None and args.chain_streams > 1:
+            wl.sides = [wl.side] + [torch.cuda.Stream(device=dev, priority=-1) for _ in range(args.chain_streams - 1)]
         wl.reuse_proxies = args.reuse_proxies
         if args.incremental_proxies:
             wl.enable_incremental()
@@ -808,6 +831,9 @@ def main():
 
     probe_ms = timer.kernel_probe.elapsed_ms()
     prune = ops.dense_prune_stats(reset=True)
+    if args.dump_timeline and rank == 0:
+        with open(args.dump_timeline, "w") as f:
+            json.dump(timer.timeline(), f)
 
     # second, informational region (N = 1 only): a few steps with the exact-fp32 dense kernel (`--dense fp32`), so that the line also
     # carries the figure of the all-fp32 arithmetic next to the headline
