@@ -238,6 +238,7 @@ class ClipWorkload:
         self.ahead = {}                                    # frame -> adaptive proxies already enqueued on a side stream
         self.pool_event = None                             # recorded when the pool of the current group is final
         self.chains = mc.MEM_EVERY                         # k-means chains enqueued ahead (bench --chains)
+        self.chain_lead = 1                                # batches enqueued ahead of the one in use (bench --chain-lead)
         self.chain_plan = None                             # batch sizes of a group's chains, e.g. [1, 2, 2] (bench --chain-plan)
         self.dense_stream = None                           # CU-masked stream for the dense kernel alone
         self.reuse_proxies = False                         # non-parity mode: one k-means per pool state
@@ -377,7 +378,7 @@ def launch_chains(wl, done=None):
         if i < len(g):
             cuts.append(g[i:])
         k = next(j for j, c in enumerate(cuts) if t in c)
-        for c in cuts[k:k + 1 + len(wl.sides)]:
+        for c in cuts[k:k + 1 + max(wl.chain_lead, len(wl.sides))]:
             todo = [f for f in c if f >= t and f != done and f not in wl.ahead]
             if todo:
                 _launch_batch(wl, todo)
@@ -598,6 +599,7 @@ def main():
                     help="batch sizes of the k-means chains of a group of MEM_EVERY frames, e.g. 1,2,2 (overrides --chains)")
     ap.add_argument("--dump-timeline", default="", help="developer output: write the timed ops' (name, stream, start, end) to this JSON file")
     ap.add_argument("--chain-streams", type=int, default=1, help="side streams per sequence for its k-means chains (with --chain-plan: the batches of a group run side by side)")
+    ap.add_argument("--chain-lead", type=int, default=1, help="with --chain-plan: batches enqueued ahead of the one in use")
     ap.add_argument("--dense-stream", dest="mask_main", action="store_false",
                     help="put only the dense kernel under the CU mask (on its own stream) instead of the whole main stream")
     ap.add_argument("--reuse-proxies", action="store_true",
@@ -697,6 +699,7 @@ def main():
     for wl in workloads:
         wl.chains = 1 if args.reuse_proxies else max(1, min(args.chains, mc.MEM_EVERY))
         wl.chain_plan = [int(x) for x in args.chain_plan.split(",")] if (args.chain_plan and not args.reuse_proxies) else None
+        wl.chain_lead = max(1, args.chain_lead)
         if wl.side is not None and args.chain_streams > 1:
             wl.sides = [wl.side] + [torch.cuda.Stream(device=dev, priority=-1) for _ in range(args.chain_streams - 1)]
         wl.reuse_proxies = args.reuse_proxies
