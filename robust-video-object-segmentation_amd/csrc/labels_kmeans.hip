@@ -649,7 +649,7 @@ __global__ __launch_bounds__(256) void km_assign_rank_kernel(const float *__rest
 // D: lane holds row j = lane & 15 and clusters (lane >> 4) * 4 + r: the argmin is 4 in-lane compares and two
 // cross-group exchanges, ties to the lowest index like scipy's strict <.
 template <int TMAX, int KT>
-__global__ __launch_bounds__(256, 3) void km_assign_mfma_kernel(const float *__restrict__ pool, int C, const int32_t *__restrict__ rows,
+__global__ __launch_bounds__(256, 2) void km_assign_mfma_kernel(const float *__restrict__ pool, int C, const int32_t *__restrict__ rows,
                                                               const int32_t *__restrict__ seg_off, const int32_t *__restrict__ seg_k, int n_seg,
                                                               const float *__restrict__ centroids, int kmax, int32_t *__restrict__ labels,
                                                               uint16_t *__restrict__ rank16, int32_t *__restrict__ hist, int nb_max,
@@ -699,24 +699,29 @@ __global__ __launch_bounds__(256, 3) void km_assign_mfma_kernel(const float *__r
         const int ibeg = seg_off[s], ilen = seg_off[s + 1] - ibeg;
         const int wave_row0 = bx * 256 + wave * 64;
         float4 pv[TPF][PIECES];
+        // the pool row of every row of this wave: ONE id load per lane (rows past the end take the segment's last row and are zeroed on
+        // the way into the image), handed to the lanes that fetch the pieces by a cross-lane read -- so the id round trip happens once per
+        // item and all piece loads of a tile are in flight together, with no exec-masked regions in between
+        const int my_p = min(wave_row0 + lane, ilen - 1);
+        const int my_id = rows[ibeg + max(my_p, 0)];
         auto issue_tile = [&](int tile, float4 (&v)[PIECES]) {
 #pragma unroll
             for (int i = 0; i < PIECES; ++i) {
-                const int idx = i * 64 + lane;
+                const int idx = min(i * 64 + lane, 16 * c4 - 1);
                 const int rr = idx / c4, t = idx - rr * c4;
-                const int p = wave_row0 + tile * 16 + rr;
-                const bool ok = idx < 16 * c4 && p < ilen;
-                v[i] = ok ? reinterpret_cast<const float4 *>(pool + (size_t)rows[ibeg + p] * C)[t] : make_float4(0.f, 0.f, 0.f, 0.f);
+                const int id = __shfl(my_id, tile * 16 + rr);
+                v[i] = reinterpret_cast<const float4 *>(pool + (size_t)id * C)[t];
             }
         };
-        auto write_tile = [&](const float4 (&v)[PIECES]) {
+        auto write_tile = [&](int tile, const float4 (&v)[PIECES]) {
 #pragma unroll
             for (int i = 0; i < PIECES; ++i) {
                 const int idx = i * 64 + lane;
                 if (idx < 16 * c4) {
                     const int rr = idx / c4, t = idx - rr * c4;
+                    const bool in = wave_row0 + tile * 16 + rr < ilen;
                     float *d = wimg + (size_t)rr * RS + t;
-                    d[0] = v[i].x; d[TP] = v[i].y; d[2 * TP] = v[i].z; d[3 * TP] = v[i].w;
+                    d[0] = in ? v[i].x : 0.f; d[TP] = in ? v[i].y : 0.f; d[2 * TP] = in ? v[i].z : 0.f; d[3 * TP] = in ? v[i].w : 0.f;
                 }
             }
         };
@@ -771,7 +776,7 @@ __global__ __launch_bounds__(256, 3) void km_assign_mfma_kernel(const float *__r
         int best = -1;                                     // label of row (wave_row0 + lane) once all four tiles are done
 #pragma unroll
         for (int tile = 0; tile < 4; ++tile) {
-            write_tile(pv[tile % TPF]);
+            write_tile(tile, pv[tile % TPF]);
             if (tile + TPF < 4) issue_tile(tile + TPF, pv[tile % TPF]);
             // B operand: lane (j, kq = g) reads its stream of row j
             const float *bs = wimg + (size_t)j * RS + g * TP;
@@ -1559,10 +1564,17 @@ __global__ __launch_bounds__(64) void km_sum_scan_kernel(const float *__restrict
     const int n_chunks = (cnt + KS_CHUNK - 1) / KS_CHUNK;
 
     auto load_offs = [&](int c, uint32_t (&o)[KS_T]) {
+        // branch-free: clamped indices, all eight offset loads issued before any is looked at, selects afterwards (the empty asm keeps
+        // hipcc from sinking each load back under its condition, which serialises eight round trips)
+        uint32_t v[KS_T];
+#pragma unroll
+        for (int b = 0; b < KS_T; ++b) v[b] = list[min((c * KS_T + b) * 64 + lane, cnt - 1)];
+#pragma unroll
+        for (int b = 0; b < KS_T; ++b) asm volatile("" : "+v"(v[b]));
 #pragma unroll
         for (int b = 0; b < KS_T; ++b) {
             const int m = (c * KS_T + b) * 64 + lane;
-            o[b] = (m < cnt) ? list[m] + qoff : KU_INVALID_OFF;
+            o[b] = (m < cnt) ? v[b] + qoff : KU_INVALID_OFF;
         }
     };
     auto load_rows = [&](const uint32_t (&o)[KS_T], KsChunk &ch) {
@@ -1835,7 +1847,8 @@ __global__ __launch_bounds__((OS_NPROD + 1) * 64) void km_ordered_sum_kernel(con
 #pragma unroll
         for (int i = 0; i < OS_PP; ++i) {
             const int m = b * OS_BATCH + prow[i];
-            o[i] = (b < nb && pvalid[i] && m < cnt) ? list[m] + pbyte[i] : KU_INVALID_OFF;
+            const uint32_t v = list[min(m, cnt - 1)];          // branch-free (clamped index, select afterwards): all offset loads of a batch in flight together
+            o[i] = (b < nb && pvalid[i] && m < cnt) ? v + pbyte[i] : KU_INVALID_OFF;
         }
     };
     auto load_rows = [&](const uint32_t (&o)[OS_PP], u32x4 (&d)[OS_PP]) {
@@ -2099,7 +2112,7 @@ int aoc_kmeans_segmented_ex(const float *pool, int64_t pool_rows, int C, const i
         if (fast && !first && mfma_assign && C == 100 && kmax <= 64) {
             const int kt = (kmax + 15) / 16;
             const size_t alds = ((size_t)kt * 16 * 116 + kt * 16 + (size_t)4 * 16 * 116) * sizeof(float) + (size_t)4 * kmax * sizeof(int32_t);
-            const unsigned pgrid = (unsigned)std::min<int64_t>(std::min<int64_t>(rows_capacity, seg_bound * n_seg) / 256 + n_seg, 768);    // persistent: 3 blocks per CU
+            const unsigned pgrid = (unsigned)std::min<int64_t>(std::min<int64_t>(rows_capacity, seg_bound * n_seg) / 256 + n_seg, 512);    // persistent: 2 blocks per CU
 #define AOC_KA(KT) hipLaunchKernelGGL((km_assign_mfma_kernel<25, KT>), dim3(pgrid), dim3(256), alds, st, pool, C, rows, seg_offsets, seg_k, n_seg, centroids, \
                                       kmax, labels, ws.rank16, ws.hist, ws.nb_max, rownorm)
             if (kt == 1) AOC_KA(1); else if (kt == 2) AOC_KA(2); else if (kt == 3) AOC_KA(3); else AOC_KA(4);

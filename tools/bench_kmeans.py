@@ -25,7 +25,20 @@ for f in range(F):
         if r is not None:
             init[o, :len(r)] = r
     inits.append(torch.from_numpy(init).cuda())
-side = torch.cuda.Stream()
+import ctypes, os
+NCU = int(os.environ.get("KM_CUS", "0"))                   # run the chain on a stream masked to the first KM_CUS CUs (what it finds free next to a dense kernel)
+if NCU > 0:
+    hip = ctypes.CDLL("libamdhip64.so")
+    n_cu = torch.cuda.get_device_properties(0).multi_processor_count
+    words = (n_cu + 31) // 32
+    mask = [0] * words
+    for cu in range(NCU):
+        mask[cu // 32] |= 1 << (cu % 32)
+    handle = ctypes.c_void_p()
+    assert hip.hipExtStreamCreateWithCUMask(ctypes.byref(handle), ctypes.c_uint32(words), (ctypes.c_uint32 * words)(*mask)) == 0
+    side = torch.cuda.ExternalStream(handle.value)
+else:
+    side = torch.cuda.Stream()
 def run():
     if F == 1:
         return hotpath.launch_cluster_proxies(mc, emb, lab, inits[0], side)
@@ -40,4 +53,4 @@ for _ in range(n):
 torch.cuda.synchronize()
 ms = (time.perf_counter() - t0) / n * 1e3
 rows = sum(counts)
-print(f"k-means chain R={R} F={F}: {ms:.3f} ms per chain ({ms / F:.3f} per frame), {rows} rows x {F} replicas", flush=True)
+print(f"k-means chain R={R} F={F} CUs={NCU or 'all'}: {ms:.3f} ms per chain ({ms / F:.3f} per frame), {rows} rows x {F} replicas", flush=True)
