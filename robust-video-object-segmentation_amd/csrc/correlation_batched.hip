@@ -100,6 +100,7 @@ constexpr int CB_TILE_BYTES = 32 * 400;
 constexpr int CB_CHUNKS = CB_TILE_BYTES / 16;    // 800
 constexpr int CB_HALF_CHUNKS = CB_CHUNKS / 2;    // 400: chunks of the first 16 pixel rows
 constexpr int CB_WBUF_BYTES = CB_TILE_BYTES / 2;
+constexpr int CB_TABLE_DW = (int)((sizeof(AocCorrTiles) + 15) / 16 * 4);      // the tile tables' copy at the start of the LDS allocation
 
 struct CbSlotDesc {          // epilogue constants of one (proxy tile, lane half), staged per frame: two store slots
     int32_t off_a, off_b;    // element offset of the slot's output plane in the frame's `out` (-1: no store)
@@ -138,9 +139,15 @@ template <int NW, int NT, bool COL0>
 __global__ __launch_bounds__(NW * 64) void proxy_corr_batched_kernel(AocCorrFrames frames, int64_t m, AocCorrTiles tiles, int transform,
                                                                       int32_t *__restrict__ gate, int dbg, int call_seq) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    // the tile tables in LDS: the staging phases index them per thread, and from the kernel-argument segment every such read is a
+    // dependent global round trip (hipcc cannot use scalar loads for a per-lane index): ~30 of them per frame before
+    AocCorrTiles &ltiles = *reinterpret_cast<AocCorrTiles *>(lds);          // first in the dynamic allocation (8-byte members: 16-byte aligned base)
+    for (int i = threadIdx.x; i < (int)(sizeof(AocCorrTiles) / 4); i += NW * 64)
+        reinterpret_cast<uint32_t *>(&ltiles)[i] = reinterpret_cast<const uint32_t *>(&tiles)[i];
+    __syncthreads();
     constexpr int NTH = NW * 64;
     constexpr int n_rows = NT * 32;
-    uint32_t *limg = lds;                                                     // [n_rows][CB_ROW_DW]
+    uint32_t *limg = lds + CB_TABLE_DW;                                       // [n_rows][CB_ROW_DW]
     int32_t *lsrc = reinterpret_cast<int32_t *>(limg + (size_t)NT * CB_TILE_DW);   // [n_rows] proxy row feeding each image row (-1: none)
     float *lnorm = reinterpret_cast<float *>(lsrc + n_rows);                  // [n_rows] |p|^2 of that proxy
     int32_t *lfirst = reinterpret_cast<int32_t *>(lnorm + n_rows);            // [AOC_CORR_MAX_OUT] first valid image row of each output column (-1: absent)
@@ -238,7 +245,7 @@ __global__ __launch_bounds__(NW * 64) void proxy_corr_batched_kernel(AocCorrFram
         // ---- stage this frame's proxy image -----------------------------------------------------------------
         // phase 1: which proxy feeds each image row, its norm
         for (int r = threadIdx.x; r < n_rows; r += NTH) {
-            const AocCorrTile &tl = tiles.t[r >> 5];
+            const AocCorrTile &tl = ltiles.t[r >> 5];
             const int rr = r & 31;
             int src = -1;
             if (tl.kind == 1) {
@@ -270,8 +277,8 @@ __global__ __launch_bounds__(NW * 64) void proxy_corr_batched_kernel(AocCorrFram
         __syncthreads();
         // phase 2: per output column the first valid row of its set (pads of the set's row groups are filled with a copy of it:
         // a duplicate never changes a min); columns of a column-wise tile are their own set
-        for (int oc = threadIdx.x; oc < tiles.n_out; oc += NTH) {
-            const int r0 = tiles.oc_row0[oc], nr = tiles.oc_rows[oc];
+        for (int oc = threadIdx.x; oc < ltiles.n_out; oc += NTH) {
+            const int r0 = ltiles.oc_row0[oc], nr = ltiles.oc_rows[oc];
             int first = -1;
             for (int r = r0; r < r0 + nr; ++r)
                 if (lsrc[r] >= 0) { first = r; break; }
@@ -291,7 +298,7 @@ __global__ __launch_bounds__(NW * 64) void proxy_corr_batched_kernel(AocCorrFram
                 srcs[u] = -1; srows[u] = -1;
                 if (it < n_rows * 25) {
                     const int r = it / 25, t = it - r * 25;
-                    const AocCorrTile &tl = tiles.t[r >> 5];
+                    const AocCorrTile &tl = ltiles.t[r >> 5];
                     int srow = r;                                             // image row whose proxy is copied here
                     if (lsrc[r] < 0) {
                         const int oc = tl.kind == 0 ? tl.oc[(r & 31) >> 3] : -1;
@@ -339,7 +346,7 @@ __global__ __launch_bounds__(NW * 64) void proxy_corr_batched_kernel(AocCorrFram
         // Slot a of half hh: gs 4 -> the set (half 0 of its last tile only); gs 2 -> set hh; gs 1 -> set 2 hh.  Slot b: gs 1 -> set 2 hh + 1.
         for (int it = threadIdx.x; it < NT * 2; it += NTH) {
             const int ti = it >> 1, hh = it & 1;
-            const AocCorrTile &tl = tiles.t[ti];
+            const AocCorrTile &tl = ltiles.t[ti];
             int oca = -1, ocb = -1;
             if (tl.kind == 0) {
                 if (tl.gs == 4) oca = (tl.last && hh == 0) ? tl.oc[0] : -1;
@@ -347,10 +354,10 @@ __global__ __launch_bounds__(NW * 64) void proxy_corr_batched_kernel(AocCorrFram
                 else { oca = tl.oc[2 * hh]; ocb = tl.oc[2 * hh + 1]; }
             }
             CbSlotDesc dsc;
-            dsc.off_a = oca >= 0 ? (int32_t)tiles.oc_offset[oca] : -1;
-            dsc.off_b = ocb >= 0 ? (int32_t)tiles.oc_offset[ocb] : -1;
-            dsc.bias_a = (oca >= 0 && fr.bias) ? fr.bias[tiles.oc_bias[oca]] : 0.0f;
-            dsc.bias_b = (ocb >= 0 && fr.bias) ? fr.bias[tiles.oc_bias[ocb]] : 0.0f;
+            dsc.off_a = oca >= 0 ? (int32_t)ltiles.oc_offset[oca] : -1;
+            dsc.off_b = ocb >= 0 ? (int32_t)ltiles.oc_offset[ocb] : -1;
+            dsc.bias_a = (oca >= 0 && fr.bias) ? fr.bias[ltiles.oc_bias[oca]] : 0.0f;
+            dsc.bias_b = (ocb >= 0 && fr.bias) ? fr.bias[ltiles.oc_bias[ocb]] : 0.0f;
             dsc.valid_a = oca >= 0 ? (lfirst[oca] >= 0) : 0;
             dsc.valid_b = ocb >= 0 ? (lfirst[ocb] >= 0) : 0;
             dsc.pad0 = dsc.pad1 = 0;
@@ -358,12 +365,12 @@ __global__ __launch_bounds__(NW * 64) void proxy_corr_batched_kernel(AocCorrFram
         }
         if (COL0) {
             for (int row = threadIdx.x; row < 32; row += NTH) {
-                const AocCorrTile &tl = tiles.t[0];
+                const AocCorrTile &tl = ltiles.t[0];
                 CbColDesc c;
                 const bool on = row < tl.cnt[0];
                 const int oc = tl.oc[0] + (on ? row : 0);
-                c.off = on ? (int32_t)tiles.oc_offset[oc] : -1;
-                c.bias = (on && fr.bias) ? fr.bias[tiles.oc_bias[oc]] : 0.0f;
+                c.off = on ? (int32_t)ltiles.oc_offset[oc] : -1;
+                c.bias = (on && fr.bias) ? fr.bias[ltiles.oc_bias[oc]] : 0.0f;
                 c.valid = on ? (lfirst[oc] >= 0) : 0;
                 c.pad = 0;
                 lcol[row] = c;
@@ -522,7 +529,7 @@ int aoc_proxy_corr_min_batched(const aoc_corr_frame *frames_host, int n_frames, 
     // ---- pack the sets into 32-row tiles: single-proxy sets -> column-wise tiles, the others by row-group class
     const size_t tile_bytes = (size_t)CB_TILE_DW * 4 + 32 * 8;
     constexpr int NW = CB_NW;
-    const size_t lds_fixed = AOC_CORR_MAX_OUT * 4 + (size_t)AOC_CORR_MAX_TILES * 2 * 32 + 32 * 16 + (size_t)NW * CB_WBUF_BYTES;
+    const size_t lds_fixed = (size_t)CB_TABLE_DW * 4 + AOC_CORR_MAX_OUT * 4 + (size_t)AOC_CORR_MAX_TILES * 2 * 32 + 32 * 16 + (size_t)NW * CB_WBUF_BYTES;
     int max_tiles = (int)(((size_t)160 * 1024 - lds_fixed) / tile_bytes);
     if (max_tiles > AOC_CORR_MAX_TILES) max_tiles = AOC_CORR_MAX_TILES;
     const int n_cu = cb_n_cus();
