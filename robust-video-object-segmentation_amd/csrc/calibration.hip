@@ -210,7 +210,19 @@ __global__ __launch_bounds__(256) void film_scale_kernel(const float *__restrict
     const int o = (int)(plane / channels), c = (int)(plane - (int64_t)o * channels);
     const float *h = head + (size_t)o * D, *w = weight + (size_t)c * D;
     float acc = 0.0f;
-    for (int d = threadIdx.x; d < D; d += blockDim.x) acc += w[d] * h[d];
+    // four strides of the dot product at a time, branch-free (clamped index, select afterwards): the eight loads are in flight together
+    // instead of one dependent round trip per stride, which is most of a workgroup's life when its slice of the plane is small
+    for (int d0 = threadIdx.x; d0 < D; d0 += 4 * blockDim.x) {
+        float wv[4], hv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int d = min(d0 + u * (int)blockDim.x, D - 1);
+            wv[u] = w[d];
+            hv[u] = h[d];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc += (d0 + u * (int)blockDim.x < D) ? wv[u] * hv[u] : 0.0f;
+    }
     acc = aoc_wave_sum(acc);
     if (aoc_lane() == 0) wsum[threadIdx.x >> 6] = acc;
     __syncthreads();
@@ -228,10 +240,21 @@ __global__ __launch_bounds__(256) void film_scale_kernel(const float *__restrict
         const int64_t body4 = (hw - headn) / 4;
         const float4 *x4 = reinterpret_cast<const float4 *>(xp + headn);
         float4 *y4 = reinterpret_cast<float4 *>(yp + headn);
-        for (int64_t i = tid; i < body4; i += nthreads) {
-            float4 v = x4[i];
-            v.x *= g; v.y *= g; v.z *= g; v.w *= g;
-            y4[i] = v;
+        for (int64_t i0 = tid; i0 < body4; i0 += 4 * nthreads) {     // four strides per trip, all loads in flight before the first store
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t i = i0 + u * nthreads;
+                v[u] = x4[i < body4 ? i : body4 - 1];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t i = i0 + u * nthreads;
+                if (i < body4) {
+                    v[u].x *= g; v[u].y *= g; v[u].z *= g; v[u].w *= g;
+                    y4[i] = v[u];
+                }
+            }
         }
         const int64_t tail0 = headn + body4 * 4;
         if (tid < hw - tail0) yp[tail0 + tid] = g * xp[tail0 + tid];
