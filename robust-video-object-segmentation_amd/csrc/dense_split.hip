@@ -48,21 +48,45 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float *__restrict
     const float *xr = x + (size_t)row * C;
     _Float16 hi[16], lo[16];
     bool bad = false;
+    {
+        // the k-step's 16 channels as four float4 loads issued together (clamped index, zero selected past the channels)
+        const int c4k = C >> 2;
+        float4 kv[4];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        const int k = ks * 16 + e;
-        const float v = (k < C) ? xr[k] * SP_SCALE : 0.0f;
-        bad |= !(fabsf(v) <= 65000.0f);
-        hi[e] = (_Float16)v;
-        lo[e] = (_Float16)(v - (float)hi[e]);
+        for (int q = 0; q < 4; ++q) kv[q] = reinterpret_cast<const float4 *>(xr)[min(ks * 4 + q, c4k - 1)];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const bool in = ks * 4 + q < c4k;
+            const float e4[4] = {kv[q].x, kv[q].y, kv[q].z, kv[q].w};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float v = in ? e4[u] * SP_SCALE : 0.0f;
+                bad |= !(fabsf(v) <= 65000.0f);
+                hi[q * 4 + u] = (_Float16)v;
+                lo[q * 4 + u] = (_Float16)(v - (float)hi[q * 4 + u]);
+            }
+        }
     }
     if (ks == SP_KS - 1) {
         float s = 0.0f, sl = 0.0f;
-        for (int t = 0; t < C; ++t) {
-            s += xr[t] * xr[t];
-            const float v = xr[t] * SP_SCALE;
-            const float l = (float)(_Float16)(v - (float)(_Float16)v);      // the lo value of channel t, as its own thread stores it
-            sl += l * l;
+        // the whole row as 25 float4 loads issued together (a scalar loop is one dependent round trip per channel); the additions keep
+        // the sequential order t = 0 .. C-1
+        float4 rv[SP_NORM_SLOT / 4];
+        const int c4n = C >> 2;
+#pragma unroll
+        for (int t4 = 0; t4 < SP_NORM_SLOT / 4; ++t4) rv[t4] = reinterpret_cast<const float4 *>(xr)[t4 < c4n ? t4 : c4n - 1];
+#pragma unroll
+        for (int t4 = 0; t4 < SP_NORM_SLOT / 4; ++t4) {
+            if (t4 < c4n) {
+                const float e[4] = {rv[t4].x, rv[t4].y, rv[t4].z, rv[t4].w};
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    s += e[u] * e[u];
+                    const float v = e[u] * SP_SCALE;
+                    const float l = (float)(_Float16)(v - (float)(_Float16)v);      // the lo value of the channel, as its own thread stores it
+                    sl += l * l;
+                }
+            }
         }
         if (sqnorm) sqnorm[row] = s;
         bad |= !(s <= 4000.0f);
