@@ -1042,13 +1042,17 @@ __device__ __forceinline__ void kc_write_block(const KcStage &st, float *__restr
     }
 }
 
-// P0: csum[chunk, f] = any-order float sum of the chunk's members (only used to predict binades)
+// P0: csum[chunk, f] = any-order float sum of the chunk's members (only used to predict binades).  Thread t owns the float4 piece
+// t % c4 of the rows t / c4, t / c4 + RPP, ... of the chunk (RPP = 256 / c4 rows per pass; consecutive threads read one row's consecutive
+// 16 bytes): private float4 partial sums, eight independent loads in flight per thread, no LDS tile and no barrier in the loop; the RPP
+// partial sums of a piece are combined through LDS at the end.
 __global__ __launch_bounds__(256) void km_chunk_sum_kernel(const float *__restrict__ pool, int C, const int32_t *__restrict__ seg_off,
                                                             const int32_t *__restrict__ counts, const int32_t *__restrict__ cbase,
                                                             const uint32_t *__restrict__ moff, int kmax,
                                                             const int32_t *__restrict__ owner_cluster, const int32_t *__restrict__ owner_local,
                                                             float *__restrict__ csum, int start_chunk) {
-    __shared__ __attribute__((aligned(16))) float tile[64 * KC_TILE_LD];
+    __shared__ uint32_t loffs[KS_CHUNK];
+    __shared__ __attribute__((aligned(16))) float4 part[256];
     const int chunk = blockIdx.x;
     const int oc = owner_cluster[chunk];
     if (oc < 0) return;
@@ -1057,36 +1061,35 @@ __global__ __launch_bounds__(256) void km_chunk_sum_kernel(const float *__restri
     const int cnt = counts[oc];
     const uint32_t *list = moff + seg_off[s] + cbase[oc];
     const int first = owner_local[chunk] * KS_CHUNK;
-    const int lane = aoc_lane(), wave = threadIdx.x >> 6;
-    const int fpw = (C + 3) / 4;                      // features per wave (4 waves)
-    float acc[AOC_MAX_CHANNELS / 2 / 4];
-#pragma unroll
-    for (int i = 0; i < AOC_MAX_CHANNELS / 2 / 4; ++i) acc[i] = 0.0f;
-    __shared__ uint32_t loffs[KS_CHUNK];
     const int members = min(KS_CHUNK, cnt - first);
-    for (int i = threadIdx.x; i < KS_CHUNK; i += blockDim.x) loffs[i] = (i < members) ? list[first + i] : 0u;
+    for (int i = threadIdx.x; i < KS_CHUNK; i += blockDim.x) loffs[i] = list[first + min(i, members - 1)];
     __syncthreads();
-    const int nblk = (members + 63) / 64;
-    KcStage stg;
-    kc_issue_block(stg, pool, loffs, 0, members, C >> 2);
-    for (int b = 0; b < nblk; ++b) {
-        __syncthreads();                       // tile free
-        kc_write_block(stg, tile, C >> 2);
-        if (b + 1 < nblk) kc_issue_block(stg, pool, loffs, b + 1, members, C >> 2);   // in flight under this block's arithmetic
-        __syncthreads();
+    const int c4 = C >> 2;                              // float4 pieces per row (C % 4 == 0 on this path)
+    const int rpp = 256 / c4;                           // rows per pass
+    const int r0 = threadIdx.x / c4, piece = threadIdx.x - r0 * c4;
+    const bool worker = r0 < rpp;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (worker) {
+        const char *base = reinterpret_cast<const char *>(pool) + piece * 16;
+        for (int m0 = r0; m0 < members; m0 += 8 * rpp) {
+            float4 v[8];
 #pragma unroll
-        for (int i = 0; i < AOC_MAX_CHANNELS / 2 / 4; ++i) {
-            const int f = wave * fpw + i;
-            if (i < fpw && f < C) acc[i] += tile[lane * KC_TILE_LD + f];
+            for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const float4 *>(base + loffs[min(m0 + u * rpp, KS_CHUNK - 1)]);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (m0 + u * rpp < members) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+            }
         }
     }
-#pragma unroll
-    for (int i = 0; i < AOC_MAX_CHANNELS / 2 / 4; ++i) {
-        const int f = wave * fpw + i;
-        if (i < fpw && f < C) {
-            const float t = aoc_wave_sum(acc[i]);
-            if (lane == 0) csum[(size_t)chunk * C + f] = t;
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    if ((int)threadIdx.x < c4) {
+        float4 t = part[threadIdx.x];
+        for (int r = 1; r < rpp; ++r) {
+            const float4 x = part[r * c4 + threadIdx.x];
+            t.x += x.x; t.y += x.y; t.z += x.z; t.w += x.w;
         }
+        *reinterpret_cast<float4 *>(csum + (size_t)chunk * C + 4 * threadIdx.x) = t;
     }
 }
 
