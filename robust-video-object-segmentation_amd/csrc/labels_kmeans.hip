@@ -680,6 +680,17 @@ __global__ __launch_bounds__(256, 2) void km_assign_mfma_kernel(const float *__r
         }
     }
 
+    // segment table in LDS (work item -> segment is a search over it; from global memory every probe is a dependent round trip)
+    constexpr int SEG_LDS = 128;
+    __shared__ int32_t lseg_off[SEG_LDS + 1], lseg_nb[SEG_LDS];
+    const bool seg_in_lds = n_seg <= SEG_LDS;
+    if (seg_in_lds) {
+        for (int i = threadIdx.x; i <= n_seg; i += 256) lseg_off[i] = seg_off[i];
+        __syncthreads();
+        for (int i = threadIdx.x; i < n_seg; i += 256) lseg_nb[i] = (seg_k[i] > 0) ? (lseg_off[i + 1] - lseg_off[i] + 255) / 256 : 0;
+        __syncthreads();
+    }
+
     float4 ca[KT][NB4];
     float cn[KT][4];
     int cur_seg = -1, k = 0, beg = 0, len = 0;
@@ -687,16 +698,24 @@ __global__ __launch_bounds__(256, 2) void km_assign_mfma_kernel(const float *__r
     // staged once per block and segment instead of once per 256 rows
     for (int w = blockIdx.x;; w += gridDim.x) {
         int s = 0, bx = w;
-        for (; s < n_seg; ++s) {
-            const int ls = seg_off[s + 1] - seg_off[s];
-            const int nbs = (seg_k[s] > 0) ? (ls + 255) / 256 : 0;
-            if (bx < nbs) break;
-            bx -= nbs;
+        if (seg_in_lds) {
+            for (; s < n_seg; ++s) {
+                const int nbs = lseg_nb[s];
+                if (bx < nbs) break;
+                bx -= nbs;
+            }
+        } else {
+            for (; s < n_seg; ++s) {
+                const int ls = seg_off[s + 1] - seg_off[s];
+                const int nbs = (seg_k[s] > 0) ? (ls + 255) / 256 : 0;
+                if (bx < nbs) break;
+                bx -= nbs;
+            }
         }
         if (s >= n_seg) break;
         // ---- this item's rows: all loads of TPF tiles are issued before anything waits (ids -> pieces in registers)
         constexpr int TPF = 2;                             // tiles in flight per wave (register budget: 3 blocks per CU)
-        const int ibeg = seg_off[s], ilen = seg_off[s + 1] - ibeg;
+        const int ibeg = seg_in_lds ? lseg_off[s] : seg_off[s], ilen = (seg_in_lds ? lseg_off[s + 1] : seg_off[s + 1]) - ibeg;
         const int wave_row0 = bx * 256 + wave * 64;
         float4 pv[TPF][PIECES];
         // the pool row of every row of this wave: ONE id load per lane (rows past the end take the segment's last row and are zeroed on
@@ -704,6 +723,7 @@ __global__ __launch_bounds__(256, 2) void km_assign_mfma_kernel(const float *__r
         // item and all piece loads of a tile are in flight together, with no exec-masked regions in between
         const int my_p = min(wave_row0 + lane, ilen - 1);
         const int my_id = rows[ibeg + max(my_p, 0)];
+        const float my_xs = rownorm[ibeg + max(my_p, 0)];      // |x|^2 of row (wave_row0 + lane), fetched with the ids instead of once per tile
         auto issue_tile = [&](int tile, float4 (&v)[PIECES]) {
 #pragma unroll
             for (int i = 0; i < PIECES; ++i) {
@@ -784,7 +804,8 @@ __global__ __launch_bounds__(256, 2) void km_assign_mfma_kernel(const float *__r
 #pragma unroll
             for (int u = 0; u < NB4; ++u) xb[u] = *reinterpret_cast<const float4 *>(bs + 4 * u);
             const int prow = wave_row0 + tile * 16 + j;
-            const float xs = (prow < len) ? rownorm[beg + prow] : 0.0f;
+            const float xs_l = __shfl(my_xs, tile * 16 + j);
+            const float xs = (prow < len) ? xs_l : 0.0f;
             float low = INFINITY;
             int arg = 0;
 #pragma unroll
