@@ -714,7 +714,7 @@ __global__ __launch_bounds__(256, 2) void km_assign_mfma_kernel(const float *__r
         }
         if (s >= n_seg) break;
         // ---- this item's rows: all loads of TPF tiles are issued before anything waits (ids -> pieces in registers)
-        constexpr int TPF = 2;                             // tiles in flight per wave (register budget: 3 blocks per CU)
+        constexpr int TPF = 2;                             // tiles in flight per wave
         const int ibeg = seg_in_lds ? lseg_off[s] : seg_off[s], ilen = (seg_in_lds ? lseg_off[s + 1] : seg_off[s + 1]) - ibeg;
         const int wave_row0 = bx * 256 + wave * 64;
         float4 pv[TPF][PIECES];
@@ -2043,6 +2043,11 @@ inline void ks_launch_sums(hipStream_t st, const float *pool, uint32_t pool_byte
 #undef AOC_KSS
 }
 
+inline int km_assign_grid_cap() {
+    static const int cap = getenv("AOC_KM_ASSIGN_GRID") ? atoi(getenv("AOC_KM_ASSIGN_GRID")) : 512;      // developer switch (measured: 128 .. 512 within 3 %)
+    return cap > 0 ? cap : 512;
+}
+
 inline int label_blocks(int64_t n) { return (int)((n + LP_BLOCK - 1) / LP_BLOCK); }
 
 }  // namespace
@@ -2136,7 +2141,7 @@ int aoc_kmeans_segmented_ex(const float *pool, int64_t pool_rows, int C, const i
         if (fast && !first && mfma_assign && C == 100 && kmax <= 64) {
             const int kt = (kmax + 15) / 16;
             const size_t alds = ((size_t)kt * 16 * 116 + kt * 16 + (size_t)4 * 16 * 116) * sizeof(float) + (size_t)4 * kmax * sizeof(int32_t);
-            const unsigned pgrid = (unsigned)std::min<int64_t>(std::min<int64_t>(rows_capacity, seg_bound * n_seg) / 256 + n_seg, 512);    // persistent: 2 blocks per CU
+            const unsigned pgrid = (unsigned)std::min<int64_t>(std::min<int64_t>(rows_capacity, seg_bound * n_seg) / 256 + n_seg, km_assign_grid_cap());    // persistent workgroups, several 256-row items each: the code book staging is paid once per workgroup
 #define AOC_KA(KT) hipLaunchKernelGGL((km_assign_mfma_kernel<25, KT>), dim3(pgrid), dim3(256), alds, st, pool, C, rows, seg_offsets, seg_k, n_seg, centroids, \
                                       kmax, labels, ws.rank16, ws.hist, ws.nb_max, rownorm)
             if (kt == 1) AOC_KA(1); else if (kt == 2) AOC_KA(2); else if (kt == 3) AOC_KA(3); else AOC_KA(4);
