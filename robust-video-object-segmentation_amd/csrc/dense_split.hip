@@ -210,12 +210,11 @@ __device__ __forceinline__ void glds4(const void *gsrc, uint32_t lds_dst) {
 
 constexpr int SP_NBUF = 2;                                        // chunk buffers in LDS
 constexpr int SP_CHUNK_BYTES = SP_NB * SP_TILE * SP_REC * 16;     // 57344: four tiles x 32 rows x 448 B, rows unpadded
-constexpr int SP_DMA_PER_WAVE = SP_CHUNK_BYTES / 1024 / SP_NW;    // 7 wave-wide 1 KiB transfers per wave and chunk
 constexpr int SP_RING_BYTES = SP_NBUF * SP_CHUNK_BYTES;
 constexpr int SP_IDS_OFF = SP_RING_BYTES;                         // 2 slots x 128 row ids
 constexpr int SP_OBJ_OFF = SP_IDS_OFF + 2 * 512;                  // 4 slots x 64 tile objects (4 used)
 constexpr int SP_BND_OFF = SP_OBJ_OFF + 4 * 256;                  // per (wave, query tile): 64 published bounds
-constexpr int SP_LDS_BYTES = SP_BND_OFF + SP_NW * SP_NQ * 256;
+constexpr int SP_LDS_BYTES = SP_BND_OFF + SP_NW * SP_NQ * 256;      // (for the widest workgroup)
 constexpr int SP_TILE_SLACK = 2;                                  // the plan always holds an empty tile after the last one
 
 // Coarse-then-rescore.  Block = 8 waves x 2 query tiles (512 query pixels; both planes of their records are the stationary B
@@ -235,14 +234,17 @@ constexpr int SP_TILE_SLACK = 2;                                  // the plan al
 // way.  LDS rows are unpadded (448 B); chunk c of row r sits at position c ^ ((r >> 3) & 3), which makes every ds_read_b128 of an A
 // fragment conflict-free -- the swizzle is applied on the SOURCE address of the DMA, whose destination is lane-linear.  The transfers
 // are asm statements that hipcc neither counts nor drains; one vmcnt(0) + barrier per step (4 tiles) publishes them.
-__global__ __launch_bounds__(SP_NW * 64, 1) void dense_prune_kernel(const uint4 *__restrict__ qrec, const float *__restrict__ q2, int64_t m,
+template <int NW>
+__global__ __launch_bounds__(NW * 64, 1) void dense_prune_kernel(const uint4 *__restrict__ qrec, const float *__restrict__ q2, int64_t m,
                                                                      const uint4 *__restrict__ prec, const int32_t *__restrict__ tile_rows,
                                                                      const int32_t *__restrict__ tile_obj, const int32_t *__restrict__ n_tiles_ptr,
                                                                      const int32_t *__restrict__ gate, const uint32_t *__restrict__ pmax_bits,
                                                                      int n_obj, uint32_t *__restrict__ gbest, int dbg) {
     if (*gate) return;
     extern __shared__ __attribute__((aligned(16))) uint4 lds4[];
-    static_assert(SP_NB == 4 && SP_NQ == 2 && SP_NW == 8 && SP_DMA_PER_WAVE == 7, "the step structure below is written for 4 tiles x 2 query tiles x 8 waves");
+    static_assert(SP_NB == 4 && SP_NQ == 2 && (NW == 8 || NW == 4), "the step structure below is written for 4 tiles x 2 query tiles x 8 (or 4) waves");
+    constexpr int SP_DMA_PER_WAVE = SP_CHUNK_BYTES / 1024 / NW;      // 7 (14) wave-wide 1 KiB transfers per wave and chunk
+    constexpr int W_ID0 = NW / 2, W_ID1 = NW - 1, W_OBJ = 1;         // the waves that also fetch the row ids / the tiles' objects
     const uint32_t lds_base = (uint32_t)reinterpret_cast<uintptr_t>(lds4);
     const char *lds_bytes = reinterpret_cast<const char *>(lds4);
 
@@ -267,7 +269,7 @@ __global__ __launch_bounds__(SP_NW * 64, 1) void dense_prune_kernel(const uint4 
 
     const int lane = aoc_lane(), wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int col = lane & 31, h = lane >> 5;
-    const int64_t wave_row0 = (int64_t)bx * SP_ROWS_PER_BLOCK + (int64_t)wave * (SP_NQ * 32);
+    const int64_t wave_row0 = (int64_t)bx * (NW * SP_NQ * 32) + (int64_t)wave * (SP_NQ * 32);
 
     // ---- stationary query operands (both planes) and the per-pixel rescoring margin
     const float pmax = sqrtf(__uint_as_float(*pmax_bits)) * 1.001f;
@@ -314,15 +316,15 @@ __global__ __launch_bounds__(SP_NW * 64, 1) void dense_prune_kernel(const uint4 
         dma_plan[k] = ((uint32_t)r << 16) | (uint32_t)((pos ^ ((r >> 3) & 3)) * 16);
     }
     const char *prec_bytes = reinterpret_cast<const char *>(prec);
-    auto dma_meta = [&](int chunk) {            // row ids (waves 4 and 6) and tile objects (wave 5) of a chunk -> their rings
+    auto dma_meta = [&](int chunk) {            // row ids (two waves, two tiles each) and tile objects (one wave) of a chunk -> their rings
         // tile i of the split is tile by + i ns of the plan; past the end everything reads the (always present) empty tile n_tiles
         const int i0 = chunk * SP_NB;
-        if (wave == 4 || wave == 6) {
-            const int i = i0 + (wave == 6 ? 2 : 0) + (lane >> 5);
+        if (wave == W_ID0 || wave == W_ID1) {
+            const int i = i0 + (wave == W_ID1 ? 2 : 0) + (lane >> 5);
             const int t = min(by + i * ns, n_tiles);
-            glds4(tile_rows + (size_t)t * SP_TILE + (lane & 31), lds_base + SP_IDS_OFF + (chunk & 1) * 512 + (wave == 6 ? 256 : 0));
+            glds4(tile_rows + (size_t)t * SP_TILE + (lane & 31), lds_base + SP_IDS_OFF + (chunk & 1) * 512 + (wave == W_ID1 ? 256 : 0));
         }
-        if (wave == 5) glds4(tile_obj + min(by + (i0 + (lane & 3)) * ns, n_tiles), lds_base + SP_OBJ_OFF + (chunk & 3) * 256);
+        if (wave == W_OBJ) glds4(tile_obj + min(by + (i0 + (lane & 3)) * ns, n_tiles), lds_base + SP_OBJ_OFF + (chunk & 3) * 256);
     };
     auto dma_rows = [&](int chunk) {            // the chunk's records -> buffer chunk % 2 (its ids must have landed and been published)
         const int32_t *ids = reinterpret_cast<const int32_t *>(lds_bytes + SP_IDS_OFF + (chunk & 1) * 512);
@@ -527,8 +529,15 @@ __global__ __launch_bounds__(256) void dense_split_finalize_kernel(const uint32_
     }
 }
 
+inline int split_waves() {
+    // developer switch AOC_DENSE_WAVES=4: workgroups of 4 waves (256 query pixels), one wave per SIMD -- half of every CU's register file stays
+    // free for the other streams' kernels, and no CU mask is needed; the default (8) fills the CUs it runs on
+    static const int nw = (getenv("AOC_DENSE_WAVES") && atoi(getenv("AOC_DENSE_WAVES")) == 4) ? 4 : 8;
+    return nw;
+}
 inline int split_nsplit(int64_t m) {
-    const int64_t row_blocks = (m + SP_ROWS_PER_BLOCK - 1) / SP_ROWS_PER_BLOCK;
+    const int64_t rpb = (int64_t)split_waves() * SP_NQ * 32;
+    const int64_t row_blocks = (m + rpb - 1) / rpb;
     static const int max_rounds = getenv("AOC_DENSE_ROUNDS") ? atoi(getenv("AOC_DENSE_ROUNDS")) : 4;
     // CUs the launching stream may use (256 unless the caller runs it under a HIP CU mask and says so)
     static const int n_cu = (getenv("AOC_DENSE_CUS") && atoi(getenv("AOC_DENSE_CUS")) > 0) ? atoi(getenv("AOC_DENSE_CUS")) : 256;
@@ -613,15 +622,23 @@ int aoc_dense_match_min_split(const float *query, const void *query_rec, const f
                        right_bits, wrong_bits, overflow_flag, static_cast<const uint4 *>(pool_rec), w.tile_capacity, w.tile_rows, w.tile_obj,
                        w.n_tiles, w.gate, w.pmax);
     const int ns = split_nsplit(m);
-    const dim3 grid((unsigned)((m + SP_ROWS_PER_BLOCK - 1) / SP_ROWS_PER_BLOCK), ns);
+    const int nw = split_waves();
+    const int64_t rpb = (int64_t)nw * SP_NQ * 32;
+    const dim3 grid((unsigned)((m + rpb - 1) / rpb), ns);
     const size_t lds = SP_LDS_BYTES;
-    static const bool lds_ok = hipFuncSetAttribute(reinterpret_cast<const void *>(dense_prune_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
+    static const bool lds_ok =
+        hipFuncSetAttribute(reinterpret_cast<const void *>(dense_prune_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
+        hipFuncSetAttribute(reinterpret_cast<const void *>(dense_prune_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
     if (!lds_ok) return AOC_ERR_LAUNCH;
     const AocDenseProbe probe = aoc_take_dense_probe();
     static const int dbg = getenv("AOC_DENSE_DEBUG") ? atoi(getenv("AOC_DENSE_DEBUG")) : 0;       // developer switch: timing experiments only
     if (probe.start) (void)hipEventRecord(probe.start, st);
-    hipLaunchKernelGGL(dense_prune_kernel, grid, dim3(SP_NW * 64), lds, st, static_cast<const uint4 *>(query_rec), query_sqnorm, m,
-                       static_cast<const uint4 *>(pool_rec), w.tile_rows, w.tile_obj, w.n_tiles, w.gate, w.pmax, n_obj, w.gbest, dbg);
+    if (nw == 4)
+        hipLaunchKernelGGL(dense_prune_kernel<4>, grid, dim3(4 * 64), lds, st, static_cast<const uint4 *>(query_rec), query_sqnorm, m,
+                           static_cast<const uint4 *>(pool_rec), w.tile_rows, w.tile_obj, w.n_tiles, w.gate, w.pmax, n_obj, w.gbest, dbg);
+    else
+        hipLaunchKernelGGL(dense_prune_kernel<8>, grid, dim3(8 * 64), lds, st, static_cast<const uint4 *>(query_rec), query_sqnorm, m,
+                           static_cast<const uint4 *>(pool_rec), w.tile_rows, w.tile_obj, w.n_tiles, w.gate, w.pmax, n_obj, w.gbest, dbg);
     if (probe.stop) (void)hipEventRecord(probe.stop, st);
     hipLaunchKernelGGL(dense_split_finalize_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, w.gbest, m, n_obj, counts, w.gate,
                        query_sqnorm, obj_bias, out, out_pixel_stride, out_obj_stride, transform);
