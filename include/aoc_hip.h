@@ -396,6 +396,9 @@ int aoc_label_mix(const float *labels, const float *rows, int64_t n, int n_obj, 
                   aoc_stream_t stream);
 /* Global average pool of planes [planes, hw] -> [planes]  (CLB:68). */
 int aoc_plane_mean(const float *x, int64_t planes, int64_t hw, float *out, aoc_stream_t stream);
+/* out [n_obj, head_dim + channels] = head [n_obj, head_dim] extended with the inter-object code of the plane means [n_obj, channels]:
+ * out[o, head_dim + c] = sum_o' px[o', c] - px[o, c]  (decoding_module.py:126-130, torch.cat([head, px.sum(0, keepdim=True) - px], 1)) */
+int aoc_head_delta(const float *head, int head_dim, const float *plane_means, int n_obj, int channels, float *out, aoc_stream_t stream);
 
 /* DynamicPreHead, decoding_module.py:228-240 (1x1 convolution n_in -> n_out, GroupNorm(n_groups), ReLU) applied to the
  * [n_obj, n_in, hw] proto-mask tensor, fused with the concatenation of aocnet.py:362: out [n_obj, C + n_out, hw] holds the

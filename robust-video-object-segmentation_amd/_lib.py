@@ -71,6 +71,7 @@ SIGNATURES = {
     "aoc_linear": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "aoc_label_mix": (_i, [_vp, _vp, _i64, _i, _i, _vp, _vp]),
     "aoc_plane_mean": (_i, [_vp, _i64, _i64, _vp, _vp]),
+    "aoc_head_delta": (_i, [_vp, _i, _vp, _i, _i, _vp, _vp]),
 }
 
 STATUS = {0: "AOC_OK", -1: "AOC_ERR_INVALID_ARG", -2: "AOC_ERR_WORKSPACE", -3: "AOC_ERR_LAUNCH", -4: "AOC_ERR_UNSUPPORTED"}

@@ -672,6 +672,25 @@ __global__ __launch_bounds__(256) void plane_mean_kernel(const float *__restrict
     if (threadIdx.x == 0) out[blockIdx.x] = (wsum[0] + wsum[1] + wsum[2] + wsum[3]) / (float)hw;
 }
 
+// out[o, :D] = head[o, :];  out[o, D + c] = sum_o' px[o', c] - px[o, c]   (decoding_module.py:126-130: the IA head extended with the
+// inter-object code of the gate's own input; replaces a reduction, a subtraction and a concatenation of tiny tensors)
+__global__ __launch_bounds__(256) void head_delta_kernel(const float *__restrict__ head, int D, const float *__restrict__ px, int n_obj, int C,
+                                                          float *__restrict__ out) {
+    const int o = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= D + C) return;
+    float v;
+    if (i < D) {
+        v = head[(size_t)o * D + i];
+    } else {
+        const int c = i - D;
+        float s = 0.0f;
+        for (int q = 0; q < n_obj; ++q) s += px[(size_t)q * C + c];          // the same left-to-right sum as torch.sum(dim=0) over a handful of objects
+        v = s - px[(size_t)o * C + c];
+    }
+    out[(size_t)o * (D + C) + i] = v;
+}
+
 // ------------------------------------------------------------------------------------------
 // Decoder-side streams that sit next to the FiLM gates.
 // plane_reduce: out[plane] = sum over the plane of x (mode 0), x^2 (mode 1) or |x| (mode 2)  (gct.py:19,27-30)
@@ -1031,6 +1050,14 @@ int aoc_label_mix(const float *labels, const float *rows, int64_t n, int n_obj, 
 int aoc_plane_mean(const float *x, int64_t planes, int64_t hw, float *out, aoc_stream_t stream) {
     if (!x || !out || planes < 1 || hw < 1) return AOC_ERR_INVALID_ARG;
     hipLaunchKernelGGL(plane_mean_kernel, dim3((unsigned)planes), dim3(256), 0, aoc_hip_stream(stream), x, hw, out);
+    AOC_RETURN_IF_LAUNCH_FAILED();
+    return AOC_OK;
+}
+
+int aoc_head_delta(const float *head, int head_dim, const float *plane_means, int n_obj, int channels, float *out, aoc_stream_t stream) {
+    if (!head || !plane_means || !out || head_dim < 1 || n_obj < 1 || channels < 1) return AOC_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(head_delta_kernel, dim3((unsigned)((head_dim + channels + 255) / 256), (unsigned)n_obj), dim3(256), 0, aoc_hip_stream(stream), head,
+                       head_dim, plane_means, n_obj, channels, out);
     AOC_RETURN_IF_LAUNCH_FAILED();
     return AOC_OK;
 }

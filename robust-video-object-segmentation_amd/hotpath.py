@@ -383,8 +383,16 @@ def proto_mask_features(cfg, ref_emb, ref_labels, prev_emb, prev_labels, cur_emb
         set_size.append(1)
         set_off.append(o * obj_stride + ch["proxy"] * hw)
         set_obj.append(o)
-    set_bias = bias.repeat_interleave(2).repeat(L) if L > 1 else bias.repeat_interleave(2)
-    set_bias = torch.cat([set_bias, bias])
+    # per-set bias table (a function of the bias vector alone: kept with the sequence's state while the vector is unchanged)
+    bkey = (bias.data_ptr(), bias._version, L, O)
+    cached_bias = dense_state.get("set_bias") if dense_state is not None else None
+    if cached_bias is not None and cached_bias[0] == bkey:
+        set_bias = cached_bias[1]
+    else:
+        set_bias = bias.repeat_interleave(2).repeat(L) if L > 1 else bias.repeat_interleave(2)
+        set_bias = torch.cat([set_bias, bias])
+        if dense_state is not None:
+            dense_state["set_bias"] = (bkey, set_bias)
     if cluster_ahead is not None:
         torch.cuda.current_stream().wait_event(cluster_ahead.done_event)   # join: the proxy table is complete
     pending = None
@@ -486,7 +494,6 @@ class CalibrationGates(nn.Module):
             else:
                 head = attention_head
                 if extra:
-                    px1 = ops.plane_mean(x)
-                    head = torch.cat([attention_head, px1.sum(dim=0, keepdim=True) - px1], dim=1)
+                    head = ops.head_delta(attention_head, ops.plane_mean(x))        # cat([head, px1.sum(0) - px1]) in one launch
                 out.append(mod(x, head))
         return out

@@ -517,6 +517,17 @@ def plane_mean(x):
     return out
 
 
+def head_delta(head, plane_means):
+    """torch.cat([head, plane_means.sum(0, keepdim=True) - plane_means], 1) in one launch (aoc_head_delta; decoding_module.py:126-130)."""
+    head, plane_means = _f32c(head), _f32c(plane_means)
+    _need_gpu(head, plane_means)
+    n_obj, D = head.shape
+    C = plane_means.shape[1]
+    out = torch.empty(n_obj, D + C, dtype=torch.float32, device=head.device)
+    _lib.check(_lib.lib().aoc_head_delta(_p(head), D, _p(plane_means), n_obj, C, _p(out), _stream()), "aoc_head_delta")
+    return out
+
+
 # ------------------------------------------------------------------------------------------ eval-loop memory policy
 def confident_labels(probs_flat, exist_bits, join_label=None, unc_ratio=1.0):
     """aoc_confident_labels: probs [n_ch, n] -> (labels [n], confident [n] with 125 = uncertain, entropy [n])."""

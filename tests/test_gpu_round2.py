@@ -468,3 +468,13 @@ def test_bottleneck_golden(aoc, golden):
     want = torch.relu(gn(x) + r)
     got = aoc.ops.groupnorm_relu(x, 32, gn.weight, gn.bias, gn.eps, r, True)
     np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=1e-5, atol=2e-6)
+
+
+def test_head_delta_equals_torch(aoc):
+    """aoc_head_delta = torch.cat([head, px.sum(0, keepdim=True) - px], 1) (decoding_module.py:126-130)."""
+    g = torch.Generator().manual_seed(5)
+    for n_obj, D, C in [(4, 400, 512), (1, 400, 320), (9, 912, 128)]:
+        head, px = torch.randn(n_obj, D, generator=g), torch.randn(n_obj, C, generator=g)
+        got = aoc.ops.head_delta(head.cuda(), px.cuda()).cpu()
+        want = torch.cat([head, px.sum(dim=0, keepdim=True) - px], dim=1)
+        assert got.shape == want.shape and float((got - want).abs().max()) <= 2e-6
