@@ -153,7 +153,9 @@ __global__ __launch_bounds__(256) void split_plan_kernel(const int32_t *__restri
     int obj = -1, local = 0;
     for (int o = 0; o < n_obj; ++o) {
         const int64_t nt = (counts[o] + SP_TILE - 1) / SP_TILE;
-        if (obj < 0 && t < base + nt) { obj = o; local = (int)(t - base); }
+        // an object's tiles in DESCENDING row order: the newest pool frame first -- that is where a video's best matches usually are, and an
+        // early good match tightens the bounds for everything after it
+        if (obj < 0 && t < base + nt) { obj = o; local = (int)(nt - 1 - (t - base)); }
         base += nt;
     }
     if (e == 0) *n_tiles = (int32_t)base;
