@@ -591,7 +591,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--exact-steps", type=int, default=10,
                     help="steps of the informational second region with the exact-fp32 dense kernel (reported as exact_fp32_dense_run; 0 = skip)")
-    ap.add_argument("--cu-reserve", type=int, default=64,
+    ap.add_argument("--cu-reserve", type=int, default=32,
                     help="keep the main streams off this many CUs (HIP CU mask) so the side-stream k-means chain always finds free CUs")
     ap.add_argument("--chains", type=int, default=3,
                     help="frames whose k-means is enqueued right after a pool update (1 = only the next frame; the others are batched into one chain)")
