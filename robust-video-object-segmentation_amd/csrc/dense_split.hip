@@ -406,10 +406,12 @@ __global__ __launch_bounds__(NW * 64, 1) void dense_prune_kernel(const uint4 *__
         const int n_here = min(SP_NB, n_mine - s * SP_NB);
         // the first two A fragments of a tile are requested while the previous tile's epilogue runs
         f16x8 pre0 = frag(chunk_base, 2 * ks_of(0)), pre1 = frag(chunk_base, 2 * ks_of(1));
+        // the four tiles' objects in one scalar (objects are < 256): two SALU operations per tile instead of a chain of selects
+        const uint32_t objs_packed = (uint32_t)__builtin_amdgcn_readfirstlane((objs.x & 0xff) | ((objs.y & 0xff) << 8) | ((objs.z & 0xff) << 16) | ((objs.w & 0xff) << 24));
 #pragma unroll 1
         for (int t = 0; t < n_here; ++t) {
             const char *tile_base = chunk_base + t * (SP_TILE * SP_REC * 16);
-            const int o = __builtin_amdgcn_readfirstlane(t == 0 ? objs.x : t == 1 ? objs.y : t == 2 ? objs.z : objs.w);
+            const int o = (int)((objs_packed >> (8 * t)) & 0xffu);
             if (o != cur) switch_object(o);
             // coarse pass: 7 k-steps x 2 query tiles, A fragments two k-steps ahead through a ring of three
             f32x16 acc[SP_NQ];
