@@ -659,7 +659,7 @@ __global__ __launch_bounds__(256, 2) void km_assign_mfma_kernel(const float *__r
     constexpr int RS = 4 * TP + 4;                     // row stride of the k-permuted image
     constexpr int NB4 = TP / 4;
     constexpr int PIECES = (16 * TMAX + 63) / 64;      // float4 pieces per lane per 16-row tile
-    const int c4 = C >> 2;
+    constexpr int c4 = TMAX;                           // launched for C == 4 TMAX only: piece indices divide by a constant (a runtime divisor costs ~20 VALU per division, ~1000 per 64 rows)
     const int lane = aoc_lane(), wave = threadIdx.x >> 6;
     const int j = lane & 15, g = lane >> 4;
 
