@@ -36,9 +36,9 @@ struct ProxyTileTable {
 
 // Stage 16-column operand tiles into the k-permuted LDS image.  row_of(c) gives the source row
 // pointer of tile column c (nullptr = zero fill).
-template <bool F16, typename RowFn>
+template <bool F16, int C4C, typename RowFn>
 __device__ __forceinline__ void stage_tile_rows(float *__restrict__ lds, int n_rows, int C, int TP, int RS, RowFn row_of) {
-    const int c4 = C >> 2;
+    const int c4 = C4C > 0 ? C4C : (C >> 2);          // compile-time when the caller knows it: the piece indices then divide by a constant
     const int total = n_rows * c4;
     constexpr int BATCH = 16;     // loads in flight per thread: a naive load->write loop would serialise on latency
     for (int base = 0; base < total; base += BATCH * (int)blockDim.x) {
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(256) void proxy_corr_min_kernel(PcFrames frames, in
     float *lp2 = lds + (size_t)ncols_total * RS;
     float *wbuf_all = lp2 + ncols_total;                      // [4 waves][16 rows][n_out + 1] raw distances
     const int nout = tiles.n_out, wld = nout + 1;
-    stage_tile_rows<F16>(lds, ncols_total, C, TP, RS, [&](int c) -> const float * {
+    stage_tile_rows<F16, (EXACT ? TMAX : 0)>(lds, ncols_total, C, TP, RS, [&](int c) -> const float * {
         const ProxyTile &pt = tiles.t[c >> 4];
         return ((c & 15) < pt.ncols) ? proxies + (size_t)(pt.proxy_begin + (c & 15)) * C : nullptr;
     });
@@ -333,7 +333,7 @@ __global__ __launch_bounds__(NW * 64, 2) void dense_match_partial_kernel(const f
     const int j = lane & 15, g = lane >> 4;
     const int64_t block_row0 = (int64_t)blockIdx.x * (16 * NA * NW);
     const int64_t wave_row0 = block_row0 + (int64_t)wave * 16 * NA;
-    const int c4 = C >> 2;
+    const int c4 = EXACT ? TMAX : (C >> 2);
 
     float a[NA][TMAX], q2r[NA][4];
 #pragma unroll

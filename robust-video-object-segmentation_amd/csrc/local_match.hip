@@ -199,7 +199,7 @@ __global__ __launch_bounds__(256) void local_window_row_kernel(const float *__re
     const int acc_per_wave = 16 * nr * n_obj;
     const int lane = aoc_lane(), wave = threadIdx.x >> 6;
     const int j = lane & 15, g = lane >> 4;
-    const int c4 = C >> 2;
+    constexpr int c4 = TMAX;                         // launched for C == 4 TMAX only: the piece indices divide by a constant
     // per wave: [NCP][RS] image, [NCP] |y|^2, [NCP] label bits; then [R+1] ring classes and the accumulators
     const size_t wave_floats = (size_t)NCP * RS + 2 * NCP;
     float *wimg = lds + (size_t)wave * wave_floats;
@@ -219,9 +219,11 @@ __global__ __launch_bounds__(256) void local_window_row_kernel(const float *__re
         lcls[threadIdx.x] = c;
     }
     // stream padding of this wave's image, once
-    for (int idx = lane; idx < NCP * 4 * (TP - c4); idx += 64) {
-        const int c = idx / (4 * (TP - c4)), rem = idx - c * 4 * (TP - c4);
-        wimg[(size_t)c * RS + (rem / (TP - c4)) * TP + c4 + rem % (TP - c4)] = 0.0f;
+    if constexpr (TP > c4) {
+        for (int idx = lane; idx < NCP * 4 * (TP - c4); idx += 64) {
+            const int c = idx / (4 * (TP - c4)), rem = idx - c * 4 * (TP - c4);
+            wimg[(size_t)c * RS + (rem / (TP - c4)) * TP + c4 + rem % (TP - c4)] = 0.0f;
+        }
     }
 
     float a[TMAX], q2r[4];
