@@ -361,6 +361,170 @@ __global__ __launch_bounds__(256) void local_window_row_kernel(const float *__re
 }
 
 // ------------------------------------------------------------------------------------------
+// Same computation with the MFMA operands fetched STRAIGHT INTO REGISTERS (no LDS image): the k dimension of a dot product may be
+// permuted freely as long as both operands agree, so lane (j, g) takes the float4 pieces g, g + 4, g + 8, ... of pixel j's row (and
+// channel 16 NP + g when C = 100) -- every load instruction is 16-byte loads of which four neighbouring lanes cover 64 contiguous
+// bytes, and a candidate group needs NP (+1) of them instead of a transposing LDS round trip (76 ds_write_b32 + 25 ds_read_b128 per
+// lane and candidate row in the row kernel above).  Without the 81 KB of wave-private images a workgroup needs 6.5 KB of LDS (the
+// per-(pixel, ring, object) minima), so every wave of the launch is resident at once (the row kernel ran one workgroup per CU = one
+// wave per SIMD, nothing to hide a latency behind, and 427 workgroups took two rounds on 256 CUs).  Work split as in the row kernel:
+// block = one query row x 16 columns, the four waves take the candidate rows round-robin; a wave walks its (candidate row, group of
+// 16 candidates) items with the next item's loads in flight under the current item's 25 MFMAs (two register buffers, loop unrolled
+// by two).  Only candidate rows at multiples of the atrous rate are visited.
+template <int TMAX>
+__global__ __launch_bounds__(256) void local_window_reg_kernel(const float *__restrict__ query, const float *__restrict__ prev,
+                                                                const uint32_t *__restrict__ right_bits, int H, int W,
+                                                                LocalRadii radii, const float *__restrict__ obj_bias, int n_obj,
+                                                                float *__restrict__ out, int transform, int rate, int f16) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int C = 4 * TMAX;
+    constexpr int NP = TMAX / 4;                        // float4 pieces per lane
+    constexpr bool TAIL = (TMAX % 4) != 0;              // TMAX = 25: one more channel per lane (16 NP + g)
+    static_assert(TMAX % 4 == 0 || TMAX % 4 == 1, "lane g takes pieces g, g + 4, ... and at most one tail channel");
+    const int nr = radii.n;
+    const int RA = radii.r[nr - 1];                     // window half-size in atrous units
+    const int R = RA * rate;
+    const float padv = f16 ? aoc_h(AOC_PAD_DISTANCE) : AOC_PAD_DISTANCE;
+    const int NC = 16 + 2 * R;                          // candidates per row
+    const int NG = (NC + 15) / 16;
+    const int acc_per_wave = 16 * nr * n_obj;
+    const int lane = aoc_lane(), wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 15, g = lane >> 4;
+    int32_t *lcls = reinterpret_cast<int32_t *>(lds);               // [RA + 1] ring -> class
+    float *lacc = lds + 32;                                         // [4 waves][16][n_radii][n_obj]
+    float *my_acc = lacc + wave * acc_per_wave;
+    const int x0 = blockIdx.x * 16;
+    const int y = blockIdx.y;
+
+    for (int i = lane; i < acc_per_wave; i += 64) my_acc[i] = padv;      // AEM:1032 pad
+    if ((int)threadIdx.x <= RA) {
+        int c = 0;
+        while (radii.r[c] < (int)threadIdx.x) ++c;
+        lcls[threadIdx.x] = c;
+    }
+
+    // this lane's 4 NP (+1) channels of a pixel row
+    auto load_row = [&](const float *__restrict__ p, float (&v)[TMAX]) {
+        const float4 *p4 = reinterpret_cast<const float4 *>(p) + g;
+#pragma unroll
+        for (int u = 0; u < NP; ++u) {
+            const float4 x = p4[4 * u];
+            v[4 * u] = x.x; v[4 * u + 1] = x.y; v[4 * u + 2] = x.z; v[4 * u + 3] = x.w;
+        }
+        if constexpr (TAIL) v[4 * NP] = p[16 * NP + g];
+    };
+    // sum of squares of the lane's channels, reduced over the four lanes (g) that share a pixel
+    auto sq_norm = [&](const float (&v)[TMAX]) -> float {
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+        for (int t = 0; t + 3 < TMAX; t += 4) {
+            if (f16) { s0 += aoc_h(v[t] * v[t]); s1 += aoc_h(v[t + 1] * v[t + 1]); s2 += aoc_h(v[t + 2] * v[t + 2]); s3 += aoc_h(v[t + 3] * v[t + 3]); }
+            else { s0 += v[t] * v[t]; s1 += v[t + 1] * v[t + 1]; s2 += v[t + 2] * v[t + 2]; s3 += v[t + 3] * v[t + 3]; }
+        }
+        if constexpr (TAIL) s0 += f16 ? aoc_h(v[TMAX - 1] * v[TMAX - 1]) : v[TMAX - 1] * v[TMAX - 1];
+        float s = (s0 + s1) + (s2 + s3);
+        s += __shfl_xor(s, 16);
+        s += __shfl_xor(s, 32);
+        return f16 ? aoc_h(s) : s;
+    };
+
+    float a[TMAX], q2r[4];
+    {   // A operand: the 16 query pixels of row y (columns beyond the map re-read the last one; they are never stored)
+        load_row(query + ((size_t)y * W + min(x0 + j, W - 1)) * C, a);
+        if (f16) {
+#pragma unroll
+            for (int t = 0; t < TMAX; ++t) a[t] = aoc_h(a[t]);
+        }
+        const float q2 = sq_norm(a);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) q2r[r] = __shfl(q2, g * 4 + r);
+    }
+    __syncthreads();                                    // lcls
+
+    // candidate rows cy = y + k rate, k in [k_beg, k_end]; this wave takes k_beg + wave, + 4, ...
+    const int k_beg = max(-RA, -(y / rate)), k_end = min(RA, (H - 1 - y) / rate);
+    const int k_first = k_beg + wave;
+    const int n_items = k_first <= k_end ? ((k_end - k_first) / 4 + 1) * NG : 0;
+
+    float b0[TMAX], b1[TMAX];
+    uint32_t bits0 = 0u, bits1 = 0u;
+    // item -> (k, gi), advanced incrementally (wave-uniform)
+    int k_ld = k_first, gi_ld = 0;
+    auto issue = [&](float (&b)[TMAX], uint32_t &bits) {
+        const int cy = y + k_ld * rate;
+        const int c = gi_ld * 16 + j, cx = x0 - R + c;
+        const bool ok = c < NC && cx >= 0 && cx < W;
+        const int cxc = min(max(cx, 0), W - 1);                       // clamped address, selected afterwards: the loads stay branch-free
+        const size_t pix = (size_t)cy * W + cxc;
+        load_row(prev + pix * C, b);
+        const uint32_t raw = right_bits[pix];
+        bits = ok ? (raw & ~AOC_ROW_KEPT_BIT) : 0u;                    // AEM:1023-1028 (pad 0)
+        if (++gi_ld == NG) { gi_ld = 0; k_ld += 4; }
+    };
+    int k_cur = k_first, gi_cur = 0;
+    auto compute = [&](float (&b)[TMAX], uint32_t bits) {
+        if (f16) {
+#pragma unroll
+            for (int t = 0; t < TMAX; ++t) b[t] = aoc_h(b[t]);
+        }
+        const float y2 = sq_norm(b);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < TMAX; ++t) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b[t], acc, 0, 0, 0);
+        const int ak = k_cur < 0 ? -k_cur : k_cur;                     // |dy| / rate
+        const int cq = gi_cur * 16 + j - R - 4 * g;                    // cx - qx for r = 0
+        if (bits != 0u) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int qi = g * 4 + r;
+                int dx = cq - r;
+                dx = dx < 0 ? -dx : dx;
+                bool on = dx <= R && x0 + qi < W;
+                int adx = dx;
+                if (rate != 1) { adx = dx / rate; on = on && adx * rate == dx; }
+                if (on) {
+                    const float d = f16 ? aoc_h(aoc_h(q2r[r] + y2) - 2.0f * aoc_h(acc[r])) : (q2r[r] + y2) - 2.0f * acc[r];   // AEM:961
+                    const int cls = lcls[max(ak, adx)];
+                    uint32_t bb = bits;
+                    while (bb) {                                        // AEM:1032 where(mask, d, pad)
+                        const int o = __builtin_ctz(bb);
+                        bb &= bb - 1;
+                        if (o < n_obj) lds_fmin(&my_acc[(qi * nr + cls) * n_obj + o], d);
+                    }
+                }
+            }
+        }
+        if (++gi_cur == NG) { gi_cur = 0; k_cur += 4; }
+    };
+
+    if (n_items > 0) issue(b0, bits0);
+    for (int it = 0; it < n_items; it += 2) {
+        if (it + 1 < n_items) issue(b1, bits1);
+        compute(b0, bits0);
+        if (it + 1 < n_items) {
+            if (it + 2 < n_items) issue(b0, bits0);
+            compute(b1, bits1);
+        }
+    }
+    __syncthreads();
+    // merge the four waves, prefix-min over rings -> nested windows; channel order [max, r_0, r_1, ...] (AEM:1034-1046)
+    for (int idx = threadIdx.x; idx < 16 * n_obj; idx += blockDim.x) {
+        const int qi = idx / n_obj, o = idx - qi * n_obj;
+        const int qx = x0 + qi;
+        if (qx >= W) continue;
+        const float bias = obj_bias ? obj_bias[o] : 0.0f;
+        float run = INFINITY;
+        for (int cls = 0; cls < nr; ++cls) {
+            const int e = (qi * nr + cls) * n_obj + o;
+            const float v = fminf(fminf(lacc[e], lacc[acc_per_wave + e]), fminf(lacc[2 * acc_per_wave + e], lacc[3 * acc_per_wave + e]));
+            run = fminf(run, v);
+            const int ch = (cls == nr - 1) ? 0 : cls + 1;
+            out[(((size_t)o * nr + ch) * H + y) * W + qx] = transform ? aoc_proto_transform(run, bias) : run;   // AEM:1049
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Resize helpers (torch semantics, fp32).
 __device__ __forceinline__ void bilinear_src(int dst, float scale, int in_size, int &i0, int &i1, float &l0, float &l1) {
     const float real = scale * (float)dst;                 // align_corners=True: area_pixel_compute_source_index
@@ -457,6 +621,18 @@ int aoc_local_window_match_ex(const float *query, const float *prev, const uint3
                        (size_t)4 * 16 * n_radii * n_obj * sizeof(float);
     if (lds > 150 * 1024) return AOC_ERR_UNSUPPORTED;
     hipStream_t st = aoc_hip_stream(stream);
+    static const char *which = getenv("AOC_LOCAL_KERNEL");            // developer switch: "row" / "block" = the LDS-image kernels
+    // register-operand kernel (no LDS image): C == 100 / 128
+    if ((C == 100 || C == 128) && !(which && (strcmp(which, "row") == 0 || strcmp(which, "block") == 0))) {
+        const dim3 rgrid((W + 15) / 16, H);
+        const size_t lds_reg = (32 + (size_t)4 * 16 * n_radii * n_obj) * sizeof(float);
+        if (C == 100)
+            hipLaunchKernelGGL(local_window_reg_kernel<25>, rgrid, dim3(256), lds_reg, st, query, prev, right_bits, H, W, radii, obj_bias, n_obj, out, transform, rate, f16);
+        else
+            hipLaunchKernelGGL(local_window_reg_kernel<32>, rgrid, dim3(256), lds_reg, st, query, prev, right_bits, H, W, radii, obj_bias, n_obj, out, transform, rate, f16);
+        AOC_RETURN_IF_LAUNCH_FAILED();
+        return AOC_OK;
+    }
     // row-per-block layout (wave-private candidate images) whenever it fits: C == 100 / 128 tiles, R <= 16
     {
         const int TPc = (C == 100) ? 28 : 32, RSc = 4 * TPc + 4;
