@@ -367,10 +367,12 @@ __global__ __launch_bounds__(256) void local_window_row_kernel(const float *__re
 // bytes, and a candidate group needs NP (+1) of them instead of a transposing LDS round trip (76 ds_write_b32 + 25 ds_read_b128 per
 // lane and candidate row in the row kernel above).  Without the 81 KB of wave-private images a workgroup needs 6.5 KB of LDS (the
 // per-(pixel, ring, object) minima), so every wave of the launch is resident at once (the row kernel ran one workgroup per CU = one
-// wave per SIMD, nothing to hide a latency behind, and 427 workgroups took two rounds on 256 CUs).  Work split as in the row kernel:
-// block = one query row x 16 columns, the four waves take the candidate rows round-robin; a wave walks its (candidate row, group of
-// 16 candidates) items with the next item's loads in flight under the current item's 25 MFMAs (two register buffers, loop unrolled
-// by two).  Only candidate rows at multiples of the atrous rate are visited.
+// wave per SIMD, nothing to hide a latency behind, and 427 workgroups took two rounds on 256 CUs).
+// The 16 query pixels of a workgroup are 2 rows x 8 columns: their windows cover 8 + 2R candidate columns -- exactly two groups of
+// 16 at R = 12, 78 % of the computed products used (16 x 1: 16 + 2R = 40 columns = three groups, 52 %) -- and 2 + 2R candidate
+// rows, each multiplied against both query rows at once.  The four waves take the candidate rows round-robin; a wave walks its
+// (candidate row, group) items with the next item's loads in flight under the current item's MFMAs (two register buffers, loop
+// unrolled by two).
 template <int TMAX>
 __global__ __launch_bounds__(256) void local_window_reg_kernel(const float *__restrict__ query, const float *__restrict__ prev,
                                                                 const uint32_t *__restrict__ right_bits, int H, int W,
@@ -385,16 +387,16 @@ __global__ __launch_bounds__(256) void local_window_reg_kernel(const float *__re
     const int RA = radii.r[nr - 1];                     // window half-size in atrous units
     const int R = RA * rate;
     const float padv = f16 ? aoc_h(AOC_PAD_DISTANCE) : AOC_PAD_DISTANCE;
-    const int NC = 16 + 2 * R;                          // candidates per row
+    const int NC = 8 + 2 * R;                           // candidate columns of the block
     const int NG = (NC + 15) / 16;
     const int acc_per_wave = 16 * nr * n_obj;
     const int lane = aoc_lane(), wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int j = lane & 15, g = lane >> 4;
     int32_t *lcls = reinterpret_cast<int32_t *>(lds);               // [RA + 1] ring -> class
-    float *lacc = lds + 32;                                         // [4 waves][16][n_radii][n_obj]
+    float *lacc = lds + 32;                                         // [4 waves][16 queries][n_radii][n_obj]
     float *my_acc = lacc + wave * acc_per_wave;
-    const int x0 = blockIdx.x * 16;
-    const int y = blockIdx.y;
+    const int x0 = blockIdx.x * 8;
+    const int y0 = blockIdx.y * 2;
 
     for (int i = lane; i < acc_per_wave; i += 64) my_acc[i] = padv;      // AEM:1032 pad
     if ((int)threadIdx.x <= RA) {
@@ -413,24 +415,29 @@ __global__ __launch_bounds__(256) void local_window_reg_kernel(const float *__re
         }
         if constexpr (TAIL) v[4 * NP] = p[16 * NP + g];
     };
-    // sum of squares of the lane's channels, reduced over the four lanes (g) that share a pixel
+    // sum of squares of the lane's channels, reduced over the four lanes (g) that share a pixel (any order: tolerance-level)
     auto sq_norm = [&](const float (&v)[TMAX]) -> float {
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
 #pragma unroll
         for (int t = 0; t + 3 < TMAX; t += 4) {
             if (f16) { s0 += aoc_h(v[t] * v[t]); s1 += aoc_h(v[t + 1] * v[t + 1]); s2 += aoc_h(v[t + 2] * v[t + 2]); s3 += aoc_h(v[t + 3] * v[t + 3]); }
-            else { s0 += v[t] * v[t]; s1 += v[t + 1] * v[t + 1]; s2 += v[t + 2] * v[t + 2]; s3 += v[t + 3] * v[t + 3]; }
+            else {
+                s0 = __builtin_fmaf(v[t], v[t], s0); s1 = __builtin_fmaf(v[t + 1], v[t + 1], s1);
+                s2 = __builtin_fmaf(v[t + 2], v[t + 2], s2); s3 = __builtin_fmaf(v[t + 3], v[t + 3], s3);
+            }
         }
-        if constexpr (TAIL) s0 += f16 ? aoc_h(v[TMAX - 1] * v[TMAX - 1]) : v[TMAX - 1] * v[TMAX - 1];
+        if constexpr (TAIL) s0 = f16 ? s0 + aoc_h(v[TMAX - 1] * v[TMAX - 1]) : __builtin_fmaf(v[TMAX - 1], v[TMAX - 1], s0);
         float s = (s0 + s1) + (s2 + s3);
         s += __shfl_xor(s, 16);
         s += __shfl_xor(s, 32);
         return f16 ? aoc_h(s) : s;
     };
 
+    // query i = 0..15 is pixel (y0 + i / 8, x0 + i % 8); as an MFMA row, lane (j, g) supplies query j; as an MFMA result, register r of
+    // lane (j, g) is query 4 g + r against candidate j: its row y0 + g / 2 is the same for the lane's four results
     float a[TMAX], q2r[4];
-    {   // A operand: the 16 query pixels of row y (columns beyond the map re-read the last one; they are never stored)
-        load_row(query + ((size_t)y * W + min(x0 + j, W - 1)) * C, a);
+    {   // A operand (pixels beyond the map re-read the last row / column; they are never stored)
+        load_row(query + ((size_t)min(y0 + (j >> 3), H - 1) * W + min(x0 + (j & 7), W - 1)) * C, a);
         if (f16) {
 #pragma unroll
             for (int t = 0; t < TMAX; ++t) a[t] = aoc_h(a[t]);
@@ -440,28 +447,28 @@ __global__ __launch_bounds__(256) void local_window_reg_kernel(const float *__re
         for (int r = 0; r < 4; ++r) q2r[r] = __shfl(q2, g * 4 + r);
     }
     __syncthreads();                                    // lcls
+    const int qy = y0 + (g >> 1);                       // query row of this lane's results
+    const int qc0 = 4 * (g & 1);                        // ... and their first column (relative to x0)
 
-    // candidate rows cy = y + k rate, k in [k_beg, k_end]; this wave takes k_beg + wave, + 4, ...
-    const int k_beg = max(-RA, -(y / rate)), k_end = min(RA, (H - 1 - y) / rate);
-    const int k_first = k_beg + wave;
-    const int n_items = k_first <= k_end ? ((k_end - k_first) / 4 + 1) * NG : 0;
+    // candidate rows cy in [y0 - R, y0 + 1 + R] (clipped); this wave takes cy_beg + wave, + 4, ...
+    const int cy_beg = max(0, y0 - R), cy_end = min(H - 1, y0 + 1 + R);
+    const int cy_first = cy_beg + wave;
+    const int n_items = cy_first <= cy_end ? ((cy_end - cy_first) / 4 + 1) * NG : 0;
 
     float b0[TMAX], b1[TMAX];
     uint32_t bits0 = 0u, bits1 = 0u;
-    // item -> (k, gi), advanced incrementally (wave-uniform)
-    int k_ld = k_first, gi_ld = 0;
+    int cy_ld = cy_first, gi_ld = 0;                    // item -> (cy, gi), advanced incrementally (wave-uniform)
     auto issue = [&](float (&b)[TMAX], uint32_t &bits) {
-        const int cy = y + k_ld * rate;
         const int c = gi_ld * 16 + j, cx = x0 - R + c;
         const bool ok = c < NC && cx >= 0 && cx < W;
         const int cxc = min(max(cx, 0), W - 1);                       // clamped address, selected afterwards: the loads stay branch-free
-        const size_t pix = (size_t)cy * W + cxc;
+        const size_t pix = (size_t)cy_ld * W + cxc;
         load_row(prev + pix * C, b);
         const uint32_t raw = right_bits[pix];
         bits = ok ? (raw & ~AOC_ROW_KEPT_BIT) : 0u;                    // AEM:1023-1028 (pad 0)
-        if (++gi_ld == NG) { gi_ld = 0; k_ld += 4; }
+        if (++gi_ld == NG) { gi_ld = 0; cy_ld += 4; }
     };
-    int k_cur = k_first, gi_cur = 0;
+    int cy_cur = cy_first, gi_cur = 0;
     auto compute = [&](float (&b)[TMAX], uint32_t bits) {
         if (f16) {
 #pragma unroll
@@ -471,30 +478,33 @@ __global__ __launch_bounds__(256) void local_window_reg_kernel(const float *__re
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int t = 0; t < TMAX; ++t) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[t], b[t], acc, 0, 0, 0);
-        const int ak = k_cur < 0 ? -k_cur : k_cur;                     // |dy| / rate
-        const int cq = gi_cur * 16 + j - R - 4 * g;                    // cx - qx for r = 0
-        if (bits != 0u) {
+        int ady = cy_cur - qy;
+        ady = ady < 0 ? -ady : ady;
+        bool row_on = ady <= R && qy < H;
+        int aky = ady;
+        if (rate != 1) { aky = ady / rate; row_on = row_on && aky * rate == ady; }
+        const int cq = gi_cur * 16 + j - R - qc0;                      // cx - qx for r = 0
+        if (bits != 0u && row_on) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int qi = g * 4 + r;
                 int dx = cq - r;
                 dx = dx < 0 ? -dx : dx;
-                bool on = dx <= R && x0 + qi < W;
-                int adx = dx;
-                if (rate != 1) { adx = dx / rate; on = on && adx * rate == dx; }
+                bool on = dx <= R && x0 + qc0 + r < W;
+                int akx = dx;
+                if (rate != 1) { akx = dx / rate; on = on && akx * rate == dx; }
                 if (on) {
                     const float d = f16 ? aoc_h(aoc_h(q2r[r] + y2) - 2.0f * aoc_h(acc[r])) : (q2r[r] + y2) - 2.0f * acc[r];   // AEM:961
-                    const int cls = lcls[max(ak, adx)];
+                    const int cls = lcls[max(aky, akx)];
                     uint32_t bb = bits;
                     while (bb) {                                        // AEM:1032 where(mask, d, pad)
                         const int o = __builtin_ctz(bb);
                         bb &= bb - 1;
-                        if (o < n_obj) lds_fmin(&my_acc[(qi * nr + cls) * n_obj + o], d);
+                        if (o < n_obj) lds_fmin(&my_acc[((g * 4 + r) * nr + cls) * n_obj + o], d);
                     }
                 }
             }
         }
-        if (++gi_cur == NG) { gi_cur = 0; k_cur += 4; }
+        if (++gi_cur == NG) { gi_cur = 0; cy_cur += 4; }
     };
 
     if (n_items > 0) issue(b0, bits0);
@@ -510,8 +520,8 @@ __global__ __launch_bounds__(256) void local_window_reg_kernel(const float *__re
     // merge the four waves, prefix-min over rings -> nested windows; channel order [max, r_0, r_1, ...] (AEM:1034-1046)
     for (int idx = threadIdx.x; idx < 16 * n_obj; idx += blockDim.x) {
         const int qi = idx / n_obj, o = idx - qi * n_obj;
-        const int qx = x0 + qi;
-        if (qx >= W) continue;
+        const int oy = y0 + (qi >> 3), ox = x0 + (qi & 7);
+        if (ox >= W || oy >= H) continue;
         const float bias = obj_bias ? obj_bias[o] : 0.0f;
         float run = INFINITY;
         for (int cls = 0; cls < nr; ++cls) {
@@ -519,7 +529,7 @@ __global__ __launch_bounds__(256) void local_window_reg_kernel(const float *__re
             const float v = fminf(fminf(lacc[e], lacc[acc_per_wave + e]), fminf(lacc[2 * acc_per_wave + e], lacc[3 * acc_per_wave + e]));
             run = fminf(run, v);
             const int ch = (cls == nr - 1) ? 0 : cls + 1;
-            out[(((size_t)o * nr + ch) * H + y) * W + qx] = transform ? aoc_proto_transform(run, bias) : run;   // AEM:1049
+            out[(((size_t)o * nr + ch) * H + oy) * W + ox] = transform ? aoc_proto_transform(run, bias) : run;   // AEM:1049
         }
     }
 }
@@ -624,7 +634,7 @@ int aoc_local_window_match_ex(const float *query, const float *prev, const uint3
     static const char *which = getenv("AOC_LOCAL_KERNEL");            // developer switch: "row" / "block" = the LDS-image kernels
     // register-operand kernel (no LDS image): C == 100 / 128
     if ((C == 100 || C == 128) && !(which && (strcmp(which, "row") == 0 || strcmp(which, "block") == 0))) {
-        const dim3 rgrid((W + 15) / 16, H);
+        const dim3 rgrid((W + 7) / 8, (H + 1) / 2);
         const size_t lds_reg = (32 + (size_t)4 * 16 * n_radii * n_obj) * sizeof(float);
         if (C == 100)
             hipLaunchKernelGGL(local_window_reg_kernel<25>, rgrid, dim3(256), lds_reg, st, query, prev, right_bits, H, W, radii, obj_bias, n_obj, out, transform, rate, f16);
