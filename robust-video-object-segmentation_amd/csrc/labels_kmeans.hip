@@ -1117,6 +1117,16 @@ __global__ __launch_bounds__(256) void km_chunk_sum_kernel(const float *__restri
 // P1: per cluster, thread = feature: running any-order prefix over the chunks -> predicted binade of each chunk
 // (KC_UNSAFE when the chunk may touch a binade boundary, starts at 0, or is not plainly positive)
 constexpr int KC_UNSAFE = -128;
+// binade of a chunk whose any-order running sum goes from `pre` to `end`, or KC_UNSAFE
+__device__ __forceinline__ int kc_predict_binade(float pre, float end) {
+    int e = KC_UNSAFE;
+    if (pre > 1e-30f && end < 1e30f && end >= pre) {
+        const int e_lo = (int)((__float_as_uint(pre * 0.9995f) >> 23) & 0xff) - 127;
+        const int e_hi = (int)((__float_as_uint(end * 1.0005f) >> 23) & 0xff) - 127;
+        if (e_lo == e_hi && e_lo >= -100 && e_lo <= 100) e = e_lo;
+    }
+    return e;
+}
 __global__ __launch_bounds__(128) void km_chunk_predict_kernel(const int32_t *__restrict__ seg_k, const int32_t *__restrict__ counts,
                                                                 const int32_t *__restrict__ cchunk, const float *__restrict__ csum, int kmax,
                                                                 int C, int8_t *__restrict__ cexp, int start_chunk,
@@ -1138,13 +1148,7 @@ __global__ __launch_bounds__(128) void km_chunk_predict_kernel(const int32_t *__
             const int c = c0 + u;
             if (c >= nch) break;
             const float end = pre + cs[u];
-            int e = KC_UNSAFE;
-            if (pre > 1e-30f && end < 1e30f && end >= pre) {
-                const int e_lo = (int)((__float_as_uint(pre * 0.9995f) >> 23) & 0xff) - 127;
-                const int e_hi = (int)((__float_as_uint(end * 1.0005f) >> 23) & 0xff) - 127;
-                if (e_lo == e_hi && e_lo >= -100 && e_lo <= 100) e = e_lo;
-            }
-            cexp[(size_t)(base + c) * C + f] = (int8_t)e;
+            cexp[(size_t)(base + c) * C + f] = (int8_t)kc_predict_binade(pre, end);
             pre = end;
           }
         }
@@ -1208,9 +1212,11 @@ __global__ __launch_bounds__(256) void km_chunk_fold_kernel(const float *__restr
                                                              const uint32_t *__restrict__ moff, int kmax,
                                                              const int32_t *__restrict__ owner_cluster, const int32_t *__restrict__ owner_local,
                                                              int8_t *__restrict__ cexp, int32_t *__restrict__ cinc0, int32_t *__restrict__ cinc1,
-                                                             int start_chunk) {
+                                                             int start_chunk, const float *__restrict__ csum, const int32_t *__restrict__ cchunk,
+                                                             const float *__restrict__ head_state) {
     __shared__ float tile[2][64 * KC_G_LD];
     __shared__ uint32_t loffs[KS_CHUNK];
+    __shared__ int lexp[KC_FG];
     const int chunk = blockIdx.x, grp = blockIdx.y;
     const int oc = owner_cluster[chunk];
     if (oc < 0) return;
@@ -1228,19 +1234,35 @@ __global__ __launch_bounds__(256) void km_chunk_fold_kernel(const float *__restr
     float inv_u[KC_FW];
     bool live[KC_FW];
     bool any_live = false;
+    // csum != nullptr: the binade prediction of km_chunk_predict_kernel happens here (one launch less per Lloyd iteration): the any-order
+    // prefix of the cluster's earlier tail chunks (lanes = predecessor chunks) on top of the exact head sum
+    const int pbase = csum ? cchunk[oc] : 0, plocal = owner_local[chunk];
 #pragma unroll
     for (int i = 0; i < KC_FW; ++i) {
         const int f = f0 + wave * KC_FW + i;
         int e = KC_UNSAFE;
-        if (f < C) e = cexp[(size_t)chunk * C + f];
+        if (f < C) {
+            if (csum) {
+                float part = 0.0f;
+                for (int c = start_chunk + lane; c < plocal; c += 64) part += csum[(size_t)(pbase + c) * C + f];
+                part = aoc_wave_sum(part);
+                const float pre = ((start_chunk > 0) ? head_state[(size_t)oc * C + f] : 0.0f) + part;
+                e = kc_predict_binade(pre, pre + csum[(size_t)chunk * C + f]);
+                if (lane == 0) cexp[(size_t)chunk * C + f] = (int8_t)e;
+            } else {
+                e = cexp[(size_t)chunk * C + f];
+            }
+        }
+        if (lane == 0) lexp[wave * KC_FW + i] = e;
         live[i] = e != KC_UNSAFE;
         inv_u[i] = __uint_as_float((uint32_t)(23 - (live[i] ? e : 0) + 127) << 23);
         k[i].acc = 0; k[i].par0 = 0; k[i].par1 = 1; k[i].bump0 = 0; k[i].bump1 = 0; k[i].bad = 0;
         any_live |= live[i];
     }
-    // does any wave of the block have a live feature?  (uniform per block: all features of the group are read by every thread)
+    __syncthreads();
+    // does any wave of the block have a live feature?  (uniform per block)
     bool block_live = false;
-    for (int f = f0; f < min(C, f0 + KC_FG); ++f) block_live |= (cexp[(size_t)chunk * C + f] != KC_UNSAFE);
+    for (int i = 0; i < KC_FG; ++i) block_live |= (lexp[i] != KC_UNSAFE);
     if (!block_live) return;
 
     for (int i = threadIdx.x; i < KS_CHUNK; i += blockDim.x) loffs[i] = (i < members) ? list[first + i] : 0u;
@@ -1959,6 +1981,7 @@ struct KsWorkspace {
     float *csum, *head;
     int8_t *cexp;
     uint32_t *cflag;          // per (chunk, feature group): local sums published (km_chunk_scanfold_kernel)
+    int seg_chunks_max;       // no segment (hence no cluster) has more chunks than this
 };
 inline int ks_chunk_capacity(int64_t cap, int n_seg, int kmax) { return (int)(cap / KS_CHUNK) + n_seg * (kmax + 1) + 2; }
 inline size_t ks_workspace_bytes(int64_t cap, int n_seg, int kmax) {
@@ -1974,6 +1997,7 @@ inline KsWorkspace ks_carve(void *workspace, int64_t cap, int n_seg, int kmax, i
     char *p = static_cast<char *>(workspace);
     const size_t nb = (size_t)(cap + 255) / 256 + 1;
     w.nb_max = (int)((seg_bound > 0 && seg_bound < cap) ? (size_t)(seg_bound + 255) / 256 + 1 : nb);   // stride of the per-block histograms
+    w.seg_chunks_max = (int)(((seg_bound > 0 && seg_bound < cap) ? seg_bound : cap) / KS_CHUNK + 1);
     w.rownorm = reinterpret_cast<float *>(p); p += aoc_align_up((size_t)cap * 4, 256);
     w.rank16 = reinterpret_cast<uint16_t *>(p); p += aoc_align_up((size_t)cap * 2, 256);
     w.hist = reinterpret_cast<int32_t *>(p); p += aoc_align_up((size_t)n_seg * nb * kmax * 4, 256);
@@ -2001,6 +2025,7 @@ inline KsWorkspace ks_carve(void *workspace, int64_t cap, int n_seg, int kmax, i
 //             with the chunk-parallel integer folds and the serial stitch (their crossings are rare from there on);
 //   "ordered": literal sums only;   "scan": chunk-parallel pipeline only.   (AOC_KM_SUM, developer switch.)
 constexpr int KS_HEAD_CHUNKS = 4;
+constexpr int KC_INLINE_PREDICT_CHUNKS = 800;   // 409 600 rows per segment
 inline int ks_sum_mode() {
     static const int mode = [] {
         const char *e = getenv("AOC_KM_SUM");
@@ -2032,9 +2057,15 @@ inline void ks_launch_sums(hipStream_t st, const float *pool, uint32_t pool_byte
     } else {
         hipLaunchKernelGGL(km_chunk_sum_kernel, dim3(ws.nch_cap), dim3(256), 0, st, pool, C, seg_offsets, counts, ws.cbase, ws.moff, kmax, ws.owner_cluster,
                            ws.owner_local, ws.csum, start);
-        hipLaunchKernelGGL(km_chunk_predict_kernel, dim3(kmax, n_seg), dim3(128), 0, st, seg_k, counts, ws.cchunk, ws.csum, kmax, C, ws.cexp, start, ws.head);
+        // the binade prediction runs inside the fold kernel (every workgroup re-adds its cluster's earlier chunk sums: quadratic in the
+        // chunks of a cluster, so only while a cluster cannot have more than KC_INLINE_PREDICT_CHUNKS); AOC_KM_PREDICT=kernel: separate launch
+        static const bool sep_predict = getenv("AOC_KM_PREDICT") && strcmp(getenv("AOC_KM_PREDICT"), "kernel") == 0;
+        const bool inline_predict = !sep_predict && ws.seg_chunks_max <= KC_INLINE_PREDICT_CHUNKS;
+        if (!inline_predict)
+            hipLaunchKernelGGL(km_chunk_predict_kernel, dim3(kmax, n_seg), dim3(128), 0, st, seg_k, counts, ws.cchunk, ws.csum, kmax, C, ws.cexp, start, ws.head);
         hipLaunchKernelGGL(km_chunk_fold_kernel, dim3(ws.nch_cap, (C + KC_FG - 1) / KC_FG), dim3(256), 0, st, pool, C, seg_offsets, counts, ws.cbase, ws.moff,
-                           kmax, ws.owner_cluster, ws.owner_local, ws.cexp, ws.cinc0, ws.cinc1, start);
+                           kmax, ws.owner_cluster, ws.owner_local, ws.cexp, ws.cinc0, ws.cinc1, start, inline_predict ? ws.csum : (const float *)nullptr,
+                           ws.cchunk, ws.head);
     }
     static const int nf = getenv("AOC_KS_NF") ? atoi(getenv("AOC_KS_NF")) : 1;       // features per stitch wave (developer switch)
 #define AOC_KSS(NF) hipLaunchKernelGGL((km_sum_scan_kernel<MODE, NF>), dim3(C / NF, kmax, n_seg), dim3(64), 0, st, pool, pool_bytes, C, seg_offsets, seg_k, \
