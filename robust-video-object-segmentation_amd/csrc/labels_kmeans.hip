@@ -1067,14 +1067,12 @@ __device__ __forceinline__ void kc_write_block(const KcStage &st, float *__restr
 // t % c4 of the rows t / c4, t / c4 + RPP, ... of the chunk (RPP = 256 / c4 rows per pass; consecutive threads read one row's consecutive
 // 16 bytes): private float4 partial sums, eight independent loads in flight per thread, no LDS tile and no barrier in the loop; the RPP
 // partial sums of a piece are combined through LDS at the end.
-__global__ __launch_bounds__(256) void km_chunk_sum_kernel(const float *__restrict__ pool, int C, const int32_t *__restrict__ seg_off,
-                                                            const int32_t *__restrict__ counts, const int32_t *__restrict__ cbase,
-                                                            const uint32_t *__restrict__ moff, int kmax,
-                                                            const int32_t *__restrict__ owner_cluster, const int32_t *__restrict__ owner_local,
-                                                            float *__restrict__ csum, int start_chunk) {
-    __shared__ uint32_t loffs[KS_CHUNK];
-    __shared__ __attribute__((aligned(16))) float4 part[256];
-    const int chunk = blockIdx.x;
+__device__ __forceinline__ void kc_chunk_sum_body(int chunk, uint32_t *__restrict__ loffs, float4 *__restrict__ part,
+                                                  const float *__restrict__ pool, int C, const int32_t *__restrict__ seg_off,
+                                                  const int32_t *__restrict__ counts, const int32_t *__restrict__ cbase,
+                                                  const uint32_t *__restrict__ moff, int kmax,
+                                                  const int32_t *__restrict__ owner_cluster, const int32_t *__restrict__ owner_local,
+                                                  float *__restrict__ csum, int start_chunk) {
     const int oc = owner_cluster[chunk];
     if (oc < 0) return;
     if (owner_local[chunk] < start_chunk) return;       // head chunks are summed literally (km_ordered_sum_kernel)
@@ -1083,7 +1081,7 @@ __global__ __launch_bounds__(256) void km_chunk_sum_kernel(const float *__restri
     const uint32_t *list = moff + seg_off[s] + cbase[oc];
     const int first = owner_local[chunk] * KS_CHUNK;
     const int members = min(KS_CHUNK, cnt - first);
-    for (int i = threadIdx.x; i < KS_CHUNK; i += blockDim.x) loffs[i] = list[first + min(i, members - 1)];
+    for (int i = threadIdx.x; i < KS_CHUNK; i += 256) loffs[i] = list[first + min(i, members - 1)];     // 256 threads run this body
     __syncthreads();
     const int c4 = C >> 2;                              // float4 pieces per row (C % 4 == 0 on this path)
     const int rpp = 256 / c4;                           // rows per pass
@@ -1112,6 +1110,15 @@ __global__ __launch_bounds__(256) void km_chunk_sum_kernel(const float *__restri
         }
         *reinterpret_cast<float4 *>(csum + (size_t)chunk * C + 4 * threadIdx.x) = t;
     }
+}
+__global__ __launch_bounds__(256) void km_chunk_sum_kernel(const float *__restrict__ pool, int C, const int32_t *__restrict__ seg_off,
+                                                            const int32_t *__restrict__ counts, const int32_t *__restrict__ cbase,
+                                                            const uint32_t *__restrict__ moff, int kmax,
+                                                            const int32_t *__restrict__ owner_cluster, const int32_t *__restrict__ owner_local,
+                                                            float *__restrict__ csum, int start_chunk) {
+    __shared__ uint32_t loffs[KS_CHUNK];
+    __shared__ __attribute__((aligned(16))) float4 part[256];
+    kc_chunk_sum_body(blockIdx.x, loffs, part, pool, C, seg_off, counts, cbase, moff, kmax, owner_cluster, owner_local, csum, start_chunk);
 }
 
 // P1: per cluster, thread = feature: running any-order prefix over the chunks -> predicted binade of each chunk
@@ -1815,15 +1822,14 @@ constexpr int OS_PP = OS_BATCH * OS_FP / (OS_NPROD * 64);
 constexpr int OS_DEPTH = 6;                     // batches of row pieces in flight per lane (even)
 static_assert(OS_PP * OS_NPROD * 64 == OS_BATCH * OS_FP && OS_DEPTH % 2 == 0 && OS_FP * 4 <= OS_LD, "ordered-sum geometry");
 inline int os_groups(int C) { return (C / 4 + OS_FP - 1) / OS_FP; }
+__device__ __forceinline__ int os_groups_dev(int C) { return (C / 4 + OS_FP - 1) / OS_FP; }
 
 template <int MODE>
-__global__ __launch_bounds__((OS_NPROD + 1) * 64) void km_ordered_sum_kernel(const float *__restrict__ pool, uint32_t pool_bytes, int C,
-                                                                              const int32_t *__restrict__ seg_off, const int32_t *__restrict__ seg_k,
-                                                                              const int32_t *__restrict__ counts, const int32_t *__restrict__ cbase,
-                                                                              const uint32_t *__restrict__ moff, int kmax, float *__restrict__ dst,
-                                                                              int member_cap, float *__restrict__ head_state) {
-    __shared__ __attribute__((aligned(16))) float os_lds[2 * OS_BATCH * OS_LD];
-    const int s = blockIdx.y, j = blockIdx.x, grp = blockIdx.z;
+__device__ __forceinline__ void os_ordered_sum_body(int j, int s, int grp, float *__restrict__ os_lds, const float *__restrict__ pool, uint32_t pool_bytes, int C,
+                                                    const int32_t *__restrict__ seg_off, const int32_t *__restrict__ seg_k,
+                                                    const int32_t *__restrict__ counts, const int32_t *__restrict__ cbase,
+                                                    const uint32_t *__restrict__ moff, int kmax, float *__restrict__ dst,
+                                                    int member_cap, float *__restrict__ head_state) {
     if (j >= seg_k[s]) return;
     const int oc = s * kmax + j;
     const int cnt_all = counts[oc];
@@ -1935,6 +1941,40 @@ __global__ __launch_bounds__((OS_NPROD + 1) * 64) void km_ordered_sum_kernel(con
         }
     }
 }
+template <int MODE>
+__global__ __launch_bounds__((OS_NPROD + 1) * 64) void km_ordered_sum_kernel(const float *__restrict__ pool, uint32_t pool_bytes, int C,
+                                                                              const int32_t *__restrict__ seg_off, const int32_t *__restrict__ seg_k,
+                                                                              const int32_t *__restrict__ counts, const int32_t *__restrict__ cbase,
+                                                                              const uint32_t *__restrict__ moff, int kmax, float *__restrict__ dst,
+                                                                              int member_cap, float *__restrict__ head_state) {
+    __shared__ __attribute__((aligned(16))) float os_lds[2 * OS_BATCH * OS_LD];
+    os_ordered_sum_body<MODE>(blockIdx.x, blockIdx.y, blockIdx.z, os_lds, pool, pool_bytes, C, seg_off, seg_k, counts, cbase, moff, kmax, dst, member_cap, head_state);
+}
+// The literal heads and the any-order sums of the tail chunks only depend on the member lists, not on each other: ONE launch, the
+// first kmax * n_seg * groups workgroups take the heads (the long ones, dispatched first), the others one tail chunk each (on the
+// first four of their eight waves; the LDS allocation of the head role is reused).
+template <int MODE>
+__global__ __launch_bounds__((OS_NPROD + 1) * 64) void km_heads_chunk_sums_kernel(const float *__restrict__ pool, uint32_t pool_bytes, int C,
+                                                                                   const int32_t *__restrict__ seg_off, const int32_t *__restrict__ seg_k,
+                                                                                   const int32_t *__restrict__ counts, const int32_t *__restrict__ cbase,
+                                                                                   const uint32_t *__restrict__ moff, int kmax, int n_seg, float *__restrict__ dst,
+                                                                                   int member_cap, float *__restrict__ head_state,
+                                                                                   const int32_t *__restrict__ owner_cluster, const int32_t *__restrict__ owner_local,
+                                                                                   float *__restrict__ csum, int start_chunk) {
+    __shared__ __attribute__((aligned(16))) float os_lds[2 * OS_BATCH * OS_LD];
+    static_assert(sizeof(float) * 2 * OS_BATCH * OS_LD >= sizeof(uint32_t) * KS_CHUNK + sizeof(float4) * 256, "the chunk role's buffers fit the head role's");
+    const int n_head = kmax * n_seg * os_groups_dev(C);
+    const int b = blockIdx.x;
+    if (b < n_head) {
+        const int j = b % kmax, s = (b / kmax) % n_seg, grp = b / (kmax * n_seg);
+        os_ordered_sum_body<MODE>(j, s, grp, os_lds, pool, pool_bytes, C, seg_off, seg_k, counts, cbase, moff, kmax, dst, member_cap, head_state);
+        return;
+    }
+    if (threadIdx.x >= 256) return;
+    uint32_t *loffs = reinterpret_cast<uint32_t *>(os_lds);
+    float4 *part = reinterpret_cast<float4 *>(os_lds + KS_CHUNK);
+    kc_chunk_sum_body(b - n_head, loffs, part, pool, C, seg_off, counts, cbase, moff, kmax, owner_cluster, owner_local, csum, start_chunk);
+}
 
 // proxy set 0 = centroids (copied) and the squared norms of both sets; one wave per (slot j, segment s)
 __global__ __launch_bounds__(64) void km_proxy_finish_kernel(const float *__restrict__ centroids, const int32_t *__restrict__ seg_k,
@@ -2040,7 +2080,14 @@ inline void ks_launch_sums(hipStream_t st, const float *pool, uint32_t pool_byte
                            const int32_t *counts, const KsWorkspace &ws, int kmax, int n_seg, float *dst) {
     const int mode = ks_sum_mode();
     const int start = (mode == 2) ? KS_HEAD_CHUNKS : 0;
-    if (mode != 0) {
+    static const bool fused = getenv("AOC_KM_FUSED") && atoi(getenv("AOC_KM_FUSED")) == 1;
+    static const bool split_heads = getenv("AOC_KM_HEADS") && strcmp(getenv("AOC_KM_HEADS"), "kernel") == 0;   // developer switch: heads and chunk sums as two launches
+    const bool merged = mode == 2 && !(fused && C <= KC_FG * 8) && !split_heads;
+    if (merged) {
+        hipLaunchKernelGGL(km_heads_chunk_sums_kernel<MODE>, dim3(kmax * n_seg * os_groups(C) + ws.nch_cap), dim3((OS_NPROD + 1) * 64), 0, st, pool, pool_bytes, C,
+                           seg_offsets, seg_k, counts, ws.cbase, ws.moff, kmax, n_seg, dst, KS_HEAD_CHUNKS * KS_CHUNK, ws.head, ws.owner_cluster, ws.owner_local,
+                           ws.csum, start);
+    } else if (mode != 0) {
         const int cap = (mode == 2) ? KS_HEAD_CHUNKS * KS_CHUNK : 0;
         hipLaunchKernelGGL(km_ordered_sum_kernel<MODE>, dim3(kmax, n_seg, os_groups(C)), dim3((OS_NPROD + 1) * 64), 0, st, pool, pool_bytes, C, seg_offsets,
                            seg_k, counts, ws.cbase, ws.moff, kmax, dst, cap, ws.head);
@@ -2050,13 +2097,13 @@ inline void ks_launch_sums(hipStream_t st, const float *pool, uint32_t pool_byte
     // pass in both modes); measured 3.5 vs 3.9 ms per 20-iteration chain at R = 6 with one frame per chain, but 6.6 vs 6.4 ms with three
     // frames per chain and 5.7 vs 5.6 at R = 12: workgroups that wait for their predecessors' sums hold CU slots, so the default stays
     // the three-kernel tail.
-    static const bool fused = getenv("AOC_KM_FUSED") && atoi(getenv("AOC_KM_FUSED")) == 1;
     if (fused && C <= KC_FG * 8) {
         hipLaunchKernelGGL(km_chunk_scanfold_kernel, dim3(ws.nch_cap, (C + KC_FG - 1) / KC_FG), dim3(256), 0, st, pool, C, seg_offsets, counts, ws.cbase,
                            ws.moff, kmax, ws.owner_cluster, ws.owner_local, ws.cchunk, ws.head, ws.csum, ws.cflag, ws.cexp, ws.cinc0, ws.cinc1, start);
     } else {
-        hipLaunchKernelGGL(km_chunk_sum_kernel, dim3(ws.nch_cap), dim3(256), 0, st, pool, C, seg_offsets, counts, ws.cbase, ws.moff, kmax, ws.owner_cluster,
-                           ws.owner_local, ws.csum, start);
+        if (!merged)
+            hipLaunchKernelGGL(km_chunk_sum_kernel, dim3(ws.nch_cap), dim3(256), 0, st, pool, C, seg_offsets, counts, ws.cbase, ws.moff, kmax, ws.owner_cluster,
+                               ws.owner_local, ws.csum, start);
         // the binade prediction runs inside the fold kernel (every workgroup re-adds its cluster's earlier chunk sums: quadratic in the
         // chunks of a cluster, so only while a cluster cannot have more than KC_INLINE_PREDICT_CHUNKS); AOC_KM_PREDICT=kernel: separate launch
         static const bool sep_predict = getenv("AOC_KM_PREDICT") && strcmp(getenv("AOC_KM_PREDICT"), "kernel") == 0;
