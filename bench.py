@@ -620,6 +620,7 @@ def main():
                     help="BASELINE.json configs[4]: run the sequence-sharded evaluation (eval_runner) over the ranks instead of the cfg2 step loop; "
                          "a fixed sequence set (strong scaling), --eval-scale of the 30 + 507 sequences")
     ap.add_argument("--eval-scale", type=float, default=0.03)
+    ap.add_argument("--eval-lanes", type=int, default=3, help="with --eval-sharded: sequences in flight per rank (each on its own HIP stream)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -667,7 +668,7 @@ def main():
         with torch.no_grad():
             eval_runner.eval_sharded(specs[:1], 0, 1, dev, max_frames=3)          # warm-up: allocator, library load
             # the rank's sequences are synthesised and made resident first; the timed region starts at the barrier inside
-            tot = eval_runner.eval_sharded(specs, rank, world, dev, barrier=barrier)
+            tot = eval_runner.eval_sharded(specs, rank, world, dev, barrier=barrier, lanes=max(1, args.eval_lanes))
             barrier()
         el = torch.tensor([tot["loop_seconds_max"]], dtype=torch.float64)
         if rank == 0:
@@ -676,7 +677,8 @@ def main():
                     "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                     "config": {"workload": f"cfg5: {len(specs)} synthetic sequences ({args.eval_scale:g} of 30 DAVIS-17-val-like 121x213 K=16 + 507 YouTube-VOS-19-like "
                                            "145x261 K in {8,16,32}), closed loop (matching -> DynamicPreHead -> linear read-out -> soft-max -> memory policy), "
-                                           "reference-API path (one host read-back of the row counts per frame for scipy's initial rows)",
+                                           "reference-API path (one host read-back of the row counts per frame for scipy's initial rows); "
+                                           f"{max(1, args.eval_lanes)} sequences in flight per rank on separate HIP streams",
                                "sharding": "sequences over ranks by LPT on frames x objects, no data-path collective; one all-reduce(SUM) + one all-reduce(MAX) of metric accumulators"},
                     "eval": {k: tot[k] for k in ("sequences", "ranks", "frames", "objects", "mean_j", "mean_f", "rank_seconds_max", "rank_seconds_mean",
                                                  "imbalance", "planned_imbalance")},

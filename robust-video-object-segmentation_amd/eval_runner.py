@@ -150,27 +150,42 @@ def load_sequence(spec: SequenceSpec, device, max_frames: Optional[int] = None):
     return emb, gt
 
 
+def _default_metric(device):
+    if device.type == "cuda":
+        from . import ops
+        return ops.MaskJF(device)
+    return HostMetric()
+
+
+def sequence_steps(spec: SequenceSpec, backend, metric, data):
+    """The per-sequence loop of eval_manager_mm.py:196-361 as a generator: one ``yield`` after every enqueued frame, so that a caller can
+    interleave the frames of several independent sequences (each on its own HIP stream)."""
+    emb, gt = data
+    backend.start(spec)
+    backend.first_frame(emb[0], gt[0])
+    yield 0
+    for t in range(1, emb.shape[0]):
+        pred = backend.frame(emb[t])
+        metric.add(pred, gt[t].to(pred.device), spec.n_obj)
+        yield t
+
+
 def run_sequence(spec: SequenceSpec, backend, device, metric=None, max_frames: Optional[int] = None, data=None):
-    """The per-sequence loop of eval_manager_mm.py:196-361.  Returns the metric accumulators of sharding.METRIC_FIELDS
-    (sum_iou = sum over frames and foreground objects of J, sum_f of F, iou_count = number of (frame, object) pairs).
+    """One sequence, start to end.  Returns the metric accumulators of sharding.METRIC_FIELDS (sum_iou = sum over frames and
+    foreground objects of J, sum_f of F, iou_count = number of (frame, object) pairs).
     data: the (embeddings, ground truth) pair of load_sequence when the caller made it resident beforehand."""
     emb, gt = data if data is not None else load_sequence(spec, device, max_frames)
     frames = emb.shape[0]
     if metric is None:
-        if device.type == "cuda":
-            from . import ops
-            metric = ops.MaskJF(device)
-        else:
-            metric = HostMetric()
+        metric = _default_metric(device)
     before = metric.totals()
-    backend.start(spec)
-    backend.first_frame(emb[0], gt[0])
+    steps = sequence_steps(spec, backend, metric, (emb, gt))
+    next(steps)                                     # pool seeded with frame 0
     if device.type == "cuda":
         torch.cuda.synchronize(device)
     t0 = time.perf_counter()
-    for t in range(1, frames):
-        pred = backend.frame(emb[t])
-        metric.add(pred, gt[t].to(pred.device), spec.n_obj)
+    for _ in steps:
+        pass
     if device.type == "cuda":
         torch.cuda.synchronize(device)
     dt = time.perf_counter() - t0
@@ -179,23 +194,69 @@ def run_sequence(spec: SequenceSpec, backend, device, metric=None, max_frames: O
                 sum_f=after["sum_f"] - before["sum_f"], iou_count=after["objects"] - before["objects"])
 
 
-def eval_sharded(specs: Sequence[SequenceSpec], rank: int, world: int, device, backend=None, metric=None, max_frames=None, barrier=None):
+def run_interleaved(specs_data, device, lanes, backend_factory=None, dense_precision=None):
+    """A rank's share with ``lanes`` sequences in flight: every lane owns a HIP stream, a backend (per-sequence state) and a metric
+    accumulator, takes the next sequence off the rank's list when it finishes one, and the lanes' frames are enqueued round-robin from
+    this one host thread.  The reference-API path reads the O + 1 row counts back once per frame (scipy's initial rows are drawn on the
+    host from them): that read-back only waits for its own lane's stream, so the other lanes' frames keep the GPU busy meanwhile.
+    specs_data: list of (spec, (embeddings, ground truth)).  Returns the summed accumulators (sharding.METRIC_FIELDS without gpu_seconds)."""
+    todo = list(specs_data)
+    n_lanes = max(1, min(lanes, len(todo)))
+    streams = [torch.cuda.Stream(device) for _ in range(n_lanes)]
+    backends = [backend_factory() if backend_factory else HotPathBackend(device, dense_precision) for _ in range(n_lanes)]
+    metrics = [_default_metric(device) for _ in range(n_lanes)]
+    running = [None] * n_lanes
+    frames = objects = 0
+    keep = []                                       # the sequences' tensors stay alive until the last lane has drained
+    torch.cuda.synchronize(device)
+    while True:
+        busy = False
+        for l in range(n_lanes):
+            with torch.cuda.stream(streams[l]):
+                if running[l] is None and todo:
+                    spec, data = todo.pop(0)
+                    keep.append(data)
+                    frames += data[0].shape[0] - 1
+                    objects += (data[0].shape[0] - 1) * (spec.n_obj - 1)
+                    running[l] = sequence_steps(spec, backends[l], metrics[l], data)
+                if running[l] is not None:
+                    busy = True
+                    if next(running[l], None) is None:
+                        running[l] = None
+        if not busy:
+            break
+    torch.cuda.synchronize(device)
+    tot = [m.totals() for m in metrics]
+    return dict(frames=frames, objects=objects, sum_iou=sum(t["sum_j"] for t in tot), sum_f=sum(t["sum_f"] for t in tot),
+                iou_count=sum(t["objects"] for t in tot))
+
+
+def eval_sharded(specs: Sequence[SequenceSpec], rank: int, world: int, device, backend=None, metric=None, max_frames=None, barrier=None, lanes=1):
     """Partition ``specs`` over ``world`` ranks (LPT on frames x objects), make this rank's sequences resident on the device, then (after
     ``barrier()`` when given) run them and all-reduce the accumulators.  Returns the job totals plus the load-balance figures (max / mean
-    rank time) and ``loop_seconds_max`` = the slowest rank's time for its share, inputs resident; identical on every rank."""
+    rank time) and ``loop_seconds_max`` = the slowest rank's time for its share, inputs resident; identical on every rank.
+    lanes > 1 (GPU only): that many of the rank's sequences are in flight at a time (run_interleaved); a rank's time is then its loop time."""
     parts = sharding.lpt_partition([s.cost for s in specs], world)
     mine = parts[rank]
-    if backend is None:
+    interleave = lanes > 1 and device.type == "cuda" and backend is None and metric is None
+    if backend is None and not interleave:
         backend = HotPathBackend(device)
     data = {i: load_sequence(specs[i], device, max_frames) for i in mine}
     if barrier is not None:
         barrier()
     local = {k: 0.0 for k in sharding.METRIC_FIELDS}
     t0 = time.perf_counter()
-    for i in mine:
-        r = run_sequence(specs[i], backend, device, metric, max_frames, data=data.pop(i))
-        for k in sharding.METRIC_FIELDS:
+    if interleave:
+        order = sorted(mine, key=lambda i: -specs[i].cost)           # longest first: the lanes finish together
+        r = run_interleaved([(specs[i], data.pop(i)) for i in order], device, lanes)
+        for k in r:
             local[k] += r[k]
+        local["gpu_seconds"] = time.perf_counter() - t0
+    else:
+        for i in mine:
+            r = run_sequence(specs[i], backend, device, metric, max_frames, data=data.pop(i))
+            for k in sharding.METRIC_FIELDS:
+                local[k] += r[k]
     loop = time.perf_counter() - t0
     dev = device if device.type == "cuda" else None
     tot = sharding.allreduce_metrics(local, device=dev)

@@ -331,6 +331,11 @@ def test_eval_runner_on_the_gpu(aoc):
     np.random.seed(0)
     again = er.eval_sharded(specs, 0, 1, torch.device("cuda"), max_frames=4)
     assert again["sum_iou"] == tot["sum_iou"] and again["sum_f"] == tot["sum_f"]
+    # three sequences in flight (one HIP stream, backend and metric accumulator each): the same per-sequence results, summed per lane
+    np.random.seed(0)
+    lanes = er.eval_sharded(specs, 0, 1, torch.device("cuda"), max_frames=4, lanes=3)
+    assert lanes["frames"] == tot["frames"] and lanes["iou_count"] == tot["iou_count"] and lanes["objects"] == tot["objects"]
+    assert abs(lanes["sum_iou"] - tot["sum_iou"]) < 1e-9 and abs(lanes["sum_f"] - tot["sum_f"]) < 1e-9
 
 
 # ------------------------------------------------------------------------------------------ local atrous, use_float16=True
