@@ -483,3 +483,33 @@ def test_head_delta_equals_torch(aoc):
         got = aoc.ops.head_delta(head.cuda(), px.cuda()).cpu()
         want = torch.cat([head, px.sum(dim=0, keepdim=True) - px], dim=1)
         assert got.shape == want.shape and float((got - want).abs().max()) <= 2e-6
+
+
+# ------------------------------------------------------------------------------------------ local matching, register-operand kernel
+@pytest.mark.parametrize("C,h,w,mld,rate,down", [
+    (100, 23, 37, [1, 3], 1, False),                 # 8 + 2R = 14 candidate columns: one group, odd map (partial 2 x 8 blocks)
+    (100, 23, 37, [2, 4, 6, 8, 10, 12], 1, False),   # the model's windows
+    (100, 21, 30, [15], 1, False),                   # R = 15: three groups
+    (128, 23, 37, [2, 4, 6, 8, 10, 12], 1, False),   # C = 128: eight float4 pieces per lane, no tail channel
+    (128, 40, 57, [3, 6, 9], 1, True),               # C = 128 with the 2x downsample
+    (100, 26, 35, [4, 8, 12], 2, False),             # atrous 2: rows / columns at odd offsets contribute nothing
+    (128, 26, 35, [3, 6, 12], 3, False),
+])
+def test_local_register_kernel_vs_oracle(aoc, C, h, w, mld, rate, down):
+    """local_window_reg_kernel (C in {100, 128}) against the oracle over map sizes that leave partial workgroups, window sizes with one,
+    two and three candidate groups, atrous rates, soft / overlapping / absent labels and a bias."""
+    from oracle import matching as om
+    rng = np.random.RandomState(C + h + len(mld) + rate)
+    O = 4
+    prev = torch.from_numpy((np.maximum(rng.randn(h, w, C), 0) * 0.3).astype(np.float32))
+    cur = torch.from_numpy((0.8 * prev.numpy() + 0.2 * np.maximum(rng.randn(h, w, C), 0) * 0.3).astype(np.float32))
+    ids = rng.randint(0, O + 1, size=(h, w))                        # id O: a pixel no object claims
+    lab = np.stack([(ids == o) for o in range(O)], -1).astype(np.float32)
+    lab[..., 1] = np.maximum(lab[..., 1], (rng.rand(h, w) < 0.1))    # overlapping labels
+    lab *= np.where(rng.rand(h, w, 1) < 0.05, 0.5, 1.0).astype(np.float32)   # soft labels below the 0.9 threshold
+    lab = torch.from_numpy(lab)
+    bias = torch.tensor([0.2, -0.1, 0.0, 0.3])
+    want = om.local_matching(prev, cur, lab, bias, mld, None, rate, False, down)
+    got = aoc.matching.local_matching(prev.cuda(), cur.cuda(), lab.cuda(), bias.cuda().view(-1, 1, 1, 1), mld, None, rate, False, down, True)
+    assert tuple(got.shape) == tuple(want.shape)
+    np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), rtol=0, atol=ATOL)
