@@ -532,9 +532,10 @@ def free_port():
     return p
 
 
-def correlation_roofline(cfg, mc, dev, batches=(1, 4, 16), reps=20):
+def correlation_roofline(cfg, mc, dev, batches=(1, 4, 16, 32), reps=20):
     """The correlation kernel by itself: B distinct frames per aoc_proxy_corr_min_batched launch, B in `batches`, each
-    timed with HIP events around `reps` back-to-back launches on an otherwise idle GPU (median)."""
+    launch bracketed by its own pair of HIP events on an otherwise idle GPU (median of `reps`; the host's preparation of the next call's
+    frame table is outside the bracket)."""
     O, C, hw = cfg.n_obj, cfg.c, cfg.h * cfg.w
     levels = mc.cluster_levels
     L, kmax = len(levels), max(levels)
@@ -566,13 +567,14 @@ def correlation_roofline(cfg, mc, dev, batches=(1, 4, 16), reps=20):
         for _ in range(3):
             ops.proxy_corr_min_batched(fr, sb, ss, so, True, "split")
         torch.cuda.synchronize()
-        evs = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
-        evs[0].record()
+        ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(reps)]
+        ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(reps)]
         for i in range(reps):
+            ev0[i].record()
             ops.proxy_corr_min_batched(fr, sb, ss, so, True, "split")
-            evs[i + 1].record()
+            ev1[i].record()
         torch.cuda.synchronize()
-        ms = float(np.median([evs[i].elapsed_time(evs[i + 1]) for i in range(reps)]))
+        ms = float(np.median([ev0[i].elapsed_time(ev1[i]) for i in range(reps)]))
         gbs = b * algo / (ms * 1e-3) / 1e9
         out.append(dict(frames_per_launch=b, avg_launch_ms=round(ms, 4), algorithmic_bytes_per_launch=b * algo, achieved=round(gbs, 1),
                         frac=round(gbs / PEAK_HBM_GBS, 4)))
