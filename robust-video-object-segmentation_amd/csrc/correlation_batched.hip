@@ -54,6 +54,18 @@ __device__ __forceinline__ uint32_t pack_f16(_Float16 a, _Float16 b) {
     return x.u;
 }
 
+// (x0, x1) -> packed fp16 pairs hi = fp16(2^10 x), lo = fp16(2^10 x - hi) in FOUR instructions: the mixed-precision FMA takes the fp32
+// value, the fp32 scale and the fp16 hi piece (read from its half of the packed register) directly, rounds once to fp16 and writes one
+// half of the destination -- the same values as scale / convert / convert back / subtract / convert / pack (15 instructions per pair as
+// hipcc compiles the scalar casts): 2^10 x is exact, and so is 2^10 x - hi in fp32 (the low bits of a 24-bit significand)
+__device__ __forceinline__ void cb_split_pair(float x0, float x1, uint32_t &hi, uint32_t &lo) {
+    const float scale = CB_SCALE;
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(hi) : "v"(x0), "s"(scale));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(hi) : "v"(x1), "s"(scale));
+    asm("v_fma_mixlo_f16 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(lo) : "v"(x0), "s"(scale), "v"(hi));
+    asm("v_fma_mixhi_f16 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(lo) : "v"(x1), "s"(scale), "v"(hi));
+}
+
 // the 50 channels of lane half h of one fp32 row in global memory: 12 x 16 B at float offset 48 h + 4 t, then 8 B at 96 + 2 h
 __device__ __forceinline__ void load_half_row(const float *__restrict__ row, int h, float (&v)[CB_CH]) {
     const float4 *p4 = reinterpret_cast<const float4 *>(row + 48 * h);
@@ -69,27 +81,25 @@ __device__ __forceinline__ void load_half_row(const float *__restrict__ row, int
 struct PixelSeq {            // B operands of one pixel tile: hi plane (7 MFMA operands; dword 25 = norm-slot constants) and lo plane + |q|^2
     u32x4 bh[CB_SEG_STEPS], bl[CB_SEG_STEPS];
     float q2part;            // this lane half's share of |q|^2
-    float amax;
 };
 
 // the 50 fp32 channels of this lane (pixel j, channel half h) -> packed hi / hi / lo planes of the operand sequence, |q|^2 share, max |x|
 __device__ __forceinline__ void convert_raw(const float (&x)[CB_CH], PixelSeq &o) {
-    float sq = 0.0f, amax = 0.0f;
+    // |x| 2^10 <= 65000 needs no test of its own on the query side: |q|^2 <= 4000 (checked per pixel) already implies |x| <= 63.25
+    float sq = 0.0f, sq1 = 0.0f;
 #pragma unroll
     for (int e = 0; e < CB_PK; ++e) {
         const float x0 = x[2 * e], x1 = x[2 * e + 1];
         sq = __builtin_fmaf(x0, x0, sq);
-        sq = __builtin_fmaf(x1, x1, sq);
-        amax = __builtin_fmaxf(amax, __builtin_fmaxf(__builtin_fabsf(x0), __builtin_fabsf(x1)));
-        const float s0 = x0 * CB_SCALE, s1 = x1 * CB_SCALE;
-        const _Float16 h0 = (_Float16)s0, h1 = (_Float16)s1;
-        o.bh[e >> 2][e & 3] = pack_f16(h0, h1);
-        o.bl[e >> 2][e & 3] = pack_f16((_Float16)(s0 - (float)h0), (_Float16)(s1 - (float)h1));
+        sq1 = __builtin_fmaf(x1, x1, sq1);
+        uint32_t hi, lo;
+        cb_split_pair(x0, x1, hi, lo);
+        o.bh[e >> 2][e & 3] = hi;
+        o.bl[e >> 2][e & 3] = lo;
     }
     o.bh[6][2] = 0u; o.bh[6][3] = 0u;                                      // dwords 26, 27: padding (dword 25 holds the norm-slot constants)
     o.bl[6][1] = 0u; o.bl[6][2] = 0u; o.bl[6][3] = 0u;
-    o.q2part = sq;
-    o.amax = amax;
+    o.q2part = sq + sq1;
 }
 
 // One 32-pixel query tile is 32 x 400 = 12 800 CONTIGUOUS bytes: a wave fetches it with 12.5 fully coalesced 16-byte loads per lane
@@ -196,10 +206,11 @@ __global__ __launch_bounds__(NW * 64) void proxy_corr_batched_kernel(AocCorrFram
         const int f = __builtin_amdgcn_readfirstlane(f_);
         const int64_t tile = ((int64_t)__builtin_amdgcn_readfirstlane((int)(tile_ >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)tile_);
         const u32x4 *q = reinterpret_cast<const u32x4 *>(frames.f[f].query);
+        // 32-bit chunk indices (the host checks m * 25 < 2^31): one add, one min and one 64-bit shift-add per load
+        const int c0 = (int)tile * CB_CHUNKS + lane, c_last = (int)frame_chunks - 1;
 #pragma unroll
         for (int t = 0; t < CB_FLAT; ++t) {
-            int64_t c = tile * CB_CHUNKS + t * 64 + lane;
-            if (c > frame_chunks - 1) c = frame_chunks - 1;                   // last tile of a frame: re-read valid data, never stored
+            const int c = min(c0 + t * 64, c_last);                           // last tile of a frame: re-read valid data, never stored
             if (t < CB_FLAT - 1 || lane < 32) flat[t] = q[c];
         }
     };
@@ -318,11 +329,9 @@ __global__ __launch_bounds__(NW * 64) void proxy_corr_batched_kernel(AocCorrFram
                 const int src = srcs[u], srow = srows[u];
                 const float am = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(x.x), __builtin_fabsf(x.y)), __builtin_fmaxf(__builtin_fabsf(x.z), __builtin_fabsf(x.w)));
                 if (am > CB_MAX_ABS) bad = true;
-                const float s0 = x.x * CB_SCALE, s1 = x.y * CB_SCALE, s2 = x.z * CB_SCALE, s3 = x.w * CB_SCALE;
-                const _Float16 h0 = (_Float16)s0, h1 = (_Float16)s1, h2 = (_Float16)s2, h3 = (_Float16)s3;
-                const uint32_t hi0 = pack_f16(h0, h1), hi1 = pack_f16(h2, h3);
-                const uint32_t lo0 = pack_f16((_Float16)(s0 - (float)h0), (_Float16)(s1 - (float)h1));
-                const uint32_t lo1 = pack_f16((_Float16)(s2 - (float)h2), (_Float16)(s3 - (float)h3));
+                uint32_t hi0, hi1, lo0, lo1;
+                cb_split_pair(x.x, x.y, hi0, lo0);
+                cb_split_pair(x.z, x.w, hi1, lo1);
                 uint32_t *row = limg + (size_t)r * CB_ROW_DW;
                 if (t < 24) {
                     uint32_t *d = row + (t >= 12 ? CB_HALF_DW : 0) + 2 * (t >= 12 ? t - 12 : t);
@@ -388,7 +397,7 @@ __global__ __launch_bounds__(NW * 64) void proxy_corr_batched_kernel(AocCorrFram
             const int64_t pix = ta * 32 + j;
             const bool live = pix < m;
             const float q2 = cb_halfsum(seq.q2part);
-            if (!(q2 <= CB_MAX_SQ) || seq.amax > CB_MAX_ABS) bad = true;
+            if (!(q2 <= CB_MAX_SQ)) bad = true;                              // also catches NaN / inf
             float *const out_pix = fr.out + pix;
             float carry = -INFINITY;
 #pragma unroll
@@ -502,6 +511,7 @@ int aoc_proxy_corr_min_batched(const aoc_corr_frame *frames_host, int n_frames, 
                                int transform, int precision, void *workspace, size_t workspace_bytes, aoc_stream_t stream) {
     if (!frames_host || !set_begin_host || !set_size_host || !set_out_offset_host) return AOC_ERR_INVALID_ARG;
     if (n_frames < 1 || m < 1 || n_set < 1 || n_proxy < 0 || C < 4) return AOC_ERR_INVALID_ARG;
+    if (m > (int64_t)80000000) return AOC_ERR_UNSUPPORTED;                    // 32-bit chunk indices inside the kernels (m * 25 < 2^31)
     if ((C & 3) || C > AOC_MAX_CHANNELS) return AOC_ERR_UNSUPPORTED;
     if (precision != AOC_CORR_SPLIT && precision != AOC_CORR_FP32) return AOC_ERR_INVALID_ARG;
     for (int s = 0; s < n_set; ++s)
