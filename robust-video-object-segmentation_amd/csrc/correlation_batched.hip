@@ -34,7 +34,7 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int CB_NW = 8;                         // waves per block (one block per CU, two waves per SIMD; 12 waves fit the LDS but spill registers: measured slower)
+constexpr int CB_NW = 12;                        // waves per block (one block per CU, three waves per SIMD: 168 VGPRs each)
 constexpr int CB_CH = 50;                        // channels per lane half (C = 100)
 constexpr int CB_PK = CB_CH / 2;                 // packed fp16 pairs per plane
 constexpr int CB_SEG_STEPS = 7;                  // k-steps per plane: 56 fp16 slots = 50 channels + norm slots + pad
@@ -105,7 +105,7 @@ __device__ __forceinline__ void convert_raw(const float (&x)[CB_CH], PixelSeq &o
 // One 32-pixel query tile is 32 x 400 = 12 800 CONTIGUOUS bytes: a wave fetches it with 12.5 fully coalesced 16-byte loads per lane
 // (1 KiB per instruction) and transposes it through its private 6.4 KB LDS buffer in two halves of 16 pixel rows: the lanes that own
 // pixels 0..15 read their (pixel, channel half) piece back after the first half is parked, the others after the second.
-constexpr int CB_FLAT = 13;                      // 16-byte chunks per lane (the 13th only for lanes 0..31)
+constexpr int CB_FLATB = 7;                      // 16-byte chunks per lane of ONE half tile (the 7th only for lanes 0..15)
 constexpr int CB_TILE_BYTES = 32 * 400;
 constexpr int CB_CHUNKS = CB_TILE_BYTES / 16;    // 800
 constexpr int CB_HALF_CHUNKS = CB_CHUNKS / 2;    // 400: chunks of the first 16 pixel rows
@@ -129,6 +129,14 @@ struct CbColDesc {           // one row of the column-wise tile
 __device__ __forceinline__ float cb_transform(float d, float bias) {
     const float e = __builtin_amdgcn_exp2f((d + bias) * -1.44269504088896341f);
     return 2.0f * __builtin_amdgcn_rcpf(1.0f + e) - 1.0f;
+}
+
+// LDS-DMA: 64 lanes x 16 bytes from per-lane global addresses to the LDS bytes [lds_dst + 16 lane, +16): no staging registers.  The
+// transfer is an asm statement hipcc does not count; the kernel only relies on loads completing in order (see convert_tile).
+__device__ __forceinline__ void cb_glds16(const void *gsrc, uint32_t lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 
 // lanes 0..31 get max over both lane halves of a, lanes 32..63 of b (one v_permlane32_swap: no LDS round trip)
@@ -199,8 +207,11 @@ __global__ __launch_bounds__(NW * 64) void proxy_corr_batched_kernel(AocCorrFram
         }
     };
 
-    // ---- the wave's pipeline: tile i in `seq` (MFMA operand), tile i+1 in flight from HBM into `flat`
-    u32x4 flat[CB_FLAT];
+    // ---- the wave's pipeline: tile i in `seq` (MFMA operand), tile i+1 in flight from HBM: its first 16 pixel rows by LDS-DMA straight
+    // into the wave's transposition buffer (free during the MFMA phase), its last 16 into `flatb` (28 registers instead of 52: twelve
+    // waves per CU fit the register file)
+    u32x4 flatb[CB_FLATB];
+    const uint32_t wbuf_lds = (uint32_t)reinterpret_cast<uintptr_t>(wbuf);
     auto issue_flat = [&](int f_, int64_t tile_) {
         // wave-uniform by construction; say so, so that the pointer comes from a scalar load instead of queueing behind the stores
         const int f = __builtin_amdgcn_readfirstlane(f_);
@@ -209,9 +220,14 @@ __global__ __launch_bounds__(NW * 64) void proxy_corr_batched_kernel(AocCorrFram
         // 32-bit chunk indices (the host checks m * 25 < 2^31): one add, one min and one 64-bit shift-add per load
         const int c0 = (int)tile * CB_CHUNKS + lane, c_last = (int)frame_chunks - 1;
 #pragma unroll
-        for (int t = 0; t < CB_FLAT; ++t) {
+        for (int t = 0; t < CB_FLATB; ++t) {                                  // chunks [0, 400): DMA (issued first: they complete first)
             const int c = min(c0 + t * 64, c_last);                           // last tile of a frame: re-read valid data, never stored
-            if (t < CB_FLAT - 1 || lane < 32) flat[t] = q[c];
+            if (t < CB_FLATB - 1 || lane < 16) cb_glds16(q + c, wbuf_lds + (uint32_t)t * 1024u);
+        }
+#pragma unroll
+        for (int t = 0; t < CB_FLATB; ++t) {                                  // chunks [400, 800): registers
+            const int c = min(c0 + CB_HALF_CHUNKS + t * 64, c_last);
+            flatb[t] = q[c];
         }
     };
     const uint32_t nconst = h == 0 ? pack_f16((_Float16)CB_QCONST, (_Float16)CB_QCONST) : pack_f16((_Float16)CB_QCONST, (_Float16)0.0f);
@@ -221,14 +237,17 @@ __global__ __launch_bounds__(NW * 64) void proxy_corr_batched_kernel(AocCorrFram
     auto convert_tile = [&]() {
         float raw[CB_CH];
         seq.bh[6][1] = nconst;
+        // memory reads return in order: once the LAST register load of the tile has arrived (hipcc's own wait for flatb[6]), the DMA
+        // transfers issued in front of it have landed in the buffer
+        asm volatile("" : "+v"(flatb[CB_FLATB - 1]) :: "memory");
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
+            if (half == 1) {
 #pragma unroll
-            for (int t = 0; t < CB_FLAT; ++t) {
-                const int c = t * 64 + lane;                                  // chunk of the tile held in flat[t]
-                const bool mine = half == 0 ? c < CB_HALF_CHUNKS : (c >= CB_HALF_CHUNKS && c < CB_CHUNKS);
-                if ((half == 0 ? t * 64 < CB_HALF_CHUNKS : t * 64 + 63 >= CB_HALF_CHUNKS) && mine)
-                    reinterpret_cast<u32x4 *>(wbuf)[c - half * CB_HALF_CHUNKS] = flat[t];
+                for (int t = 0; t < CB_FLATB; ++t) {
+                    const int c = t * 64 + lane;                              // chunk of the second half held in flatb[t]
+                    if (c < CB_HALF_CHUNKS) reinterpret_cast<u32x4 *>(wbuf)[c] = flatb[t];
+                }
             }
             if ((j >> 4) == half) {                                           // only the LDS reads are predicated; the arithmetic runs once
 #pragma unroll
