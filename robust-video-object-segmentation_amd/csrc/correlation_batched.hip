@@ -424,19 +424,16 @@ __global__ __launch_bounds__(NW * 64) void proxy_corr_batched_kernel(AocCorrFram
                 const uint4 *arow = reinterpret_cast<const uint4 *>(limg + (size_t)(ti * 32 + j) * CB_ROW_DW + h * CB_HALF_DW);
                 f32x16 acc;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-                if (dbg != 1) {
+                for (int r = 0; r < 16; ++r) acc[r] = 0.0f;           // folds into the first MFMA's constant C operand (no unconditional path around the chain)
 #pragma unroll
-                    for (int s = 0; s < CB_SEG_STEPS; ++s) {          // q.p = qh.ph + qh.pl + ql.ph (the norm slots ride in the hi x hi product)
-                        const f16x8 ah = __builtin_bit_cast(f16x8, arow[s]);
-                        const f16x8 al = __builtin_bit_cast(f16x8, arow[CB_SEG_STEPS + s]);
-                        const f16x8 bh = __builtin_bit_cast(f16x8, seq.bh[s]);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, __builtin_bit_cast(f16x8, seq.bl[s]), acc, 0, 0, 0);
-                    }
+                for (int s = 0; s < CB_SEG_STEPS; ++s) {              // q.p = qh.ph + qh.pl + ql.ph (the norm slots ride in the hi x hi product)
+                    const f16x8 ah = __builtin_bit_cast(f16x8, arow[s]);
+                    const f16x8 al = __builtin_bit_cast(f16x8, arow[CB_SEG_STEPS + s]);
+                    const f16x8 bh = __builtin_bit_cast(f16x8, seq.bh[s]);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, __builtin_bit_cast(f16x8, seq.bl[s]), acc, 0, 0, 0);
                 }
-                if (dbg == 3) { asm volatile("" :: "v"(acc[0]), "v"(acc[5]), "v"(acc[10]), "v"(acc[15])); continue; }
                 if (COL0 && ti == 0) {
                     // column-wise tile: every row is its own output (k = 1 proxies, no min: AEM:127).  Register r of lane half h is
                     // row (r / 4) * 8 + 4 h + r % 4; row groups beyond the tile's rows are skipped with uniform branches.
