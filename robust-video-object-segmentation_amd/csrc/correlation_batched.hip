@@ -151,7 +151,7 @@ __device__ __forceinline__ float cb_halfsum(float a) {
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
-// NT = proxy tiles of the launch; COL0: tile 0 is the column-wise tile (k = 1 proxies).  Block = NW waves, two per SIMD: while one
+// NT = proxy tiles of the launch; COL0: tile 0 is the column-wise tile (k = 1 proxies).  Block = NW waves, three per SIMD: while one
 // wave converts its next pixel tile (VALU) or waits for LDS, its partner's MFMA chain keeps the matrix pipe busy.
 template <int NW, int NT, bool COL0>
 __global__ __launch_bounds__(NW * 64) void proxy_corr_batched_kernel(AocCorrFrames frames, int64_t m, AocCorrTiles tiles, int transform,
@@ -578,7 +578,7 @@ int aoc_proxy_corr_min_batched(const aoc_corr_frame *frames_host, int n_frames, 
             const size_t lds = (size_t)tab.n * tile_bytes + lds_fixed;
             int64_t grid = T * fr.n;
             if (grid > n_cu) grid = n_cu;
-            static const int dbg = getenv("AOC_CORR_DEBUG") ? atoi(getenv("AOC_CORR_DEBUG")) : 0;
+            static const int dbg = getenv("AOC_CORR_DEBUG") ? atoi(getenv("AOC_CORR_DEBUG")) : 0;   // developer switch: 2 = no tile loads, 4 = no conversion (timing experiments; wrong results)
             const bool col0 = tab.t[0].kind == 1;
 #define AOC_CB(N, COL)                                                                                                                  \
     do {                                                                                                                                \
