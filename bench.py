@@ -938,7 +938,7 @@ def main():
             corr_roof = dict(kernel="proxy_corr_batched_kernel (aoc_proxy_corr_min_batched)" if corr_name.endswith("batched") else "proxy_corr_min_kernel",
                              bound="hbm", achieved=corr["gbs"], peak=PEAK_HBM_GBS, unit="GB/s",
                              frac=round(corr["gbs"] / PEAK_HBM_GBS, 4), avg_launch_ms=corr["avg_ms"], algorithmic_bytes_per_launch=corr["avg_bytes"],
-                             frames_per_launch=n_streams if corr_name.endswith("batched") else 1,
+                             frames_per_launch=n_streams if batch_corr else 1,
                              note="in-run figure: the event pair also spans the time the launch waits behind the other streams' kernels; "
                                   "`isolated` = the same kernel with B distinct frames per launch on an idle GPU")
             if C == 100:
@@ -994,7 +994,7 @@ def main():
                        "intra_frame_overlap": ("none" if args.no_overlap else "k-means chain on a side HIP stream" +
                                                ("" if args.no_pipeline else ", enqueued as soon as the pool it depends on is final")),
                        "correlation": ("ONE aoc_proxy_corr_min_batched launch per step for the frames of all in-flight sequences" if batch_corr
-                                       else "one aoc_proxy_corr_min launch per sequence and frame"),
+                                       else "one aoc_proxy_corr_min_batched launch (fp16-split kernel, one frame) per sequence and frame"),
                        "cu_reserve": (f"main streams masked off {args.cu_reserve} of {n_cu} CUs (hipExtStreamCreateWithCUMask), left to the side-stream "
                                       "k-means chains" if args.cu_reserve > 0 else "none"),
                        "proxy_mode": ("NON-PARITY: every reference frame clustered once when it joins the pool, frames matched against the union of the "

@@ -249,7 +249,8 @@ def proto_mask_features(cfg, ref_emb, ref_labels, prev_emb, prev_labels, cur_emb
                  reference heads, which only depend on the pool (recomputed when the number of pool frames changes).  The pool
                  must be append-only while the dict lives (the reference's memory policy, eval_manager_mm.py:329-361): a call may see
                  any PREFIX of it; the caller sets dense_state["frames"] = 0 when the pool restarts (next sequence).
-    dense_precision  "split" (default, ops.DENSE_PRECISION) or "fp32": see ops.dense_match.
+    dense_precision  "split" (default, ops.DENSE_PRECISION) or "fp32": see ops.dense_match; the correlation launch follows it (fp16-split
+                 kernel with device-side take-over / exact-fp32 kernel).
     dense_stream  optional stream for the dense matching kernel alone (e.g. one created with a HIP CU mask): the call forks
                  to it for that kernel and joins in front of the background maps, so the light kernels of this frame (and
                  of other sequences) are not queued behind the one kernel that fills every CU it may use.
@@ -404,7 +405,10 @@ def proto_mask_features(cfg, ref_emb, ref_labels, prev_emb, prev_labels, cur_emb
         pending.ready = torch.cuda.Event()
         pending.ready.record(pending.stream)
     else:
-        ops.proxy_corr_min(query_flat, table, sqn, set_begin, set_size, set_off, set_bias, feat, 1, True)
+        # the fp16-split correlation kernel (fp32-equivalent, device-side take-over to exact fp32), also for one frame per launch: with
+        # hundreds of proxies (cfg3: 1158, cfg4: 1161) the exact-fp32 MFMA kernel is ten times slower; "fp32" asks for that kernel
+        ops.proxy_corr_min_batched([(query_flat, table, sqn, set_bias, feat)], set_begin, set_size, set_off, True,
+                                   "fp32" if (dense_precision or ops.DENSE_PRECISION) == "fp32" else "split")
 
     # ---- previous-frame mask channel (aocnet.py:356 to_cat_previous_frame)
     feat[:, ch["prev_mask"]].copy_(prev_labels.permute(2, 0, 1))
