@@ -32,6 +32,9 @@ constexpr int MP_SPLIT = 4;      // pixel sub-ranges per block (threads = MP_SPL
 // pcount[blk][o] = sum lab[o,p].   emb [F, hw, C] channel-last, lab [F, O, hw] (or [F, hw, O] pixel-major).
 // Block = 256 threads = MP_SPLIT pixel sub-ranges x 64 channel lanes (lane handles channels c, c+64, ...);
 // loads are coalesced along channels and unrolled along pixels for memory-level parallelism.
+// OM: compile-time bound of the object loop (4, 8 or MP_OMAX): the accumulators live in registers and the per-object work is not
+// 32 predicated iterations for a 4-object frame
+template <int OM>
 __global__ __launch_bounds__(256) void masked_pool_partial_kernel(const float *__restrict__ emb, const float *__restrict__ lab,
                                                                    int64_t hw, int C, int n_obj, int chunks_per_frame, int pixel_major,
                                                                    float *__restrict__ partial, float *__restrict__ pcount) {
@@ -50,9 +53,9 @@ __global__ __launch_bounds__(256) void masked_pool_partial_kernel(const float *_
     const float *e = emb + ((size_t)f * hw + p0) * C;
     for (int c0 = 0; c0 < C; c0 += 64) {
         const int c = c0 + lane;
-        float acc[MP_OMAX + 1];
+        float acc[OM + 1];
 #pragma unroll
-        for (int o = 0; o <= MP_OMAX; ++o) acc[o] = 0.0f;
+        for (int o = 0; o <= OM; ++o) acc[o] = 0.0f;
         if (c < C) {
             for (int p = pb; p < pe; p += 8) {
                 float v[8];
@@ -60,9 +63,9 @@ __global__ __launch_bounds__(256) void masked_pool_partial_kernel(const float *_
                 for (int u = 0; u < 8; ++u) v[u] = (p + u < pe) ? e[(size_t)(p + u) * C + c] : 0.0f;
 #pragma unroll
                 for (int u = 0; u < 8; ++u) {
-                    acc[MP_OMAX] += v[u];
+                    acc[OM] += v[u];
 #pragma unroll
-                    for (int o = 0; o < MP_OMAX; ++o)
+                    for (int o = 0; o < OM; ++o)
                         if (o < n_obj) acc[o] += v[u] * llab[o * MP_PIX + min(p + u, MP_PIX - 1)];
                 }
             }
@@ -70,9 +73,9 @@ __global__ __launch_bounds__(256) void masked_pool_partial_kernel(const float *_
         // combine the MP_SPLIT sub-ranges in a fixed order (deterministic)
         __syncthreads();
 #pragma unroll
-        for (int o = 0; o < MP_OMAX; ++o)
+        for (int o = 0; o < OM; ++o)
             if (o < n_obj) lcomb[(sub * (n_obj + 1) + o) * 64 + lane] = acc[o];
-        lcomb[(sub * (n_obj + 1) + n_obj) * 64 + lane] = acc[MP_OMAX];
+        lcomb[(sub * (n_obj + 1) + n_obj) * 64 + lane] = acc[OM];
         __syncthreads();
         if (sub == 0 && c < C) {
             for (int o = 0; o <= n_obj; ++o) {
@@ -87,6 +90,79 @@ __global__ __launch_bounds__(256) void masked_pool_partial_kernel(const float *_
         for (int p = 0; p < np; ++p) s += llab[threadIdx.x * MP_PIX + p];
         pcount[(size_t)blockIdx.x * n_obj + threadIdx.x] = s;
     }
+}
+
+// The same partial sums with 16-byte loads (C % 4 == 0, up to 8 objects): thread t owns the float4 piece t % (C/4) of the pixels
+// t / (C/4), + RPP, ... of the chunk (RPP = 256 / (C/4) pixels per pass; consecutive threads read one pixel's consecutive 16 bytes), four
+// loads in flight per thread; the RPP partial sums of a piece are combined through LDS in a fixed order (deterministic).
+template <int OM>
+__global__ __launch_bounds__(256) void masked_pool_partial4_kernel(const float *__restrict__ emb, const float *__restrict__ lab,
+                                                                    int64_t hw, int C, int n_obj, int chunks_per_frame, int cpb, int pixel_major,
+                                                                    float *__restrict__ partial, float *__restrict__ pcount) {
+    extern __shared__ __attribute__((aligned(16))) float llab4[];   // [n_obj][MP_PIX] labels, then [RPP][n_obj + 1][C / 4] float4 combine buffer
+    float *llab = llab4;
+    float4 *lcomb = reinterpret_cast<float4 *>(llab4 + n_obj * MP_PIX);
+    // block = cpb consecutive chunks of one frame (large pools: fewer, fatter partial blocks for the final kernel to add up)
+    const int bpf = (chunks_per_frame + cpb - 1) / cpb;
+    const int f = blockIdx.x / bpf, cb = blockIdx.x - f * bpf;
+    const int c4 = C >> 2, rpp = 256 / c4;
+    const int r0 = threadIdx.x / c4, piece = threadIdx.x - r0 * c4;
+    const bool worker = r0 < rpp;
+    float4 acc[OM + 1];
+#pragma unroll
+    for (int o = 0; o <= OM; ++o) acc[o] = make_float4(0.f, 0.f, 0.f, 0.f);
+    float cnt = 0.0f;
+    for (int chunk = cb * cpb; chunk < min(chunks_per_frame, (cb + 1) * cpb); ++chunk) {
+        const int64_t p0 = (int64_t)chunk * MP_PIX;
+        const int np = (int)min((int64_t)MP_PIX, hw - p0);
+        __syncthreads();                                   // the previous chunk's labels are no longer read
+        for (int i = threadIdx.x; i < n_obj * MP_PIX; i += 256) {
+            const int o = i / MP_PIX, p = i - o * MP_PIX;
+            llab[i] = (p >= np) ? 0.0f : (pixel_major ? lab[((size_t)f * hw + p0 + p) * n_obj + o] : lab[((size_t)f * n_obj + o) * hw + p0 + p]);
+        }
+        __syncthreads();
+        if (worker) {
+            const float4 *e = reinterpret_cast<const float4 *>(emb + ((size_t)f * hw + p0) * C) + piece;
+            for (int p = r0; p < np; p += 4 * rpp) {
+                float4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = e[(size_t)min(p + u * rpp, np - 1) * c4];       // clamped: the loads stay branch-free
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int pp = p + u * rpp;
+                    if (pp < np) {
+                        acc[OM].x += v[u].x; acc[OM].y += v[u].y; acc[OM].z += v[u].z; acc[OM].w += v[u].w;
+#pragma unroll
+                        for (int o = 0; o < OM; ++o) {
+                            if (o < n_obj) {
+                                const float w = llab[o * MP_PIX + pp];
+                                acc[o].x += v[u].x * w; acc[o].y += v[u].y * w; acc[o].z += v[u].z * w; acc[o].w += v[u].w * w;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        if ((int)threadIdx.x < n_obj)
+            for (int p = 0; p < np; ++p) cnt += llab[threadIdx.x * MP_PIX + p];
+    }
+    if (worker) {
+#pragma unroll
+        for (int o = 0; o < OM; ++o)
+            if (o < n_obj) lcomb[(r0 * (n_obj + 1) + o) * c4 + piece] = acc[o];
+        lcomb[(r0 * (n_obj + 1) + n_obj) * c4 + piece] = acc[OM];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < (n_obj + 1) * c4; i += 256) {
+        const int o = i / c4, pc = i - o * c4;
+        float4 t = lcomb[o * c4 + pc];
+        for (int r = 1; r < rpp; ++r) {
+            const float4 x = lcomb[(r * (n_obj + 1) + o) * c4 + pc];
+            t.x += x.x; t.y += x.y; t.z += x.z; t.w += x.w;
+        }
+        *reinterpret_cast<float4 *>(partial + ((size_t)blockIdx.x * (n_obj + 1) + o) * C + 4 * pc) = t;
+    }
+    if ((int)threadIdx.x < n_obj) pcount[(size_t)blockIdx.x * n_obj + threadIdx.x] = cnt;
 }
 
 // block = object; 1024 threads = 8 slices of the partial blocks x 128 channel lanes; fixed combine order
@@ -110,6 +186,16 @@ __global__ __launch_bounds__(1024) void masked_pool_final_kernel(const float *__
         float pos = 0.0f, tot = 0.0f;
         if (c < C) {
             int b = b0;
+            for (; b + 16 <= b1; b += 16) {              // 32 loads in flight per thread; the additions keep their order
+                float p[16], t[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    p[u] = partial[((size_t)(b + u) * (n_obj + 1) + o) * C + c];
+                    t[u] = partial[((size_t)(b + u) * (n_obj + 1) + n_obj) * C + c];
+                }
+#pragma unroll
+                for (int u = 0; u < 16; ++u) { pos += p[u]; tot += t[u]; }
+            }
             for (; b + 4 <= b1; b += 4) {
                 float p[4], t[4];
 #pragma unroll
@@ -920,7 +1006,26 @@ int aoc_masked_mean_pool(const float *emb, const float *labels, int n_frames, in
     const int nb = n_frames * cpf;
     float *partial = static_cast<float *>(workspace);
     float *pcount = reinterpret_cast<float *>(static_cast<char *>(workspace) + aoc_align_up((size_t)nb * (n_obj + 1) * C * sizeof(float), 256));
-    hipLaunchKernelGGL(masked_pool_partial_kernel, dim3(nb), dim3(256), ((size_t)n_obj * MP_PIX + (size_t)MP_SPLIT * (n_obj + 1) * 64) * sizeof(float), st, emb, labels, hw, C, n_obj, cpf, labels_pixel_major, partial, pcount);
+    const size_t plds = ((size_t)n_obj * MP_PIX + (size_t)MP_SPLIT * (n_obj + 1) * 64) * sizeof(float);
+    const bool vec4 = (C & 3) == 0 && C >= 16 && C <= 256 && n_obj <= 8 && (reinterpret_cast<uintptr_t>(emb) & 15) == 0;
+    const size_t plds4 = ((size_t)n_obj * MP_PIX + (size_t)(vec4 ? 256 / (C / 4) : 0) * (n_obj + 1) * C) * sizeof(float);
+    if (vec4) {
+        const int cpb = (nb + 767) / 768;                     // chunks per workgroup: at most ~768 partial blocks whatever the pool size
+        const int nb4 = n_frames * ((cpf + cpb - 1) / cpb);
+        if (n_obj <= 4)
+            hipLaunchKernelGGL(masked_pool_partial4_kernel<4>, dim3(nb4), dim3(256), plds4, st, emb, labels, hw, C, n_obj, cpf, cpb, labels_pixel_major, partial, pcount);
+        else
+            hipLaunchKernelGGL(masked_pool_partial4_kernel<8>, dim3(nb4), dim3(256), plds4, st, emb, labels, hw, C, n_obj, cpf, cpb, labels_pixel_major, partial, pcount);
+        hipLaunchKernelGGL(masked_pool_final_kernel, dim3(n_obj), dim3(1024), 0, st, partial, pcount, nb4, C, n_obj, (float)((double)hw * n_frames), epsilon, out_pos, out_neg, out_pos_sqnorm);
+        AOC_RETURN_IF_LAUNCH_FAILED();
+        return AOC_OK;
+    }
+    if (n_obj <= 4)
+        hipLaunchKernelGGL(masked_pool_partial_kernel<4>, dim3(nb), dim3(256), plds, st, emb, labels, hw, C, n_obj, cpf, labels_pixel_major, partial, pcount);
+    else if (n_obj <= 8)
+        hipLaunchKernelGGL(masked_pool_partial_kernel<8>, dim3(nb), dim3(256), plds, st, emb, labels, hw, C, n_obj, cpf, labels_pixel_major, partial, pcount);
+    else
+        hipLaunchKernelGGL(masked_pool_partial_kernel<MP_OMAX>, dim3(nb), dim3(256), plds, st, emb, labels, hw, C, n_obj, cpf, labels_pixel_major, partial, pcount);
     hipLaunchKernelGGL(masked_pool_final_kernel, dim3(n_obj), dim3(1024), 0, st, partial, pcount, nb, C, n_obj, (float)((double)hw * n_frames), epsilon, out_pos, out_neg, out_pos_sqnorm);
     AOC_RETURN_IF_LAUNCH_FAILED();
     return AOC_OK;
