@@ -513,3 +513,13 @@ def test_local_register_kernel_vs_oracle(aoc, C, h, w, mld, rate, down):
     got = aoc.matching.local_matching(prev.cuda(), cur.cuda(), lab.cuda(), bias.cuda().view(-1, 1, 1, 1), mld, None, rate, False, down, True)
     assert tuple(got.shape) == tuple(want.shape)
     np.testing.assert_allclose(got.cpu().numpy(), want.numpy(), rtol=0, atol=ATOL)
+
+
+@pytest.mark.parametrize("hw", [1, 3, 7, 1021, 121 * 213, 61 * 107])
+def test_plane_mean_every_alignment(aoc, hw):
+    """aoc_plane_mean with plane sizes that put the planes at every 4-byte phase of a 16-byte line (scalar head, 16-byte body, scalar tail)."""
+    g = torch.Generator().manual_seed(hw)
+    x = torch.randn(3, 5, hw, 1, generator=g)
+    got = aoc.ops.plane_mean(x.cuda()).cpu()
+    want = x.double().mean(dim=(2, 3)).float()
+    np.testing.assert_allclose(got.numpy(), want.numpy(), rtol=2e-5, atol=2e-6)
