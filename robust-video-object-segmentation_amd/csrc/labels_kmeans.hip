@@ -2064,7 +2064,10 @@ inline KsWorkspace ks_carve(void *workspace, int64_t cap, int n_seg, int kmax, i
 //             every doubling -- are summed literally, lanes = features (km_ordered_sum_kernel); larger clusters continue
 //             with the chunk-parallel integer folds and the serial stitch (their crossings are rare from there on);
 //   "ordered": literal sums only;   "scan": chunk-parallel pipeline only.   (AOC_KM_SUM, developer switch.)
-constexpr int KS_HEAD_CHUNKS = 4;
+// 6 chunks = 3072 members: since the heads share a launch with the tail's chunk sums they are off the critical path up to about there,
+// and every chunk they take is one the fold / stitch kernels do not see (sweep 1 .. 8 at R = 6: 3.13, 3.03, 2.90, 2.89, 2.76, 2.78, 2.81,
+// 2.84 ms per chain; three frames per chain 5.13 -> 4.61 ms).  AOC_KM_HEAD_CHUNKS: developer switch.
+static const int KS_HEAD_CHUNKS = (getenv("AOC_KM_HEAD_CHUNKS") && atoi(getenv("AOC_KM_HEAD_CHUNKS")) > 0) ? atoi(getenv("AOC_KM_HEAD_CHUNKS")) : 6;
 constexpr int KC_INLINE_PREDICT_CHUNKS = 800;   // 409 600 rows per segment
 inline int ks_sum_mode() {
     static const int mode = [] {
