@@ -542,7 +542,10 @@ inline int split_waves() {
 inline int split_nsplit(int64_t m) {
     const int64_t rpb = (int64_t)split_waves() * SP_NQ * 32;
     const int64_t row_blocks = (m + rpb - 1) / rpb;
-    static const int max_rounds = getenv("AOC_DENSE_ROUNDS") ? atoi(getenv("AOC_DENSE_ROUNDS")) : 4;
+    // at most two rounds of workgroups (developer switch AOC_DENSE_ROUNDS): fewer splits share their bounds sooner (in-run launch 1.43 /
+    // 1.50 / 1.56 ms at 1 / 2 / 4 rounds), but with one round the other streams' kernels wait for a whole dense launch before a CU
+    // comes free: bench 320 / 324 / 320 frames/s
+    static const int max_rounds = getenv("AOC_DENSE_ROUNDS") ? atoi(getenv("AOC_DENSE_ROUNDS")) : 2;
     // CUs the launching stream may use (256 unless the caller runs it under a HIP CU mask and says so)
     static const int n_cu = (getenv("AOC_DENSE_CUS") && atoi(getenv("AOC_DENSE_CUS")) > 0) ? atoi(getenv("AOC_DENSE_CUS")) : 256;
     int best = 1;
