@@ -70,3 +70,9 @@ int aoc_dense_match_min_gated(const float *query, int64_t m, int C, const float 
 // measurement probe of aoc_dense_match_set_probe (thread-local; defined in correlation.hip)
 struct AocDenseProbe { hipEvent_t start, stop; };
 AocDenseProbe aoc_take_dense_probe();
+
+// persistent k-means chain (kmeans_persistent.hip): the Lloyd iterations of one aoc_kmeans_segmented_ex call in ONE launch
+bool aoc_kp_supported(int C, int n_seg, int kmax);
+size_t aoc_kp_workspace_bytes(int64_t rows_capacity, int n_seg, int kmax);
+int aoc_kp_chain(const float *pool, const int32_t *rows, const int32_t *seg_offsets, const int32_t *seg_k, int n_seg, int kmax, int iters,
+                 int64_t rows_capacity, float *centroids, int32_t *labels, int32_t *cluster_counts, float *rownorm, void *workspace, hipStream_t st);

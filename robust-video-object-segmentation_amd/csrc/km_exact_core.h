@@ -31,7 +31,7 @@ KX_HD float kx_u2f(uint32_t u) { return __builtin_bit_cast(float, u); }
 //   bits 14-21  eB + 128   binade of the B part (0: no B part)
 //   bits 22-27  nlit       literal members between A and B (0..KX_MAX_LIT)
 enum { KX_PLAIN = 0, KX_CROSS = 1, KX_SET = 2, KX_UNSAFE = 3 };
-constexpr int KX_MAX_LIT = 32;
+constexpr int KX_MAX_LIT = 16;
 constexpr int KX_E_MIN = -100, KX_E_MAX = 100;
 
 // ebA / ebB: binade + 128, or 0 when the part is absent (binade -128 does not exist: KX_E_MIN)

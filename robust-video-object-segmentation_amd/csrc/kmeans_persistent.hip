@@ -1,0 +1,840 @@
+// The 20-iteration k-means chain of one call (scipy.cluster.vq.kmeans2, AEM:276) as ONE persistent launch: every Lloyd iteration is four
+// phases of the same resident grid, separated by grid barriers --
+//   A  assignment on the fp32 matrix pipe (bit-identical to scipy's vq, see labels_kmeans.hip) + per-(64-row mini-block, cluster)
+//      any-order sums of |x| and their running prefix: the PREDICTION of the exact sequential sum in front of every chunk;
+//   B  fold: every chunk (the members of one cluster inside one mini-block, in row order) becomes a record per feature -- integer
+//      increments in the predicted binade(s), the members around a predicted binade crossing kept as literals (km_exact_core.h);
+//   C  merge: consecutive pure-integer records of a part (64 mini-blocks) collapse into runs;
+//   S  stitch: one wave per (segment, cluster, 64 features) walks parts -> runs -> records with the EXACT float state, verifies
+//      every assumption and replaces what does not verify by the literal additions of that chunk's rows.
+// The result equals scipy's sequential float32 sums bit for bit for ANY input; predictions only decide how much of it runs in
+// parallel.  Chunks are tied to row blocks, not to member ranks (no rank / scan / scatter passes, no member lists), rows are read
+// twice per iteration (A, B) plus once from cache (A's chunk sums).
+#include "aoc_common.h"
+#include "km_exact_core.h"
+
+#include <algorithm>
+#include <stdlib.h>
+
+namespace {
+
+constexpr int KP_C = 100;                 // embedding width served by this path
+constexpr int KP_C1 = KP_C - 64;          // features of the second lane half
+constexpr int KP_TM = 25;                 // float4 pieces per row
+constexpr int KP_TP = 28;                 // floats per kq-stream, padded to float4
+constexpr int KP_RS = 4 * KP_TP + 4;      // row stride of the k-permuted operand image
+constexpr int KP_NB4 = KP_TP / 4;
+constexpr int KP_PIECES = (16 * KP_TM + 63) / 64;
+constexpr int KP_SEG_MAX = 128;
+constexpr int KP_REC = 6;                 // words per (chunk, feature): hdr, A0, B0, literal | literal offset, run hdr, run R0
+constexpr int KP_LITCAP = 8192;           // literal pool per workgroup (floats)
+constexpr int KP_GMAX = 1024;
+constexpr int KP_LIT = KX_MAX_LIT;        // literals a lane can hold per chunk
+constexpr long long KP_TIMEOUT_TICKS = 300000000ll;   // 3 s of the 100 MHz wall clock: a barrier that does not complete poisons the output instead of hanging
+
+struct KpBar {
+    uint32_t count;
+    uint32_t error;
+    uint32_t pad[62];
+};
+
+struct KpArgs {
+    const float *pool;
+    const int32_t *rows, *seg_off, *seg_k;
+    int n_seg, kmax, iters, grid, prof;
+    float *centroids;
+    int32_t *labels, *cluster_counts;
+    float *rownorm;
+    unsigned long long *pres;     // [mini-block] bit kk: cluster kk has members there
+    int32_t *ccnt;                // [slot] members of the chunk
+    float *bsum;                  // [slot][C] any-order sum of |x| over the chunk
+    uint32_t *rec;                // [slot][KP_REC][C]
+    float *PB;                    // [block][kmax][C] prefix of bsum over the earlier blocks of this workgroup's range (same segment)
+    int32_t *PBC;                 // [block][kmax]
+    float *T;                     // [workgroup][kmax][C] sum over the workgroup's blocks of its last segment
+    int32_t *TC;
+    float *litpool;               // [workgroup][KP_LITCAP]
+    uint32_t *part_post;          // [part][kmax][2][C] last run of the part
+    unsigned long long *part_np;  // [part][kmax][C] positions of the records the stitch has to look at
+    int32_t *part_cnt;            // [part][kmax] members
+    KpBar *bar;
+};
+
+struct KpTables {
+    int32_t seg_off[KP_SEG_MAX + 1];
+    int32_t seg_k[KP_SEG_MAX];
+    int32_t blk_base[KP_SEG_MAX + 1];     // 256-row blocks in front of the segment
+    int32_t part_base[KP_SEG_MAX + 1];    // parts (64 mini-blocks = 16 blocks) in front of the segment
+    int32_t error;
+    int32_t litcnt;
+    int32_t pad[2];
+};
+
+// developer counters (aoc_kmeans_chain_profile): what workgroup 0 spends where, in ticks of the 100 MHz wall clock
+__device__ unsigned long long g_kp_prof[16];
+#define KP_TICK(slot)                                                         \
+    do {                                                                      \
+        if (prof && wg == 0 && threadIdx.x == 0) {                            \
+            const long long now_ = wall_clock64();                            \
+            g_kp_prof[slot] += (unsigned long long)(now_ - tprev);            \
+            tprev = now_;                                                     \
+        }                                                                     \
+    } while (0)
+
+__device__ __forceinline__ unsigned long long kp_below(int n) { return n >= 64 ? ~0ull : ((1ull << n) - 1ull); }
+
+// ------------------------------------------------------------------------------------------ grid barrier
+// One monotonic counter; release fence by the arriving lane, relaxed polling, one acquire fence after the match (guide: §6 G16).
+__device__ __forceinline__ bool kp_grid_barrier(KpBar *bar, KpTables *tab, uint32_t &epoch, int grid) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    ++epoch;
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const uint32_t target = epoch * (uint32_t)grid;
+        uint32_t v = __hip_atomic_fetch_add(&bar->count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+        const long long t0 = wall_clock64();
+        int err = 0;
+        while (v < target) {
+            __builtin_amdgcn_s_sleep(1);
+            v = __hip_atomic_load(&bar->count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__hip_atomic_load(&bar->error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { err = 1; break; }
+            if (wall_clock64() - t0 > KP_TIMEOUT_TICKS) {
+                __hip_atomic_store(&bar->error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                err = 1;
+                break;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        tab->error = err;
+    }
+    __syncthreads();
+    return tab->error == 0;
+}
+
+// sequential |x|^2 of a row: multiply, then add (scipy's order)
+__device__ __forceinline__ float kp_sqnorm_row(const float4 *__restrict__ xr) {
+    float xs = 0.0f;
+#pragma unroll 5
+    for (int t = 0; t < KP_TM; ++t) {
+        const float4 v = xr[t];
+        float p0 = v.x * v.x; xs = xs + p0;
+        float p1 = v.y * v.y; xs = xs + p1;
+        float p2 = v.z * v.z; xs = xs + p2;
+        float p3 = v.w * v.w; xs = xs + p3;
+    }
+    return xs;
+}
+
+// ------------------------------------------------------------------------------------------ phase A
+template <int KT>
+__device__ __forceinline__ void kp_phase_assign(const KpArgs &a, KpTables *tab, float *lds, int blk_begin, int blk_end, int wg) {
+    constexpr int c4 = KP_TM;
+    const int lane = aoc_lane(), wave = threadIdx.x >> 6;
+    const int j = lane & 15, g = lane >> 4;
+    const int kmax = a.kmax;
+    float *cimg = lds;                                           // [KT*16][RS]
+    float *lcn = cimg + (size_t)KT * 16 * KP_RS;                 // [KT*16]
+    float *wimg = lcn + KT * 16 + (size_t)wave * 16 * KP_RS;     // this wave's row-tile image
+    float *run = lcn + KT * 16 + (size_t)4 * 16 * KP_RS;         // [kmax][C] prefix of bsum over this workgroup's earlier blocks of the segment
+    float *blks = run + (size_t)kmax * KP_C;                     // [kmax][C] sums of the current block
+    int32_t *runc = reinterpret_cast<int32_t *>(blks + (size_t)kmax * KP_C);   // [kmax]
+    int32_t *blkc = runc + kmax;                                 // [kmax]
+
+    // stream padding of the images: zero once
+    for (int idx = lane; idx < 16 * 4 * (KP_TP - c4); idx += 64) {
+        const int rr = idx / (4 * (KP_TP - c4)), rem = idx - rr * 4 * (KP_TP - c4);
+        wimg[(size_t)rr * KP_RS + (rem / (KP_TP - c4)) * KP_TP + c4 + rem % (KP_TP - c4)] = 0.0f;
+    }
+    for (int idx = threadIdx.x; idx < KT * 16 * 4 * (KP_TP - c4); idx += 256) {
+        const int rr = idx / (4 * (KP_TP - c4)), rem = idx - rr * 4 * (KP_TP - c4);
+        cimg[(size_t)rr * KP_RS + (rem / (KP_TP - c4)) * KP_TP + c4 + rem % (KP_TP - c4)] = 0.0f;
+    }
+    for (int i = threadIdx.x; i < kmax * KP_C; i += 256) { run[i] = 0.0f; blks[i] = 0.0f; }
+    if ((int)threadIdx.x < kmax) { runc[threadIdx.x] = 0; blkc[threadIdx.x] = 0; }
+    __syncthreads();
+
+    float4 ca[KT][KP_NB4];
+    float cn[KT][4];
+    int cur_seg = -1, k = 0, beg = 0, len = 0;
+    int s = 0;
+    for (int blk = blk_begin; blk < blk_end; ++blk) {
+        while (blk >= tab->blk_base[s + 1]) ++s;
+        const int bx = blk - tab->blk_base[s];
+        const int ibeg = tab->seg_off[s], ilen = tab->seg_off[s + 1] - ibeg;
+        const int wave_row0 = bx * 256 + wave * 64;
+        const int my_p = max(min(wave_row0 + lane, ilen - 1), 0);
+        const int my_id = a.rows[ibeg + my_p];
+        const float my_xs = a.rownorm[ibeg + my_p];
+        constexpr int TPF = 2;
+        float4 pv[TPF][KP_PIECES];
+        auto issue_tile = [&](int tile, float4 (&v)[KP_PIECES]) {
+#pragma unroll
+            for (int i = 0; i < KP_PIECES; ++i) {
+                const int idx = min(i * 64 + lane, 16 * c4 - 1);
+                const int rr = idx / c4, t = idx - rr * c4;
+                const int id = __shfl(my_id, tile * 16 + rr);
+                v[i] = reinterpret_cast<const float4 *>(a.pool + (size_t)id * KP_C)[t];
+            }
+        };
+        auto write_tile = [&](int tile, const float4 (&v)[KP_PIECES]) {
+#pragma unroll
+            for (int i = 0; i < KP_PIECES; ++i) {
+                const int idx = i * 64 + lane;
+                if (idx < 16 * c4) {
+                    const int rr = idx / c4, t = idx - rr * c4;
+                    const bool in = wave_row0 + tile * 16 + rr < ilen;
+                    float *d = wimg + (size_t)rr * KP_RS + t;
+                    d[0] = in ? v[i].x : 0.f; d[KP_TP] = in ? v[i].y : 0.f; d[2 * KP_TP] = in ? v[i].z : 0.f; d[3 * KP_TP] = in ? v[i].w : 0.f;
+                }
+            }
+        };
+#pragma unroll
+        for (int t = 0; t < TPF; ++t) issue_tile(t, pv[t]);
+        if (s != cur_seg) {
+            cur_seg = s;
+            k = tab->seg_k[s];
+            beg = ibeg;
+            len = ilen;
+            __syncthreads();                                   // previous users of cimg / lcn / run are done
+            for (int i = threadIdx.x; i < kmax * KP_C; i += 256) run[i] = 0.0f;
+            if ((int)threadIdx.x < kmax) runc[threadIdx.x] = 0;
+            const float *csrc = a.centroids + (size_t)s * kmax * KP_C;
+            for (int idx = threadIdx.x; idx < KT * 16 * c4; idx += 256) {
+                const int cc = idx / c4, t = idx - cc * c4;
+                const float4 v = (cc < k) ? reinterpret_cast<const float4 *>(csrc + (size_t)cc * KP_C)[t] : make_float4(0.f, 0.f, 0.f, 0.f);
+                float *d = cimg + (size_t)cc * KP_RS + t;
+                d[0] = v.x; d[KP_TP] = v.y; d[2 * KP_TP] = v.z; d[3 * KP_TP] = v.w;
+            }
+            __syncthreads();
+            if ((int)threadIdx.x < KT * 16) {                  // |c|^2 in scipy's order: t = 0..C-1, multiply then add
+                float nrm = INFINITY;
+                if ((int)threadIdx.x < k) {
+                    const float *im = cimg + (size_t)threadIdx.x * KP_RS;
+                    nrm = 0.0f;
+#pragma unroll
+                    for (int t = 0; t < KP_TM; ++t) {
+#pragma unroll
+                        for (int kq = 0; kq < 4; ++kq) {
+                            const float v = im[kq * KP_TP + t];
+                            const float prod = v * v;
+                            nrm = nrm + prod;
+                        }
+                    }
+                }
+                lcn[threadIdx.x] = nrm;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) {
+                const float *st = cimg + (size_t)(kt * 16 + j) * KP_RS + g * KP_TP;
+#pragma unroll
+                for (int u = 0; u < KP_NB4; ++u) ca[kt][u] = *reinterpret_cast<const float4 *>(st + 4 * u);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) cn[kt][r] = lcn[kt * 16 + g * 4 + r];
+            }
+        }
+
+        int best = -1;
+#pragma unroll
+        for (int tile = 0; tile < 4; ++tile) {
+            write_tile(tile, pv[tile % TPF]);
+            if (tile + TPF < 4) issue_tile(tile + TPF, pv[tile % TPF]);
+            const float *bs = wimg + (size_t)j * KP_RS + g * KP_TP;
+            float4 xb[KP_NB4];
+#pragma unroll
+            for (int u = 0; u < KP_NB4; ++u) xb[u] = *reinterpret_cast<const float4 *>(bs + 4 * u);
+            const int prow = wave_row0 + tile * 16 + j;
+            const float xs_l = __shfl(my_xs, tile * 16 + j);
+            const float xs = (prow < len) ? xs_l : 0.0f;
+            float low = INFINITY;
+            int arg = 0;
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) {
+                f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int u = 0; u < KP_NB4; ++u) {
+                    const float aa[4] = {ca[kt][u].x, ca[kt][u].y, ca[kt][u].z, ca[kt][u].w};
+                    const float bb[4] = {xb[u].x, xb[u].y, xb[u].z, xb[u].w};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (4 * u + e < KP_TM) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aa[e], bb[e], acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float mm = -2.0f * acc[r];
+                    const float dist = (mm + xs) + cn[kt][r];
+                    if (dist < low) { low = dist; arg = kt * 16 + g * 4 + r; }
+                }
+            }
+#pragma unroll
+            for (int off = 16; off <= 32; off <<= 1) {
+                const float d2 = __shfl_xor(low, off);
+                const int a2 = __shfl_xor(arg, off);
+                if (d2 < low || (d2 == low && a2 < arg)) { low = d2; arg = a2; }
+            }
+            const int mine = __shfl(arg, lane & 15);
+            if ((lane >> 4) == tile) best = mine;
+        }
+        const int p = wave_row0 + lane;
+        const bool valid = p < len;
+        if (!valid) best = -1;
+        if (valid) a.labels[beg + p] = best;
+
+        // ---- chunks of this mini-block: presence mask, member counts, any-order sums of |x| (lanes = features)
+        const int mb = 4 * blk + wave;
+        unsigned long long pm = 0ull;
+        for (int kk = 0; kk < k; ++kk)
+            if (__ballot(best == kk) != 0ull) pm |= 1ull << kk;
+        if (lane == 0) a.pres[mb] = pm;
+        const int l1 = min(lane, KP_C1 - 1);
+        unsigned long long rem = pm;
+        while (rem) {
+            const int kk = __builtin_ctzll(rem);
+            rem &= rem - 1;
+            unsigned long long mm = __ballot(best == kk);
+            const int cnt = __popcll(mm);
+            float a0 = 0.0f, a1 = 0.0f;
+            while (mm) {
+                float x0[8], x1[8];
+                bool on[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    on[u] = mm != 0ull;
+                    const int b = on[u] ? __builtin_ctzll(mm) : 0;
+                    if (on[u]) mm &= mm - 1;
+                    const int id = __builtin_amdgcn_readlane(my_id, b);
+                    const float *row = a.pool + (size_t)id * KP_C;
+                    x0[u] = row[lane];
+                    x1[u] = row[64 + l1];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if (on[u]) { a0 += fabsf(x0[u]); a1 += fabsf(x1[u]); }
+                }
+            }
+            const size_t slot = (size_t)mb * kmax + kk;
+            a.bsum[slot * KP_C + lane] = a0;
+            if (lane < KP_C1) a.bsum[slot * KP_C + 64 + lane] = a1;
+            atomicAdd(&blks[kk * KP_C + lane], a0);
+            if (lane < KP_C1) atomicAdd(&blks[kk * KP_C + 64 + lane], a1);
+            if (lane == 0) { a.ccnt[slot] = cnt; atomicAdd(&blkc[kk], cnt); }
+        }
+        __syncthreads();
+        // ---- running prefix at block granularity (present clusters only)
+        for (int i = threadIdx.x; i < k * KP_C; i += 256) {
+            const int kk = i / KP_C;
+            if (blkc[kk] > 0) {
+                a.PB[((size_t)blk * kmax + kk) * KP_C + (i - kk * KP_C)] = run[i];
+                run[i] += blks[i];
+                blks[i] = 0.0f;
+            }
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < k) {
+            const int c = blkc[threadIdx.x];
+            if (c > 0) { a.PBC[(size_t)blk * kmax + threadIdx.x] = runc[threadIdx.x]; runc[threadIdx.x] += c; blkc[threadIdx.x] = 0; }
+        }
+        __syncthreads();
+    }
+    // tail sums of this workgroup (its last segment)
+    for (int i = threadIdx.x; i < kmax * KP_C; i += 256) a.T[(size_t)wg * kmax * KP_C + i] = run[i];
+    if ((int)threadIdx.x < kmax) a.TC[(size_t)wg * kmax + threadIdx.x] = runc[threadIdx.x];
+}
+
+// ------------------------------------------------------------------------------------------ phase B
+__device__ __forceinline__ void kp_phase_fold(const KpArgs &a, KpTables *tab, float *lds, int blk_begin, int blk_end, int wg, int q, int nb_total) {
+    const int lane = aoc_lane(), wave = threadIdx.x >> 6;
+    const int kmax = a.kmax;
+    float *base = lds;                                              // [kmax][C]
+    int32_t *basec = reinterpret_cast<int32_t *>(base + (size_t)kmax * KP_C);        // [kmax]
+    float *lits = reinterpret_cast<float *>(basec + kmax) + (size_t)wave * 2 * KP_LIT * 64;   // [2][KP_LIT][64] per wave
+    if (blk_begin >= blk_end) return;
+    int s = 0;
+    while (blk_begin >= tab->blk_base[s + 1]) ++s;
+    // sums of the earlier workgroups' blocks in this workgroup's first segment
+    {
+        const int seg_first_blk = tab->blk_base[s];
+        for (int i = threadIdx.x; i < kmax * KP_C + kmax; i += 256) {
+            float accf = 0.0f;
+            int acci = 0;
+            for (int w2 = wg - 1; w2 >= 0; --w2) {
+                const int last = min((w2 + 1) * q, nb_total) - 1;
+                if (last < seg_first_blk) break;
+                if (i < kmax * KP_C) accf += a.T[(size_t)w2 * kmax * KP_C + i];
+                else acci += a.TC[(size_t)w2 * kmax + (i - kmax * KP_C)];
+                if (w2 * q <= seg_first_blk) break;
+            }
+            if (i < kmax * KP_C) base[i] = accf; else basec[i - kmax * KP_C] = acci;
+        }
+        if (threadIdx.x == 0) tab->litcnt = 0;
+        __syncthreads();
+    }
+    const int l1 = min(lane, KP_C1 - 1);
+    int cur_seg = s;
+    for (int blk = blk_begin; blk < blk_end; ++blk) {
+        while (blk >= tab->blk_base[s + 1]) ++s;
+        if (s != cur_seg) {                                     // a new segment starts inside this workgroup's range: nothing in front of it
+            cur_seg = s;
+            __syncthreads();
+            for (int i = threadIdx.x; i < kmax * KP_C; i += 256) base[i] = 0.0f;
+            if ((int)threadIdx.x < kmax) basec[threadIdx.x] = 0;
+            __syncthreads();
+        }
+        const int bx = blk - tab->blk_base[s];
+        const int beg = tab->seg_off[s], len = tab->seg_off[s + 1] - beg;
+        const int p = bx * 256 + wave * 64 + lane;
+        const bool valid = p < len;
+        const int my_id = a.rows[beg + max(min(p, len - 1), 0)];
+        const int lab = valid ? a.labels[beg + p] : -1;
+        const int mb = 4 * blk + wave;
+        const unsigned long long pm = a.pres[mb];
+        unsigned long long pprev[3];
+#pragma unroll
+        for (int qq = 0; qq < 3; ++qq) pprev[qq] = (qq < wave) ? a.pres[4 * blk + qq] : 0ull;
+        unsigned long long rem = pm;
+        while (rem) {
+            const int kk = __builtin_ctzll(rem);
+            rem &= rem - 1;
+            unsigned long long mm = __ballot(lab == kk);
+            const int total = __popcll(mm);
+            // prediction of the exact running sums in front of this chunk
+            const size_t pbo = ((size_t)blk * kmax + kk) * KP_C;
+            float P0 = base[kk * KP_C + lane] + a.PB[pbo + lane];
+            float P1 = base[kk * KP_C + 64 + l1] + a.PB[pbo + 64 + l1];
+            int mbf = basec[kk] + a.PBC[(size_t)blk * kmax + kk];
+#pragma unroll
+            for (int qq = 0; qq < 3; ++qq) {
+                if ((pprev[qq] >> kk) & 1ull) {
+                    const size_t sl = (size_t)(4 * blk + qq) * kmax + kk;
+                    P0 += a.bsum[sl * KP_C + lane];
+                    P1 += a.bsum[sl * KP_C + 64 + l1];
+                    mbf += a.ccnt[sl];
+                }
+            }
+            KxFold k0, k1;
+            kx_fold_init(k0, P0, mbf);
+            kx_fold_init(k1, P1, mbf);
+            float *lit0 = lits + lane, *lit1 = lits + KP_LIT * 64 + lane;
+            int idx = 0;
+            while (mm) {
+                float x0[8], x1[8];
+                bool on[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    on[u] = mm != 0ull;
+                    const int b = on[u] ? __builtin_ctzll(mm) : 0;
+                    if (on[u]) mm &= mm - 1;
+                    const int id = __builtin_amdgcn_readlane(my_id, b);
+                    const float *row = a.pool + (size_t)id * KP_C;
+                    x0[u] = row[lane];
+                    x1[u] = row[64 + l1];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    if (on[u]) {
+                        const KxStep s0 = kx_fold_probe(k0, x0[u]);
+                        const KxStep s1 = kx_fold_probe(k1, x1[u]);
+                        if (__all(s0.fast && s1.fast)) {
+                            k0.acc = (int32_t)s0.cand;
+                            k1.acc = (int32_t)s1.cand;
+                        } else {
+                            kx_fold_member(k0, x0[u], idx, lit0, 64);
+                            kx_fold_member(k1, x1[u], idx, lit1, 64);
+                        }
+                        ++idx;
+                    }
+                }
+            }
+            // records
+            const size_t slot = (size_t)mb * kmax + kk;
+            uint32_t *r = a.rec + slot * KP_REC * KP_C;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const KxFold &kf = half ? k1 : k0;
+                const float *lt = half ? lit1 : lit0;
+                int32_t A0, B0;
+                uint32_t hdr = kx_fold_finish(kf, total, A0, B0);
+                uint32_t w3 = 0u;
+                const int nlit = kx_hdr_nlit(hdr);
+                if (nlit == 1) w3 = kx_f2u(lt[0]);
+                const int f = half * 64 + lane;
+                if (nlit > 1 && f < KP_C) {
+                    const int off = atomicAdd(&tab->litcnt, nlit);
+                    if (off + nlit > KP_LITCAP) {
+                        hdr = kx_hdr(KX_UNSAFE, 0, 0, 0, 0, 0);
+                    } else {
+                        float *dst = a.litpool + (size_t)wg * KP_LITCAP + off;
+                        for (int i = 0; i < nlit; ++i) dst[i] = lt[i * 64];
+                        w3 = (uint32_t)(wg * KP_LITCAP + off);
+                    }
+                }
+                if (f < KP_C) {
+                    r[f] = hdr;
+                    r[KP_C + f] = (uint32_t)A0;
+                    r[2 * KP_C + f] = (uint32_t)B0;
+                    r[3 * KP_C + f] = w3;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ phase C
+__device__ __forceinline__ void kp_phase_merge(const KpArgs &a, KpTables *tab, int wg, int n_part) {
+    const int lane = aoc_lane(), wave = threadIdx.x >> 6;
+    const int kmax = a.kmax;
+    const int ntask = n_part * kmax * 2;
+    int s = 0;
+    for (int task = wg * 4 + wave; task < ntask; task += a.grid * 4) {
+        const int h = task & 1, kk = (task >> 1) % kmax, part = (task >> 1) / kmax;
+        while (part >= tab->part_base[s + 1]) ++s;
+        if (kk >= tab->seg_k[s]) continue;
+        const int pp = part - tab->part_base[s];
+        const int nmb = 4 * (tab->blk_base[s + 1] - tab->blk_base[s]);
+        const int mb0 = 4 * tab->blk_base[s] + 64 * pp;
+        const int nm = min(64, nmb - 64 * pp);
+        const unsigned long long pw = (lane < nm) ? a.pres[mb0 + lane] : 0ull;
+        const bool here = ((pw >> kk) & 1ull) != 0ull;
+        const unsigned long long pmask = __ballot(here);
+        if (h == 0) {
+            int c = here ? a.ccnt[(size_t)(mb0 + lane) * kmax + kk] : 0;
+            for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+            if (lane == 0) a.part_cnt[(size_t)part * kmax + kk] = c;
+        }
+        const int f = 64 * h + lane;
+        const bool fvalid = f < KP_C;
+        const int fc = fvalid ? f : KP_C - 1;
+        KxRun run{0, 0, 0};
+        unsigned long long np = 0ull;
+        unsigned long long mm = pmask;
+        while (mm) {
+            const int pos = __builtin_ctzll(mm);
+            mm &= mm - 1;
+            uint32_t *r = a.rec + ((size_t)(mb0 + pos) * kmax + kk) * KP_REC * KP_C + fc;
+            const uint32_t hdr = r[0];
+            const int32_t A0 = (int32_t)r[KP_C];
+            if (!kx_run_merge(run, hdr, A0)) {
+                if (fvalid) { r[4 * KP_C] = kx_run_hdr(run); r[5 * KP_C] = (uint32_t)run.R0; }
+                np |= 1ull << pos;
+                run = KxRun{0, 0, 0};
+            }
+        }
+        if (fvalid) {
+            uint32_t *po = a.part_post + ((size_t)part * kmax + kk) * 2 * KP_C + f;
+            po[0] = kx_run_hdr(run);
+            po[KP_C] = (uint32_t)run.R0;
+            a.part_np[((size_t)part * kmax + kk) * KP_C + f] = np;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------ phase S
+__device__ __forceinline__ void kp_phase_stitch(const KpArgs &a, KpTables *tab, int wg) {
+    const int lane = aoc_lane(), wave = threadIdx.x >> 6;
+    const int kmax = a.kmax;
+    const int ntask = a.n_seg * kmax * 2;
+    for (int task = wg * 4 + wave; task < ntask; task += a.grid * 4) {
+        const int h = task & 1, kk = (task >> 1) % kmax, s = (task >> 1) / kmax;
+        if (kk >= tab->seg_k[s]) continue;
+        const int f = 64 * h + lane;
+        const bool fvalid = f < KP_C;
+        const int fc = fvalid ? f : KP_C - 1;
+        const int beg = tab->seg_off[s], len = tab->seg_off[s + 1] - beg;
+        const int mb_base = 4 * tab->blk_base[s];
+        const int nmb = 4 * (tab->blk_base[s + 1] - tab->blk_base[s]);
+        const int nparts = tab->part_base[s + 1] - tab->part_base[s];
+        float sv = 0.0f;
+        int cnt_total = 0;
+        for (int pp = 0; pp < nparts; ++pp) {
+            const int part = tab->part_base[s] + pp;
+            const int mb0 = mb_base + 64 * pp;
+            const int nm = min(64, nmb - 64 * pp);
+            const unsigned long long pw = (lane < nm) ? a.pres[mb0 + lane] : 0ull;
+            const unsigned long long pmask = __ballot(((pw >> kk) & 1ull) != 0ull);
+            if (pmask == 0ull) continue;
+            cnt_total += a.part_cnt[(size_t)part * kmax + kk];
+            unsigned long long np = a.part_np[((size_t)part * kmax + kk) * KP_C + fc];
+            const uint32_t *po = a.part_post + ((size_t)part * kmax + kk) * 2 * KP_C + fc;
+            const uint32_t post_h = po[0];
+            const int32_t post_R = (int32_t)po[KP_C];
+            bool norun = false, stuck = false, post_done = false;
+            int done = 0, spos = 64;
+            for (;;) {
+                // ---- every lane walks its own list of records until it is through or stuck
+                for (;;) {
+                    const int pos = (!stuck && np != 0ull) ? __builtin_ctzll(np) : 64;
+                    const bool act = pos < 64;
+                    if (!__any(act)) break;
+                    if (act) {
+                        const uint32_t *r = a.rec + ((size_t)(mb0 + pos) * kmax + kk) * KP_REC * KP_C + fc;
+                        const uint32_t hdr = r[0];
+                        const int32_t A0 = (int32_t)r[KP_C], B0 = (int32_t)r[2 * KP_C];
+                        const uint32_t w3 = r[3 * KP_C];
+                        bool expand = false;
+                        if (!norun) {
+                            const KxRun run = kx_run_unpack(r[4 * KP_C], (int32_t)r[5 * KP_C]);
+                            float t = sv;
+                            if (kx_apply_run(t, run)) sv = t;
+                            else expand = true;
+                        }
+                        if (expand) {
+                            // a chunk of the run in front of this record did not happen as predicted: this lane takes the rest of the part record by record
+                            norun = true;
+                            np = pmask & ~kp_below(done);
+                        } else {
+                            done = pos;
+                            // the record itself, on a copy of the state
+                            float t = sv;
+                            bool ok = true;
+                            const int kind = kx_hdr_kind(hdr);
+                            if (kind == KX_UNSAFE) ok = false;
+                            else if (kind == KX_SET) {
+                                ok = kx_f2u(t) == 0u;
+                                t = kx_u2f((uint32_t)A0);
+                            } else {
+                                const int eA = kx_hdr_eA(hdr), eB = kx_hdr_eB(hdr), nlit = kx_hdr_nlit(hdr);
+                                if (eA) ok = kx_apply_int(t, eA - 1, A0, kx_hdr_dA(hdr));
+                                if (nlit == 1) t = t + kx_u2f(w3);
+                                else
+                                    for (int i = 0; i < nlit; ++i) t = t + a.litpool[w3 + i];
+                                if (ok && eB) ok = kx_apply_int(t, eB - 1, B0, kx_hdr_dB(hdr));
+                            }
+                            if (ok) { sv = t; np &= np - 1; done = pos + 1; }
+                            else { stuck = true; spos = pos; }
+                        }
+                    }
+                }
+                // ---- stuck lanes: the lowest stuck position is summed literally from its rows (lanes = features, coalesced)
+                if (__any(stuck)) {
+                    int pmin = stuck ? spos : 64;
+                    for (int o = 32; o > 0; o >>= 1) pmin = min(pmin, __shfl_xor(pmin, o));
+                    const int prow = (mb0 + pmin - mb_base) * 64 + lane;
+                    const int lab = (prow < len) ? a.labels[beg + prow] : -1;
+                    const int id = a.rows[beg + max(min(prow, len - 1), 0)];
+                    unsigned long long mm = __ballot(lab == kk);
+                    const bool mine = stuck && spos == pmin;
+                    while (mm) {
+                        float x[8];
+                        bool on[8];
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) {
+                            on[u] = mm != 0ull;
+                            const int b = on[u] ? __builtin_ctzll(mm) : 0;
+                            if (on[u]) mm &= mm - 1;
+                            x[u] = a.pool[(size_t)__builtin_amdgcn_readlane(id, b) * KP_C + fc];
+                        }
+#pragma unroll
+                        for (int u = 0; u < 8; ++u)
+                            if (on[u] && mine) sv = sv + x[u];
+                    }
+                    if (mine) { stuck = false; np &= ~(1ull << pmin); done = pmin + 1; }
+                    continue;
+                }
+                // ---- the part's last run
+                bool again = false;
+                if (!norun && !post_done) {
+                    post_done = true;
+                    const KxRun run = kx_run_unpack(post_h, post_R);
+                    float t = sv;
+                    if (kx_apply_run(t, run)) sv = t;
+                    else { norun = true; np = pmask & ~kp_below(done); again = np != 0ull; }
+                }
+                if (!__any(again)) break;
+            }
+        }
+        if (h == 0 && lane == 0) a.cluster_counts[s * kmax + kk] = cnt_total;
+        if (cnt_total > 0 && fvalid) a.centroids[((size_t)s * kmax + kk) * KP_C + f] = sv / (float)cnt_total;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ the chain
+template <int KT>
+__global__ __launch_bounds__(256, 2) void km_chain_kernel(KpArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds_raw[];
+    KpTables *tab = reinterpret_cast<KpTables *>(lds_raw);
+    float *lds = lds_raw + (sizeof(KpTables) + 15) / 16 * 4;
+    const int wg = blockIdx.x;
+    for (int i = threadIdx.x; i <= a.n_seg; i += 256) tab->seg_off[i] = a.seg_off[i];
+    for (int i = threadIdx.x; i < a.n_seg; i += 256) tab->seg_k[i] = a.seg_k[i];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int nb = 0, np = 0;
+        for (int s = 0; s < a.n_seg; ++s) {
+            tab->blk_base[s] = nb;
+            tab->part_base[s] = np;
+            const int len = tab->seg_off[s + 1] - tab->seg_off[s];
+            const int b = (tab->seg_k[s] > 0) ? (len + 255) / 256 : 0;
+            nb += b;
+            np += (b + 15) / 16;
+        }
+        tab->blk_base[a.n_seg] = nb;
+        tab->part_base[a.n_seg] = np;
+        tab->error = 0;
+        tab->litcnt = 0;
+    }
+    __syncthreads();
+    const int nb_total = tab->blk_base[a.n_seg], n_part = tab->part_base[a.n_seg];
+    const int q = (nb_total + a.grid - 1) / a.grid;
+    const int blk_begin = min(wg * q, nb_total), blk_end = min(blk_begin + q, nb_total);
+
+    const bool prof = a.prof != 0;
+    long long tprev = prof ? wall_clock64() : 0ll;
+    // row norms (sequential, scipy's order): every thread for the rows it also assigns -- no exchange between workgroups
+    {
+        int s = 0;
+        for (int blk = blk_begin; blk < blk_end; ++blk) {
+            while (blk >= tab->blk_base[s + 1]) ++s;
+            const int beg = tab->seg_off[s], len = tab->seg_off[s + 1] - beg;
+            const int p = (blk - tab->blk_base[s]) * 256 + threadIdx.x;
+            if (p < len) a.rownorm[beg + p] = kp_sqnorm_row(reinterpret_cast<const float4 *>(a.pool + (size_t)a.rows[beg + p] * KP_C));
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    KP_TICK(0);
+    uint32_t epoch = 0;
+    bool ok = true;
+    for (int it = 0; it < a.iters && ok; ++it) {
+        kp_phase_assign<KT>(a, tab, lds, blk_begin, blk_end, wg);
+        KP_TICK(1);
+        ok = kp_grid_barrier(a.bar, tab, epoch, a.grid);
+        KP_TICK(2);
+        if (!ok) break;
+        kp_phase_fold(a, tab, lds, blk_begin, blk_end, wg, q, nb_total);
+        KP_TICK(3);
+        ok = kp_grid_barrier(a.bar, tab, epoch, a.grid);
+        KP_TICK(4);
+        if (!ok) break;
+        kp_phase_merge(a, tab, wg, n_part);
+        KP_TICK(5);
+        ok = kp_grid_barrier(a.bar, tab, epoch, a.grid);
+        KP_TICK(6);
+        if (!ok) break;
+        kp_phase_stitch(a, tab, wg);
+        KP_TICK(7);
+        ok = kp_grid_barrier(a.bar, tab, epoch, a.grid);
+        KP_TICK(8);
+    }
+    if (prof && wg == 0 && threadIdx.x == 0) g_kp_prof[9] += 1ull;
+    if (!ok) {
+        // a barrier timed out (the grid was not resident as a whole): poison the code books so that nothing downstream looks plausible
+        for (int i = wg * 256 + threadIdx.x; i < a.n_seg * a.kmax * KP_C; i += a.grid * 256) a.centroids[i] = __builtin_nanf("");
+    }
+}
+
+size_t kp_lds_bytes(int kt, int kmax) {
+    const size_t tabs = (sizeof(KpTables) + 15) / 16 * 16;
+    const size_t pa = ((size_t)kt * 16 * KP_RS + kt * 16 + (size_t)4 * 16 * KP_RS + (size_t)2 * kmax * KP_C + 2 * kmax) * 4;
+    const size_t pb = ((size_t)kmax * KP_C + kmax + (size_t)4 * 2 * KP_LIT * 64) * 4;
+    return tabs + std::max(pa, pb) + 16;
+}
+
+struct KpLayout {
+    size_t pres, ccnt, bsum, rec, PB, PBC, T, TC, litpool, part_post, part_np, part_cnt, bar, total;
+};
+KpLayout kp_layout(int64_t cap, int n_seg, int kmax) {
+    const size_t nblk = (size_t)(cap / 256) + n_seg + 1, nmb = 4 * nblk, slots = nmb * kmax, nparts = nblk / 16 + n_seg + 1;
+    KpLayout l;
+    size_t o = 0;
+    auto take = [&](size_t bytes) { const size_t at = o; o += aoc_align_up(bytes, 256); return at; };
+    l.bar = take(sizeof(KpBar));
+    l.pres = take(nmb * 8);
+    l.ccnt = take(slots * 4);
+    l.bsum = take(slots * KP_C * 4);
+    l.rec = take(slots * KP_REC * KP_C * 4);
+    l.PB = take(nblk * kmax * KP_C * 4);
+    l.PBC = take(nblk * kmax * 4);
+    l.T = take((size_t)KP_GMAX * kmax * KP_C * 4);
+    l.TC = take((size_t)KP_GMAX * kmax * 4);
+    l.litpool = take((size_t)KP_GMAX * KP_LITCAP * 4);
+    l.part_post = take(nparts * kmax * 2 * KP_C * 4);
+    l.part_np = take(nparts * kmax * KP_C * 8);
+    l.part_cnt = take(nparts * kmax * 4);
+    l.total = o;
+    return l;
+}
+
+int kp_grid_request() {
+    static const int g = getenv("AOC_KM_GRID") ? atoi(getenv("AOC_KM_GRID")) : 0;
+    return g;
+}
+int g_kp_grid_override = 0;
+
+}  // namespace
+
+// ---- internal interface (labels_kmeans.hip)
+bool aoc_kp_supported(int C, int n_seg, int kmax) { return C == KP_C && n_seg <= KP_SEG_MAX && kmax <= 64 && kmax >= 1; }
+size_t aoc_kp_workspace_bytes(int64_t rows_capacity, int n_seg, int kmax) { return kp_layout(rows_capacity, n_seg, kmax).total; }
+
+// The chain after km_init_kernel (code books = initial rows): `iters` Lloyd iterations in one launch.  rownorm: [rows_capacity] scratch.
+int aoc_kp_chain(const float *pool, const int32_t *rows, const int32_t *seg_offsets, const int32_t *seg_k, int n_seg, int kmax, int iters,
+                 int64_t rows_capacity, float *centroids, int32_t *labels, int32_t *cluster_counts, float *rownorm, void *workspace, hipStream_t st) {
+    const int kt = (kmax + 15) / 16;
+    const size_t lds = kp_lds_bytes(kt, kmax);
+    // the grid has to be resident as a whole: workgroups per CU from the occupancy query (cached per code-book tile count), minus a margin
+    static int max_grid[5] = {0, 0, 0, 0, 0};
+    static int n_cu = 0;
+    if (max_grid[kt] == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return AOC_ERR_LAUNCH;
+        n_cu = prop.multiProcessorCount;
+        int per_cu = 0;
+        hipError_t e = hipErrorUnknown;
+        if (kt == 1) { (void)hipFuncSetAttribute((const void *)km_chain_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, km_chain_kernel<1>, 256, lds); }
+        if (kt == 2) { (void)hipFuncSetAttribute((const void *)km_chain_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, km_chain_kernel<2>, 256, lds); }
+        if (kt == 3) { (void)hipFuncSetAttribute((const void *)km_chain_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, km_chain_kernel<3>, 256, lds); }
+        if (kt == 4) { (void)hipFuncSetAttribute((const void *)km_chain_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, km_chain_kernel<4>, 256, lds); }
+        if (e != hipSuccess || per_cu < 1) return AOC_ERR_LAUNCH;
+        max_grid[kt] = std::max(1, (per_cu > 1 ? per_cu - 1 : 1) * n_cu);
+    }
+    int grid = g_kp_grid_override > 0 ? g_kp_grid_override : (kp_grid_request() > 0 ? kp_grid_request() : n_cu);
+    grid = std::max(1, std::min(std::min(grid, max_grid[kt]), KP_GMAX));
+    const KpLayout l = kp_layout(rows_capacity, n_seg, kmax);
+    char *w = static_cast<char *>(workspace);
+    KpArgs a;
+    a.pool = pool; a.rows = rows; a.seg_off = seg_offsets; a.seg_k = seg_k;
+    a.n_seg = n_seg; a.kmax = kmax; a.iters = iters; a.grid = grid;
+    static const int prof = (getenv("AOC_KM_PROF") && atoi(getenv("AOC_KM_PROF")) > 0) ? 1 : 0;
+    a.prof = prof;
+    a.centroids = centroids; a.labels = labels; a.cluster_counts = cluster_counts; a.rownorm = rownorm;
+    a.pres = reinterpret_cast<unsigned long long *>(w + l.pres);
+    a.ccnt = reinterpret_cast<int32_t *>(w + l.ccnt);
+    a.bsum = reinterpret_cast<float *>(w + l.bsum);
+    a.rec = reinterpret_cast<uint32_t *>(w + l.rec);
+    a.PB = reinterpret_cast<float *>(w + l.PB);
+    a.PBC = reinterpret_cast<int32_t *>(w + l.PBC);
+    a.T = reinterpret_cast<float *>(w + l.T);
+    a.TC = reinterpret_cast<int32_t *>(w + l.TC);
+    a.litpool = reinterpret_cast<float *>(w + l.litpool);
+    a.part_post = reinterpret_cast<uint32_t *>(w + l.part_post);
+    a.part_np = reinterpret_cast<unsigned long long *>(w + l.part_np);
+    a.part_cnt = reinterpret_cast<int32_t *>(w + l.part_cnt);
+    a.bar = reinterpret_cast<KpBar *>(w + l.bar);
+    if (hipMemsetAsync(a.bar, 0, sizeof(KpBar), st) != hipSuccess) return AOC_ERR_LAUNCH;
+    if (kt == 1) hipLaunchKernelGGL(km_chain_kernel<1>, dim3(grid), dim3(256), lds, st, a);
+    else if (kt == 2) hipLaunchKernelGGL(km_chain_kernel<2>, dim3(grid), dim3(256), lds, st, a);
+    else if (kt == 3) hipLaunchKernelGGL(km_chain_kernel<3>, dim3(grid), dim3(256), lds, st, a);
+    else hipLaunchKernelGGL(km_chain_kernel<4>, dim3(grid), dim3(256), lds, st, a);
+    AOC_RETURN_IF_LAUNCH_FAILED();
+    return AOC_OK;
+}
+
+extern "C" int aoc_kmeans_chain_profile(unsigned long long *out16_host, int reset) {
+    if (!out16_host) return AOC_ERR_INVALID_ARG;
+    if (hipMemcpyFromSymbol(out16_host, HIP_SYMBOL(g_kp_prof), 16 * sizeof(unsigned long long)) != hipSuccess) return AOC_ERR_LAUNCH;
+    if (reset) {
+        unsigned long long z[16] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_kp_prof), z, sizeof(z)) != hipSuccess) return AOC_ERR_LAUNCH;
+    }
+    return AOC_OK;
+}
+
+extern "C" int aoc_kmeans_set_grid(int workgroups) {
+    if (workgroups < 0) return AOC_ERR_INVALID_ARG;
+    g_kp_grid_override = workgroups;
+    return AOC_OK;
+}

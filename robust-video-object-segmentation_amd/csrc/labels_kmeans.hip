@@ -2176,10 +2176,20 @@ int aoc_kmeans_plan(const int32_t *counts, int n_seg, int cluster_num, int32_t *
     return AOC_OK;
 }
 
+// the launch-per-phase pipeline's share of the workspace (the persistent chain's tables follow it)
+static size_t km_launches_workspace_bytes(int64_t rows_capacity, int n_seg, int kmax) {
+    return aoc_align_up((size_t)n_seg * kmax * sizeof(float), 256) + aoc_align_up(ks_workspace_bytes(rows_capacity, n_seg, kmax), 256);
+}
+static bool km_chain_enabled() {
+    static const bool on = !(getenv("AOC_KM_CHAIN") && strcmp(getenv("AOC_KM_CHAIN"), "launches") == 0);   // developer switch: the launch-per-phase pipeline
+    return on;
+}
+
 size_t aoc_kmeans_workspace_bytes(int64_t rows_capacity, int n_seg, int kmax, int C) {
-    (void)C;
     if (rows_capacity < 0 || n_seg < 1 || kmax < 1) return 0;
-    return aoc_align_up((size_t)n_seg * kmax * sizeof(float), 256) + ks_workspace_bytes(rows_capacity, n_seg, kmax);
+    size_t b = km_launches_workspace_bytes(rows_capacity, n_seg, kmax);
+    if (aoc_kp_supported(C, n_seg, kmax)) b += aoc_kp_workspace_bytes(rows_capacity, n_seg, kmax);
+    return b;
 }
 
 int aoc_kmeans_segmented(const float *pool, int C, const int32_t *rows, const int32_t *seg_offsets, const int32_t *seg_k,
@@ -2213,6 +2223,12 @@ int aoc_kmeans_segmented_ex(const float *pool, int64_t pool_rows, int C, const i
 
     hipLaunchKernelGGL(km_init_kernel, dim3(kmax, n_seg), dim3(64), 0, st, pool, C, rows, seg_offsets, seg_k, init_rows, kmax,
                        centroids, cnorm, cluster_counts);
+    // one persistent launch for all iterations (kmeans_persistent.hip): the default where it applies
+    if (fast && km_chain_enabled() && aoc_kp_supported(C, n_seg, kmax)) {
+        AOC_RETURN_IF_LAUNCH_FAILED();
+        return aoc_kp_chain(pool, rows, seg_offsets, seg_k, n_seg, kmax, iters, rows_capacity, centroids, labels, cluster_counts, rownorm,
+                            static_cast<char *>(workspace) + km_launches_workspace_bytes(rows_capacity, n_seg, kmax), st);
+    }
     const dim3 agrid((unsigned)((seg_bound + 255) / 256), (unsigned)n_seg);
     const size_t lds = ((size_t)kmax * C + kmax) * sizeof(float);
     const size_t lds_fast = lds + (size_t)4 * kmax * sizeof(int32_t);

@@ -54,3 +54,10 @@ torch.cuda.synchronize()
 ms = (time.perf_counter() - t0) / n * 1e3
 rows = sum(counts)
 print(f"k-means chain R={R} F={F} CUs={NCU or 'all'}: {ms:.3f} ms per chain ({ms / F:.3f} per frame), {rows} rows x {F} replicas", flush=True)
+
+if os.environ.get("AOC_KM_PROF"):
+    v = (ctypes.c_uint64 * 16)()
+    aoc_amd._lib.lib().aoc_kmeans_chain_profile(v, 1)
+    chains = max(int(v[9]), 1)
+    names = ["norms", "assign", "bar", "fold", "bar", "merge", "bar", "stitch", "bar"]
+    print("  per chain (workgroup 0, us): " + ", ".join(f"{n} {v[i] / chains / 100:.1f}" for i, n in enumerate(names)) + f"  [{chains} chains]")
