@@ -137,10 +137,10 @@ int aoc_kmeans_segmented(const float *pool, int C,
  * must be resident as a whole; aoc_kmeans_set_grid states how many workgroups (of 256 threads) a chain may take -- e.g. what fits the
  * CUs a caller leaves to its k-means streams -- 0 = default (one per CU, capped by the occupancy of the kernel).  Process-wide. */
 int aoc_kmeans_set_grid(int workgroups);
-/* Developer counters of the persistent chain (only filled when the process runs with AOC_KM_PROF=1): what workgroup 0 spent, in ticks
+/* Developer counters of the persistent chain (only filled when the process runs with AOC_KM_PROF=w+1): what workgroup w spent, in ticks
  * of the 100 MHz wall clock, in [0] row norms, [1] assignment, [3] fold, [5] merge, [7] stitch, [2][4][6][8] the grid barrier behind
- * each, [9] chains.  Host pointer to 16 values. */
-int aoc_kmeans_chain_profile(unsigned long long *out16_host, int reset);
+ * each, [9] chains, [12][13] fold steps / general steps of its first thread, [16..] sections inside a phase.  Host pointer to 32 values. */
+int aoc_kmeans_chain_profile(unsigned long long *out32_host, int reset);
 
 /* The reference's second proxy set, AEM:280: for every non-empty cluster j of segment s the mean of
  * the rows  fg[p], p in {segment-local indices with label == j}  of the GLOBAL kept-row array (the

@@ -106,6 +106,9 @@ enum { KXM_A = 0, KXM_WIN = 1, KXM_B = 2, KXM_DEAD = 3, KXM_SET = 4 };
 constexpr float KX_MAGIC = 8388608.0f;          // 2^23: fl(y + 2^23) = 2^23 + rne(y) for 0 <= y < 2^23
 constexpr uint32_t KX_MAGIC_BITS = 0x4B000000u;
 
+// a lane that gives up: it folds nothing from here on and never asks the wave for the general step
+KX_HD void kx_kill(KxFold &k) { k.mode = KXM_DEAD; k.inv_u = 0.0f; k.lim = 0xffffffffu; }
+
 // P: any-order sum of |x| over the members before this chunk (the prediction of the exact running sum); m_before: their number.
 KX_HD void kx_fold_init(KxFold &k, float P, int32_t m_before) {
     k.acc = 0; k.dvar = 0; k.nA = 0; k.nlit = 0; k.A0 = 0; k.dA = 0; k.eA = 0; k.eB = 0; k.trk = 0.0f; k.s = 0.0f;
@@ -113,7 +116,7 @@ KX_HD void kx_fold_init(KxFold &k, float P, int32_t m_before) {
     if (P == 0.0f) { k.mode = KXM_SET; return; }               // every earlier member was +-0: the exact state is +0
     const uint32_t pb = kx_f2u(P);
     const int eP = (int)(pb >> 23) - 127;                      // sign bit set (never: sum of |x|) or NaN/inf end up out of range
-    if (!(P > 0.0f) || eP < KX_E_MIN + 1 || eP > KX_E_MAX) { k.mode = KXM_DEAD; return; }
+    if (!(P > 0.0f) || eP < KX_E_MIN + 1 || eP > KX_E_MAX) { kx_kill(k); return; }
     // how far the exact sequential sum may be from the prediction, in ulps of P: both are float sums of the same m_before
     // non-negative numbers; their roundings behave like a random walk.  4 sigma-ish; a miss only costs the slow path.
     float delta = 16.0f + 4.0f * __builtin_sqrtf((float)m_before);
@@ -144,6 +147,32 @@ KX_HD KxStep kx_fold_probe(const KxFold &k, float x) {
     const bool tie = (dd == 0.5f) || (dd == -0.5f);
     st.fast = (k.mode == KXM_A || k.mode == KXM_B) && r < 0x800000u && st.cand <= k.lim && !tie;
     return st;
+}
+
+// The branch-free common step: folds x into the part at hand unless something is special about it (value out of range, the
+// binade may end here, a literal window is open).  Ties (frac(x/u) == 1/2) are part of it: both incoming parities are tracked.
+// `over` lanes are left untouched; a wave commits only when NO lane is over and otherwise calls kx_fold_member for all lanes.
+// Lanes that fold nothing ride along: KXM_DEAD / KXM_SET have inv_u = 0 and lim = ~0 (r = 0, no tie), KXM_SET also needs s += x.
+struct KxFast {
+    int32_t acc, dvar;
+    bool over;
+};
+KX_HD KxFast kx_fold_fast(const KxFold &k, float x) {
+    KxFast f;
+    const float t = __builtin_fmaf(x, k.inv_u, KX_MAGIC);
+    const uint32_t r = kx_f2u(t) - KX_MAGIC_BITS;              // rne(y) for 0 <= y < 2^23; anything else gives r >= 2^23 (as unsigned)
+    const float rn = t - KX_MAGIC;
+    const float dd = __builtin_fmaf(x, k.inv_u, -rn);          // y - rne(y), exact
+    const bool tie = (dd == 0.5f) || (dd == -0.5f);
+    const int32_t fl = (int32_t)r - ((dd == -0.5f) ? 1 : 0);   // floor(y) at a tie, rne(y) otherwise
+    const int32_t b0 = k.acc + fl;
+    const int32_t bump0 = tie ? (b0 & 1) : 0;                  // n + floor(y) odd -> the tie rounds up (even incoming parity)
+    const int32_t b1 = b0 + k.dvar + 1;
+    const int32_t bump1 = tie ? (b1 & 1) : 0;                  // odd incoming parity
+    f.acc = b0 + bump0;
+    f.dvar = k.dvar + bump1 - bump0;
+    f.over = r >= 0x800000u || (uint32_t)b0 + 2u > k.lim || k.mode == KXM_WIN;
+    return f;
 }
 
 // lits: this lane's literal buffer (KX_MAX_LIT floats, stride lit_stride)
@@ -180,7 +209,7 @@ KX_HD void kx_fold_member(KxFold &k, float x, int idx, float *lits, int lit_stri
             }
         }
         // the binade may end at this member (or the value is not a plain number)
-        if (k.mode == KXM_B || !plain_value) { k.mode = KXM_DEAD; return; }
+        if (k.mode == KXM_B || !plain_value) { kx_kill(k); return; }
         k.A0 = k.acc; k.dA = k.dvar;
         k.nA = idx;                                            // members folded in the A part
         k.trk = (float)k.acc;
@@ -188,17 +217,17 @@ KX_HD void kx_fold_member(KxFold &k, float x, int idx, float *lits, int lit_stri
         // fall through: this member is the first literal
     }
     // KXM_WIN: a literal member
-    if (!plain_value || k.nlit >= KX_MAX_LIT) { k.mode = KXM_DEAD; return; }
+    if (!plain_value || k.nlit >= KX_MAX_LIT) { kx_kill(k); return; }
     lits[k.nlit * lit_stride] = x;
     ++k.nlit;
     k.trk = k.trk + x * k.inv_u;
-    if (k.n_hi + k.trk >= 33554000.0f) { k.mode = KXM_DEAD; return; }   // two binades at once: not handled here
+    if (k.n_hi + k.trk >= 33554000.0f) { kx_kill(k); return; }   // two binades at once: not handled here
     if (k.n_lo + k.trk >= 16777216.0f) {
         // even the lowest plausible state is past 2^24 now: the rest of the chunk is folded one binade up
         k.eB = k.eA + 1;
-        if (k.eB > KX_E_MAX) { k.mode = KXM_DEAD; return; }
+        if (k.eB > KX_E_MAX) { kx_kill(k); return; }
         const float n1_hi = (k.n_hi + k.trk) * 0.5f + 2.0f;
-        if (n1_hi > 16777214.0f) { k.mode = KXM_DEAD; return; }
+        if (n1_hi > 16777214.0f) { kx_kill(k); return; }
         k.inv_u = k.inv_u * 0.5f;
         k.acc = 0; k.dvar = 0;
         k.lim = (uint32_t)(int32_t)(16777215.0f - n1_hi);

@@ -30,6 +30,8 @@ constexpr int KP_REC = 6;                 // words per (chunk, feature): hdr, A0
 constexpr int KP_LITCAP = 8192;           // literal pool per workgroup (floats)
 constexpr int KP_GMAX = 1024;
 constexpr int KP_LIT = KX_MAX_LIT;        // literals a lane can hold per chunk
+constexpr int KP_ROWF = 64 * KP_C;        // floats of a staged mini-block
+constexpr int KP_EV = 2;                  // records per (part, cluster, feature) the merge phase also stores inline for the stitch
 constexpr long long KP_TIMEOUT_TICKS = 300000000ll;   // 3 s of the 100 MHz wall clock: a barrier that does not complete poisons the output instead of hanging
 
 struct KpBar {
@@ -56,6 +58,7 @@ struct KpArgs {
     float *litpool;               // [workgroup][KP_LITCAP]
     uint32_t *part_post;          // [part][kmax][2][C] last run of the part
     unsigned long long *part_np;  // [part][kmax][C] positions of the records the stitch has to look at
+    uint32_t *part_ev;            // [part][kmax][KP_EV][KP_REC][C] the first of them, inline
     int32_t *part_cnt;            // [part][kmax] members
     KpBar *bar;
 };
@@ -71,14 +74,24 @@ struct KpTables {
 };
 
 // developer counters (aoc_kmeans_chain_profile): what workgroup 0 spends where, in ticks of the 100 MHz wall clock
-__device__ unsigned long long g_kp_prof[16];
+__device__ unsigned long long g_kp_prof[32];
 #define KP_TICK(slot)                                                         \
     do {                                                                      \
-        if (prof && wg == 0 && threadIdx.x == 0) {                            \
+        if (prof && wg == a.prof - 1 && threadIdx.x == 0) {                   \
             const long long now_ = wall_clock64();                            \
             g_kp_prof[slot] += (unsigned long long)(now_ - tprev);            \
             tprev = now_;                                                     \
         }                                                                     \
+    } while (0)
+
+// finer developer timing inside a phase: accumulators live in registers of the profiled thread, flushed once per phase
+#define KP_SEC(i)                                                  \
+    do {                                                           \
+        if (pf) {                                                  \
+            const long long now_ = wall_clock64();                 \
+            sec[i] += (unsigned)(now_ - tsec);                     \
+            tsec = now_;                                           \
+        }                                                          \
     } while (0)
 
 __device__ __forceinline__ unsigned long long kp_below(int n) { return n >= 64 ? ~0ull : ((1ull << n) - 1ull); }
@@ -127,217 +140,224 @@ __device__ __forceinline__ float kp_sqnorm_row(const float4 *__restrict__ xr) {
     return xs;
 }
 
+// The 64 rows of a wave's mini-block, staged row-major in the wave's private LDS buffer (64 x 100 floats = 25 coalesced float4 per lane).
+// A wave owns one SIMD (one workgroup of four waves per CU: the buffers take 100 KB), so the rows of the NEXT block travel in registers
+// while the current one is worked on.  Row-major serves every consumer without bank conflicts: lanes = features read consecutive words,
+// and the MFMA operand (lane (j, g) reads x[16 tile + j][4 t + g]) has 100 j + g distinct modulo 64 for j < 16, g < 4.
+// (25 NAMED float4 values: an array that lives across the block loop is left in scratch memory by hipcc -- 400 bytes per lane written and
+// read back through memory -- named values become registers)
+#define KP_R25(M) M(0) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14) M(15) M(16) M(17) M(18) M(19) M(20) M(21) M(22) M(23) M(24)
+#define KP_ROW_DECL(i) float4 rw##i;
+#define KP_ROW_ISSUE1(i)                                                                       \
+    {                                                                                          \
+        const int idx_ = i * 64 + lane;                                                        \
+        const int row_ = idx_ / KP_TM, t_ = idx_ - row_ * KP_TM;                               \
+        const int id_ = __shfl(my_id, row_);                                                   \
+        rw##i = reinterpret_cast<const float4 *>(a.pool + (size_t)id_ * KP_C)[t_];             \
+    }
+#define KP_ROW_COMMIT1(i) reinterpret_cast<float4 *>(wrow)[i * 64 + lane] = rw##i;
+#define KP_ROWS_DECL() KP_R25(KP_ROW_DECL)
+#define KP_ROWS_ISSUE() KP_R25(KP_ROW_ISSUE1)          /* uses a.pool, my_id, lane */
+#define KP_ROWS_COMMIT() KP_R25(KP_ROW_COMMIT1)        /* uses wrow, lane */
+__device__ __forceinline__ int kp_locate(const KpTables *tab, int blk, int s) {
+    while (blk >= tab->blk_base[s + 1]) ++s;
+    return s;
+}
+
 // ------------------------------------------------------------------------------------------ phase A
 template <int KT>
 __device__ __forceinline__ void kp_phase_assign(const KpArgs &a, KpTables *tab, float *lds, int blk_begin, int blk_end, int wg) {
-    constexpr int c4 = KP_TM;
     const int lane = aoc_lane(), wave = threadIdx.x >> 6;
     const int j = lane & 15, g = lane >> 4;
     const int kmax = a.kmax;
-    float *cimg = lds;                                           // [KT*16][RS]
-    float *lcn = cimg + (size_t)KT * 16 * KP_RS;                 // [KT*16]
-    float *wimg = lcn + KT * 16 + (size_t)wave * 16 * KP_RS;     // this wave's row-tile image
-    float *run = lcn + KT * 16 + (size_t)4 * 16 * KP_RS;         // [kmax][C] prefix of bsum over this workgroup's earlier blocks of the segment
+    float *lc = lds;                                             // [KT*16][C] code book, row-major (rows >= k are zero)
+    float *lcn = lc + (size_t)KT * 16 * KP_C;                    // [KT*16] |c|^2 (+inf beyond k)
+    float *wrow = lcn + KT * 16 + (size_t)wave * KP_ROWF;        // this wave's rows
+    float *run = lcn + KT * 16 + (size_t)4 * KP_ROWF;            // [kmax][C] prefix of bsum over this workgroup's earlier blocks of the segment
     float *blks = run + (size_t)kmax * KP_C;                     // [kmax][C] sums of the current block
     int32_t *runc = reinterpret_cast<int32_t *>(blks + (size_t)kmax * KP_C);   // [kmax]
     int32_t *blkc = runc + kmax;                                 // [kmax]
 
-    // stream padding of the images: zero once
-    for (int idx = lane; idx < 16 * 4 * (KP_TP - c4); idx += 64) {
-        const int rr = idx / (4 * (KP_TP - c4)), rem = idx - rr * 4 * (KP_TP - c4);
-        wimg[(size_t)rr * KP_RS + (rem / (KP_TP - c4)) * KP_TP + c4 + rem % (KP_TP - c4)] = 0.0f;
-    }
-    for (int idx = threadIdx.x; idx < KT * 16 * 4 * (KP_TP - c4); idx += 256) {
-        const int rr = idx / (4 * (KP_TP - c4)), rem = idx - rr * 4 * (KP_TP - c4);
-        cimg[(size_t)rr * KP_RS + (rem / (KP_TP - c4)) * KP_TP + c4 + rem % (KP_TP - c4)] = 0.0f;
-    }
+    const bool pf = a.prof != 0 && wg == a.prof - 1 && threadIdx.x == 0;
+    unsigned sec[6] = {0u, 0u, 0u, 0u, 0u, 0u};
+    long long tsec = pf ? wall_clock64() : 0ll;
     for (int i = threadIdx.x; i < kmax * KP_C; i += 256) { run[i] = 0.0f; blks[i] = 0.0f; }
     if ((int)threadIdx.x < kmax) { runc[threadIdx.x] = 0; blkc[threadIdx.x] = 0; }
     __syncthreads();
-
-    float4 ca[KT][KP_NB4];
-    float cn[KT][4];
-    int cur_seg = -1, k = 0, beg = 0, len = 0;
-    int s = 0;
-    for (int blk = blk_begin; blk < blk_end; ++blk) {
-        while (blk >= tab->blk_base[s + 1]) ++s;
-        const int bx = blk - tab->blk_base[s];
-        const int ibeg = tab->seg_off[s], ilen = tab->seg_off[s + 1] - ibeg;
-        const int wave_row0 = bx * 256 + wave * 64;
-        const int my_p = max(min(wave_row0 + lane, ilen - 1), 0);
-        const int my_id = a.rows[ibeg + my_p];
-        const float my_xs = a.rownorm[ibeg + my_p];
-        constexpr int TPF = 2;
-        float4 pv[TPF][KP_PIECES];
-        auto issue_tile = [&](int tile, float4 (&v)[KP_PIECES]) {
-#pragma unroll
-            for (int i = 0; i < KP_PIECES; ++i) {
-                const int idx = min(i * 64 + lane, 16 * c4 - 1);
-                const int rr = idx / c4, t = idx - rr * c4;
-                const int id = __shfl(my_id, tile * 16 + rr);
-                v[i] = reinterpret_cast<const float4 *>(a.pool + (size_t)id * KP_C)[t];
+    if (blk_begin < blk_end) {
+        float ca[KT][KP_TM];
+        float cn[KT][4];
+        int cur_seg = -1, k = 0, beg = 0, len = 0;
+        int s = kp_locate(tab, blk_begin, 0);
+        KP_ROWS_DECL()
+        int my_id, id_next = 0;
+        float my_xs, xs_next = 0.0f;
+        {
+            const int ibeg = tab->seg_off[s], ilen = tab->seg_off[s + 1] - ibeg;
+            const int p = max(min((blk_begin - tab->blk_base[s]) * 256 + wave * 64 + lane, ilen - 1), 0);
+            my_id = a.rows[ibeg + p];
+            my_xs = a.rownorm[ibeg + p];
+            KP_ROWS_ISSUE()
+        }
+        const int l1 = min(lane, KP_C1 - 1);
+        for (int blk = blk_begin; blk < blk_end; ++blk) {
+            s = kp_locate(tab, blk, s);
+            const int bx = blk - tab->blk_base[s];
+            const int ibeg = tab->seg_off[s], ilen = tab->seg_off[s + 1] - ibeg;
+            const int wave_row0 = bx * 256 + wave * 64;
+            if (blk + 1 < blk_end) {                               // ids of the next block: one round trip ahead of its rows
+                const int s1 = kp_locate(tab, blk + 1, s);
+                const int b1 = tab->seg_off[s1], l1n = tab->seg_off[s1 + 1] - b1;
+                const int p1 = max(min((blk + 1 - tab->blk_base[s1]) * 256 + wave * 64 + lane, l1n - 1), 0);
+                id_next = a.rows[b1 + p1];
+                xs_next = a.rownorm[b1 + p1];
             }
-        };
-        auto write_tile = [&](int tile, const float4 (&v)[KP_PIECES]) {
-#pragma unroll
-            for (int i = 0; i < KP_PIECES; ++i) {
-                const int idx = i * 64 + lane;
-                if (idx < 16 * c4) {
-                    const int rr = idx / c4, t = idx - rr * c4;
-                    const bool in = wave_row0 + tile * 16 + rr < ilen;
-                    float *d = wimg + (size_t)rr * KP_RS + t;
-                    d[0] = in ? v[i].x : 0.f; d[KP_TP] = in ? v[i].y : 0.f; d[2 * KP_TP] = in ? v[i].z : 0.f; d[3 * KP_TP] = in ? v[i].w : 0.f;
+            if (s != cur_seg) {
+                cur_seg = s;
+                k = tab->seg_k[s];
+                beg = ibeg;
+                len = ilen;
+                __syncthreads();                               // previous users of lc / lcn / run are done
+                for (int i = threadIdx.x; i < kmax * KP_C; i += 256) run[i] = 0.0f;
+                if ((int)threadIdx.x < kmax) runc[threadIdx.x] = 0;
+                const float *csrc = a.centroids + (size_t)s * kmax * KP_C;
+                for (int idx = threadIdx.x; idx < KT * 16 * KP_TM; idx += 256) {
+                    const int cc = idx / KP_TM, t = idx - cc * KP_TM;
+                    const float4 v = (cc < k) ? reinterpret_cast<const float4 *>(csrc + (size_t)cc * KP_C)[t] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    reinterpret_cast<float4 *>(lc + (size_t)cc * KP_C)[t] = v;
                 }
-            }
-        };
-#pragma unroll
-        for (int t = 0; t < TPF; ++t) issue_tile(t, pv[t]);
-        if (s != cur_seg) {
-            cur_seg = s;
-            k = tab->seg_k[s];
-            beg = ibeg;
-            len = ilen;
-            __syncthreads();                                   // previous users of cimg / lcn / run are done
-            for (int i = threadIdx.x; i < kmax * KP_C; i += 256) run[i] = 0.0f;
-            if ((int)threadIdx.x < kmax) runc[threadIdx.x] = 0;
-            const float *csrc = a.centroids + (size_t)s * kmax * KP_C;
-            for (int idx = threadIdx.x; idx < KT * 16 * c4; idx += 256) {
-                const int cc = idx / c4, t = idx - cc * c4;
-                const float4 v = (cc < k) ? reinterpret_cast<const float4 *>(csrc + (size_t)cc * KP_C)[t] : make_float4(0.f, 0.f, 0.f, 0.f);
-                float *d = cimg + (size_t)cc * KP_RS + t;
-                d[0] = v.x; d[KP_TP] = v.y; d[2 * KP_TP] = v.z; d[3 * KP_TP] = v.w;
-            }
-            __syncthreads();
-            if ((int)threadIdx.x < KT * 16) {                  // |c|^2 in scipy's order: t = 0..C-1, multiply then add
-                float nrm = INFINITY;
-                if ((int)threadIdx.x < k) {
-                    const float *im = cimg + (size_t)threadIdx.x * KP_RS;
-                    nrm = 0.0f;
-#pragma unroll
-                    for (int t = 0; t < KP_TM; ++t) {
-#pragma unroll
-                        for (int kq = 0; kq < 4; ++kq) {
-                            const float v = im[kq * KP_TP + t];
+                __syncthreads();
+                if ((int)threadIdx.x < KT * 16) {              // |c|^2 in scipy's order: t = 0..C-1, multiply then add
+                    float nrm = INFINITY;
+                    if ((int)threadIdx.x < k) {
+                        const float *im = lc + (size_t)threadIdx.x * KP_C;
+                        nrm = 0.0f;
+                        for (int t = 0; t < KP_C; ++t) {
+                            const float v = im[t];
                             const float prod = v * v;
                             nrm = nrm + prod;
                         }
                     }
+                    lcn[threadIdx.x] = nrm;
                 }
-                lcn[threadIdx.x] = nrm;
+                __syncthreads();
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt) {
+                    const float *st = lc + (size_t)(kt * 16 + j) * KP_C + g;
+#pragma unroll
+                    for (int t = 0; t < KP_TM; ++t) ca[kt][t] = st[4 * t];      // lane (i = j, kq = g): c[16 kt + i][4 t + kq]
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) cn[kt][r] = lcn[kt * 16 + g * 4 + r];
+                }
+            }
+            KP_SEC(0);
+            KP_ROWS_COMMIT()
+            KP_SEC(1);
+            const int cur_id = my_id;
+            const float cur_xs = my_xs;
+            if (blk + 1 < blk_end) {
+                my_id = id_next;
+                my_xs = xs_next;
+                KP_ROWS_ISSUE()     // in flight under this block's work
+            }
+
+            int best = -1;
+#pragma unroll
+            for (int tile = 0; tile < 4; ++tile) {
+                const float *br = wrow + (size_t)(16 * tile + j) * KP_C + g;
+                float xb[KP_TM];
+#pragma unroll
+                for (int t = 0; t < KP_TM; ++t) xb[t] = br[4 * t];
+                const int prow = wave_row0 + tile * 16 + j;
+                const float xs_l = __shfl(cur_xs, tile * 16 + j);
+                const float xs = (prow < len) ? xs_l : 0.0f;
+                float low = INFINITY;
+                int arg = 0;
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt) {
+                    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int t = 0; t < KP_TM; ++t) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(ca[kt][t], xb[t], acc, 0, 0, 0);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float mm = -2.0f * acc[r];
+                        const float dist = (mm + xs) + cn[kt][r];
+                        if (dist < low) { low = dist; arg = kt * 16 + g * 4 + r; }
+                    }
+                }
+#pragma unroll
+                for (int off = 16; off <= 32; off <<= 1) {
+                    const float d2 = __shfl_xor(low, off);
+                    const int a2 = __shfl_xor(arg, off);
+                    if (d2 < low || (d2 == low && a2 < arg)) { low = d2; arg = a2; }
+                }
+                const int mine = __shfl(arg, lane & 15);
+                if ((lane >> 4) == tile) best = mine;
+            }
+            (void)cur_id;
+            KP_SEC(2);
+            const int p = wave_row0 + lane;
+            const bool valid = p < len;
+            if (!valid) best = -1;
+            if (valid) a.labels[beg + p] = best;
+
+            // ---- chunks of this mini-block: presence mask, member counts, any-order sums of |x| (lanes = features, rows from LDS)
+            const int mb = 4 * blk + wave;
+            unsigned long long pm = 0ull;
+            for (int kk = 0; kk < k; ++kk)
+                if (__ballot(best == kk) != 0ull) pm |= 1ull << kk;
+            if (lane == 0) a.pres[mb] = pm;
+            unsigned long long rem = pm;
+            while (rem) {
+                const int kk = __builtin_ctzll(rem);
+                rem &= rem - 1;
+                unsigned long long mm = __ballot(best == kk);
+                const int cnt = __popcll(mm);
+                float a0 = 0.0f, a1 = 0.0f;
+                while (mm) {
+                    float x0[4], x1[4];
+                    bool on[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        on[u] = mm != 0ull;
+                        const int b = on[u] ? __builtin_ctzll(mm) : 0;
+                        if (on[u]) mm &= mm - 1;
+                        x0[u] = wrow[b * KP_C + lane];
+                        x1[u] = wrow[b * KP_C + 64 + l1];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (on[u]) { a0 += fabsf(x0[u]); a1 += fabsf(x1[u]); }
+                }
+                const size_t slot = (size_t)mb * kmax + kk;
+                a.bsum[slot * KP_C + lane] = a0;
+                if (lane < KP_C1) a.bsum[slot * KP_C + 64 + lane] = a1;
+                atomicAdd(&blks[kk * KP_C + lane], a0);
+                if (lane < KP_C1) atomicAdd(&blks[kk * KP_C + 64 + lane], a1);
+                if (lane == 0) { a.ccnt[slot] = cnt; atomicAdd(&blkc[kk], cnt); }
+            }
+            KP_SEC(3);
+            __syncthreads();
+            KP_SEC(4);
+            // ---- running prefix at block granularity (present clusters only)
+            for (int i = threadIdx.x; i < k * KP_C; i += 256) {
+                const int kk = i / KP_C;
+                if (blkc[kk] > 0) {
+                    a.PB[((size_t)blk * kmax + kk) * KP_C + (i - kk * KP_C)] = run[i];
+                    run[i] += blks[i];
+                    blks[i] = 0.0f;
+                }
             }
             __syncthreads();
-#pragma unroll
-            for (int kt = 0; kt < KT; ++kt) {
-                const float *st = cimg + (size_t)(kt * 16 + j) * KP_RS + g * KP_TP;
-#pragma unroll
-                for (int u = 0; u < KP_NB4; ++u) ca[kt][u] = *reinterpret_cast<const float4 *>(st + 4 * u);
-#pragma unroll
-                for (int r = 0; r < 4; ++r) cn[kt][r] = lcn[kt * 16 + g * 4 + r];
+            if ((int)threadIdx.x < k) {
+                const int c = blkc[threadIdx.x];
+                if (c > 0) { a.PBC[(size_t)blk * kmax + threadIdx.x] = runc[threadIdx.x]; runc[threadIdx.x] += c; blkc[threadIdx.x] = 0; }
             }
+            __syncthreads();
+            KP_SEC(5);
         }
-
-        int best = -1;
-#pragma unroll
-        for (int tile = 0; tile < 4; ++tile) {
-            write_tile(tile, pv[tile % TPF]);
-            if (tile + TPF < 4) issue_tile(tile + TPF, pv[tile % TPF]);
-            const float *bs = wimg + (size_t)j * KP_RS + g * KP_TP;
-            float4 xb[KP_NB4];
-#pragma unroll
-            for (int u = 0; u < KP_NB4; ++u) xb[u] = *reinterpret_cast<const float4 *>(bs + 4 * u);
-            const int prow = wave_row0 + tile * 16 + j;
-            const float xs_l = __shfl(my_xs, tile * 16 + j);
-            const float xs = (prow < len) ? xs_l : 0.0f;
-            float low = INFINITY;
-            int arg = 0;
-#pragma unroll
-            for (int kt = 0; kt < KT; ++kt) {
-                f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int u = 0; u < KP_NB4; ++u) {
-                    const float aa[4] = {ca[kt][u].x, ca[kt][u].y, ca[kt][u].z, ca[kt][u].w};
-                    const float bb[4] = {xb[u].x, xb[u].y, xb[u].z, xb[u].w};
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (4 * u + e < KP_TM) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aa[e], bb[e], acc, 0, 0, 0);
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float mm = -2.0f * acc[r];
-                    const float dist = (mm + xs) + cn[kt][r];
-                    if (dist < low) { low = dist; arg = kt * 16 + g * 4 + r; }
-                }
-            }
-#pragma unroll
-            for (int off = 16; off <= 32; off <<= 1) {
-                const float d2 = __shfl_xor(low, off);
-                const int a2 = __shfl_xor(arg, off);
-                if (d2 < low || (d2 == low && a2 < arg)) { low = d2; arg = a2; }
-            }
-            const int mine = __shfl(arg, lane & 15);
-            if ((lane >> 4) == tile) best = mine;
-        }
-        const int p = wave_row0 + lane;
-        const bool valid = p < len;
-        if (!valid) best = -1;
-        if (valid) a.labels[beg + p] = best;
-
-        // ---- chunks of this mini-block: presence mask, member counts, any-order sums of |x| (lanes = features)
-        const int mb = 4 * blk + wave;
-        unsigned long long pm = 0ull;
-        for (int kk = 0; kk < k; ++kk)
-            if (__ballot(best == kk) != 0ull) pm |= 1ull << kk;
-        if (lane == 0) a.pres[mb] = pm;
-        const int l1 = min(lane, KP_C1 - 1);
-        unsigned long long rem = pm;
-        while (rem) {
-            const int kk = __builtin_ctzll(rem);
-            rem &= rem - 1;
-            unsigned long long mm = __ballot(best == kk);
-            const int cnt = __popcll(mm);
-            float a0 = 0.0f, a1 = 0.0f;
-            while (mm) {
-                float x0[8], x1[8];
-                bool on[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    on[u] = mm != 0ull;
-                    const int b = on[u] ? __builtin_ctzll(mm) : 0;
-                    if (on[u]) mm &= mm - 1;
-                    const int id = __builtin_amdgcn_readlane(my_id, b);
-                    const float *row = a.pool + (size_t)id * KP_C;
-                    x0[u] = row[lane];
-                    x1[u] = row[64 + l1];
-                }
-#pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    if (on[u]) { a0 += fabsf(x0[u]); a1 += fabsf(x1[u]); }
-                }
-            }
-            const size_t slot = (size_t)mb * kmax + kk;
-            a.bsum[slot * KP_C + lane] = a0;
-            if (lane < KP_C1) a.bsum[slot * KP_C + 64 + lane] = a1;
-            atomicAdd(&blks[kk * KP_C + lane], a0);
-            if (lane < KP_C1) atomicAdd(&blks[kk * KP_C + 64 + lane], a1);
-            if (lane == 0) { a.ccnt[slot] = cnt; atomicAdd(&blkc[kk], cnt); }
-        }
-        __syncthreads();
-        // ---- running prefix at block granularity (present clusters only)
-        for (int i = threadIdx.x; i < k * KP_C; i += 256) {
-            const int kk = i / KP_C;
-            if (blkc[kk] > 0) {
-                a.PB[((size_t)blk * kmax + kk) * KP_C + (i - kk * KP_C)] = run[i];
-                run[i] += blks[i];
-                blks[i] = 0.0f;
-            }
-        }
-        __syncthreads();
-        if ((int)threadIdx.x < k) {
-            const int c = blkc[threadIdx.x];
-            if (c > 0) { a.PBC[(size_t)blk * kmax + threadIdx.x] = runc[threadIdx.x]; runc[threadIdx.x] += c; blkc[threadIdx.x] = 0; }
-        }
-        __syncthreads();
     }
+    if (pf) for (int i = 0; i < 6; ++i) g_kp_prof[24 + i] += (unsigned long long)sec[i];
     // tail sums of this workgroup (its last segment)
     for (int i = threadIdx.x; i < kmax * KP_C; i += 256) a.T[(size_t)wg * kmax * KP_C + i] = run[i];
     if ((int)threadIdx.x < kmax) a.TC[(size_t)wg * kmax + threadIdx.x] = runc[threadIdx.x];
@@ -349,10 +369,13 @@ __device__ __forceinline__ void kp_phase_fold(const KpArgs &a, KpTables *tab, fl
     const int kmax = a.kmax;
     float *base = lds;                                              // [kmax][C]
     int32_t *basec = reinterpret_cast<int32_t *>(base + (size_t)kmax * KP_C);        // [kmax]
-    float *lits = reinterpret_cast<float *>(basec + kmax) + (size_t)wave * 2 * KP_LIT * 64;   // [2][KP_LIT][64] per wave
+    float *wrow = reinterpret_cast<float *>(basec + ((kmax + 3) & ~3)) + (size_t)wave * KP_ROWF;
+    float *lits = reinterpret_cast<float *>(basec + ((kmax + 3) & ~3)) + (size_t)4 * KP_ROWF + (size_t)wave * 2 * KP_LIT * 64;   // [2][KP_LIT][64] per wave
     if (blk_begin >= blk_end) return;
-    int s = 0;
-    while (blk_begin >= tab->blk_base[s + 1]) ++s;
+    const bool pf = a.prof != 0 && wg == a.prof - 1 && threadIdx.x == 0;
+    unsigned sec[6] = {0u, 0u, 0u, 0u, 0u, 0u};
+    long long tsec = pf ? wall_clock64() : 0ll;
+    int s = kp_locate(tab, blk_begin, 0);
     // sums of the earlier workgroups' blocks in this workgroup's first segment
     {
         const int seg_first_blk = tab->blk_base[s];
@@ -371,10 +394,21 @@ __device__ __forceinline__ void kp_phase_fold(const KpArgs &a, KpTables *tab, fl
         if (threadIdx.x == 0) tab->litcnt = 0;
         __syncthreads();
     }
+    KP_SEC(0);
     const int l1 = min(lane, KP_C1 - 1);
     int cur_seg = s;
+    KP_ROWS_DECL()
+    int my_id, id_next = 0, lab, lab_next = -1;
+    {
+        const int beg = tab->seg_off[s], len = tab->seg_off[s + 1] - beg;
+        const int p = (blk_begin - tab->blk_base[s]) * 256 + wave * 64 + lane;
+        my_id = a.rows[beg + max(min(p, len - 1), 0)];
+        lab = (p < len) ? a.labels[beg + p] : -1;
+        KP_ROWS_ISSUE()
+    }
+    int n_steps = 0, n_generic = 0;
     for (int blk = blk_begin; blk < blk_end; ++blk) {
-        while (blk >= tab->blk_base[s + 1]) ++s;
+        s = kp_locate(tab, blk, s);
         if (s != cur_seg) {                                     // a new segment starts inside this workgroup's range: nothing in front of it
             cur_seg = s;
             __syncthreads();
@@ -382,102 +416,148 @@ __device__ __forceinline__ void kp_phase_fold(const KpArgs &a, KpTables *tab, fl
             if ((int)threadIdx.x < kmax) basec[threadIdx.x] = 0;
             __syncthreads();
         }
-        const int bx = blk - tab->blk_base[s];
-        const int beg = tab->seg_off[s], len = tab->seg_off[s + 1] - beg;
-        const int p = bx * 256 + wave * 64 + lane;
-        const bool valid = p < len;
-        const int my_id = a.rows[beg + max(min(p, len - 1), 0)];
-        const int lab = valid ? a.labels[beg + p] : -1;
+        if (blk + 1 < blk_end) {
+            const int s1 = kp_locate(tab, blk + 1, s);
+            const int b1 = tab->seg_off[s1], l1n = tab->seg_off[s1 + 1] - b1;
+            const int p1 = (blk + 1 - tab->blk_base[s1]) * 256 + wave * 64 + lane;
+            id_next = a.rows[b1 + max(min(p1, l1n - 1), 0)];
+            lab_next = (p1 < l1n) ? a.labels[b1 + p1] : -1;
+        }
         const int mb = 4 * blk + wave;
         const unsigned long long pm = a.pres[mb];
         unsigned long long pprev[3];
 #pragma unroll
         for (int qq = 0; qq < 3; ++qq) pprev[qq] = (qq < wave) ? a.pres[4 * blk + qq] : 0ull;
+        KP_ROWS_COMMIT()
+        const int cur_lab = lab;
+        if (blk + 1 < blk_end) {
+            my_id = id_next;
+            lab = lab_next;
+            KP_ROWS_ISSUE()
+        }
         unsigned long long rem = pm;
+        KP_SEC(1);
         while (rem) {
-            const int kk = __builtin_ctzll(rem);
-            rem &= rem - 1;
-            unsigned long long mm = __ballot(lab == kk);
-            const int total = __popcll(mm);
-            // prediction of the exact running sums in front of this chunk
-            const size_t pbo = ((size_t)blk * kmax + kk) * KP_C;
-            float P0 = base[kk * KP_C + lane] + a.PB[pbo + lane];
-            float P1 = base[kk * KP_C + 64 + l1] + a.PB[pbo + 64 + l1];
-            int mbf = basec[kk] + a.PBC[(size_t)blk * kmax + kk];
+            // ---- predictions of up to four chunks at once: every load is issued before any is used
+            int kks[4];
+            float P0[4], P1[4];
+            int mbf[4];
+            int ng = 0;
 #pragma unroll
-            for (int qq = 0; qq < 3; ++qq) {
-                if ((pprev[qq] >> kk) & 1ull) {
+            for (int u = 0; u < 4; ++u) {
+                const bool on = rem != 0ull;
+                const int kk = on ? __builtin_ctzll(rem) : 0;
+                if (on) { rem &= rem - 1; ++ng; }
+                kks[u] = kk;
+                const size_t pbo = ((size_t)blk * kmax + kk) * KP_C;
+                float p0 = a.PB[pbo + lane], p1 = a.PB[pbo + 64 + l1];
+                int mc = a.PBC[(size_t)blk * kmax + kk];
+                float b0[3], b1[3];
+                int cc[3];
+#pragma unroll
+                for (int qq = 0; qq < 3; ++qq) {
                     const size_t sl = (size_t)(4 * blk + qq) * kmax + kk;
-                    P0 += a.bsum[sl * KP_C + lane];
-                    P1 += a.bsum[sl * KP_C + 64 + l1];
-                    mbf += a.ccnt[sl];
+                    b0[qq] = a.bsum[sl * KP_C + lane];
+                    b1[qq] = a.bsum[sl * KP_C + 64 + l1];
+                    cc[qq] = a.ccnt[sl];
                 }
+                p0 += base[kk * KP_C + lane];
+                p1 += base[kk * KP_C + 64 + l1];
+                mc += basec[kk];
+#pragma unroll
+                for (int qq = 0; qq < 3; ++qq) {
+                    const bool here = ((pprev[qq] >> kk) & 1ull) != 0ull;
+                    p0 += here ? b0[qq] : 0.0f;
+                    p1 += here ? b1[qq] : 0.0f;
+                    mc += here ? cc[qq] : 0;
+                }
+                P0[u] = p0; P1[u] = p1; mbf[u] = mc;
             }
-            KxFold k0, k1;
-            kx_fold_init(k0, P0, mbf);
-            kx_fold_init(k1, P1, mbf);
-            float *lit0 = lits + lane, *lit1 = lits + KP_LIT * 64 + lane;
-            int idx = 0;
-            while (mm) {
-                float x0[8], x1[8];
-                bool on[8];
+            KP_SEC(2);
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    on[u] = mm != 0ull;
-                    const int b = on[u] ? __builtin_ctzll(mm) : 0;
-                    if (on[u]) mm &= mm - 1;
-                    const int id = __builtin_amdgcn_readlane(my_id, b);
-                    const float *row = a.pool + (size_t)id * KP_C;
-                    x0[u] = row[lane];
-                    x1[u] = row[64 + l1];
-                }
+            for (int u = 0; u < 4; ++u) {
+                if (u < ng) {
+                    const int kk = kks[u];
+                    unsigned long long mm = __ballot(cur_lab == kk);
+                    const int total = __popcll(mm);
+                    KxFold k0, k1;
+                    kx_fold_init(k0, P0[u], mbf[u]);
+                    kx_fold_init(k1, P1[u], mbf[u]);
+                    float *lit0 = lits + lane, *lit1 = lits + KP_LIT * 64 + lane;
+                    int idx = 0;
+                    KP_SEC(3);
+                    while (mm) {
+                        float x0[4], x1[4];
+                        bool on[4];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    if (on[u]) {
-                        const KxStep s0 = kx_fold_probe(k0, x0[u]);
-                        const KxStep s1 = kx_fold_probe(k1, x1[u]);
-                        if (__all(s0.fast && s1.fast)) {
-                            k0.acc = (int32_t)s0.cand;
-                            k1.acc = (int32_t)s1.cand;
-                        } else {
-                            kx_fold_member(k0, x0[u], idx, lit0, 64);
-                            kx_fold_member(k1, x1[u], idx, lit1, 64);
+                        for (int v = 0; v < 4; ++v) {
+                            on[v] = mm != 0ull;
+                            const int b = on[v] ? __builtin_ctzll(mm) : 0;
+                            if (on[v]) mm &= mm - 1;
+                            x0[v] = wrow[b * KP_C + lane];
+                            x1[v] = wrow[b * KP_C + 64 + l1];
                         }
-                        ++idx;
-                    }
-                }
-            }
-            // records
-            const size_t slot = (size_t)mb * kmax + kk;
-            uint32_t *r = a.rec + slot * KP_REC * KP_C;
 #pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                const KxFold &kf = half ? k1 : k0;
-                const float *lt = half ? lit1 : lit0;
-                int32_t A0, B0;
-                uint32_t hdr = kx_fold_finish(kf, total, A0, B0);
-                uint32_t w3 = 0u;
-                const int nlit = kx_hdr_nlit(hdr);
-                if (nlit == 1) w3 = kx_f2u(lt[0]);
-                const int f = half * 64 + lane;
-                if (nlit > 1 && f < KP_C) {
-                    const int off = atomicAdd(&tab->litcnt, nlit);
-                    if (off + nlit > KP_LITCAP) {
-                        hdr = kx_hdr(KX_UNSAFE, 0, 0, 0, 0, 0);
-                    } else {
-                        float *dst = a.litpool + (size_t)wg * KP_LITCAP + off;
-                        for (int i = 0; i < nlit; ++i) dst[i] = lt[i * 64];
-                        w3 = (uint32_t)(wg * KP_LITCAP + off);
+                        for (int v = 0; v < 4; ++v) {
+                            if (on[v]) {
+                                const KxFast s0 = kx_fold_fast(k0, x0[v]);
+                                const KxFast s1 = kx_fold_fast(k1, x1[v]);
+                                const bool allfast = !__any(s0.over || s1.over);
+                                ++n_steps;
+                                if (allfast) {
+                                    k0.acc = s0.acc; k0.dvar = s0.dvar;
+                                    k1.acc = s1.acc; k1.dvar = s1.dvar;
+                                    k0.s = k0.s + x0[v];
+                                    k1.s = k1.s + x1[v];
+                                } else {
+                                    ++n_generic;
+                                    kx_fold_member(k0, x0[v], idx, lit0, 64);
+                                    kx_fold_member(k1, x1[v], idx, lit1, 64);
+                                }
+                                ++idx;
+                            }
+                        }
                     }
-                }
-                if (f < KP_C) {
-                    r[f] = hdr;
-                    r[KP_C + f] = (uint32_t)A0;
-                    r[2 * KP_C + f] = (uint32_t)B0;
-                    r[3 * KP_C + f] = w3;
+                    KP_SEC(4);
+                    // records
+                    const size_t slot = (size_t)mb * kmax + kk;
+                    uint32_t *r = a.rec + slot * KP_REC * KP_C;
+#pragma unroll
+                    for (int half = 0; half < 2; ++half) {
+                        const KxFold &kf = half ? k1 : k0;
+                        const float *lt = half ? lit1 : lit0;
+                        int32_t A0, B0;
+                        uint32_t hdr = kx_fold_finish(kf, total, A0, B0);
+                        uint32_t w3 = 0u;
+                        const int nlit = kx_hdr_nlit(hdr);
+                        if (nlit == 1) w3 = kx_f2u(lt[0]);
+                        const int f = half * 64 + lane;
+                        if (nlit > 1 && f < KP_C) {
+                            const int off = atomicAdd(&tab->litcnt, nlit);
+                            if (off + nlit > KP_LITCAP) {
+                                hdr = kx_hdr(KX_UNSAFE, 0, 0, 0, 0, 0);
+                            } else {
+                                float *dst = a.litpool + (size_t)wg * KP_LITCAP + off;
+                                for (int i = 0; i < nlit; ++i) dst[i] = lt[i * 64];
+                                w3 = (uint32_t)(wg * KP_LITCAP + off);
+                            }
+                        }
+                        if (f < KP_C) {
+                            r[f] = hdr;
+                            r[KP_C + f] = (uint32_t)A0;
+                            r[2 * KP_C + f] = (uint32_t)B0;
+                            r[3 * KP_C + f] = w3;
+                        }
+                    }
+                    KP_SEC(5);
                 }
             }
         }
+    }
+    if (pf) {
+        g_kp_prof[12] += (unsigned long long)n_steps;
+        g_kp_prof[13] += (unsigned long long)n_generic;
+        for (int i = 0; i < 6; ++i) g_kp_prof[16 + i] += (unsigned long long)sec[i];
     }
 }
 
@@ -508,17 +588,42 @@ __device__ __forceinline__ void kp_phase_merge(const KpArgs &a, KpTables *tab, i
         const int fc = fvalid ? f : KP_C - 1;
         KxRun run{0, 0, 0};
         unsigned long long np = 0ull;
+        int nev = 0;
+        uint32_t *evb = a.part_ev + ((size_t)part * kmax + kk) * KP_EV * KP_REC * KP_C + fc;
         unsigned long long mm = pmask;
         while (mm) {
-            const int pos = __builtin_ctzll(mm);
-            mm &= mm - 1;
-            uint32_t *r = a.rec + ((size_t)(mb0 + pos) * kmax + kk) * KP_REC * KP_C + fc;
-            const uint32_t hdr = r[0];
-            const int32_t A0 = (int32_t)r[KP_C];
-            if (!kx_run_merge(run, hdr, A0)) {
-                if (fvalid) { r[4 * KP_C] = kx_run_hdr(run); r[5 * KP_C] = (uint32_t)run.R0; }
-                np |= 1ull << pos;
-                run = KxRun{0, 0, 0};
+            // eight positions at a time: all loads first
+            int poss[8];
+            uint32_t hd[8], w1[8], w2[8], w3[8];
+            int ng = 0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const bool on = mm != 0ull;
+                const int pos = on ? __builtin_ctzll(mm) : 0;
+                if (on) { mm &= mm - 1; ++ng; }
+                poss[u] = pos;
+                const uint32_t *r = a.rec + ((size_t)(mb0 + pos) * kmax + kk) * KP_REC * KP_C + fc;
+                hd[u] = r[0]; w1[u] = r[KP_C]; w2[u] = r[2 * KP_C]; w3[u] = r[3 * KP_C];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (u < ng) {
+                    if (!kx_run_merge(run, hd[u], (int32_t)w1[u])) {
+                        const uint32_t rh = kx_run_hdr(run), rR = (uint32_t)run.R0;
+                        if (fvalid) {
+                            uint32_t *r = a.rec + ((size_t)(mb0 + poss[u]) * kmax + kk) * KP_REC * KP_C + fc;
+                            r[4 * KP_C] = rh;
+                            r[5 * KP_C] = rR;
+                            if (nev < KP_EV) {                    // the first records of the part also inline, where the stitch finds them without looking
+                                uint32_t *e = evb + (size_t)nev * KP_REC * KP_C;
+                                e[0] = hd[u]; e[KP_C] = w1[u]; e[2 * KP_C] = w2[u]; e[3 * KP_C] = w3[u]; e[4 * KP_C] = rh; e[5 * KP_C] = rR;
+                            }
+                        }
+                        ++nev;
+                        np |= 1ull << poss[u];
+                        run = KxRun{0, 0, 0};
+                    }
+                }
             }
         }
         if (fvalid) {
@@ -531,6 +636,24 @@ __device__ __forceinline__ void kp_phase_merge(const KpArgs &a, KpTables *tab, i
 }
 
 // ------------------------------------------------------------------------------------------ phase S
+struct KpPart {                       // what the stitch needs of one part, per lane; loaded one part ahead
+    unsigned long long np;
+    uint32_t post_h, post_R;
+    uint32_t ev[KP_EV][KP_REC];
+    int cnt;
+};
+__device__ __forceinline__ void kp_part_load(KpPart &pd, const KpArgs &a, int part, int kk, int fc) {
+    const size_t pk = (size_t)part * a.kmax + kk;
+    pd.np = a.part_np[pk * KP_C + fc];
+    pd.post_h = a.part_post[pk * 2 * KP_C + fc];
+    pd.post_R = a.part_post[pk * 2 * KP_C + KP_C + fc];
+    pd.cnt = a.part_cnt[pk];
+#pragma unroll
+    for (int e = 0; e < KP_EV; ++e)
+#pragma unroll
+        for (int w = 0; w < KP_REC; ++w) pd.ev[e][w] = a.part_ev[(pk * KP_EV + e) * KP_REC * KP_C + (size_t)w * KP_C + fc];
+}
+
 __device__ __forceinline__ void kp_phase_stitch(const KpArgs &a, KpTables *tab, int wg) {
     const int lane = aoc_lane(), wave = threadIdx.x >> 6;
     const int kmax = a.kmax;
@@ -547,34 +670,54 @@ __device__ __forceinline__ void kp_phase_stitch(const KpArgs &a, KpTables *tab, 
         const int nparts = tab->part_base[s + 1] - tab->part_base[s];
         float sv = 0.0f;
         int cnt_total = 0;
+        KpPart nxt;
+        if (nparts > 0) kp_part_load(nxt, a, tab->part_base[s], kk, fc);
         for (int pp = 0; pp < nparts; ++pp) {
             const int part = tab->part_base[s] + pp;
             const int mb0 = mb_base + 64 * pp;
-            const int nm = min(64, nmb - 64 * pp);
-            const unsigned long long pw = (lane < nm) ? a.pres[mb0 + lane] : 0ull;
-            const unsigned long long pmask = __ballot(((pw >> kk) & 1ull) != 0ull);
-            if (pmask == 0ull) continue;
-            cnt_total += a.part_cnt[(size_t)part * kmax + kk];
-            unsigned long long np = a.part_np[((size_t)part * kmax + kk) * KP_C + fc];
-            const uint32_t *po = a.part_post + ((size_t)part * kmax + kk) * 2 * KP_C + fc;
-            const uint32_t post_h = po[0];
-            const int32_t post_R = (int32_t)po[KP_C];
+            const KpPart pd = nxt;
+            if (pp + 1 < nparts) kp_part_load(nxt, a, part + 1, kk, fc);
+            if (pd.cnt == 0) continue;                          // the cluster has no member in this part (uniform)
+            cnt_total += pd.cnt;
+            unsigned long long np = pd.np;
+            unsigned long long pmask = 0ull;
+            bool have_pmask = false;
             bool norun = false, stuck = false, post_done = false;
-            int done = 0, spos = 64;
+            int done = 0, spos = 64, evi = 0;
             for (;;) {
                 // ---- every lane walks its own list of records until it is through or stuck
                 for (;;) {
                     const int pos = (!stuck && np != 0ull) ? __builtin_ctzll(np) : 64;
                     const bool act = pos < 64;
                     if (!__any(act)) break;
+                    // the record of this lane: inline copy (the first KP_EV of the part, while no run failed) or from the record array
+                    const bool inl = act && !norun && evi < KP_EV;
+                    bool renew = false;
+                    uint32_t w[KP_REC];
+#pragma unroll
+                    for (int i = 0; i < KP_REC; ++i) w[i] = 0u;
+                    if (__any(act && !inl)) {
+                        if (act && !inl) {
+                            const uint32_t *r = a.rec + ((size_t)(mb0 + pos) * kmax + kk) * KP_REC * KP_C + fc;
+#pragma unroll
+                            for (int i = 0; i < KP_REC; ++i) w[i] = r[(size_t)i * KP_C];
+                        }
+                    }
+                    if (inl) {
+#pragma unroll
+                        for (int e = 0; e < KP_EV; ++e)
+                            if (evi == e) {
+#pragma unroll
+                                for (int i = 0; i < KP_REC; ++i) w[i] = pd.ev[e][i];
+                            }
+                    }
                     if (act) {
-                        const uint32_t *r = a.rec + ((size_t)(mb0 + pos) * kmax + kk) * KP_REC * KP_C + fc;
-                        const uint32_t hdr = r[0];
-                        const int32_t A0 = (int32_t)r[KP_C], B0 = (int32_t)r[2 * KP_C];
-                        const uint32_t w3 = r[3 * KP_C];
+                        const uint32_t hdr = w[0];
+                        const int32_t A0 = (int32_t)w[1], B0 = (int32_t)w[2];
+                        const uint32_t w3 = w[3];
                         bool expand = false;
                         if (!norun) {
-                            const KxRun run = kx_run_unpack(r[4 * KP_C], (int32_t)r[5 * KP_C]);
+                            const KxRun run = kx_run_unpack(w[4], (int32_t)w[5]);
                             float t = sv;
                             if (kx_apply_run(t, run)) sv = t;
                             else expand = true;
@@ -582,10 +725,9 @@ __device__ __forceinline__ void kp_phase_stitch(const KpArgs &a, KpTables *tab, 
                         if (expand) {
                             // a chunk of the run in front of this record did not happen as predicted: this lane takes the rest of the part record by record
                             norun = true;
-                            np = pmask & ~kp_below(done);
+                            renew = true;
                         } else {
                             done = pos;
-                            // the record itself, on a copy of the state
                             float t = sv;
                             bool ok = true;
                             const int kind = kx_hdr_kind(hdr);
@@ -601,10 +743,18 @@ __device__ __forceinline__ void kp_phase_stitch(const KpArgs &a, KpTables *tab, 
                                     for (int i = 0; i < nlit; ++i) t = t + a.litpool[w3 + i];
                                 if (ok && eB) ok = kx_apply_int(t, eB - 1, B0, kx_hdr_dB(hdr));
                             }
-                            if (ok) { sv = t; np &= np - 1; done = pos + 1; }
+                            if (ok) { sv = t; np &= np - 1; done = pos + 1; ++evi; }
                             else { stuck = true; spos = pos; }
                         }
                     }
+                    // lanes that gave up on the runs need the part's presence mask: every present position from `done` on becomes a record to visit
+                    if (__any(renew) && !have_pmask) {
+                        const int nm = min(64, nmb - 64 * pp);
+                        const unsigned long long pw = (lane < nm) ? a.pres[mb0 + lane] : 0ull;
+                        pmask = __ballot(((pw >> kk) & 1ull) != 0ull);
+                        have_pmask = true;
+                    }
+                    if (renew) np = pmask & ~kp_below(done);
                 }
                 // ---- stuck lanes: the lowest stuck position is summed literally from its rows (lanes = features, coalesced)
                 if (__any(stuck)) {
@@ -629,19 +779,27 @@ __device__ __forceinline__ void kp_phase_stitch(const KpArgs &a, KpTables *tab, 
                         for (int u = 0; u < 8; ++u)
                             if (on[u] && mine) sv = sv + x[u];
                     }
-                    if (mine) { stuck = false; np &= ~(1ull << pmin); done = pmin + 1; }
+                    if (mine) { stuck = false; np &= ~(1ull << pmin); done = pmin + 1; ++evi; }
                     continue;
                 }
                 // ---- the part's last run
                 bool again = false;
                 if (!norun && !post_done) {
                     post_done = true;
-                    const KxRun run = kx_run_unpack(post_h, post_R);
+                    const KxRun run = kx_run_unpack(pd.post_h, (int32_t)pd.post_R);
                     float t = sv;
                     if (kx_apply_run(t, run)) sv = t;
-                    else { norun = true; np = pmask & ~kp_below(done); again = np != 0ull; }
+                    else { norun = true; again = true; }
                 }
                 if (!__any(again)) break;
+                // a failed last run: the positions from `done` on, one by one
+                if (!have_pmask) {
+                    const int nm = min(64, nmb - 64 * pp);
+                    const unsigned long long pw = (lane < nm) ? a.pres[mb0 + lane] : 0ull;
+                    pmask = __ballot(((pw >> kk) & 1ull) != 0ull);
+                    have_pmask = true;
+                }
+                if (again) np = pmask & ~kp_below(done);
             }
         }
         if (h == 0 && lane == 0) a.cluster_counts[s * kmax + kk] = cnt_total;
@@ -651,7 +809,7 @@ __device__ __forceinline__ void kp_phase_stitch(const KpArgs &a, KpTables *tab, 
 
 // ------------------------------------------------------------------------------------------ the chain
 template <int KT>
-__global__ __launch_bounds__(256, 2) void km_chain_kernel(KpArgs a) {
+__global__ __launch_bounds__(256, 1) void km_chain_kernel(KpArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds_raw[];
     KpTables *tab = reinterpret_cast<KpTables *>(lds_raw);
     float *lds = lds_raw + (sizeof(KpTables) + 15) / 16 * 4;
@@ -718,7 +876,7 @@ __global__ __launch_bounds__(256, 2) void km_chain_kernel(KpArgs a) {
         ok = kp_grid_barrier(a.bar, tab, epoch, a.grid);
         KP_TICK(8);
     }
-    if (prof && wg == 0 && threadIdx.x == 0) g_kp_prof[9] += 1ull;
+    if (prof && wg == a.prof - 1 && threadIdx.x == 0) g_kp_prof[9] += 1ull;
     if (!ok) {
         // a barrier timed out (the grid was not resident as a whole): poison the code books so that nothing downstream looks plausible
         for (int i = wg * 256 + threadIdx.x; i < a.n_seg * a.kmax * KP_C; i += a.grid * 256) a.centroids[i] = __builtin_nanf("");
@@ -727,13 +885,13 @@ __global__ __launch_bounds__(256, 2) void km_chain_kernel(KpArgs a) {
 
 size_t kp_lds_bytes(int kt, int kmax) {
     const size_t tabs = (sizeof(KpTables) + 15) / 16 * 16;
-    const size_t pa = ((size_t)kt * 16 * KP_RS + kt * 16 + (size_t)4 * 16 * KP_RS + (size_t)2 * kmax * KP_C + 2 * kmax) * 4;
-    const size_t pb = ((size_t)kmax * KP_C + kmax + (size_t)4 * 2 * KP_LIT * 64) * 4;
+    const size_t pa = ((size_t)kt * 16 * KP_C + kt * 16 + (size_t)4 * KP_ROWF + (size_t)2 * kmax * KP_C + 2 * kmax) * 4;
+    const size_t pb = ((size_t)kmax * KP_C + ((kmax + 3) & ~3) + (size_t)4 * KP_ROWF + (size_t)4 * 2 * KP_LIT * 64) * 4;
     return tabs + std::max(pa, pb) + 16;
 }
 
 struct KpLayout {
-    size_t pres, ccnt, bsum, rec, PB, PBC, T, TC, litpool, part_post, part_np, part_cnt, bar, total;
+    size_t pres, ccnt, bsum, rec, PB, PBC, T, TC, litpool, part_post, part_np, part_ev, part_cnt, bar, total;
 };
 KpLayout kp_layout(int64_t cap, int n_seg, int kmax) {
     const size_t nblk = (size_t)(cap / 256) + n_seg + 1, nmb = 4 * nblk, slots = nmb * kmax, nparts = nblk / 16 + n_seg + 1;
@@ -752,6 +910,7 @@ KpLayout kp_layout(int64_t cap, int n_seg, int kmax) {
     l.litpool = take((size_t)KP_GMAX * KP_LITCAP * 4);
     l.part_post = take(nparts * kmax * 2 * KP_C * 4);
     l.part_np = take(nparts * kmax * KP_C * 8);
+    l.part_ev = take(nparts * kmax * KP_EV * KP_REC * KP_C * 4);
     l.part_cnt = take(nparts * kmax * 4);
     l.total = o;
     return l;
@@ -766,7 +925,7 @@ int g_kp_grid_override = 0;
 }  // namespace
 
 // ---- internal interface (labels_kmeans.hip)
-bool aoc_kp_supported(int C, int n_seg, int kmax) { return C == KP_C && n_seg <= KP_SEG_MAX && kmax <= 64 && kmax >= 1; }
+bool aoc_kp_supported(int C, int n_seg, int kmax) { return C == KP_C && n_seg <= KP_SEG_MAX && kmax <= 32 && kmax >= 1; }
 size_t aoc_kp_workspace_bytes(int64_t rows_capacity, int n_seg, int kmax) { return kp_layout(rows_capacity, n_seg, kmax).total; }
 
 // The chain after km_init_kernel (code books = initial rows): `iters` Lloyd iterations in one launch.  rownorm: [rows_capacity] scratch.
@@ -786,10 +945,8 @@ int aoc_kp_chain(const float *pool, const int32_t *rows, const int32_t *seg_offs
         hipError_t e = hipErrorUnknown;
         if (kt == 1) { (void)hipFuncSetAttribute((const void *)km_chain_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, km_chain_kernel<1>, 256, lds); }
         if (kt == 2) { (void)hipFuncSetAttribute((const void *)km_chain_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, km_chain_kernel<2>, 256, lds); }
-        if (kt == 3) { (void)hipFuncSetAttribute((const void *)km_chain_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, km_chain_kernel<3>, 256, lds); }
-        if (kt == 4) { (void)hipFuncSetAttribute((const void *)km_chain_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, km_chain_kernel<4>, 256, lds); }
         if (e != hipSuccess || per_cu < 1) return AOC_ERR_LAUNCH;
-        max_grid[kt] = std::max(1, (per_cu > 1 ? per_cu - 1 : 1) * n_cu);
+        max_grid[kt] = std::max(1, per_cu * n_cu);          // one workgroup per CU by construction (its LDS buffers take most of a CU's 160 KB)
     }
     int grid = g_kp_grid_override > 0 ? g_kp_grid_override : (kp_grid_request() > 0 ? kp_grid_request() : n_cu);
     grid = std::max(1, std::min(std::min(grid, max_grid[kt]), KP_GMAX));
@@ -798,7 +955,7 @@ int aoc_kp_chain(const float *pool, const int32_t *rows, const int32_t *seg_offs
     KpArgs a;
     a.pool = pool; a.rows = rows; a.seg_off = seg_offsets; a.seg_k = seg_k;
     a.n_seg = n_seg; a.kmax = kmax; a.iters = iters; a.grid = grid;
-    static const int prof = (getenv("AOC_KM_PROF") && atoi(getenv("AOC_KM_PROF")) > 0) ? 1 : 0;
+    static const int prof = (getenv("AOC_KM_PROF") && atoi(getenv("AOC_KM_PROF")) > 0) ? atoi(getenv("AOC_KM_PROF")) : 0;   // workgroup + 1
     a.prof = prof;
     a.centroids = centroids; a.labels = labels; a.cluster_counts = cluster_counts; a.rownorm = rownorm;
     a.pres = reinterpret_cast<unsigned long long *>(w + l.pres);
@@ -813,21 +970,20 @@ int aoc_kp_chain(const float *pool, const int32_t *rows, const int32_t *seg_offs
     a.part_post = reinterpret_cast<uint32_t *>(w + l.part_post);
     a.part_np = reinterpret_cast<unsigned long long *>(w + l.part_np);
     a.part_cnt = reinterpret_cast<int32_t *>(w + l.part_cnt);
+    a.part_ev = reinterpret_cast<uint32_t *>(w + l.part_ev);
     a.bar = reinterpret_cast<KpBar *>(w + l.bar);
     if (hipMemsetAsync(a.bar, 0, sizeof(KpBar), st) != hipSuccess) return AOC_ERR_LAUNCH;
     if (kt == 1) hipLaunchKernelGGL(km_chain_kernel<1>, dim3(grid), dim3(256), lds, st, a);
-    else if (kt == 2) hipLaunchKernelGGL(km_chain_kernel<2>, dim3(grid), dim3(256), lds, st, a);
-    else if (kt == 3) hipLaunchKernelGGL(km_chain_kernel<3>, dim3(grid), dim3(256), lds, st, a);
-    else hipLaunchKernelGGL(km_chain_kernel<4>, dim3(grid), dim3(256), lds, st, a);
+    else hipLaunchKernelGGL(km_chain_kernel<2>, dim3(grid), dim3(256), lds, st, a);
     AOC_RETURN_IF_LAUNCH_FAILED();
     return AOC_OK;
 }
 
-extern "C" int aoc_kmeans_chain_profile(unsigned long long *out16_host, int reset) {
-    if (!out16_host) return AOC_ERR_INVALID_ARG;
-    if (hipMemcpyFromSymbol(out16_host, HIP_SYMBOL(g_kp_prof), 16 * sizeof(unsigned long long)) != hipSuccess) return AOC_ERR_LAUNCH;
+extern "C" int aoc_kmeans_chain_profile(unsigned long long *out32_host, int reset) {
+    if (!out32_host) return AOC_ERR_INVALID_ARG;
+    if (hipMemcpyFromSymbol(out32_host, HIP_SYMBOL(g_kp_prof), 32 * sizeof(unsigned long long)) != hipSuccess) return AOC_ERR_LAUNCH;
     if (reset) {
-        unsigned long long z[16] = {0};
+        unsigned long long z[32] = {0};
         if (hipMemcpyToSymbol(HIP_SYMBOL(g_kp_prof), z, sizeof(z)) != hipSuccess) return AOC_ERR_LAUNCH;
     }
     return AOC_OK;

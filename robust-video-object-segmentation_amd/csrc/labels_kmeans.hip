@@ -2180,8 +2180,10 @@ int aoc_kmeans_plan(const int32_t *counts, int n_seg, int cluster_num, int32_t *
 static size_t km_launches_workspace_bytes(int64_t rows_capacity, int n_seg, int kmax) {
     return aoc_align_up((size_t)n_seg * kmax * sizeof(float), 256) + aoc_align_up(ks_workspace_bytes(rows_capacity, n_seg, kmax), 256);
 }
+// AOC_KM_CHAIN=persistent: the whole call as ONE persistent launch (kmeans_persistent.hip).  Bit-identical (the k-means tests are re-run
+// with it), but measured slower than the launch-per-phase pipeline so far: opt-in.
 static bool km_chain_enabled() {
-    static const bool on = !(getenv("AOC_KM_CHAIN") && strcmp(getenv("AOC_KM_CHAIN"), "launches") == 0);   // developer switch: the launch-per-phase pipeline
+    static const bool on = getenv("AOC_KM_CHAIN") && strcmp(getenv("AOC_KM_CHAIN"), "persistent") == 0;
     return on;
 }
 
@@ -2223,7 +2225,7 @@ int aoc_kmeans_segmented_ex(const float *pool, int64_t pool_rows, int C, const i
 
     hipLaunchKernelGGL(km_init_kernel, dim3(kmax, n_seg), dim3(64), 0, st, pool, C, rows, seg_offsets, seg_k, init_rows, kmax,
                        centroids, cnorm, cluster_counts);
-    // one persistent launch for all iterations (kmeans_persistent.hip): the default where it applies
+    // one persistent launch for all iterations (kmeans_persistent.hip), where asked for and applicable
     if (fast && km_chain_enabled() && aoc_kp_supported(C, n_seg, kmax)) {
         AOC_RETURN_IF_LAUNCH_FAILED();
         return aoc_kp_chain(pool, rows, seg_offsets, seg_k, n_seg, kmax, iters, rows_capacity, centroids, labels, cluster_counts, rownorm,

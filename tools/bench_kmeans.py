@@ -56,8 +56,11 @@ rows = sum(counts)
 print(f"k-means chain R={R} F={F} CUs={NCU or 'all'}: {ms:.3f} ms per chain ({ms / F:.3f} per frame), {rows} rows x {F} replicas", flush=True)
 
 if os.environ.get("AOC_KM_PROF"):
-    v = (ctypes.c_uint64 * 16)()
+    v = (ctypes.c_uint64 * 32)()
     aoc_amd._lib.lib().aoc_kmeans_chain_profile(v, 1)
     chains = max(int(v[9]), 1)
     names = ["norms", "assign", "bar", "fold", "bar", "merge", "bar", "stitch", "bar"]
+    print("  assign sections (thread 0, us per chain): " + ", ".join(f"{n} {v[24 + i] / chains / 100:.1f}" for i, n in enumerate(["setup+codebook", "row commit (wait)", "mfma+argmin", "chunk sums", "sync", "prefix"])))
+    print("  fold sections (thread 0, us per chain): " + ", ".join(f"{n} {v[16 + i] / chains / 100:.1f}" for i, n in enumerate(["base", "block setup", "predict", "init", "members", "finish"])))
+    print(f"  fold (wave 0): member steps {v[12] / chains:.0f} per chain, general step {v[13] / chains:.0f}")
     print("  per chain (workgroup 0, us): " + ", ".join(f"{n} {v[i] / chains / 100:.1f}" for i, n in enumerate(names)) + f"  [{chains} chains]")
