@@ -141,6 +141,8 @@ int aoc_kmeans_set_grid(int workgroups);
  * of the 100 MHz wall clock, in [0] row norms, [1] assignment, [3] fold, [5] merge, [7] stitch, [2][4][6][8] the grid barrier behind
  * each, [9] chains, [12][13] fold steps / general steps of its first thread, [16..] sections inside a phase.  Host pointer to 32 values. */
 int aoc_kmeans_chain_profile(unsigned long long *out32_host, int reset);
+/* The same per workgroup, for the last chain (16 slots of ticks per workgroup, indexed as above; [10][11] = prefix phase and its barrier). */
+int aoc_kmeans_chain_profile_workgroups(unsigned int *out_host, int n_workgroups);
 
 /* The reference's second proxy set, AEM:280: for every non-empty cluster j of segment s the mean of
  * the rows  fg[p], p in {segment-local indices with label == j}  of the GLOBAL kept-row array (the

@@ -35,6 +35,7 @@ SIGNATURES = {
     "aoc_mask_jf_accumulate": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _sz, _i, _vp, _vp]),
     "aoc_kmeans_set_grid": (_i, [_i]),
     "aoc_kmeans_chain_profile": (_i, [_vp, _i]),
+    "aoc_kmeans_chain_profile_workgroups": (_i, [_vp, _i]),
     "aoc_kmeans_replicate": (_i, [_vp, _vp, _vp, _i, _i, _i64, _vp, _vp, _vp, _vp]),
     "aoc_kmeans_replicate_levels": (_i, [_vp, _vp, _i, _i, _vp, _i, _i64, _vp, _vp, _vp, _vp]),
     "aoc_build_proxies_workspace_bytes": (_sz, [_i64, _i, _i]),

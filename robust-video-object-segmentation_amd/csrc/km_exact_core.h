@@ -132,23 +132,6 @@ KX_HD void kx_fold_init(KxFold &k, float P, int32_t m_before) {
     else { k.mode = KXM_A; k.lim = (uint32_t)(int32_t)(16777215.0f - k.n_hi); }
 }
 
-// the common case of kx_fold_member, for a wave to test: true = nothing special about this member (acc was advanced)
-struct KxStep {
-    uint32_t cand;      // acc + rne(y)
-    bool fast;          // in a folding mode, value in range, no tie, no chance of crossing
-};
-KX_HD KxStep kx_fold_probe(const KxFold &k, float x) {
-    KxStep st;
-    const float t = __builtin_fmaf(x, k.inv_u, KX_MAGIC);
-    const uint32_t r = kx_f2u(t) - KX_MAGIC_BITS;              // rne(y) if 0 <= y < 2^23, else garbage >= 2^23 (as unsigned)
-    st.cand = (uint32_t)k.acc + r;
-    const float rn = t - KX_MAGIC;
-    const float dd = __builtin_fmaf(x, k.inv_u, -rn);          // y - rne(y), exact
-    const bool tie = (dd == 0.5f) || (dd == -0.5f);
-    st.fast = (k.mode == KXM_A || k.mode == KXM_B) && r < 0x800000u && st.cand <= k.lim && !tie;
-    return st;
-}
-
 // The branch-free common step: folds x into the part at hand unless something is special about it (value out of range, the
 // binade may end here, a literal window is open).  Ties (frac(x/u) == 1/2) are part of it: both incoming parities are tracked.
 // `over` lanes are left untouched; a wave commits only when NO lane is over and otherwise calls kx_fold_member for all lanes.
@@ -175,49 +158,23 @@ KX_HD KxFast kx_fold_fast(const KxFold &k, float x) {
     return f;
 }
 
-// lits: this lane's literal buffer (KX_MAX_LIT floats, stride lit_stride)
-// idx: ordinal of this member inside the chunk (0, 1, ...)
-KX_HD void kx_fold_member(KxFold &k, float x, int idx, float *lits, int lit_stride) {
-    if (k.mode == KXM_DEAD) return;
-    if (k.mode == KXM_SET) { k.s = k.s + x; return; }
-    const bool plain_value = kx_f2u(x) < 0x7f800000u || kx_f2u(x) == 0x80000000u;   // +-0 .. largest finite positive
-    if (k.mode == KXM_A || k.mode == KXM_B) {
-        const KxStep st = kx_fold_probe(k, x);
-        if (st.fast) {
-            k.acc = (int32_t)st.cand;
-            return;
-        }
-        const float y = x * k.inv_u;                           // exact (power-of-two scale) for plain values in range
-        const bool in_range = plain_value && y < 8388608.0f;
-        if (in_range) {
-            // exact integer for both incoming parities; a tie (frac(y) == 1/2) rounds n + y to even
-            const float fl = __builtin_floorf(y);
-            const bool tie = (y - fl) == 0.5f;
-            int32_t a0, a1;
-            if (tie) {
-                const int32_t b0 = k.acc + (int32_t)fl, b1 = k.acc + k.dvar + (int32_t)fl + 1;
-                a0 = k.acc + (int32_t)fl + (b0 & 1);
-                a1 = k.acc + k.dvar + (int32_t)fl + (b1 & 1);
-            } else {
-                const int32_t r = (int32_t)__builtin_rintf(y);
-                a0 = k.acc + r;
-                a1 = k.acc + k.dvar + r;
-            }
-            if ((uint32_t)a0 <= k.lim && (uint32_t)a1 <= k.lim + 1u) {
-                k.acc = a0; k.dvar = a1 - a0;
-                return;
-            }
-        }
-        // the binade may end at this member (or the value is not a plain number)
-        if (k.mode == KXM_B || !plain_value) { kx_kill(k); return; }
+// The general step, for a wave in which SOME lane is over: the other lanes take their fast result, an over lane opens, continues or
+// closes its literal window, or gives up (a second binade end inside one chunk, a value that is not a plain non-negative number, more
+// literals than a record holds).  f = kx_fold_fast(k, x); idx: ordinal of this member inside the chunk; lits: this lane's literal buffer
+// (KX_MAX_LIT floats, stride lit_stride).
+KX_HD void kx_fold_step(KxFold &k, const KxFast &f, float x, int idx, float *lits, int lit_stride) {
+    if (!f.over) { k.acc = f.acc; k.dvar = f.dvar; k.s = k.s + x; return; }
+    const uint32_t xb = kx_f2u(x);
+    const bool plain_value = xb < 0x7f800000u || xb == 0x80000000u;       // +-0 .. largest finite positive
+    if (k.mode == KXM_B || !plain_value) { kx_kill(k); return; }
+    if (k.mode == KXM_A) {                                     // the binade may end at this member: it is the first literal
         k.A0 = k.acc; k.dA = k.dvar;
-        k.nA = idx;                                            // members folded in the A part
+        k.nA = idx;
         k.trk = (float)k.acc;
+        k.acc = 0; k.dvar = 0;
         k.mode = KXM_WIN;
-        // fall through: this member is the first literal
     }
-    // KXM_WIN: a literal member
-    if (!plain_value || k.nlit >= KX_MAX_LIT) { kx_kill(k); return; }
+    if (k.nlit >= KX_MAX_LIT) { kx_kill(k); return; }
     lits[k.nlit * lit_stride] = x;
     ++k.nlit;
     k.trk = k.trk + x * k.inv_u;
@@ -225,14 +182,17 @@ KX_HD void kx_fold_member(KxFold &k, float x, int idx, float *lits, int lit_stri
     if (k.n_lo + k.trk >= 16777216.0f) {
         // even the lowest plausible state is past 2^24 now: the rest of the chunk is folded one binade up
         k.eB = k.eA + 1;
-        if (k.eB > KX_E_MAX) { kx_kill(k); return; }
         const float n1_hi = (k.n_hi + k.trk) * 0.5f + 2.0f;
-        if (n1_hi > 16777214.0f) { kx_kill(k); return; }
+        if (k.eB > KX_E_MAX || n1_hi > 16777214.0f) { kx_kill(k); return; }
         k.inv_u = k.inv_u * 0.5f;
         k.acc = 0; k.dvar = 0;
         k.lim = (uint32_t)(int32_t)(16777215.0f - n1_hi);
         k.mode = KXM_B;
     }
+}
+KX_HD void kx_fold_member(KxFold &k, float x, int idx, float *lits, int lit_stride) {
+    const KxFast f = kx_fold_fast(k, x);
+    kx_fold_step(k, f, x, idx, lits, lit_stride);
 }
 
 // total: members of the chunk.  -> header, A0 (KX_SET: the bits of the literal sum), B0.  The literals stay where kx_fold_member put them.

@@ -51,7 +51,7 @@ static bool run_chain(const std::vector<float> &x, const std::vector<size_t> &cb
         kx_fold_init(k, P[c], mb[c]);
         for (size_t i = cb[c]; i < cb[c + 1]; ++i) {
             const KxFast f = kx_fold_fast(k, x[i]);
-            if (f.over || (rng() % 16 == 0)) kx_fold_member(k, x[i], (int)(i - cb[c]), rec[c].lits, 1);      // a wave takes the general step when ANY lane needs it
+            if (f.over || (rng() % 16 == 0)) kx_fold_step(k, f, x[i], (int)(i - cb[c]), rec[c].lits, 1);      // a wave takes the general step when ANY lane needs it
             else { k.acc = f.acc; k.dvar = f.dvar; k.s = k.s + x[i]; }
         }
         rec[c].hdr = kx_fold_finish(k, (int)(cb[c + 1] - cb[c]), rec[c].A0, rec[c].B0);
