@@ -1125,7 +1125,7 @@ int aoc_groupnorm_relu(const float *x, int N, int C, int64_t hw, int groups, con
                        const float *residual, int relu, float *y, void *workspace, size_t workspace_bytes, aoc_stream_t stream) {
     if (!x || !y || !workspace || N < 1 || C < 1 || hw < 1 || groups < 1) return AOC_ERR_INVALID_ARG;
     if (C % groups) return AOC_ERR_INVALID_ARG;
-    if ((int64_t)N * C > 65535ll * 16) return AOC_ERR_UNSUPPORTED;
+    if ((int64_t)N * C > 65535ll) return AOC_ERR_UNSUPPORTED;                  // gn_apply_kernel: one grid row per plane (grid.y limit); nothing is enqueued
     if (workspace_bytes < aoc_groupnorm_relu_workspace_bytes(N, groups)) return AOC_ERR_WORKSPACE;
     hipStream_t st = aoc_hip_stream(stream);
     float *stats = static_cast<float *>(workspace);

@@ -560,6 +560,13 @@ int aoc_proxy_corr_min_batched(const aoc_corr_frame *frames_host, int n_frames, 
     if (max_tiles > AOC_CORR_MAX_TILES) max_tiles = AOC_CORR_MAX_TILES;
     const int n_cu = cb_n_cus();
     const int64_t T = (m + 31) / 32;
+    // a set whose proxies do not fit the LDS image of one launch (more than max_tiles * 32 = 160 of them at C = 100, e.g. the union of the
+    // per-frame code books of hotpath.IncrementalProxyBank beyond 10 pool frames): the whole call takes the exact-fp32 kernel, which
+    // handles any set size -- decided before anything is enqueued
+    for (int s = 0; s < n_set; ++s)
+        if ((set_size_host[s] + 31) / 32 > max_tiles)
+            return aoc_corr_fp32_batched(frames_host, n_frames, m, C, n_proxy, n_set, set_begin_host, set_size_host, set_out_offset_host, 1, transform,
+                                         nullptr, stream);
 
     for (int f0 = 0; f0 < n_frames; f0 += AOC_CORR_MAX_FRAMES) {
         AocCorrFrames fr;

@@ -384,15 +384,18 @@ def proto_mask_features(cfg, ref_emb, ref_labels, prev_emb, prev_labels, cur_emb
         set_size.append(1)
         set_off.append(o * obj_stride + ch["proxy"] * hw)
         set_obj.append(o)
-    # per-set bias table (a function of the bias vector alone: kept with the sequence's state while the vector is unchanged)
-    bkey = (bias.data_ptr(), bias._version, L, O)
-    cached_bias = dense_state.get("set_bias") if dense_state is not None else None
+    # per-set bias table (a function of the bias vector alone: kept with the sequence's state while the vector is unchanged).  The cache is
+    # keyed on the CALLER's tensor; when _bias_vec had to build a new tensor (float, one element, other dtype / shape) its address says nothing
+    # about its value, so nothing is cached then
+    src = dis_bias if (torch.is_tensor(dis_bias) and dis_bias.is_cuda and dis_bias.dtype == torch.float32 and dis_bias.numel() == O) else None
+    bkey = (src.data_ptr(), src._version, L, O) if src is not None else None
+    cached_bias = dense_state.get("set_bias") if (dense_state is not None and bkey is not None) else None
     if cached_bias is not None and cached_bias[0] == bkey:
         set_bias = cached_bias[1]
     else:
         set_bias = bias.repeat_interleave(2).repeat(L) if L > 1 else bias.repeat_interleave(2)
         set_bias = torch.cat([set_bias, bias])
-        if dense_state is not None:
+        if dense_state is not None and bkey is not None:
             dense_state["set_bias"] = (bkey, set_bias)
     if cluster_ahead is not None:
         torch.cuda.current_stream().wait_event(cluster_ahead.done_event)   # join: the proxy table is complete

@@ -146,7 +146,9 @@ def global_matching_for_eval_cluster(all_reference_embeddings, query_embeddings,
                                      n_chunks=20, dis_bias=0., ori_size=None, atrous_rate=1, use_float16=True,
                                      atrous_obj_pixel_num=0, init_rows=None, cluster_num=DEFAULT_CLUSTER_NUM):
     """AEM:480-613.  -> [1, H, W, O, 2]; [1, h, w, O, 1] of ones when no reference pixel is labelled.
-    ``cluster_num`` (AEM:232; matching.py:1711 ``cluster_number``) may be a sequence of levels -> [1, H, W, O, 2 * levels]."""
+    ``cluster_num`` (AEM:232) may be a sequence of levels -> [1, H, W, O, 2 * levels].  Every level follows AEM:231-332 semantics (20 Lloyd
+    iterations, sticky K, failure -> constant), i.e. the function the model calls once per level; NOT matching.py:1711
+    ``global_matching_for_eval_cluster2`` (iter=50, per-object K without the sticky rule, no try/except), whose per-level outputs differ."""
     ops.inference_only("global_matching_for_eval_cluster", query_embeddings, dis_bias, *all_reference_embeddings)
     h, w, embedding_dim = query_embeddings.size()
     obj_nums = all_reference_labels[0].size(2)

@@ -606,7 +606,10 @@ def groupnorm_relu(x, groups, gamma, beta, eps=1e-5, residual=None, relu=True, o
     L = _lib.lib()
     y = torch.empty_like(x) if out is None else out
     ws = _ws(L.aoc_groupnorm_relu_workspace_bytes(N, int(groups)), x.device)
-    _lib.check(L.aoc_groupnorm_relu(_p(x), N, C, hw, int(groups), _p(_f32c(gamma)) if gamma is not None else None, _p(_f32c(beta)) if beta is not None else None,
+    # converted copies stay bound until the launch is enqueued: a temporary freed right after data_ptr() can be handed out again by the allocator
+    g = _f32c(gamma) if gamma is not None else None
+    b = _f32c(beta) if beta is not None else None
+    _lib.check(L.aoc_groupnorm_relu(_p(x), N, C, hw, int(groups), _p(g), _p(b),
                                     float(eps), _p(residual), int(bool(relu)), _p(y), _p(ws), ws.numel(), _stream()), "aoc_groupnorm_relu")
     return y
 
@@ -616,7 +619,8 @@ def gct_gate(plane_sums, alpha, gamma, beta, eps, l1_mode=False):
     _need_gpu(plane_sums, alpha, gamma, beta)
     N, C = plane_sums.shape
     gate = torch.empty(N, C, dtype=torch.float32, device=plane_sums.device)
-    _lib.check(_lib.lib().aoc_gct_gate(_p(plane_sums), _p(_f32c(alpha).reshape(-1)), _p(_f32c(gamma).reshape(-1)), _p(_f32c(beta).reshape(-1)), N, C,
+    al, ga, be = _f32c(alpha).reshape(-1), _f32c(gamma).reshape(-1), _f32c(beta).reshape(-1)      # kept alive across the launch
+    _lib.check(_lib.lib().aoc_gct_gate(_p(plane_sums), _p(al), _p(ga), _p(be), N, C,
                                        float(eps), int(bool(l1_mode)), _p(gate), _stream()), "aoc_gct_gate")
     return gate
 
@@ -662,6 +666,7 @@ def prehead(feat, weight, bias, n_groups, gamma, beta, eps, emb_hwc=None):
     L = _lib.lib()
     out = torch.empty(O, C + n_out, h, w, dtype=torch.float32, device=feat.device)
     ws = _ws(L.aoc_prehead_workspace_bytes(O, n_out, n_out // n_groups, h * w), feat.device)
-    _lib.check(L.aoc_prehead(_p(feat), O, n_in, h * w, _p(weight), _p(_f32c(bias)), n_out, int(n_groups), _p(_f32c(gamma)), _p(_f32c(beta)), float(eps),
+    bi, g, b = _f32c(bias), _f32c(gamma), _f32c(beta)            # kept alive across the launch (see groupnorm_relu)
+    _lib.check(L.aoc_prehead(_p(feat), O, n_in, h * w, _p(weight), _p(bi), n_out, int(n_groups), _p(g), _p(b), float(eps),
                              _p(emb_hwc), C, _p(out), _p(ws), ws.numel(), _stream()), "aoc_prehead")
     return out

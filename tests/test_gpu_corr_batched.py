@@ -108,3 +108,22 @@ def test_batched_takeover_when_values_do_not_fit(aoc):
     aoc.ops.proxy_corr_min_batched([(f[0], f[1], f[2], f[3], r) for f, r in zip(dev_frames, ref)], sb, ss, so, True, "fp32")
     for f, r in zip(dev_frames, ref):
         assert torch.equal(f[4], r)                               # bit-identical: it IS the fp32 kernel's result
+
+
+@pytest.mark.gpu
+def test_sets_beyond_the_lds_image_take_the_exact_kernel(aoc):
+    """A set with more than 160 proxies does not fit the split kernel's LDS image: the whole call must run on the exact-fp32 kernel
+    (IncrementalProxyBank builds sets of R x K proxies, 192 at R = 12) and still match the oracle."""
+    import torch
+    from oracle import matching as om
+    torch.manual_seed(3)
+    m, C = 1500, 100
+    q = torch.relu(torch.randn(m, C)) * 0.3
+    tab = torch.relu(torch.randn(200 + 16 + 1, C)) * 0.3
+    sb, ss = [0, 200, 216], [200, 16, 1]
+    bias = torch.tensor([0.1, -0.2, 0.0])
+    out = torch.empty(3, m).cuda()
+    aoc.ops.proxy_corr_min_batched([(q.cuda(), tab.cuda(), None, bias.cuda(), out)], sb, ss, [s * m for s in range(3)])
+    dist = om.flattened_pairwise_distances(tab, tab.pow(2).sum(1), q, q.pow(2).sum(1))
+    want = torch.stack([om.proto_transform(dist[:, b:b + n].min(1)[0], bias[i]) for i, (b, n) in enumerate(zip(sb, ss))])
+    assert torch.allclose(out.cpu(), want, rtol=0, atol=5e-6)
