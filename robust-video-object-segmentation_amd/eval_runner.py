@@ -21,6 +21,7 @@ from typing import List, Optional, Sequence
 import numpy as np
 import torch
 
+from . import ops
 from . import sharding
 from . import synthetic as syn
 
@@ -69,12 +70,14 @@ class HotPathBackend:
     local-window proto-mask channels, i.e. nearest-neighbour label propagation) plus a small seeded linear read-out of the pre-head output,
     which is computed because the real decoder consumes it.  Seeded, so every rank decodes identically."""
 
-    def __init__(self, device, dense_precision=None):
+    def __init__(self, device, dense_precision=None, ahead=True):
         from . import hotpath
         self.hot = hotpath
         self.device = device
         self.dense_precision = dense_precision
         self._heads = {}
+        self.ahead = bool(ahead)               # False: the per-frame reference-API path (label prep + count read-back + chain on the frame's stream)
+        self.side = None
 
     def _head(self, n_ch):
         if n_ch not in self._heads:
@@ -96,17 +99,74 @@ class HotPathBackend:
         self.bias = torch.zeros(spec.n_obj, device=self.device)
         self.rng = np.random.RandomState(spec.seed)
         self.dense_state = {}                   # per sequence: split records of the (append-only) pool, pooled reference heads
+        # the pool as ONE resident tensor that grows in place (aocnet.py:128-156 re-stacks the lists every frame), and the adaptive proxies
+        # of the frames that will see the same pool, enqueued ahead on a side stream
+        cap = spec.frames // max(spec.mem_every, 1) + 2 if spec.mem_every > 0 else 2
+        self._pool_emb = torch.empty(cap, spec.h, spec.w, 100, dtype=torch.float32, device=self.device)
+        self._pool_lab = torch.empty(cap, spec.h, spec.w, spec.n_obj, dtype=torch.float32, device=self.device)
+        self._pool_R = 0
+        self._ahead = []
+        if self.ahead and self.side is None:
+            self.side = torch.cuda.Stream(self.device, priority=-1)
 
     def first_frame(self, emb, gt_label):
         self.policy.start(emb, gt_label)
+
+    def _reference_pool(self):
+        """policy.reference_pool() without re-stacking: the frames that joined the pool since the last call are appended in place."""
+        spec, pol = self.spec, self.policy
+        R = len(pol.ref_embeddings)
+        if R > self._pool_emb.shape[0]:                     # more joins than planned (ground truth on later frames): grow
+            grow = lambda t: torch.cat([t, torch.empty_like(t)], dim=0)
+            self._pool_emb, self._pool_lab = grow(self._pool_emb), grow(self._pool_lab)
+        for r in range(self._pool_R, R):
+            self._pool_emb[r].copy_(pol.ref_embeddings[r])
+            self._pool_lab[r].copy_(ops.label_onehot_nearest(pol.ref_mask_confident[r], spec.h, spec.w, spec.n_obj))
+        changed = R != self._pool_R
+        self._pool_R = R
+        return self._pool_emb[:R], self._pool_lab[:R], pol.prev_embedding, ops.label_onehot_nearest(pol.prev_mask, spec.h, spec.w, spec.n_obj), changed
+
+    def _launch_ahead(self, ref_emb, ref_lab):
+        """The pool has changed: ONE read-back of the O + 1 row counts for all frames that will see this pool (the reference reads them
+        every frame, AEM:263-276), their initial rows drawn from the RandomState in the reference's order (frame, level, object), and their
+        k-means chains enqueued on the side stream -- the first frame's alone, the others as one batched chain."""
+        spec, mc = self.spec, self.mc
+        t = self.policy.frame_idx
+        m = spec.mem_every
+        n = (-(-t // m) * m - t + 1) if m > 0 else 5
+        n = max(1, min(n, spec.frames - t))
+        O = spec.n_obj
+        prep = ops.label_prep(ref_lab.reshape(-1, O))
+        counts = prep.counts.cpu().numpy()
+        self._ahead = []
+        if int(counts[O]) == 0:
+            return                                           # nothing labelled: the per-frame path handles it (AEM:588-589)
+        levels = mc.cluster_levels
+        kmax = max(levels)
+        inits = []
+        for _ in range(n):
+            rows = np.zeros((len(levels) * O, kmax), np.int32)
+            for li, k in enumerate(levels):
+                for i in range(O):
+                    k = min(k, int(counts[i]))               # AEM:268 (sticky, per level)
+                    if k > 0:
+                        rows[li * O + i, :k] = self.rng.permutation(int(counts[i]))[:k]
+            inits.append(torch.from_numpy(rows).to(self.device, non_blocking=True))
+        out = [self.hot.launch_cluster_proxies(mc, ref_emb, ref_lab, inits[0], self.side)]
+        if n > 1:
+            out += self.hot.launch_cluster_proxies_batch(mc, ref_emb, ref_lab, inits[1:], self.side)
+        self._ahead = out
 
     @torch.no_grad()
     def frame(self, emb):
         """emb [h, w, C] -> predicted label map [H, W] int32 (H = 4 h: the reference's masks live at image resolution)."""
         spec, h, w = self.spec, self.spec.h, self.spec.w
-        ref_emb, ref_lab, prev_emb, prev_lab = self.policy.reference_pool(h, w, spec.n_obj)
+        ref_emb, ref_lab, prev_emb, prev_lab, changed = self._reference_pool()
+        if self.ahead and (changed or not self._ahead):
+            self._launch_ahead(ref_emb, ref_lab)
+        ahead = self._ahead.pop(0) if self._ahead else None
         feat, _, _ = self.hot.proto_mask_features(self.mc, ref_emb, ref_lab, prev_emb, prev_lab, emb, self.bias, dense_precision=self.dense_precision,
-                                                  dense_state=self.dense_state, rng=self.rng)
+                                                  dense_state=self.dense_state, rng=self.rng, cluster_ahead=ahead)
         pre, wv = self._head(feat.shape[1])
         y = pre(feat)                                                          # [O, 64, h, w]
         ch = self.hot.channel_slices(self.mc)

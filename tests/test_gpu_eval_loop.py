@@ -180,3 +180,26 @@ def test_bench_two_ranks_on_one_gpu_over_gloo():
     line = lines[0]
     assert line["n_gpus"] == 2 and line["steps"] == 4 and line["scaling"] == "weak"
     assert line["value"] > 0 and abs(line["value"] - 2 * line["config"]["frames_per_step"] * 1e3 / line["ms_per_step"]) < 0.05 * line["value"]
+
+
+@pytest.mark.gpu
+def test_chains_ahead_equal_the_per_frame_reference_api_path():
+    """HotPathBackend(ahead=True) reads the row counts once per pool state, draws the initial rows of the frames that will see that pool
+    in the reference's order and enqueues their k-means chains ahead on a side stream; the predicted label maps must equal those of the
+    per-frame path (label prep + read-back + chain on every frame) bit for bit."""
+    import torch
+    from aoc_amd import eval_runner as er
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    dev = torch.device("cuda", 0)
+    spec = er.SequenceSpec("davis-like", 41, 57, 3, 14, seed=5, levels=(16,), mem_every=5)
+    data = er.load_sequence(spec, dev)
+    outs = []
+    for ahead in (False, True):
+        be = er.HotPathBackend(dev, ahead=ahead)
+        be.start(spec)
+        be.first_frame(data[0][0], data[1][0])
+        outs.append([be.frame(data[0][t]).clone() for t in range(1, spec.frames)])
+    torch.cuda.synchronize()
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
