@@ -76,3 +76,9 @@ bool aoc_kp_supported(int C, int n_seg, int kmax);
 size_t aoc_kp_workspace_bytes(int64_t rows_capacity, int n_seg, int kmax);
 int aoc_kp_chain(const float *pool, const int32_t *rows, const int32_t *seg_offsets, const int32_t *seg_k, int n_seg, int kmax, int iters,
                  int64_t rows_capacity, float *centroids, int32_t *labels, int32_t *cluster_counts, float *rownorm, void *workspace, hipStream_t st);
+
+// record pipeline for the ordered sums of the launch-per-phase k-means (kmeans_records.hip)
+bool aoc_kr_supported(int C, int kmax);
+size_t aoc_kr_workspace_bytes(int64_t rows_capacity, int n_seg, int kmax);
+int aoc_kr_sums(const float *pool, const int32_t *seg_offsets, const int32_t *seg_k, const int32_t *counts, const int32_t *cbase, const uint32_t *moff,
+                int n_seg, int kmax, int64_t rows_capacity, int64_t seg_bound, float *centroids, void *workspace, hipStream_t st);

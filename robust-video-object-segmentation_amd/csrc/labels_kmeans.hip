@@ -2022,6 +2022,8 @@ struct KsWorkspace {
     int8_t *cexp;
     uint32_t *cflag;          // per (chunk, feature group): local sums published (km_chunk_scanfold_kernel)
     int seg_chunks_max;       // no segment (hence no cluster) has more chunks than this
+    void *kr_ws = nullptr;    // workspace of the record pipeline (kmeans_records.hip), when the call has one
+    int64_t kr_cap = 0, kr_seg_bound = 0;
 };
 inline int ks_chunk_capacity(int64_t cap, int n_seg, int kmax) { return (int)(cap / KS_CHUNK) + n_seg * (kmax + 1) + 2; }
 inline size_t ks_workspace_bytes(int64_t cap, int n_seg, int kmax) {
@@ -2074,6 +2076,7 @@ inline int ks_sum_mode() {
         const char *e = getenv("AOC_KM_SUM");
         if (e && strcmp(e, "scan") == 0) return 0;
         if (e && strcmp(e, "ordered") == 0) return 1;
+        if (e && strcmp(e, "records") == 0) return 3;
         return 2;
     }();
     return mode;
@@ -2082,16 +2085,21 @@ template <int MODE>
 inline void ks_launch_sums(hipStream_t st, const float *pool, uint32_t pool_bytes, int C, const int32_t *seg_offsets, const int32_t *seg_k,
                            const int32_t *counts, const KsWorkspace &ws, int kmax, int n_seg, float *dst) {
     const int mode = ks_sum_mode();
-    const int start = (mode == 2) ? KS_HEAD_CHUNKS : 0;
+    if (MODE == 0 && mode == 3 && ws.kr_ws && aoc_kr_supported(C, kmax)) {
+        // "records": chunk-parallel exact sums with verified records on the member lists (kmeans_records.hip)
+        aoc_kr_sums(pool, seg_offsets, seg_k, counts, ws.cbase, ws.moff, n_seg, kmax, ws.kr_cap, ws.kr_seg_bound, dst, ws.kr_ws, st);
+        return;
+    }
+    const int start = (mode == 2 || mode == 3) ? KS_HEAD_CHUNKS : 0;
     static const bool fused = getenv("AOC_KM_FUSED") && atoi(getenv("AOC_KM_FUSED")) == 1;
     static const bool split_heads = getenv("AOC_KM_HEADS") && strcmp(getenv("AOC_KM_HEADS"), "kernel") == 0;   // developer switch: heads and chunk sums as two launches
-    const bool merged = mode == 2 && !(fused && C <= KC_FG * 8) && !split_heads;
+    const bool merged = (mode == 2 || mode == 3) && !(fused && C <= KC_FG * 8) && !split_heads;
     if (merged) {
         hipLaunchKernelGGL(km_heads_chunk_sums_kernel<MODE>, dim3(kmax * n_seg * os_groups(C) + ws.nch_cap), dim3((OS_NPROD + 1) * 64), 0, st, pool, pool_bytes, C,
                            seg_offsets, seg_k, counts, ws.cbase, ws.moff, kmax, n_seg, dst, KS_HEAD_CHUNKS * KS_CHUNK, ws.head, ws.owner_cluster, ws.owner_local,
                            ws.csum, start);
     } else if (mode != 0) {
-        const int cap = (mode == 2) ? KS_HEAD_CHUNKS * KS_CHUNK : 0;
+        const int cap = (mode == 2 || mode == 3) ? KS_HEAD_CHUNKS * KS_CHUNK : 0;
         hipLaunchKernelGGL(km_ordered_sum_kernel<MODE>, dim3(kmax, n_seg, os_groups(C)), dim3((OS_NPROD + 1) * 64), 0, st, pool, pool_bytes, C, seg_offsets,
                            seg_k, counts, ws.cbase, ws.moff, kmax, dst, cap, ws.head);
         if (mode == 1) return;
@@ -2191,6 +2199,7 @@ size_t aoc_kmeans_workspace_bytes(int64_t rows_capacity, int n_seg, int kmax, in
     if (rows_capacity < 0 || n_seg < 1 || kmax < 1) return 0;
     size_t b = km_launches_workspace_bytes(rows_capacity, n_seg, kmax);
     if (aoc_kp_supported(C, n_seg, kmax)) b += aoc_kp_workspace_bytes(rows_capacity, n_seg, kmax);
+    if (aoc_kr_supported(C, kmax)) b += aoc_kr_workspace_bytes(rows_capacity, n_seg, kmax);
     return b;
 }
 
@@ -2225,6 +2234,12 @@ int aoc_kmeans_segmented_ex(const float *pool, int64_t pool_rows, int C, const i
 
     hipLaunchKernelGGL(km_init_kernel, dim3(kmax, n_seg), dim3(64), 0, st, pool, C, rows, seg_offsets, seg_k, init_rows, kmax,
                        centroids, cnorm, cluster_counts);
+    if (fast && aoc_kr_supported(C, kmax)) {
+        ws.kr_ws = static_cast<char *>(workspace) + km_launches_workspace_bytes(rows_capacity, n_seg, kmax) +
+                   (aoc_kp_supported(C, n_seg, kmax) ? aoc_kp_workspace_bytes(rows_capacity, n_seg, kmax) : 0);
+        ws.kr_cap = rows_capacity;
+        ws.kr_seg_bound = seg_bound;
+    }
     // one persistent launch for all iterations (kmeans_persistent.hip), where asked for and applicable
     if (fast && km_chain_enabled() && aoc_kp_supported(C, n_seg, kmax)) {
         AOC_RETURN_IF_LAUNCH_FAILED();
