@@ -2198,8 +2198,9 @@ static bool km_chain_enabled() {
 size_t aoc_kmeans_workspace_bytes(int64_t rows_capacity, int n_seg, int kmax, int C) {
     if (rows_capacity < 0 || n_seg < 1 || kmax < 1) return 0;
     size_t b = km_launches_workspace_bytes(rows_capacity, n_seg, kmax);
-    if (aoc_kp_supported(C, n_seg, kmax)) b += aoc_kp_workspace_bytes(rows_capacity, n_seg, kmax);
-    if (aoc_kr_supported(C, kmax)) b += aoc_kr_workspace_bytes(rows_capacity, n_seg, kmax);
+    // the alternative pipelines' tables only when this process has asked for them (their switches are read once per process)
+    if (km_chain_enabled() && aoc_kp_supported(C, n_seg, kmax)) b += aoc_kp_workspace_bytes(rows_capacity, n_seg, kmax);
+    if (ks_sum_mode() == 3 && aoc_kr_supported(C, kmax)) b += aoc_kr_workspace_bytes(rows_capacity, n_seg, kmax);
     return b;
 }
 
@@ -2234,9 +2235,9 @@ int aoc_kmeans_segmented_ex(const float *pool, int64_t pool_rows, int C, const i
 
     hipLaunchKernelGGL(km_init_kernel, dim3(kmax, n_seg), dim3(64), 0, st, pool, C, rows, seg_offsets, seg_k, init_rows, kmax,
                        centroids, cnorm, cluster_counts);
-    if (fast && aoc_kr_supported(C, kmax)) {
+    if (fast && ks_sum_mode() == 3 && aoc_kr_supported(C, kmax)) {
         ws.kr_ws = static_cast<char *>(workspace) + km_launches_workspace_bytes(rows_capacity, n_seg, kmax) +
-                   (aoc_kp_supported(C, n_seg, kmax) ? aoc_kp_workspace_bytes(rows_capacity, n_seg, kmax) : 0);
+                   ((km_chain_enabled() && aoc_kp_supported(C, n_seg, kmax)) ? aoc_kp_workspace_bytes(rows_capacity, n_seg, kmax) : 0);
         ws.kr_cap = rows_capacity;
         ws.kr_seg_bound = seg_bound;
     }
