@@ -540,9 +540,10 @@ def free_port():
 
 
 def correlation_roofline(cfg, mc, dev, batches=(1, 4, 16, 32), reps=20):
-    """The correlation kernel by itself: B distinct frames per aoc_proxy_corr_min_batched launch, B in `batches`, each
-    launch bracketed by its own pair of HIP events on an otherwise idle GPU (median of `reps`; the host's preparation of the next call's
-    frame table is outside the bracket)."""
+    """The correlation kernel by itself: B distinct frames per aoc_proxy_corr_min_records launch (the product path's entry
+    point: the queries as the tile-major split records the dense kernel consumes), B in `batches`, each launch bracketed by its own pair of
+    HIP events on an otherwise idle GPU (median of `reps`; the argument marshalling is done once, outside the bracket -- the bracket holds the
+    C call, i.e. the tile-table packing, the kernel and the 4 us gated exact-fp32 take-over kernel)."""
     O, C, hw = cfg.n_obj, cfg.c, cfg.h * cfg.w
     levels = mc.cluster_levels
     L, kmax = len(levels), max(levels)
@@ -568,17 +569,19 @@ def correlation_roofline(cfg, mc, dev, batches=(1, 4, 16, 32), reps=20):
         table = torch.from_numpy((np.maximum(rng.randn(n_ad + O, C), 0) * 0.1).astype(np.float32)).to(dev)
         frames.append((q, table, table.pow(2).sum(1), torch.zeros(n_set, device=dev), torch.empty(O, mc.proto_channels, cfg.h, cfg.w, device=dev)))
     algo = hw * C * 4 + (n_ad + O) * C * 4 + 4 * hw * n_set
+    splits = [ops.split_rows(f[0], tiled=True) for f in frames]           # what the product path has made for the dense kernel anyway
     out = []
     for b in batches:
-        fr = frames[:b]
+        launch = ops.proxy_corr_min_records([(f[0], sp, f[1], f[2], f[3], f[4]) for f, sp in zip(frames[:b], splits)], sb, ss, so, True,
+                                            prepare_only=True)
         for _ in range(3):
-            ops.proxy_corr_min_batched(fr, sb, ss, so, True, "split")
+            launch()
         torch.cuda.synchronize()
         ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(reps)]
         ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(reps)]
         for i in range(reps):
             ev0[i].record()
-            ops.proxy_corr_min_batched(fr, sb, ss, so, True, "split")
+            launch()
             ev1[i].record()
         torch.cuda.synchronize()
         ms = float(np.median([ev0[i].elapsed_time(ev1[i]) for i in range(reps)]))
@@ -773,6 +776,10 @@ def main():
         m, npx = frames[0][0].shape[0], frames[0][1].shape[0]
         return dict(flops=2.0 * m * npx * C * len(frames), bytes=(m * C * 4 + npx * C * 4 + m * len(set_begin) * 4) * len(frames), frames=len(frames))
 
+    def meta_proxy_records(frames, set_begin, *a, **k):
+        m, npx = frames[0][0].shape[0], frames[0][2].shape[0]
+        return dict(flops=2.0 * m * npx * C * len(frames), bytes=(m * C * 4 + npx * C * 4 + m * len(set_begin) * 4) * len(frames), frames=len(frames))
+
     def meta_kmeans(pool, rows, seg_offsets, seg_k, init_rows, kmax, iters=20, rows_capacity=None):
         n = pool.shape[0]
         return dict(flops=2.0 * iters * n * kmax * C, bytes=float(iters) * n * C * 4 * 2 + n * 4)
@@ -785,11 +792,12 @@ def main():
 
     # HIP-event pairs only around the ops the roofline objects need (an event pair costs ~25 us of host time, and the host
     # enqueues ~60 ops per frame); every kernel's duration is in the rocprofv3 summary under profiles/
-    timer = OpTimer(["dense_match_min", "dense_match_min_split", "proxy_corr_min", "proxy_corr_min_batched", "kmeans_segmented", "local_window_match",
+    timer = OpTimer(["dense_match_min", "dense_match_min_split", "proxy_corr_min", "proxy_corr_min_batched", "proxy_corr_min_records", "kmeans_segmented",
+                     "local_window_match",
                      "film_scale", "cond_gate_pool"])
     timer.serialize_dense = not args.no_dense_order
     timer.install(dict(dense_match_min=meta_dense, dense_match_min_split=meta_dense_split, proxy_corr_min=meta_proxy,
-                       proxy_corr_min_batched=meta_proxy_batched, kmeans_segmented=meta_kmeans, film_scale=meta_film, cond_gate_pool=meta_cond))
+                       proxy_corr_min_batched=meta_proxy_batched, proxy_corr_min_records=meta_proxy_records, kmeans_segmented=meta_kmeans, film_scale=meta_film, cond_gate_pool=meta_cond))
     corr_stream = torch.cuda.Stream(device=dev) if batch_corr else None
 
     def run_steps(n):
@@ -968,11 +976,13 @@ def main():
         cond_roof = hbm_roof("cond_gate_pool", "cond_scores / cond_kth_largest / cond_masked_gap (aoc_cond_gate_pool)",
                              "in-run average over the 4 conditioning blocks; algorithmic bytes O C H W 4 = ONE read of z (SURVEY 8d); the op reads z twice "
                              "(scores, masked pooling) around the exact k-th-largest selection")
-        corr_name = "proxy_corr_min_batched" if "proxy_corr_min_batched" in kernels else "proxy_corr_min"
+        corr_name = next((k for k in ("proxy_corr_min_records", "proxy_corr_min_batched") if k in kernels), "proxy_corr_min")
         corr = kernels.get(corr_name)
         corr_roof = None
         if corr and "gbs" in corr:
-            corr_roof = dict(kernel="proxy_corr_batched_kernel (aoc_proxy_corr_min_batched)" if corr_name.endswith("batched") else "proxy_corr_min_kernel",
+            corr_roof = dict(kernel={"proxy_corr_min_records": "proxy_corr_records_kernel (aoc_proxy_corr_min_records: the query as the tile-major "
+                                                               "split records the dense kernel consumes)",
+                                     "proxy_corr_min_batched": "proxy_corr_batched_kernel (aoc_proxy_corr_min_batched)"}.get(corr_name, "proxy_corr_min_kernel"),
                              bound="hbm", achieved=corr["gbs"], peak=PEAK_HBM_GBS, unit="GB/s",
                              frac=round(corr["gbs"] / PEAK_HBM_GBS, 4), avg_launch_ms=corr["avg_ms"], algorithmic_bytes_per_launch=corr["avg_bytes"],
                              frames_per_launch=n_streams if batch_corr else 1,
@@ -1054,8 +1064,8 @@ def main():
                        "sequences_per_gpu": n_streams, "frames_per_step": n_streams, "sharding": "sequences over ranks, no data-path collective",
                        "intra_frame_overlap": ("none" if args.no_overlap else "k-means chain on a side HIP stream" +
                                                ("" if args.no_pipeline else ", enqueued as soon as the pool it depends on is final")),
-                       "correlation": ("ONE aoc_proxy_corr_min_batched launch per step for the frames of all in-flight sequences" if batch_corr
-                                       else "one aoc_proxy_corr_min_batched launch (fp16-split kernel, one frame) per sequence and frame"),
+                       "correlation": ("ONE aoc_proxy_corr_min_records launch per step for the frames of all in-flight sequences" if batch_corr
+                                       else "one aoc_proxy_corr_min_records launch (fp16-split kernel on the query's split records, one frame) per sequence and frame"),
                        "cu_reserve": (f"main streams masked off {args.cu_reserve} of {n_cu} CUs (hipExtStreamCreateWithCUMask), left to the side-stream "
                                       "k-means chains" if args.cu_reserve > 0 else "none"),
                        "proxy_mode": ("NON-PARITY: every reference frame clustered once when it joins the pool, frames matched against the union of the "

@@ -221,6 +221,26 @@ int aoc_proxy_corr_min_batched(const aoc_corr_frame *frames_host, int n_frames, 
                                const int64_t *set_out_offset_host, int transform, int precision,
                                void *workspace, size_t workspace_bytes, aoc_stream_t stream);
 
+/* The same correlation (AEM:92-128 + 316-319, proto-mask transform of AEM:393/602/864) with the query side handed over as the
+ * tile-major fp16 split records of aoc_split_rows_tiled -- what the dense kernel consumes for the same frame (aoc_dense_match_min_split
+ * with query_rec_tiled = 1), so a frame's query is converted once and both kernels stream it in their MFMA operand layout.  Always the
+ * fp16-split arithmetic (C = 100) with the same device-side take-over by the exact-fp32 kernel (which reads `query`); results equal
+ * aoc_proxy_corr_min_batched(precision = AOC_CORR_SPLIT) up to the summation order of |q|^2 (query_sqnorm is the sequential sum).
+ * Same workspace as aoc_proxy_corr_min_batched. */
+typedef struct aoc_corr_frame_rec {
+    const float *query;         /* [m, C] fp32 rows (take-over only) */
+    const void *query_rec;      /* aoc_split_rows_tiled(query) */
+    const float *query_sqnorm;  /* [m], from the same call */
+    const float *proxies;       /* [n_proxy, C] */
+    const float *proxy_sqnorm;  /* [n_proxy] (+inf = ignore) or NULL */
+    const float *set_bias;      /* [n_set] or NULL */
+    float *out;
+} aoc_corr_frame_rec;
+int aoc_proxy_corr_min_records(const aoc_corr_frame_rec *frames_host, int n_frames, int64_t m, int C, int n_proxy, int n_set,
+                               const int32_t *set_begin_host, const int32_t *set_size_host,
+                               const int64_t *set_out_offset_host, int transform,
+                               void *workspace, size_t workspace_bytes, aoc_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Dense pixel-level matching: AEM:178-227 + 61-89 without materialising [m, O, n]:
  *   out[i,o] = min_j ( (|q_i|^2 + |r_j|^2) - 2 q_i.r_j + 5e4 * wrong[j,o] ),  j over kept rows,
@@ -271,16 +291,23 @@ int aoc_dense_match_min_f16(const float *query, int64_t m, int C,
  *  aoc_split_record_bytes(C)   bytes per record (448) or 0 when C is unsupported (C % 4 != 0 or C > 100)
  *  aoc_split_rows              x [n, C] -> records [n * record_bytes], sqnorm [n] (may be NULL);
  *                              *overflow_flag |= 1 when a value does not fit (flag is sticky, caller zeroes it)
+ *  aoc_split_rows_tiled        the same 16-byte chunks in tile-major order: per 32-row tile, per plane (hi, lo), per k-step the
+ *                              64 chunks [k-half][row % 32] -- one coalesced 1 KiB wave load per MFMA B operand.  The buffer
+ *                              holds whole tiles (aoc_split_rows_tiled_bytes(n, C)); rows past n are zero records.
  *  aoc_dense_match_min_split   query/pool [*, C] fp32 (only read by the fp32 take-over), query_rec/pool_rec
- *                              their records, query_sqnorm [m]; n = pool rows; right_bits, wrong_bits, fg_rows,
+ *                              their records (query_rec_tiled != 0: query_rec is tile-major; the pool's are always row-major),
+ *                              query_sqnorm [m]; n = pool rows; right_bits, wrong_bits, fg_rows,
  *                              obj_rows, counts, obj_offsets as produced by aoc_label_prep on the n pool rows;
  *                              out / strides / transform as aoc_dense_match_min.  n_obj <= 16.
  */
 size_t aoc_split_record_bytes(int C);
 int aoc_split_rows(const float *x, int64_t n, int C, void *records, float *sqnorm,
                    int32_t *overflow_flag, aoc_stream_t stream);
+size_t aoc_split_rows_tiled_bytes(int64_t n, int C);
+int aoc_split_rows_tiled(const float *x, int64_t n, int C, void *records, float *sqnorm,
+                         int32_t *overflow_flag, aoc_stream_t stream);
 size_t aoc_dense_match_split_workspace_bytes(int64_t m, int64_t n, int n_obj);
-int aoc_dense_match_min_split(const float *query, const void *query_rec, const float *query_sqnorm,
+int aoc_dense_match_min_split(const float *query, const void *query_rec, const float *query_sqnorm, int query_rec_tiled,
                               int64_t m, int C, const float *pool, const void *pool_rec,
                               const int32_t *overflow_flag, int64_t n,
                               const uint32_t *right_bits, const uint32_t *wrong_bits,

@@ -43,6 +43,7 @@ SIGNATURES = {
     "aoc_proxy_corr_min": (_i, [_vp, _i64, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i64, _i, _vp]),
     "aoc_proxy_corr_min_batched_workspace_bytes": (_sz, []),
     "aoc_proxy_corr_min_batched": (_i, [_vp, _i, _i64, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _sz, _vp]),
+    "aoc_proxy_corr_min_records": (_i, [_vp, _i, _i64, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
     "aoc_dense_match_workspace_bytes": (_sz, [_i64, _i64, _i]),
     "aoc_dense_match_min": (_i, [_vp, _i64, _i, _vp, _vp, _vp, _i64, _vp, _vp, _i, _vp, _i64, _i64, _i, _vp, _sz, _vp]),
     "aoc_dense_match_min_f16": (_i, [_vp, _i64, _i, _vp, _vp, _vp, _i64, _vp, _vp, _i, _vp, _i64, _i64, _i, _vp, _sz, _vp]),
@@ -50,9 +51,11 @@ SIGNATURES = {
     "aoc_dense_match_set_probe": (_i, [_vp, _vp]),
     "aoc_split_record_bytes": (_sz, [_i]),
     "aoc_split_rows": (_i, [_vp, _i64, _i, _vp, _vp, _vp, _vp]),
+    "aoc_split_rows_tiled_bytes": (_sz, [_i64, _i]),
+    "aoc_split_rows_tiled": (_i, [_vp, _i64, _i, _vp, _vp, _vp, _vp]),
     "aoc_dense_match_split_workspace_bytes": (_sz, [_i64, _i64, _i]),
     "aoc_dense_prune_stats": (_i, [_vp, _i]),
-    "aoc_dense_match_min_split": (_i, [_vp, _vp, _vp, _i64, _i, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i64, _i64, _i,
+    "aoc_dense_match_min_split": (_i, [_vp, _vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i64, _i64, _i,
                                        _vp, _sz, _vp]),
     "aoc_local_window_match": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp]),
     "aoc_resize_bilinear_hwc": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _vp]),

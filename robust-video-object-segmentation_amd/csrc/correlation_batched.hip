@@ -151,6 +151,264 @@ __device__ __forceinline__ float cb_halfsum(float a) {
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
+struct CbImage {            // the block's LDS image of one frame's proxies and its epilogue tables
+    AocCorrTiles *tiles;
+    uint32_t *img;           // [n_rows][CB_ROW_DW]
+    int32_t *src;            // [n_rows] proxy row feeding each image row (-1: none)
+    float *norm;             // [n_rows] |p|^2 of that proxy
+    int32_t *first;          // [AOC_CORR_MAX_OUT] first valid image row of each output column (-1: absent)
+    CbSlotDesc *slot;        // [NT][2]
+    CbColDesc *col;          // [32]
+};
+
+// Stage one frame's proxy image (all threads of the block; ends with a barrier).  REC: k order of the split records (the query side is
+// consumed straight from aoc_split_rows_tiled records); else the lane-half order of proxy_corr_batched_kernel.
+template <int NTH, int NT, bool COL0, bool REC>
+__device__ __forceinline__ void cb_stage_frame(const CbImage &L, const float *__restrict__ proxies, const float *__restrict__ sqnorm,
+                                               const float *__restrict__ bias, bool &bad) {
+    constexpr int n_rows = NT * 32;
+    // phase 1: which proxy feeds each image row, its norm
+    for (int r = threadIdx.x; r < n_rows; r += NTH) {
+        const AocCorrTile &tl = L.tiles->t[r >> 5];
+        const int rr = r & 31;
+        int src = -1;
+        if (tl.kind == 1) {
+            if (rr < tl.cnt[0]) src = tl.begin[0] + rr;
+            else if (tl.gs == 1 && rr >= 16 && rr - 16 < tl.cnt[0]) src = tl.begin[0] + rr - 16;   // stacked: row 16 + i = the lo pieces of proxy i
+        } else {
+            const int g = rr >> 3, e = rr & 7;
+            if (e < tl.cnt[g]) src = tl.begin[g] + e;
+        }
+        float nrm = INFINITY;
+        if (src >= 0) {
+            if (sqnorm) {
+                nrm = sqnorm[src];
+            } else {
+                const float4 *p = reinterpret_cast<const float4 *>(proxies + (size_t)src * 100);
+                float sacc = 0.0f;
+                for (int t = 0; t < 25; ++t) {
+                    const float4 x = p[t];
+                    sacc = __builtin_fmaf(x.x, x.x, sacc); sacc = __builtin_fmaf(x.y, x.y, sacc);
+                    sacc = __builtin_fmaf(x.z, x.z, sacc); sacc = __builtin_fmaf(x.w, x.w, sacc);
+                }
+                nrm = sacc;
+            }
+            if (!(nrm < INFINITY)) src = -1;                              // +inf (or NaN) norm: proxy absent (AEM:271-273, 283-286)
+            else if (nrm > CB_MAX_SQ) bad = true;
+        }
+        L.src[r] = src;
+        L.norm[r] = nrm;
+    }
+    __syncthreads();
+    // phase 2: per output column the first valid row of its set (pads of the set's row groups are filled with a copy of it:
+    // a duplicate never changes a min); columns of a column-wise tile are their own set
+    for (int oc = threadIdx.x; oc < L.tiles->n_out; oc += NTH) {
+        const int r0 = L.tiles->oc_row0[oc], nr = L.tiles->oc_rows[oc];
+        int first = -1;
+        for (int r = r0; r < r0 + nr; ++r)
+            if (L.src[r] >= 0) { first = r; break; }
+        L.first[oc] = first;
+    }
+    __syncthreads();
+    // phase 3: one item per (image row, float4 of the proxy row): consecutive threads read consecutive 16 bytes; the two packed
+    // hi pairs land at dwords e, e+1 of the half's hi plane, the lo pairs at the same place of its lo plane
+    for (int it0 = threadIdx.x; it0 < n_rows * 25; it0 += 4 * NTH) {
+        // four items per trip: their global loads are all in flight before the first is converted
+        float4 xs[4];
+        int srcs[4], srows[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int it = it0 + u * NTH;
+            xs[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            srcs[u] = -1; srows[u] = -1;
+            if (it < n_rows * 25) {
+                const int r = it / 25, t = it - r * 25;
+                const AocCorrTile &tl = L.tiles->t[r >> 5];
+                int srow = r;                                             // image row whose proxy is copied here
+                if (L.src[r] < 0) {
+                    const int oc = tl.kind == 0 ? tl.oc[(r & 31) >> 3] : -1;
+                    srow = oc >= 0 ? L.first[oc] : -1;
+                }
+                srows[u] = srow;
+                srcs[u] = srow >= 0 ? L.src[srow] : -1;
+                if (srcs[u] >= 0) xs[u] = reinterpret_cast<const float4 *>(proxies + (size_t)srcs[u] * 100)[t];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int it = it0 + u * NTH;
+            if (it >= n_rows * 25) continue;
+            const int r = it / 25, t = it - r * 25;
+            const float4 x = xs[u];
+            const int src = srcs[u], srow = srows[u];
+            const float am = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(x.x), __builtin_fabsf(x.y)), __builtin_fmaxf(__builtin_fabsf(x.z), __builtin_fabsf(x.w)));
+            if (am > CB_MAX_ABS) bad = true;
+            uint32_t hi0, hi1, lo0, lo1;
+            cb_split_pair(x.x, x.y, hi0, lo0);
+            cb_split_pair(x.z, x.w, hi1, lo1);
+            // stacked column-wise tile: rows 16 .. 31 carry the lo pieces of proxies 0 .. 15 in the HI plane (and no norm pieces), so that
+            // [ph ; pl] x qh and [ph ; pl] x ql -- 14 MFMAs -- give all four partial products in two row groups of one accumulator
+            const AocCorrTile &tl3 = L.tiles->t[r >> 5];
+            const bool lo_row = tl3.kind == 1 && tl3.gs == 1 && (r & 31) >= 16;
+            if (lo_row) { hi0 = lo0; hi1 = lo1; lo0 = 0u; lo1 = 0u; }
+            uint32_t *row = L.img + (size_t)r * CB_ROW_DW;
+            if (REC) {
+                // record order (dense_split.hip): k-step s holds slots 16 s .. 16 s + 15, lane half hh the slots 16 s + 8 hh .. + 7; channels
+                // 4 t .. 4 t + 3 are slots of k-step t / 4, half (t / 2) % 2, dwords 2 (t % 2), + 1 of that chunk; norm pieces in slots 100 .. 102
+                uint32_t *d = row + ((t >> 1) & 1) * CB_HALF_DW + (t >> 2) * 4 + (t & 1) * 2;
+                d[0] = hi0; d[1] = hi1;
+                d[CB_SEG_DW] = lo0; d[CB_SEG_DW + 1] = lo1;
+                if (t == 24) {
+                    const float a = (src >= 0 && !lo_row) ? -16.0f * L.norm[srow] : 0.0f;
+                    const _Float16 n0 = (_Float16)a;
+                    const _Float16 n1 = (_Float16)(a - (float)n0);
+                    const _Float16 n2 = (_Float16)((a - (float)n0) - (float)n1);
+                    uint32_t *d1 = row + CB_HALF_DW;
+                    d[2] = pack_f16(n0, n1); d[3] = pack_f16(n2, (_Float16)0.0f);
+                    d[CB_SEG_DW + 2] = 0u; d[CB_SEG_DW + 3] = 0u;
+#pragma unroll
+                    for (int z = 24; z < 28; ++z) { d1[z] = 0u; d1[CB_SEG_DW + z] = 0u; }
+                }
+            } else if (t < 24) {
+                uint32_t *d = row + (t >= 12 ? CB_HALF_DW : 0) + 2 * (t >= 12 ? t - 12 : t);
+                d[0] = hi0; d[1] = hi1;
+                d[CB_SEG_DW] = lo0; d[CB_SEG_DW + 1] = lo1;
+            } else {
+                // channels 96, 97 -> pair 24 of half 0; 98, 99 -> pair 24 of half 1; then the norm slots (hi plane, dword 25) and the padding
+                const float a = (src >= 0 && !lo_row) ? -16.0f * L.norm[srow] : 0.0f;
+                const _Float16 n0 = (_Float16)a;
+                const _Float16 n1 = (_Float16)(a - (float)n0);
+                const _Float16 n2 = (_Float16)((a - (float)n0) - (float)n1);
+                uint32_t *d0 = row, *d1 = row + CB_HALF_DW;
+                d0[24] = hi0; d0[25] = pack_f16(n0, n1); d0[26] = 0u; d0[27] = 0u;
+                d0[CB_SEG_DW + 24] = lo0; d0[CB_SEG_DW + 25] = 0u; d0[CB_SEG_DW + 26] = 0u; d0[CB_SEG_DW + 27] = 0u;
+                d1[24] = hi1; d1[25] = pack_f16(n2, (_Float16)0.0f); d1[26] = 0u; d1[27] = 0u;
+                d1[CB_SEG_DW + 24] = lo1; d1[CB_SEG_DW + 25] = 0u; d1[CB_SEG_DW + 26] = 0u; d1[CB_SEG_DW + 27] = 0u;
+            }
+        }
+    }
+    // phase 4: epilogue constants per (tile, lane half): which output plane each store slot writes, its bias, whether its set exists.
+    // Slot a of half hh: gs 4 -> the set (half 0 of its last tile only); gs 2 -> set hh; gs 1 -> set 2 hh.  Slot b: gs 1 -> set 2 hh + 1.
+    for (int it = threadIdx.x; it < NT * 2; it += NTH) {
+        const int ti = it >> 1, hh = it & 1;
+        const AocCorrTile &tl = L.tiles->t[ti];
+        int oca = -1, ocb = -1;
+        if (tl.kind == 0) {
+            if (tl.gs == 4) oca = (tl.last && hh == 0) ? tl.oc[0] : -1;
+            else if (tl.gs == 2) oca = tl.oc[2 * hh];
+            else { oca = tl.oc[2 * hh]; ocb = tl.oc[2 * hh + 1]; }
+        }
+        CbSlotDesc dsc;
+        dsc.off_a = oca >= 0 ? (int32_t)L.tiles->oc_offset[oca] : -1;
+        dsc.off_b = ocb >= 0 ? (int32_t)L.tiles->oc_offset[ocb] : -1;
+        dsc.bias_a = (oca >= 0 && bias) ? bias[L.tiles->oc_bias[oca]] : 0.0f;
+        dsc.bias_b = (ocb >= 0 && bias) ? bias[L.tiles->oc_bias[ocb]] : 0.0f;
+        dsc.valid_a = oca >= 0 ? (L.first[oca] >= 0) : 0;
+        dsc.valid_b = ocb >= 0 ? (L.first[ocb] >= 0) : 0;
+        dsc.pad0 = dsc.pad1 = 0;
+        L.slot[it] = dsc;
+    }
+    if (COL0) {
+        for (int row = threadIdx.x; row < 32; row += NTH) {
+            const AocCorrTile &tl = L.tiles->t[0];
+            CbColDesc c;
+            const bool on = row < tl.cnt[0];
+            const int oc = tl.oc[0] + (on ? row : 0);
+            c.off = on ? (int32_t)L.tiles->oc_offset[oc] : -1;
+            c.bias = (on && bias) ? bias[L.tiles->oc_bias[oc]] : 0.0f;
+            c.valid = on ? (L.first[oc] >= 0) : 0;
+            c.pad = 0;
+            L.col[row] = c;
+        }
+    }
+    __syncthreads();
+
+}
+
+// One 32-pixel tile against the NT proxy tiles of the image: 21 chained MFMAs per proxy tile, the in-register min (a max over raw
+// accumulators), the proto-mask transform and the stores.  `after_last_chain` runs once the last chain has consumed `seq`.
+template <int NT, bool COL0, typename Hook>
+__device__ __forceinline__ void cb_tile_compute(const CbImage &L, const AocCorrTiles &tiles, const PixelSeq &seq, float q2, float *out_pix,
+                                                bool live, float *dump, int transform, int j, int h, Hook after_last_chain) {
+    float carry = -INFINITY;
+#pragma unroll
+    for (int ti = 0; ti < NT; ++ti) {
+        const uint4 *arow = reinterpret_cast<const uint4 *>(L.img + (size_t)(ti * 32 + j) * CB_ROW_DW + h * CB_HALF_DW);
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;           // folds into the first MFMA's constant C operand (no unconditional path around the chain)
+        const bool stacked = COL0 && ti == 0 && tiles.t[0].gs == 1;           // rows [ph ; pl]: no separate lo-plane product
+#pragma unroll
+        for (int s = 0; s < CB_SEG_STEPS; ++s) {              // q.p = qh.ph + qh.pl + ql.ph (the norm slots ride in the hi x hi product)
+            const f16x8 ah = __builtin_bit_cast(f16x8, arow[s]);
+            const f16x8 bh = __builtin_bit_cast(f16x8, seq.bh[s]);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
+            if (!stacked) {
+                const f16x8 al = __builtin_bit_cast(f16x8, arow[CB_SEG_STEPS + s]);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc, 0, 0, 0);
+            }
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, __builtin_bit_cast(f16x8, seq.bl[s]), acc, 0, 0, 0);
+        }
+        if (ti == NT - 1) after_last_chain();                     // `seq` is free from here on
+        if (COL0 && ti == 0) {
+            // column-wise tile: every row is its own output (k = 1 proxies, no min: AEM:127).  Register r of lane half h is
+            // row (r / 4) * 8 + 4 h + r % 4; row groups beyond the tile's rows are skipped with uniform branches.
+            const int cnt = tiles.t[0].cnt[0];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                if (8 * g < cnt) {
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const CbColDesc c = L.col[8 * g + 4 * h + u];
+                        // stacked (cnt <= 16, g < 2): row r holds ph.(qh + ql), row 16 + r = register + 8 of the same lane holds pl.(qh + ql)
+                        const float raw = (stacked && g < 2) ? acc[4 * g + u] + acc[4 * g + 8 + u] : acc[4 * g + u];
+                        float d = c.valid ? q2 + CB_UNSCALE * raw : AOC_PAD_DISTANCE;
+                        const float td = cb_transform(d, c.bias);
+                        d = transform ? td : d;
+                        float *p = (c.off >= 0 && live) ? out_pix + c.off : dump;
+                        *p = d;
+                    }
+                }
+            }
+            continue;
+        }
+        // grouped tile: group g = rows 8g .. 8g+7 = registers 4g .. 4g+3 of both lane halves
+        const CbSlotDesc sd = L.slot[ti * 2 + h];
+        const int gs = tiles.t[ti].gs;
+        float gm[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            gm[g] = __builtin_fmaxf(__builtin_fmaxf(acc[4 * g], acc[4 * g + 1]), __builtin_fmaxf(acc[4 * g + 2], acc[4 * g + 3]));
+        float va, vb = 0.0f;
+        if (gs == 4) {                                                // one set spanning the tile (possibly continued from / into neighbours)
+            float v = __builtin_fmaxf(__builtin_fmaxf(gm[0], gm[1]), __builtin_fmaxf(gm[2], gm[3]));
+            v = cb_halfmax2(v, v);
+            if (!tiles.t[ti].first) v = __builtin_fmaxf(v, carry);
+            carry = v;
+            va = v;
+        } else if (gs == 2) {                                         // two sets: lane half h ends up with set h
+            va = cb_halfmax2(__builtin_fmaxf(gm[0], gm[1]), __builtin_fmaxf(gm[2], gm[3]));
+        } else {                                                      // four sets: lane half h ends up with sets 2h (slot a), 2h + 1 (slot b)
+            va = cb_halfmax2(gm[0], gm[2]);
+            vb = cb_halfmax2(gm[1], gm[3]);
+        }
+        {
+            float d = sd.valid_a ? q2 + CB_UNSCALE * va : AOC_PAD_DISTANCE;
+            const float td = cb_transform(d, sd.bias_a);
+            d = transform ? td : d;
+            float *p = (sd.off_a >= 0 && live) ? out_pix + sd.off_a : dump;
+            *p = d;
+        }
+        if (gs == 1) {
+            float d = sd.valid_b ? q2 + CB_UNSCALE * vb : AOC_PAD_DISTANCE;
+            const float td = cb_transform(d, sd.bias_b);
+            d = transform ? td : d;
+            float *p = (sd.off_b >= 0 && live) ? out_pix + sd.off_b : dump;
+            *p = d;
+        }
+    }
+}
+
 // NT = proxy tiles of the launch; COL0: tile 0 is the column-wise tile (k = 1 proxies).  Block = NW waves, three per SIMD: while one
 // wave converts its next pixel tile (VALU) or waits for LDS, its partner's MFMA chain keeps the matrix pipe busy.
 template <int NW, int NT, bool COL0>
@@ -172,6 +430,7 @@ __global__ __launch_bounds__(NW * 64) void proxy_corr_batched_kernel(AocCorrFram
     CbSlotDesc *lslot = reinterpret_cast<CbSlotDesc *>(lfirst + AOC_CORR_MAX_OUT);   // [NT][2]
     CbColDesc *lcol = reinterpret_cast<CbColDesc *>(lslot + NT * 2);          // [32]
     uint32_t *wbuf_all = reinterpret_cast<uint32_t *>(lcol + 32);             // [NW][6 400 B]
+    const CbImage img = {&ltiles, limg, lsrc, lnorm, lfirst, lslot, lcol};
     float *dump = reinterpret_cast<float *>(gate) + 16 + (threadIdx.x & 31);  // where masked-off lanes store
 
     const int lane = threadIdx.x & 63;
@@ -272,139 +531,7 @@ __global__ __launch_bounds__(NW * 64) void proxy_corr_batched_kernel(AocCorrFram
 
     for (int f = f_beg; f < f_end; ++f) {
         const AocCorrFrame fr = frames.f[f];
-        // ---- stage this frame's proxy image -----------------------------------------------------------------
-        // phase 1: which proxy feeds each image row, its norm
-        for (int r = threadIdx.x; r < n_rows; r += NTH) {
-            const AocCorrTile &tl = ltiles.t[r >> 5];
-            const int rr = r & 31;
-            int src = -1;
-            if (tl.kind == 1) {
-                if (rr < tl.cnt[0]) src = tl.begin[0] + rr;
-            } else {
-                const int g = rr >> 3, e = rr & 7;
-                if (e < tl.cnt[g]) src = tl.begin[g] + e;
-            }
-            float nrm = INFINITY;
-            if (src >= 0) {
-                if (fr.sqnorm) {
-                    nrm = fr.sqnorm[src];
-                } else {
-                    const float4 *p = reinterpret_cast<const float4 *>(fr.proxies + (size_t)src * 100);
-                    float sacc = 0.0f;
-                    for (int t = 0; t < 25; ++t) {
-                        const float4 x = p[t];
-                        sacc = __builtin_fmaf(x.x, x.x, sacc); sacc = __builtin_fmaf(x.y, x.y, sacc);
-                        sacc = __builtin_fmaf(x.z, x.z, sacc); sacc = __builtin_fmaf(x.w, x.w, sacc);
-                    }
-                    nrm = sacc;
-                }
-                if (!(nrm < INFINITY)) src = -1;                              // +inf (or NaN) norm: proxy absent (AEM:271-273, 283-286)
-                else if (nrm > CB_MAX_SQ) bad = true;
-            }
-            lsrc[r] = src;
-            lnorm[r] = nrm;
-        }
-        __syncthreads();
-        // phase 2: per output column the first valid row of its set (pads of the set's row groups are filled with a copy of it:
-        // a duplicate never changes a min); columns of a column-wise tile are their own set
-        for (int oc = threadIdx.x; oc < ltiles.n_out; oc += NTH) {
-            const int r0 = ltiles.oc_row0[oc], nr = ltiles.oc_rows[oc];
-            int first = -1;
-            for (int r = r0; r < r0 + nr; ++r)
-                if (lsrc[r] >= 0) { first = r; break; }
-            lfirst[oc] = first;
-        }
-        __syncthreads();
-        // phase 3: one item per (image row, float4 of the proxy row): consecutive threads read consecutive 16 bytes; the two packed
-        // hi pairs land at dwords e, e+1 of the half's hi plane, the lo pairs at the same place of its lo plane
-        for (int it0 = threadIdx.x; it0 < n_rows * 25; it0 += 4 * NTH) {
-            // four items per trip: their global loads are all in flight before the first is converted
-            float4 xs[4];
-            int srcs[4], srows[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int it = it0 + u * NTH;
-                xs[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                srcs[u] = -1; srows[u] = -1;
-                if (it < n_rows * 25) {
-                    const int r = it / 25, t = it - r * 25;
-                    const AocCorrTile &tl = ltiles.t[r >> 5];
-                    int srow = r;                                             // image row whose proxy is copied here
-                    if (lsrc[r] < 0) {
-                        const int oc = tl.kind == 0 ? tl.oc[(r & 31) >> 3] : -1;
-                        srow = oc >= 0 ? lfirst[oc] : -1;
-                    }
-                    srows[u] = srow;
-                    srcs[u] = srow >= 0 ? lsrc[srow] : -1;
-                    if (srcs[u] >= 0) xs[u] = reinterpret_cast<const float4 *>(fr.proxies + (size_t)srcs[u] * 100)[t];
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int it = it0 + u * NTH;
-                if (it >= n_rows * 25) continue;
-                const int r = it / 25, t = it - r * 25;
-                const float4 x = xs[u];
-                const int src = srcs[u], srow = srows[u];
-                const float am = __builtin_fmaxf(__builtin_fmaxf(__builtin_fabsf(x.x), __builtin_fabsf(x.y)), __builtin_fmaxf(__builtin_fabsf(x.z), __builtin_fabsf(x.w)));
-                if (am > CB_MAX_ABS) bad = true;
-                uint32_t hi0, hi1, lo0, lo1;
-                cb_split_pair(x.x, x.y, hi0, lo0);
-                cb_split_pair(x.z, x.w, hi1, lo1);
-                uint32_t *row = limg + (size_t)r * CB_ROW_DW;
-                if (t < 24) {
-                    uint32_t *d = row + (t >= 12 ? CB_HALF_DW : 0) + 2 * (t >= 12 ? t - 12 : t);
-                    d[0] = hi0; d[1] = hi1;
-                    d[CB_SEG_DW] = lo0; d[CB_SEG_DW + 1] = lo1;
-                } else {
-                    // channels 96, 97 -> pair 24 of half 0; 98, 99 -> pair 24 of half 1; then the norm slots (hi plane, dword 25) and the padding
-                    const float a = src >= 0 ? -16.0f * lnorm[srow] : 0.0f;
-                    const _Float16 n0 = (_Float16)a;
-                    const _Float16 n1 = (_Float16)(a - (float)n0);
-                    const _Float16 n2 = (_Float16)((a - (float)n0) - (float)n1);
-                    uint32_t *d0 = row, *d1 = row + CB_HALF_DW;
-                    d0[24] = hi0; d0[25] = pack_f16(n0, n1); d0[26] = 0u; d0[27] = 0u;
-                    d0[CB_SEG_DW + 24] = lo0; d0[CB_SEG_DW + 25] = 0u; d0[CB_SEG_DW + 26] = 0u; d0[CB_SEG_DW + 27] = 0u;
-                    d1[24] = hi1; d1[25] = pack_f16(n2, (_Float16)0.0f); d1[26] = 0u; d1[27] = 0u;
-                    d1[CB_SEG_DW + 24] = lo1; d1[CB_SEG_DW + 25] = 0u; d1[CB_SEG_DW + 26] = 0u; d1[CB_SEG_DW + 27] = 0u;
-                }
-            }
-        }
-        // phase 4: epilogue constants per (tile, lane half): which output plane each store slot writes, its bias, whether its set exists.
-        // Slot a of half hh: gs 4 -> the set (half 0 of its last tile only); gs 2 -> set hh; gs 1 -> set 2 hh.  Slot b: gs 1 -> set 2 hh + 1.
-        for (int it = threadIdx.x; it < NT * 2; it += NTH) {
-            const int ti = it >> 1, hh = it & 1;
-            const AocCorrTile &tl = ltiles.t[ti];
-            int oca = -1, ocb = -1;
-            if (tl.kind == 0) {
-                if (tl.gs == 4) oca = (tl.last && hh == 0) ? tl.oc[0] : -1;
-                else if (tl.gs == 2) oca = tl.oc[2 * hh];
-                else { oca = tl.oc[2 * hh]; ocb = tl.oc[2 * hh + 1]; }
-            }
-            CbSlotDesc dsc;
-            dsc.off_a = oca >= 0 ? (int32_t)ltiles.oc_offset[oca] : -1;
-            dsc.off_b = ocb >= 0 ? (int32_t)ltiles.oc_offset[ocb] : -1;
-            dsc.bias_a = (oca >= 0 && fr.bias) ? fr.bias[ltiles.oc_bias[oca]] : 0.0f;
-            dsc.bias_b = (ocb >= 0 && fr.bias) ? fr.bias[ltiles.oc_bias[ocb]] : 0.0f;
-            dsc.valid_a = oca >= 0 ? (lfirst[oca] >= 0) : 0;
-            dsc.valid_b = ocb >= 0 ? (lfirst[ocb] >= 0) : 0;
-            dsc.pad0 = dsc.pad1 = 0;
-            lslot[it] = dsc;
-        }
-        if (COL0) {
-            for (int row = threadIdx.x; row < 32; row += NTH) {
-                const AocCorrTile &tl = ltiles.t[0];
-                CbColDesc c;
-                const bool on = row < tl.cnt[0];
-                const int oc = tl.oc[0] + (on ? row : 0);
-                c.off = on ? (int32_t)ltiles.oc_offset[oc] : -1;
-                c.bias = (on && fr.bias) ? fr.bias[ltiles.oc_bias[oc]] : 0.0f;
-                c.valid = on ? (lfirst[oc] >= 0) : 0;
-                c.pad = 0;
-                lcol[row] = c;
-            }
-        }
-        __syncthreads();
+        cb_stage_frame<NTH, NT, COL0, false>(img, fr.proxies, fr.sqnorm, fr.bias, bad);
 
         // ---- this wave's pixel tiles of frame f ----------------------------------------------------------------
         if (!primed && fa < f_end) {
@@ -418,77 +545,7 @@ __global__ __launch_bounds__(NW * 64) void proxy_corr_batched_kernel(AocCorrFram
             const float q2 = cb_halfsum(seq.q2part);
             if (!(q2 <= CB_MAX_SQ)) bad = true;                              // also catches NaN / inf
             float *const out_pix = fr.out + pix;
-            float carry = -INFINITY;
-#pragma unroll
-            for (int ti = 0; ti < NT; ++ti) {
-                const uint4 *arow = reinterpret_cast<const uint4 *>(limg + (size_t)(ti * 32 + j) * CB_ROW_DW + h * CB_HALF_DW);
-                f32x16 acc;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] = 0.0f;           // folds into the first MFMA's constant C operand (no unconditional path around the chain)
-#pragma unroll
-                for (int s = 0; s < CB_SEG_STEPS; ++s) {              // q.p = qh.ph + qh.pl + ql.ph (the norm slots ride in the hi x hi product)
-                    const f16x8 ah = __builtin_bit_cast(f16x8, arow[s]);
-                    const f16x8 al = __builtin_bit_cast(f16x8, arow[CB_SEG_STEPS + s]);
-                    const f16x8 bh = __builtin_bit_cast(f16x8, seq.bh[s]);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, __builtin_bit_cast(f16x8, seq.bl[s]), acc, 0, 0, 0);
-                }
-                if (COL0 && ti == 0) {
-                    // column-wise tile: every row is its own output (k = 1 proxies, no min: AEM:127).  Register r of lane half h is
-                    // row (r / 4) * 8 + 4 h + r % 4; row groups beyond the tile's rows are skipped with uniform branches.
-                    const int cnt = tiles.t[0].cnt[0];
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        if (8 * g < cnt) {
-#pragma unroll
-                            for (int u = 0; u < 4; ++u) {
-                                const CbColDesc c = lcol[8 * g + 4 * h + u];
-                                float d = c.valid ? q2 + CB_UNSCALE * acc[4 * g + u] : AOC_PAD_DISTANCE;
-                                const float td = cb_transform(d, c.bias);
-                                d = transform ? td : d;
-                                float *p = (c.off >= 0 && live) ? out_pix + c.off : dump;
-                                *p = d;
-                            }
-                        }
-                    }
-                    continue;
-                }
-                // grouped tile: group g = rows 8g .. 8g+7 = registers 4g .. 4g+3 of both lane halves
-                const CbSlotDesc sd = lslot[ti * 2 + h];
-                const int gs = tiles.t[ti].gs;
-                float gm[4];
-#pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    gm[g] = __builtin_fmaxf(__builtin_fmaxf(acc[4 * g], acc[4 * g + 1]), __builtin_fmaxf(acc[4 * g + 2], acc[4 * g + 3]));
-                float va, vb = 0.0f;
-                if (gs == 4) {                                                // one set spanning the tile (possibly continued from / into neighbours)
-                    float v = __builtin_fmaxf(__builtin_fmaxf(gm[0], gm[1]), __builtin_fmaxf(gm[2], gm[3]));
-                    v = cb_halfmax2(v, v);
-                    if (!tiles.t[ti].first) v = __builtin_fmaxf(v, carry);
-                    carry = v;
-                    va = v;
-                } else if (gs == 2) {                                         // two sets: lane half h ends up with set h
-                    va = cb_halfmax2(__builtin_fmaxf(gm[0], gm[1]), __builtin_fmaxf(gm[2], gm[3]));
-                } else {                                                      // four sets: lane half h ends up with sets 2h (slot a), 2h + 1 (slot b)
-                    va = cb_halfmax2(gm[0], gm[2]);
-                    vb = cb_halfmax2(gm[1], gm[3]);
-                }
-                {
-                    float d = sd.valid_a ? q2 + CB_UNSCALE * va : AOC_PAD_DISTANCE;
-                    const float td = cb_transform(d, sd.bias_a);
-                    d = transform ? td : d;
-                    float *p = (sd.off_a >= 0 && live) ? out_pix + sd.off_a : dump;
-                    *p = d;
-                }
-                if (gs == 1) {
-                    float d = sd.valid_b ? q2 + CB_UNSCALE * vb : AOC_PAD_DISTANCE;
-                    const float td = cb_transform(d, sd.bias_b);
-                    d = transform ? td : d;
-                    float *p = (sd.off_b >= 0 && live) ? out_pix + sd.off_b : dump;
-                    *p = d;
-                }
-            }
+            cb_tile_compute<NT, COL0>(img, tiles, seq, q2, out_pix, live, dump, transform, j, h, [] {});
             // next tile: flat -> seq (its loads were issued one tile ago), then request the one after it
             fa = fb; ta = tb;
             if (fa < f_end) {
@@ -500,6 +557,117 @@ __global__ __launch_bounds__(NW * 64) void proxy_corr_batched_kernel(AocCorrFram
         __syncthreads();                                                      // every wave is done with this frame's image
     }
     if (bad && dbg == 0) atomicExch(gate, call_seq);      // raised for THIS call only: no memset between calls
+}
+
+// ------------------------------------------------------------------------------------------
+// The same correlation with the query side read as split records in tile-major order (aoc_split_rows_tiled: what the dense kernel of
+// dense_split.hip consumes for the same frame).  A B operand is ONE coalesced 1 KiB wave load straight into the MFMA register layout:
+// no transposition buffer, no fp32 -> hi | lo conversion, |q|^2 from the records' norm array -- the wave's work per pixel tile is 14 loads,
+// the MFMA chains and the epilogue.  The next tile's loads are issued as soon as the last chain has consumed the operand registers and
+// fly under the epilogue and the other waves' chains.  Two blocks of 8 waves per CU: one block's staging of a frame's proxy image runs
+// under the other's MFMAs.
+struct AocCorrRecFrame {
+    const uint4 *qrec;          // tile-major split records of the frame's query
+    const float *q2;            // |q|^2 per pixel
+    const float *proxies, *sqnorm, *bias;
+    float *out;
+};
+struct AocCorrRecFrames {
+    AocCorrRecFrame f[AOC_CORR_MAX_FRAMES];
+    int32_t n;
+};
+constexpr int CR_NW = 8;
+constexpr int CR_TILE_CHUNKS = 2 * CB_SEG_STEPS * 64;                         // 16-byte chunks of one 32-pixel tile: [plane][k-step][lane]
+
+template <int NW, int NT, bool COL0>
+__global__ __launch_bounds__(NW * 64, 4) void proxy_corr_records_kernel(AocCorrRecFrames frames, int64_t m, AocCorrTiles tiles, int transform,
+                                                                         int32_t *__restrict__ gate, int dbg, int call_seq) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    AocCorrTiles &ltiles = *reinterpret_cast<AocCorrTiles *>(lds);
+    for (int i = threadIdx.x; i < (int)(sizeof(AocCorrTiles) / 4); i += NW * 64)
+        reinterpret_cast<uint32_t *>(&ltiles)[i] = reinterpret_cast<const uint32_t *>(&tiles)[i];
+    __syncthreads();
+    constexpr int NTH = NW * 64;
+    constexpr int n_rows = NT * 32;
+    uint32_t *limg = lds + CB_TABLE_DW;
+    int32_t *lsrc = reinterpret_cast<int32_t *>(limg + (size_t)NT * CB_TILE_DW);
+    float *lnorm = reinterpret_cast<float *>(lsrc + n_rows);
+    int32_t *lfirst = reinterpret_cast<int32_t *>(lnorm + n_rows);
+    CbSlotDesc *lslot = reinterpret_cast<CbSlotDesc *>(lfirst + AOC_CORR_MAX_OUT);
+    CbColDesc *lcol = reinterpret_cast<CbColDesc *>(lslot + NT * 2);
+    const CbImage img = {&ltiles, limg, lsrc, lnorm, lfirst, lslot, lcol};
+    float *dump = reinterpret_cast<float *>(gate) + 16 + (threadIdx.x & 31);  // where masked-off lanes store
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = lane & 31, h = lane >> 5;
+    const int64_t T = (m + 31) >> 5;
+    const int64_t total = T * frames.n;
+    int vb;                                                                   // XCD-aware virtual block id (see proxy_corr_batched_kernel)
+    {
+        const int nb = gridDim.x, lin = blockIdx.x;
+        const int xcd = lin & 7, slot = lin >> 3, q = nb >> 3, r = nb & 7;
+        vb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    }
+    const int64_t g0 = total * vb / gridDim.x, g1 = total * (vb + 1) / gridDim.x;
+    if (g0 >= g1) return;
+    const int f_beg = (int)(g0 / T), f_end = (int)((g1 - 1) / T) + 1;
+    auto seg_lo = [&](int f) -> int64_t { return f == f_beg ? g0 - (int64_t)f * T : 0; };
+    auto seg_hi = [&](int f) -> int64_t { return f == f_end - 1 ? g1 - (int64_t)f * T : T; };
+    auto advance = [&](int &f, int64_t &t) {
+        t += NW;
+        while (f < f_end && t >= seg_hi(f)) {
+            ++f;
+            if (f < f_end) t = seg_lo(f) + wave;
+        }
+    };
+
+    PixelSeq seq;
+    float q2_next = 0.0f;
+    auto issue = [&](int f_, int64_t tile_) {
+        const int f = __builtin_amdgcn_readfirstlane(f_);
+        const int tile = __builtin_amdgcn_readfirstlane((int)tile_);
+        const u32x4 *q = reinterpret_cast<const u32x4 *>(frames.f[f].qrec) + (size_t)tile * CR_TILE_CHUNKS + lane;
+#pragma unroll
+        for (int s = 0; s < CB_SEG_STEPS; ++s) seq.bh[s] = q[s * 64];
+#pragma unroll
+        for (int s = 0; s < CB_SEG_STEPS; ++s) seq.bl[s] = q[(CB_SEG_STEPS + s) * 64];
+        const int64_t pix = (int64_t)tile * 32 + j;
+        q2_next = frames.f[f].q2[pix < m ? pix : m - 1];
+    };
+    // query-side value of the norm slots 100 .. 102 (k-step 6, lane half 0, halves 4 .. 6) and zero for slot 103 (the record keeps the
+    // pixel's own norm pieces there)
+    const uint32_t nc2 = pack_f16((_Float16)CB_QCONST, (_Float16)CB_QCONST), nc3 = pack_f16((_Float16)CB_QCONST, (_Float16)0.0f);
+
+    bool bad = false;
+    int fa = f_beg;
+    int64_t ta = seg_lo(fa) + wave - NW;
+    advance(fa, ta);
+    if (fa < f_end) issue(fa, ta);                     // in flight under the first staging pass
+
+    for (int f = f_beg; f < f_end; ++f) {
+        const AocCorrRecFrame fr = frames.f[f];
+        cb_stage_frame<NTH, NT, COL0, true>(img, fr.proxies, fr.sqnorm, fr.bias, bad);
+        while (fa == f) {
+            // the image is loop-invariant and nothing in this loop writes LDS: without this, hipcc hoists all NT x 14 operand reads out of
+            // the loop (280 registers at NT = 5) and spills
+            asm volatile("" ::: "memory");
+            const int64_t pix = ta * 32 + j;
+            const bool live = pix < m;
+            const float q2 = q2_next;
+            if (!(q2 <= CB_MAX_SQ)) bad = true;                              // also catches NaN / inf; implies |x| 2^10 <= 65000
+            if (h == 0) { seq.bh[CB_SEG_STEPS - 1][2] = nc2; seq.bh[CB_SEG_STEPS - 1][3] = nc3; }
+            int fn = fa;
+            int64_t tn = ta;
+            advance(fn, tn);
+            cb_tile_compute<NT, COL0>(img, tiles, seq, q2, fr.out + pix, live, dump, transform, j, h, [&] {
+                if (fn < f_end && dbg != 2) issue(fn, tn);
+            });
+            fa = fn; ta = tn;
+        }
+        __syncthreads();                                                      // every wave is done with this frame's image
+    }
+    if (bad && dbg == 0) atomicExch(gate, call_seq);
 }
 
 inline int cb_n_cus() {
@@ -516,15 +684,13 @@ inline int cb_n_cus() {
     return n;
 }
 
-}  // namespace
+constexpr size_t CB_WS_BYTES = 256;
 
-extern "C" {
-
-size_t aoc_proxy_corr_min_batched_workspace_bytes(void) { return 256; }
-
-int aoc_proxy_corr_min_batched(const aoc_corr_frame *frames_host, int n_frames, int64_t m, int C, int n_proxy, int n_set,
-                               const int32_t *set_begin_host, const int32_t *set_size_host, const int64_t *set_out_offset_host,
-                               int transform, int precision, void *workspace, size_t workspace_bytes, aoc_stream_t stream) {
+// rec_host != NULL: the frames' queries as tile-major split records (proxy_corr_records_kernel); frames_host always carries the fp32 rows
+// (the exact-fp32 take-over reads them)
+int cb_run(const aoc_corr_frame *frames_host, const AocCorrRecFrame *rec_host, int n_frames, int64_t m, int C, int n_proxy, int n_set,
+           const int32_t *set_begin_host, const int32_t *set_size_host, const int64_t *set_out_offset_host,
+           int transform, int precision, void *workspace, size_t workspace_bytes, aoc_stream_t stream) {
     if (!frames_host || !set_begin_host || !set_size_host || !set_out_offset_host) return AOC_ERR_INVALID_ARG;
     if (n_frames < 1 || m < 1 || n_set < 1 || n_proxy < 0 || C < 4) return AOC_ERR_INVALID_ARG;
     if (m > (int64_t)80000000) return AOC_ERR_UNSUPPORTED;                    // 32-bit chunk indices inside the kernels (m * 25 < 2^31)
@@ -536,11 +702,11 @@ int aoc_proxy_corr_min_batched(const aoc_corr_frame *frames_host, int n_frames, 
         if (!frames_host[f].query || !frames_host[f].proxies || !frames_host[f].out) return AOC_ERR_INVALID_ARG;
     hipStream_t st = aoc_hip_stream(stream);
 
-    bool split_ok = precision == AOC_CORR_SPLIT && C == 100 && workspace && workspace_bytes >= aoc_proxy_corr_min_batched_workspace_bytes();
+    bool split_ok = precision == AOC_CORR_SPLIT && C == 100 && workspace && workspace_bytes >= CB_WS_BYTES;
     for (int f = 0; f < n_frames && split_ok; ++f)
         if ((reinterpret_cast<uintptr_t>(frames_host[f].query) | reinterpret_cast<uintptr_t>(frames_host[f].proxies)) & 15) split_ok = false;
     if (!split_ok) {
-        if (precision == AOC_CORR_SPLIT && (!workspace || workspace_bytes < aoc_proxy_corr_min_batched_workspace_bytes())) return AOC_ERR_WORKSPACE;
+        if (precision == AOC_CORR_SPLIT && (!workspace || workspace_bytes < CB_WS_BYTES)) return AOC_ERR_WORKSPACE;
         return aoc_corr_fp32_batched(frames_host, n_frames, m, C, n_proxy, n_set, set_begin_host, set_size_host, set_out_offset_host, 1, transform,
                                      nullptr, stream);
     }
@@ -555,8 +721,9 @@ int aoc_proxy_corr_min_batched(const aoc_corr_frame *frames_host, int n_frames, 
     // ---- pack the sets into 32-row tiles: single-proxy sets -> column-wise tiles, the others by row-group class
     const size_t tile_bytes = (size_t)CB_TILE_DW * 4 + 32 * 8;
     constexpr int NW = CB_NW;
-    const size_t lds_fixed = (size_t)CB_TABLE_DW * 4 + AOC_CORR_MAX_OUT * 4 + (size_t)AOC_CORR_MAX_TILES * 2 * 32 + 32 * 16 + (size_t)NW * CB_WBUF_BYTES;
-    int max_tiles = (int)(((size_t)160 * 1024 - lds_fixed) / tile_bytes);
+    // records kernel: no transposition buffers, two blocks per CU (80 KB each)
+    const size_t lds_fixed = (size_t)CB_TABLE_DW * 4 + AOC_CORR_MAX_OUT * 4 + (size_t)AOC_CORR_MAX_TILES * 2 * 32 + 32 * 16 + (rec_host ? 0 : (size_t)NW * CB_WBUF_BYTES);
+    int max_tiles = (int)(((size_t)(rec_host ? 80 : 160) * 1024 - lds_fixed) / tile_bytes);
     if (max_tiles > AOC_CORR_MAX_TILES) max_tiles = AOC_CORR_MAX_TILES;
     const int n_cu = cb_n_cus();
     const int64_t T = (m + 31) / 32;
@@ -584,6 +751,37 @@ int aoc_proxy_corr_min_batched(const aoc_corr_frame *frames_host, int n_frames, 
             if (tab.n == 0) return AOC_OK;
             const size_t lds = (size_t)tab.n * tile_bytes + lds_fixed;
             int64_t grid = T * fr.n;
+            if (rec_host) {
+                AocCorrRecFrames rf;
+                rf.n = fr.n;
+                for (int f = 0; f < fr.n; ++f) rf.f[f] = rec_host[f0 + f];
+                static const int dbg_r = getenv("AOC_CORR_DEBUG") ? atoi(getenv("AOC_CORR_DEBUG")) : 0;
+                const bool col0_r = tab.t[0].kind == 1;
+                if (grid > 2 * (int64_t)n_cu) grid = 2 * (int64_t)n_cu;
+#define AOC_CR(N, COL)                                                                                                                  \
+    do {                                                                                                                                \
+        static const bool lds_ok = hipFuncSetAttribute(reinterpret_cast<const void *>(proxy_corr_records_kernel<CR_NW, N, COL>),         \
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) == hipSuccess;             \
+        if (!lds_ok) return AOC_ERR_LAUNCH;                                                                                              \
+        hipLaunchKernelGGL((proxy_corr_records_kernel<CR_NW, N, COL>), dim3((unsigned)grid), dim3(CR_NW * 64), lds, st, rf, m, tab, transform, gate, dbg_r, call_seq); \
+    } while (0)
+                switch (tab.n * 2 + (col0_r ? 1 : 0)) {
+                    case 2: AOC_CR(1, false); break;
+                    case 3: AOC_CR(1, true); break;
+                    case 4: AOC_CR(2, false); break;
+                    case 5: AOC_CR(2, true); break;
+                    case 6: AOC_CR(3, false); break;
+                    case 7: AOC_CR(3, true); break;
+                    case 8: AOC_CR(4, false); break;
+                    case 9: AOC_CR(4, true); break;
+                    case 10: AOC_CR(5, false); break;
+                    case 11: AOC_CR(5, true); break;
+                    default: return AOC_ERR_UNSUPPORTED;
+                }
+#undef AOC_CR
+                reset();
+                return hipGetLastError() == hipSuccess ? AOC_OK : AOC_ERR_LAUNCH;
+            }
             if (grid > n_cu) grid = n_cu;
             static const int dbg = getenv("AOC_CORR_DEBUG") ? atoi(getenv("AOC_CORR_DEBUG")) : 0;   // developer switch: 2 = no tile loads, 4 = no conversion (timing experiments; wrong results)
             const bool col0 = tab.t[0].kind == 1;
@@ -649,6 +847,7 @@ int aoc_proxy_corr_min_batched(const aoc_corr_frame *frames_host, int n_frames, 
                     AocCorrTile &tl = tab.t[open_tile];
                     add_out(set_out_offset_host[s], s, open_tile * 32 + tl.cnt[0], 1);
                     tl.cnt[0]++;
+                    tl.gs = tl.cnt[0] <= 16 ? 1 : 0;                          // <= 16 proxies: rows 16 .. 31 take their lo pieces (stacked tile, 14 MFMAs)
                 } else if (cls == 1 || cls == 2) {
                     const int gs = cls;                                       // row groups per set
                     if (open_tile < 0 || open_groups + gs > 4 || tab.n_out + 1 > AOC_CORR_MAX_OUT) {
@@ -695,6 +894,43 @@ int aoc_proxy_corr_min_batched(const aoc_corr_frame *frames_host, int n_frames, 
     // exact-fp32 kernel: runs only when a precondition of the split arithmetic failed somewhere in the launch
     return aoc_corr_fp32_batched(frames_host, n_frames, m, C, n_proxy, n_set, set_begin_host, set_size_host, set_out_offset_host, 1, transform,
                                  gate, stream, 0, call_seq);
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t aoc_proxy_corr_min_batched_workspace_bytes(void) { return CB_WS_BYTES; }
+
+int aoc_proxy_corr_min_batched(const aoc_corr_frame *frames_host, int n_frames, int64_t m, int C, int n_proxy, int n_set,
+                               const int32_t *set_begin_host, const int32_t *set_size_host, const int64_t *set_out_offset_host,
+                               int transform, int precision, void *workspace, size_t workspace_bytes, aoc_stream_t stream) {
+    return cb_run(frames_host, nullptr, n_frames, m, C, n_proxy, n_set, set_begin_host, set_size_host, set_out_offset_host, transform, precision,
+                  workspace, workspace_bytes, stream);
+}
+
+int aoc_proxy_corr_min_records(const aoc_corr_frame_rec *frames_host, int n_frames, int64_t m, int C, int n_proxy, int n_set,
+                               const int32_t *set_begin_host, const int32_t *set_size_host, const int64_t *set_out_offset_host,
+                               int transform, void *workspace, size_t workspace_bytes, aoc_stream_t stream) {
+    if (!frames_host || n_frames < 1 || n_frames > 4096) return AOC_ERR_INVALID_ARG;
+    if (C != 100) return AOC_ERR_UNSUPPORTED;                                 // the records of dense_split.hip at the kernel's channel count
+    if (!workspace || workspace_bytes < CB_WS_BYTES) return AOC_ERR_WORKSPACE;
+    aoc_corr_frame *plain = static_cast<aoc_corr_frame *>(malloc(sizeof(aoc_corr_frame) * (size_t)n_frames));
+    AocCorrRecFrame *rec = static_cast<AocCorrRecFrame *>(malloc(sizeof(AocCorrRecFrame) * (size_t)n_frames));
+    int rc = (plain && rec) ? AOC_OK : AOC_ERR_LAUNCH;
+    for (int f = 0; f < n_frames && rc == AOC_OK; ++f) {
+        const aoc_corr_frame_rec &s = frames_host[f];
+        if (!s.query || !s.query_rec || !s.query_sqnorm || (reinterpret_cast<uintptr_t>(s.query_rec) & 15)) { rc = AOC_ERR_INVALID_ARG; break; }
+        plain[f].query = s.query; plain[f].proxies = s.proxies; plain[f].proxy_sqnorm = s.proxy_sqnorm; plain[f].set_bias = s.set_bias; plain[f].out = s.out;
+        rec[f].qrec = static_cast<const uint4 *>(s.query_rec); rec[f].q2 = s.query_sqnorm;
+        rec[f].proxies = s.proxies; rec[f].sqnorm = s.proxy_sqnorm; rec[f].bias = s.set_bias; rec[f].out = s.out;
+    }
+    if (rc == AOC_OK)
+        rc = cb_run(plain, rec, n_frames, m, C, n_proxy, n_set, set_begin_host, set_size_host, set_out_offset_host, transform, AOC_CORR_SPLIT,
+                    workspace, workspace_bytes, stream);
+    free(plain);
+    free(rec);
+    return rc;
 }
 
 }  // extern "C"

@@ -4,6 +4,7 @@
 
 constexpr int AOC_CORR_MAX_FRAMES = 32;   // frames per launch (kernel-argument table)
 constexpr int AOC_CORR_MAX_TILES = 5;     // 32-row proxy tiles resident in LDS per launch (5 x 19.5 KB next to the waves' pixel-tile buffers)
+constexpr int AOC_CORR_TABLE_TILES = 8;   // entries of a launch's tile table (the streaming records kernel keeps its proxy tiles in registers: up to 8)
 constexpr int AOC_CORR_MAX_OUT = 64;      // output columns (sets) per launch
 
 struct AocCorrFrame {
@@ -26,7 +27,7 @@ struct AocCorrTile {
     int64_t step;
 };
 struct AocCorrTiles {
-    AocCorrTile t[AOC_CORR_MAX_TILES];
+    AocCorrTile t[AOC_CORR_TABLE_TILES];
     int64_t oc_offset[AOC_CORR_MAX_OUT];   // element offset of each output column's plane in a frame's `out`
     int32_t oc_bias[AOC_CORR_MAX_OUT];     // index into the frame's set_bias
     int16_t oc_row0[AOC_CORR_MAX_OUT];     // image rows [row0, row0 + rows) belong to the column's set

@@ -39,13 +39,29 @@ static_assert(SP_NORM_SLOT + 4 <= SP_K && SP_NORM_SLOT / 16 == SP_KS - 1 && (SP_
 // ------------------------------------------------------------------------------------------
 // fp32 rows -> split records (+ |x|^2).  One thread per (row, k-step).  Record = hi plane (14 x 16 B: per k-step [k0-7][k8-15]), then the
 // lo plane in the same order; hi-plane slots 100..102 = the three fp16 pieces of -16 |x|^2, slot 103 = an upper bound of the lo plane's norm.
+//
+// TILED: the same chunks in the order a wave consumes them as MFMA B operands -- per 32-row tile, per plane, per k-step the 64 chunks
+// [k-half h][row j] (1 KiB: ONE fully coalesced wave load per operand, no transposition on the consumer's side).  The buffer holds whole
+// tiles; rows past n are written as zeros.  Threads: j fastest, so that a half wave writes 512 consecutive bytes.
+template <bool TILED>
 __global__ __launch_bounds__(256) void split_rows_kernel(const float *__restrict__ x, int64_t n, int C, uint4 *__restrict__ rec,
                                                           float *__restrict__ sqnorm, int32_t *__restrict__ overflow) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t row = idx / SP_KS;
-    const int ks = (int)(idx - row * SP_KS);
-    if (row >= n) return;
-    const float *xr = x + (size_t)row * C;
+    int64_t row;
+    int ks;
+    if (TILED) {
+        const int64_t tile = idx / (SP_KS * 32);
+        const int rem = (int)(idx - tile * (SP_KS * 32));
+        ks = rem >> 5;
+        row = tile * 32 + (rem & 31);
+        if (tile * 32 >= n) return;
+    } else {
+        row = idx / SP_KS;
+        ks = (int)(idx - row * SP_KS);
+        if (row >= n) return;
+    }
+    const bool live = row < n;                    // TILED: the last tile's rows past n are zero records
+    const float *xr = x + (size_t)(live ? row : n - 1) * C;
     _Float16 hi[16], lo[16];
     bool bad = false;
     {
@@ -88,7 +104,7 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float *__restrict
                 }
             }
         }
-        if (sqnorm) sqnorm[row] = s;
+        if (sqnorm && live) sqnorm[row] = s;
         bad |= !(s <= 4000.0f);
         const float p = -16.0f * s;
         const _Float16 p1 = (_Float16)p;
@@ -101,15 +117,24 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float *__restrict
         // query side multiplies it by zero
         hi[SP_NORM_SLOT % 16 + 3] = (_Float16)(sqrtf(sl) * 1.002f + 1e-6f);
     }
-    if (bad) atomicOr(overflow, 1);
+    if (bad && live) atomicOr(overflow, 1);
     union { _Float16 h[32]; uint4 q[4]; } u;
 #pragma unroll
     for (int e = 0; e < 16; ++e) { u.h[e] = hi[e]; u.h[16 + e] = lo[e]; }
-    uint4 *dst = rec + (size_t)row * SP_REC + ks * 2;
-    dst[0] = u.q[0];
-    dst[1] = u.q[1];
-    dst[SP_HALF] = u.q[2];
-    dst[SP_HALF + 1] = u.q[3];
+    if (TILED) {
+        if (!live) u.q[0] = u.q[1] = u.q[2] = u.q[3] = make_uint4(0, 0, 0, 0);
+        uint4 *dst = rec + ((size_t)(row >> 5) * 2 * SP_KS + ks) * 64 + (row & 31);
+        dst[0] = u.q[0];
+        dst[32] = u.q[1];
+        dst[SP_KS * 64] = u.q[2];
+        dst[SP_KS * 64 + 32] = u.q[3];
+    } else {
+        uint4 *dst = rec + (size_t)row * SP_REC + ks * 2;
+        dst[0] = u.q[0];
+        dst[1] = u.q[1];
+        dst[SP_HALF] = u.q[2];
+        dst[SP_HALF + 1] = u.q[3];
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -241,7 +266,7 @@ __global__ __launch_bounds__(NW * 64, 1) void dense_prune_kernel(const uint4 *__
                                                                      const uint4 *__restrict__ prec, const int32_t *__restrict__ tile_rows,
                                                                      const int32_t *__restrict__ tile_obj, const int32_t *__restrict__ n_tiles_ptr,
                                                                      const int32_t *__restrict__ gate, const uint32_t *__restrict__ pmax_bits,
-                                                                     int n_obj, uint32_t *__restrict__ gbest, int dbg) {
+                                                                     int n_obj, uint32_t *__restrict__ gbest, int dbg, int q_tiled) {
     if (*gate) return;
     extern __shared__ __attribute__((aligned(16))) uint4 lds4[];
     static_assert(SP_NB == 4 && SP_NQ == 2 && (NW == 8 || NW == 4), "the step structure below is written for 4 tiles x 2 query tiles x 8 (or 4) waves");
@@ -283,10 +308,14 @@ __global__ __launch_bounds__(NW * 64, 1) void dense_prune_kernel(const uint4 *__
     for (int iq = 0; iq < SP_NQ; ++iq) {
         const int64_t row = wave_row0 + iq * 32 + col;
         valid[iq] = row < m;
-        const uint4 *r = qrec + (size_t)(valid[iq] ? row : 0) * SP_REC;
+        // row-major records: chunk (plane, ks, h) of row r at r * 28 + plane * 14 + ks * 2 + h; tile-major (aoc_split_rows_tiled): per
+        // (32-row tile, plane, ks) the 64 chunks [h][row % 32] -- one coalesced 1 KiB wave load per operand
+        const int64_t rr = valid[iq] ? row : 0;
+        const uint4 *r = q_tiled ? qrec + (size_t)(rr >> 5) * (2 * SP_KS * 64) + h * 32 + (rr & 31) : qrec + (size_t)rr * SP_REC + h;
+        const int ks_step = q_tiled ? 64 : 2, plane_step = q_tiled ? SP_KS * 64 : SP_HALF;
 #pragma unroll
         for (int ks = 0; ks < SP_KS; ++ks) {
-            uint4 u = r[ks * 2 + h], v = r[SP_HALF + ks * 2 + h];
+            uint4 u = r[ks * ks_step], v = r[plane_step + ks * ks_step];
             if (!valid[iq]) { u = make_uint4(0, 0, 0, 0); v = make_uint4(0, 0, 0, 0); }
             bh[iq][ks] = __builtin_bit_cast(f16x8, u);
             bl[iq][ks] = __builtin_bit_cast(f16x8, v);
@@ -598,7 +627,23 @@ int aoc_split_rows(const float *x, int64_t n, int C, void *records, float *sqnor
     if (aoc_split_record_bytes(C) == 0) return AOC_ERR_UNSUPPORTED;
     if (n == 0) return AOC_OK;
     const int64_t total = n * SP_KS;
-    hipLaunchKernelGGL(split_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, aoc_hip_stream(stream), x, n, C,
+    hipLaunchKernelGGL(split_rows_kernel<false>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, aoc_hip_stream(stream), x, n, C,
+                       static_cast<uint4 *>(records), sqnorm, overflow_flag);
+    AOC_RETURN_IF_LAUNCH_FAILED();
+    return AOC_OK;
+}
+
+size_t aoc_split_rows_tiled_bytes(int64_t n, int C) {
+    if (n < 0 || aoc_split_record_bytes(C) == 0) return 0;
+    return (size_t)((n + 31) / 32) * 32 * SP_REC * 16;
+}
+
+int aoc_split_rows_tiled(const float *x, int64_t n, int C, void *records, float *sqnorm, int32_t *overflow_flag, aoc_stream_t stream) {
+    if (!x || !records || !overflow_flag || n < 0) return AOC_ERR_INVALID_ARG;
+    if (aoc_split_record_bytes(C) == 0) return AOC_ERR_UNSUPPORTED;
+    if (n == 0) return AOC_OK;
+    const int64_t total = (n + 31) / 32 * 32 * SP_KS;
+    hipLaunchKernelGGL(split_rows_kernel<true>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, aoc_hip_stream(stream), x, n, C,
                        static_cast<uint4 *>(records), sqnorm, overflow_flag);
     AOC_RETURN_IF_LAUNCH_FAILED();
     return AOC_OK;
@@ -609,7 +654,7 @@ size_t aoc_dense_match_split_workspace_bytes(int64_t m, int64_t n, int n_obj) {
     return split_carve(nullptr, m, n, n_obj).total;
 }
 
-int aoc_dense_match_min_split(const float *query, const void *query_rec, const float *query_sqnorm, int64_t m, int C, const float *pool,
+int aoc_dense_match_min_split(const float *query, const void *query_rec, const float *query_sqnorm, int query_rec_tiled, int64_t m, int C, const float *pool,
                               const void *pool_rec, const int32_t *overflow_flag, int64_t n, const uint32_t *right_bits,
                               const uint32_t *wrong_bits, const int32_t *fg_rows, const int32_t *obj_rows, const int32_t *counts,
                               const int32_t *obj_offsets, const float *obj_bias, int n_obj, float *out, int64_t out_pixel_stride,
@@ -642,10 +687,10 @@ int aoc_dense_match_min_split(const float *query, const void *query_rec, const f
     if (probe.start) (void)hipEventRecord(probe.start, st);
     if (nw == 4)
         hipLaunchKernelGGL(dense_prune_kernel<4>, grid, dim3(4 * 64), lds, st, static_cast<const uint4 *>(query_rec), query_sqnorm, m,
-                           static_cast<const uint4 *>(pool_rec), w.tile_rows, w.tile_obj, w.n_tiles, w.gate, w.pmax, n_obj, w.gbest, dbg);
+                           static_cast<const uint4 *>(pool_rec), w.tile_rows, w.tile_obj, w.n_tiles, w.gate, w.pmax, n_obj, w.gbest, dbg, query_rec_tiled ? 1 : 0);
     else
         hipLaunchKernelGGL(dense_prune_kernel<8>, grid, dim3(8 * 64), lds, st, static_cast<const uint4 *>(query_rec), query_sqnorm, m,
-                           static_cast<const uint4 *>(pool_rec), w.tile_rows, w.tile_obj, w.n_tiles, w.gate, w.pmax, n_obj, w.gbest, dbg);
+                           static_cast<const uint4 *>(pool_rec), w.tile_rows, w.tile_obj, w.n_tiles, w.gate, w.pmax, n_obj, w.gbest, dbg, query_rec_tiled ? 1 : 0);
     if (probe.stop) (void)hipEventRecord(probe.stop, st);
     hipLaunchKernelGGL(dense_split_finalize_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, w.gbest, m, n_obj, counts, w.gate,
                        query_sqnorm, obj_bias, out, out_pixel_stride, out_obj_stride, transform);

@@ -32,10 +32,10 @@ struct KrArgs {
     const float *pool;
     const int32_t *seg_off, *seg_k, *counts, *cbase;
     const uint32_t *moff;             // byte offsets of the members' pool rows, per cluster in row order
-    int n_seg, kmax, nch_cap, pmax;
+    int n_seg, kmax, nch_cap, pmax, dbg;
     float *centroids;
     int32_t *cc64;                    // [cluster] first chunk id
-    int32_t *own;                     // [chunk id] cluster (-1: unused)
+    int4 *cdesc;                      // [chunk id] {first member (index into moff), members (0: unused id), cluster, chunk index inside the cluster}
     float *hstate, *habs;             // [cluster][C] exact sum / sum of |x| of the head
     float *PT;                        // [C][nch_cap] sum of |x| per tail chunk -> exclusive prefix within the cluster
     uint32_t *rec;                    // [chunk id][KR_REC][C]
@@ -63,13 +63,14 @@ __global__ __launch_bounds__(256) void kr_plan_kernel(KrArgs a) {
     }
     __syncthreads();
     for (int i = threadIdx.x; i < end - cb; i += 256) {
-        int oc = -1;
+        int4 d = make_int4(0, 0, -1, 0);
         if (i < lbase[kmax]) {
             int j = 0;
             while (j + 1 < kmax && lbase[j + 1] <= i) ++j;
-            oc = s * kmax + j;
+            const int oc = s * kmax + j, c = i - lbase[j];
+            d = make_int4(beg + a.cbase[oc] + c * KR_CH, min(KR_CH, a.counts[oc] - c * KR_CH), oc, c);
         }
-        a.own[cb + i] = oc;
+        a.cdesc[cb + i] = d;
     }
 }
 
@@ -89,18 +90,35 @@ __global__ __launch_bounds__(256) void kr_heads_sums_kernel(KrArgs a) {
         const int fc = fvalid ? f : KR_C - 1;
         const int cnt = a.counts[oc];
         const int nh = min(cnt, KR_HEADC * KR_CH);
+        if (nh == 0) {
+            if (fvalid) { a.hstate[(size_t)oc * KR_C + f] = 0.0f; a.habs[(size_t)oc * KR_C + f] = 0.0f; }
+            return;
+        }
         const uint32_t *list = a.moff + a.seg_off[s] + a.cbase[oc];
         float sv = 0.0f, sa = 0.0f;
-        for (int i0 = 0; i0 < nh; i0 += 64) {
-            const uint32_t offl = list[min(i0 + lane, max(nh - 1, 0))];
-#pragma unroll 1
-            for (int u0 = 0; u0 < 64 && i0 + u0 < nh; u0 += 16) {
-                float x[16];
+        // member offsets of the whole head (lane = member, eight loads), then the rows 32 at a time, the next 32 in flight under the additions
+        uint32_t offv[KR_HEADC];
 #pragma unroll
-                for (int u = 0; u < 16; ++u) x[u] = *reinterpret_cast<const float *>(poolb + __builtin_amdgcn_readlane(offl, min(u0 + u, 63)) + fc * 4);
+        for (int b = 0; b < KR_HEADC; ++b) offv[b] = list[min(b * 64 + lane, max(nh - 1, 0))];
+        const char *pb = poolb + fc * 4;
+        float xa[32], xb[32];
 #pragma unroll
-                for (int u = 0; u < 16; ++u)
-                    if (i0 + u0 + u < nh) { sv = sv + x[u]; sa += fabsf(x[u]); }
+        for (int u = 0; u < 32; ++u) xa[u] = *reinterpret_cast<const float *>(pb + __builtin_amdgcn_readlane(offv[0], u));
+#pragma unroll
+        for (int b = 0; b < KR_HEADC; ++b) {
+            if (b * 64 < nh) {
+#pragma unroll
+                for (int u = 0; u < 32; ++u) xb[u] = *reinterpret_cast<const float *>(pb + __builtin_amdgcn_readlane(offv[b], 32 + u));
+#pragma unroll
+                for (int u = 0; u < 32; ++u)
+                    if (b * 64 + u < nh) { sv = sv + xa[u]; sa += fabsf(xa[u]); }
+                if (b + 1 < KR_HEADC) {
+#pragma unroll
+                    for (int u = 0; u < 32; ++u) xa[u] = *reinterpret_cast<const float *>(pb + __builtin_amdgcn_readlane(offv[b + 1 < KR_HEADC ? b + 1 : b], u));
+                }
+#pragma unroll
+                for (int u = 0; u < 32; ++u)
+                    if (b * 64 + 32 + u < nh) { sv = sv + xb[u]; sa += fabsf(xb[u]); }
             }
         }
         if (fvalid) { a.hstate[(size_t)oc * KR_C + f] = sv; a.habs[(size_t)oc * KR_C + f] = sa; }
@@ -110,18 +128,13 @@ __global__ __launch_bounds__(256) void kr_heads_sums_kernel(KrArgs a) {
     const int t2 = task - nc * 2;
     const int g = t2 >> 1, h = t2 & 1;
     if (g >= a.nch_cap) return;
-    const int oc = a.own[g];
-    if (oc < 0) return;
-    const int c = g - a.cc64[oc];
-    if (c < KR_HEADC) return;
-    const int s = oc / kmax;
+    const int4 d = a.cdesc[g];
+    const int n = d.y;
+    if (n == 0 || d.w < KR_HEADC) return;
     const int f = 64 * h + lane;
     const bool fvalid = f < KR_C;
     const int fc = fvalid ? f : KR_C - 1;
-    const int cnt = a.counts[oc];
-    const int n = min(KR_CH, cnt - c * KR_CH);
-    const uint32_t *list = a.moff + a.seg_off[s] + a.cbase[oc] + c * KR_CH;
-    const uint32_t offl = list[min(lane, n - 1)];
+    const uint32_t offl = a.moff[d.x + min(lane, n - 1)];
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
     for (int u0 = 0; u0 < n; u0 += 16) {
@@ -159,97 +172,130 @@ __global__ __launch_bounds__(256) void kr_prefix_kernel(KrArgs a) {
     }
 }
 
-// ---- fold: wave per (tail chunk, feature half); the chunk's rows staged in the wave's LDS tile [member][64 features]
+// ---- fold: wave per tail chunk; lane l < 50 folds features l and 50 + l as one packed pair (v_pk_fma_f32 and friends).  Members come
+// sixteen at a time into registers (the next sixteen in flight) and are folded FOUR at a time without looking: the integer increments are
+// summed blindly while three maxima remember whether any of the four was special -- an increment out of range (a value that is not a plain
+// number below the running sum), a remainder of exactly one half (a tie), the sum too close to the end of its binade; only then the four
+// are taken again one by one through kx_fold_fast / kx_fold_step from the saved state.  Five packed operations per member instead of fifty.
+typedef float kr_f2 __attribute__((ext_vector_type(2)));
+constexpr int KR_HALF = KR_C / 2;
 __global__ __launch_bounds__(256) void kr_fold_kernel(KrArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
     __shared__ int litcnt;
+    __shared__ float lits_s[4][2][KX_MAX_LIT * 64];
     const int lane = aoc_lane(), wave = threadIdx.x >> 6;
-    const int kmax = a.kmax;
-    float *tile = lds + (size_t)wave * (KR_CH * 64 + KX_MAX_LIT * 64);
-    float *lits = tile + KR_CH * 64 + lane;
+    float *lits0 = &lits_s[wave][0][lane], *lits1 = &lits_s[wave][1][lane];
     if (threadIdx.x == 0) litcnt = 0;
     __syncthreads();
-    const int task = blockIdx.x * 4 + wave;
-    const int g = task >> 1, h = task & 1;
+    const int g = blockIdx.x * 4 + wave;
     if (g >= a.nch_cap) return;
-    const int oc = a.own[g];
-    if (oc < 0) return;
-    const int c = g - a.cc64[oc];
-    if (c < KR_HEADC) return;
-    const int s = oc / kmax;
-    const int f = 64 * h + lane;
-    const bool fvalid = f < KR_C;
-    const int fc = fvalid ? f : KR_C - 1;
-    const int cnt = a.counts[oc];
-    const int n = min(KR_CH, cnt - c * KR_CH);
-    const uint32_t *list = a.moff + a.seg_off[s] + a.cbase[oc] + c * KR_CH;
-    const uint32_t offl = list[min(lane, n - 1)];
-    const float P = a.habs[(size_t)oc * KR_C + fc] + a.PT[(size_t)fc * a.nch_cap + g];
-    const char *poolb = reinterpret_cast<const char *>(a.pool);
-    // rows -> LDS (one round trip for all of them)
+    const int4 d = a.cdesc[g];
+    const int n = d.y, oc = d.z, c = d.w;
+    if (n == 0 || c < KR_HEADC) return;
+    const bool lvalid = lane < KR_HALF;
+    const int lc = lvalid ? lane : KR_HALF - 1;
+    const int f0 = lc, f1 = KR_HALF + lc;
+    const uint32_t offl = a.moff[d.x + min(lane, n - 1)];
+    const float P0 = a.habs[(size_t)oc * KR_C + f0] + a.PT[(size_t)f0 * a.nch_cap + g];
+    const float P1 = a.habs[(size_t)oc * KR_C + f1] + a.PT[(size_t)f1 * a.nch_cap + g];
+    const char *pb0 = reinterpret_cast<const char *>(a.pool) + f0 * 4, *pb1 = reinterpret_cast<const char *>(a.pool) + f1 * 4;
+    kr_f2 xa[16], xb[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const uint32_t o = __builtin_amdgcn_readlane(offl, u);      // (lanes past n repeat member n - 1: never used)
+        xa[u].x = *reinterpret_cast<const float *>(pb0 + o);
+        xa[u].y = *reinterpret_cast<const float *>(pb1 + o);
+    }
+    KxFold k0, k1;
+    kx_fold_init(k0, P0, c * KR_CH);
+    kx_fold_init(k1, P1, c * KR_CH);
+    const kr_f2 magic = {KX_MAGIC, KX_MAGIC};
 #pragma unroll 1
-    for (int u0 = 0; u0 < n; u0 += 16) {
-        float x[16];
+    for (int b = 0; b < KR_CH / 16; ++b) {
+        if (b * 16 >= n || (a.dbg & 1)) break;
+        if ((b + 1) * 16 < n) {
 #pragma unroll
-        for (int u = 0; u < 16; ++u) x[u] = *reinterpret_cast<const float *>(poolb + __builtin_amdgcn_readlane(offl, min(u0 + u, 63)) + fc * 4);
+            for (int u = 0; u < 16; ++u) {
+                const uint32_t o = __builtin_amdgcn_readlane(offl, min((b + 1) * 16 + u, 63));
+                xb[u].x = *reinterpret_cast<const float *>(pb0 + o);
+                xb[u].y = *reinterpret_cast<const float *>(pb1 + o);
+            }
+        }
 #pragma unroll
-        for (int u = 0; u < 16; ++u) tile[(u0 + u) * 64 + lane] = x[u];
-    }
-    KxFold k0;
-    kx_fold_init(k0, P, c * KR_CH);
-    int i = 0;
-    float xn = tile[lane], xnn = tile[min(1, n - 1) * 64 + lane];
-    while (i < n) {
-        int32_t acc = k0.acc;
-        float ss = k0.s;
-        const float inv_u = k0.inv_u;
-        const uint32_t lim = k0.lim;
-        const bool win = k0.mode == KXM_WIN;
-        float x = xn;
-        while (i < n) {
-            x = xn;
-            xn = xnn;
-            xnn = tile[min(i + 2, n - 1) * 64 + lane];
-            const float t = __builtin_fmaf(x, inv_u, KX_MAGIC);
-            const uint32_t rr = kx_f2u(t) - KX_MAGIC_BITS;
-            const float rn = t - KX_MAGIC;
-            const float dd = __builtin_fmaf(x, inv_u, -rn);
-            const uint32_t cand = (uint32_t)acc + rr;
-            const bool special = __builtin_fabsf(dd) == 0.5f || rr >= 0x800000u || cand + 2u > lim || win;
-            if (__any(special)) break;
-            acc = (int32_t)cand;
-            ss = ss + x;
-            ++i;
+        for (int q = 0; q < 4; ++q) {
+            const int i0 = b * 16 + q * 4;
+            if (i0 < n) {
+                const int nq = min(4, n - i0);
+                // ---- blind: four members
+                const kr_f2 inv_u = {k0.inv_u, k1.inv_u};
+                uint32_t acc0 = (uint32_t)k0.acc, acc1 = (uint32_t)k1.acc, mx = 0u;
+                kr_f2 ss = {k0.s, k1.s};
+                float md = 0.0f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    kr_f2 xv = xa[q * 4 + e];
+                    if (e >= nq) xv = (kr_f2){0.0f, 0.0f};              // (adds nothing: r = 0, no remainder)
+                    const kr_f2 t = __builtin_elementwise_fma(xv, inv_u, magic);
+                    const kr_f2 rn = t - magic;
+                    const kr_f2 dd = __builtin_elementwise_fma(xv, inv_u, -rn);
+                    const uint32_t r0 = kx_f2u(t.x) - KX_MAGIC_BITS, r1 = kx_f2u(t.y) - KX_MAGIC_BITS;
+                    acc0 += r0;
+                    acc1 += r1;
+                    mx = max(mx, max(r0, r1));
+                    md = __builtin_fmaxf(md, __builtin_fmaxf(__builtin_fabsf(dd.x), __builtin_fabsf(dd.y)));
+                    ss = ss + xv;
+                }
+                const bool special = mx >= 0x800000u || md == 0.5f || acc0 + 2u > k0.lim || acc1 + 2u > k1.lim || k0.mode == KXM_WIN || k1.mode == KXM_WIN;
+                if (!__any(special)) {
+                    k0.acc = (int32_t)acc0; k1.acc = (int32_t)acc1;
+                    k0.s = ss.x; k1.s = ss.y;
+                } else {
+                    // ---- the four again, one by one (ties, windows, literals, give-ups)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (e >= nq) break;
+                        const kr_f2 xv = xa[q * 4 + e];
+                        const KxFast s0 = kx_fold_fast(k0, xv.x), s1 = kx_fold_fast(k1, xv.y);
+                        if (!__any(s0.over || s1.over)) {
+                            k0.acc = s0.acc; k0.dvar = s0.dvar; k0.s = k0.s + xv.x;
+                            k1.acc = s1.acc; k1.dvar = s1.dvar; k1.s = k1.s + xv.y;
+                        } else {
+                            kx_fold_step(k0, s0, xv.x, i0 + e, lits0, 64);
+                            kx_fold_step(k1, s1, xv.y, i0 + e, lits1, 64);
+                        }
+                    }
+                }
+            }
         }
-        k0.acc = acc;
-        k0.s = ss;
-        if (i < n) {
-            const KxFast s0 = kx_fold_fast(k0, x);
-            kx_fold_step(k0, s0, x, i, lits, 64);
-            ++i;
-        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) xa[u] = xb[u];
     }
-    int32_t A0, B0;
-    uint32_t hdr = kx_fold_finish(k0, n, A0, B0);
-    uint32_t w3 = 0u;
-    const int nlit = kx_hdr_nlit(hdr);
-    if (nlit == 1) w3 = kx_f2u(lits[0]);
-    if (nlit > 1 && fvalid) {
-        const int off = atomicAdd(&litcnt, nlit);
-        if (off + nlit > KR_LITCAP) {
-            hdr = kx_hdr(KX_UNSAFE, 0, 0, 0, 0, 0);
-        } else {
-            float *dst = a.litpool + (size_t)blockIdx.x * KR_LITCAP + off;
-            for (int q = 0; q < nlit; ++q) dst[q] = lits[q * 64];
-            w3 = (uint32_t)(blockIdx.x * KR_LITCAP + off);
+    // ---- records of the two features
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        const float *lits = half ? lits1 : lits0;
+        const int f = half ? f1 : f0;
+        int32_t A0, B0;
+        uint32_t hdr = half ? kx_fold_finish(k1, n, A0, B0) : kx_fold_finish(k0, n, A0, B0);
+        uint32_t w3 = 0u;
+        const int nlit = kx_hdr_nlit(hdr);
+        if (nlit == 1) w3 = kx_f2u(lits[0]);
+        if (nlit > 1 && lvalid) {
+            const int off = atomicAdd(&litcnt, nlit);
+            if (off + nlit > KR_LITCAP) {
+                hdr = kx_hdr(KX_UNSAFE, 0, 0, 0, 0, 0);
+            } else {
+                float *dst = a.litpool + (size_t)blockIdx.x * KR_LITCAP + off;
+                for (int q = 0; q < nlit; ++q) dst[q] = lits[q * 64];
+                w3 = (uint32_t)(blockIdx.x * KR_LITCAP + off);
+            }
         }
-    }
-    if (fvalid) {
-        uint32_t *r = a.rec + (size_t)g * KR_REC * KR_C + f;
-        r[0] = hdr;
-        r[KR_C] = (uint32_t)A0;
-        r[2 * KR_C] = (uint32_t)B0;
-        r[3 * KR_C] = w3;
+        if (lvalid) {
+            uint32_t *r = a.rec + (size_t)g * KR_REC * KR_C + f;
+            r[0] = hdr;
+            r[KR_C] = (uint32_t)A0;
+            r[2 * KR_C] = (uint32_t)B0;
+            r[3 * KR_C] = w3;
+        }
     }
 }
 
@@ -271,15 +317,15 @@ __global__ __launch_bounds__(256) void kr_merge_kernel(KrArgs a) {
     const int g0 = a.cc64[oc];
     KxRun run{0, 0, 0};
     unsigned long long np = 0ull;
-    for (int c0 = c_begin; c0 < c_end; c0 += 16) {
-        uint32_t hd[16], w1[16];
+    for (int c0 = c_begin; c0 < c_end; c0 += 32) {
+        uint32_t hd[32], w1[32];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
+        for (int u = 0; u < 32; ++u) {
             const uint32_t *r = a.rec + (size_t)(g0 + min(c0 + u, c_end - 1)) * KR_REC * KR_C + fc;
             hd[u] = r[0]; w1[u] = r[KR_C];
         }
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
+        for (int u = 0; u < 32; ++u) {
             if (c0 + u < c_end && !kx_run_merge(run, hd[u], (int32_t)w1[u])) {
                 if (fvalid) {
                     uint32_t *r = a.rec + (size_t)(g0 + c0 + u) * KR_REC * KR_C + fc;
@@ -464,7 +510,7 @@ __global__ __launch_bounds__(256) void kr_stitch_kernel(KrArgs a) {
 }
 
 struct KrLayout {
-    size_t cc64, own, hstate, habs, PT, rec, litpool, ppost, pnp, total;
+    size_t cc64, cdesc, hstate, habs, PT, rec, litpool, ppost, pnp, total;
     int nch_cap, pmax, fold_wgs;
 };
 KrLayout kr_layout(int64_t cap, int n_seg, int kmax, int64_t seg_bound) {
@@ -472,12 +518,12 @@ KrLayout kr_layout(int64_t cap, int n_seg, int kmax, int64_t seg_bound) {
     l.nch_cap = (int)(cap / KR_CH) + n_seg * (kmax + 1) + 2;
     const int64_t sb = (seg_bound > 0 && seg_bound < cap) ? seg_bound : cap;
     l.pmax = (int)((sb / KR_CH + 1 + 63) / 64) + 1;
-    l.fold_wgs = (l.nch_cap * 2 + 3) / 4;
+    l.fold_wgs = (l.nch_cap + 3) / 4;
     const size_t nc = (size_t)n_seg * kmax;
     size_t o = 0;
     auto take = [&](size_t bytes) { const size_t at = o; o += aoc_align_up(bytes, 256); return at; };
     l.cc64 = take(nc * 4);
-    l.own = take((size_t)l.nch_cap * 4);
+    l.cdesc = take((size_t)l.nch_cap * 16);
     l.hstate = take(nc * KR_C * 4);
     l.habs = take(nc * KR_C * 4);
     l.PT = take((size_t)KR_C * l.nch_cap * 4);
@@ -503,9 +549,11 @@ int aoc_kr_sums(const float *pool, const int32_t *seg_offsets, const int32_t *se
     KrArgs a;
     a.pool = pool; a.seg_off = seg_offsets; a.seg_k = seg_k; a.counts = counts; a.cbase = cbase; a.moff = moff;
     a.n_seg = n_seg; a.kmax = kmax; a.nch_cap = l.nch_cap; a.pmax = std::min(l.pmax, lb.pmax);
+    static const int dbg = getenv("AOC_KR_DEBUG") ? atoi(getenv("AOC_KR_DEBUG")) : 0;      // developer switch (timing experiments; wrong results)
+    a.dbg = dbg;
     a.centroids = centroids;
     a.cc64 = reinterpret_cast<int32_t *>(w + l.cc64);
-    a.own = reinterpret_cast<int32_t *>(w + l.own);
+    a.cdesc = reinterpret_cast<int4 *>(w + l.cdesc);
     a.hstate = reinterpret_cast<float *>(w + l.hstate);
     a.habs = reinterpret_cast<float *>(w + l.habs);
     a.PT = reinterpret_cast<float *>(w + l.PT);
@@ -514,13 +562,10 @@ int aoc_kr_sums(const float *pool, const int32_t *seg_offsets, const int32_t *se
     a.ppost = reinterpret_cast<uint32_t *>(w + l.ppost);
     a.pnp = reinterpret_cast<unsigned long long *>(w + l.pnp);
     const int nc = n_seg * kmax;
-    static const bool lds_ok = hipFuncSetAttribute(reinterpret_cast<const void *>(kr_fold_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) == hipSuccess;
-    if (!lds_ok) return AOC_ERR_LAUNCH;
-    const size_t fold_lds = (size_t)4 * (KR_CH * 64 + KX_MAX_LIT * 64) * 4;
     hipLaunchKernelGGL(kr_plan_kernel, dim3(n_seg), dim3(256), 0, st, a);
     hipLaunchKernelGGL(kr_heads_sums_kernel, dim3((nc * 2 + l.nch_cap * 2 + 3) / 4), dim3(256), 0, st, a);
     hipLaunchKernelGGL(kr_prefix_kernel, dim3((nc * KR_C + 3) / 4), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(kr_fold_kernel, dim3(l.fold_wgs), dim3(256), fold_lds, st, a);
+    hipLaunchKernelGGL(kr_fold_kernel, dim3(l.fold_wgs), dim3(256), 0, st, a);
     hipLaunchKernelGGL(kr_merge_kernel, dim3((nc * a.pmax * 2 + 3) / 4), dim3(256), 0, st, a);
     hipLaunchKernelGGL(kr_stitch_kernel, dim3((nc * 2 + 3) / 4), dim3(256), 0, st, a);
     AOC_RETURN_IF_LAUNCH_FAILED();

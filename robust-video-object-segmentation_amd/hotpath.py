@@ -208,7 +208,7 @@ class PendingCorrelation:
     """The correlation launch of one frame, deferred (proto_mask_features(defer_correlation=True)) so that the frames of several
     sequences in flight can share ONE batched launch (launch_correlations).  `ready` is recorded on the frame's stream when everything
     the launch reads (query, proxy table incl. the k = 1 rows) is final."""
-    __slots__ = ("query", "table", "sqn", "set_begin", "set_size", "set_off", "set_bias", "feat", "ready", "stream")
+    __slots__ = ("query", "query_split", "table", "sqn", "set_begin", "set_size", "set_off", "set_bias", "feat", "ready", "stream")
 
 
 def launch_correlations(pending, stream=None, precision="split"):
@@ -223,8 +223,16 @@ def launch_correlations(pending, stream=None, precision="split"):
                 for t in (p.query, p.table, p.sqn, p.set_bias, p.feat):
                     t.record_stream(stream)
         p0 = pending[0]
-        ops.proxy_corr_min_batched([(p.query, p.table, p.sqn, p.set_bias, p.feat) for p in pending], p0.set_begin, p0.set_size, p0.set_off, True,
-                                   precision)
+        if precision == "split" and all(p.query_split is not None for p in pending):
+            for p in pending:
+                if p.stream is not stream:
+                    p.query_split.records.record_stream(stream)
+                    p.query_split.sqnorm.record_stream(stream)
+            ops.proxy_corr_min_records([(p.query, p.query_split, p.table, p.sqn, p.set_bias, p.feat) for p in pending], p0.set_begin, p0.set_size,
+                                       p0.set_off, True)
+        else:
+            ops.proxy_corr_min_batched([(p.query, p.table, p.sqn, p.set_bias, p.feat) for p in pending], p0.set_begin, p0.set_size, p0.set_off, True,
+                                       precision)
         done = torch.cuda.Event()
         done.record(stream)
     return done
@@ -334,17 +342,27 @@ def proto_mask_features(cfg, ref_emb, ref_labels, prev_emb, prev_labels, cur_emb
             ops.split_rows(pool[done * hw:R * hw], out=pool_split, row0=done * hw)
         # records of pool frames [0, max(done, R)) are valid; a caller that restarts the pool (new sequence) resets "frames" to 0
         dense_state["pool_split"], dense_state["frames"] = pool_split, max(done, R)
+    # the query's split records, ONCE per frame and tile-major: the dense kernel and the correlation kernel both stream them in their MFMA
+    # operand layout (the correlation kernel reads the fp32 rows only on its exact-fp32 take-over)
+    query_split = None
+    if (dense_precision or ops.DENSE_PRECISION) == "split" and ops.split_record_bytes(C) and C == 100 and prep.n_obj <= 16:
+        query_split = ops.split_rows(query_flat, overflow=pool_split.overflow if pool_split is not None else None, tiled=True)
     dense_done = None
     if dense_stream is not None:
         main = torch.cuda.current_stream()
         dense_stream.wait_stream(main)
         with torch.cuda.stream(dense_stream):
-            ops.dense_match(query_flat, pool, prep, bias, feat, 1, obj_stride, True, precision=dense_precision, pool_split=pool_split)
+            ops.dense_match(query_flat, pool, prep, bias, feat, 1, obj_stride, True, precision=dense_precision, query_split=query_split,
+                            pool_split=pool_split)
             dense_done = torch.cuda.Event()
             dense_done.record(dense_stream)
         feat.record_stream(dense_stream)
+        if query_split is not None:
+            query_split.records.record_stream(dense_stream)
+            query_split.sqnorm.record_stream(dense_stream)
     else:
-        ops.dense_match(query_flat, pool, prep, bias, feat, 1, obj_stride, True, precision=dense_precision, pool_split=pool_split)
+        ops.dense_match(query_flat, pool, prep, bias, feat, 1, obj_stride, True, precision=dense_precision, query_split=query_split,
+                        pool_split=pool_split)
 
     # ---- local matching against the previous frame and against its per-pixel proxy map (aocnet.py:255,325-337)
     radii = list(cfg.MODEL_MULTI_LOCAL_DISTANCE)
@@ -403,6 +421,7 @@ def proto_mask_features(cfg, ref_emb, ref_labels, prev_emb, prev_labels, cur_emb
     if defer_correlation:
         pending = PendingCorrelation()
         pending.query, pending.table, pending.sqn, pending.set_bias, pending.feat = query_flat, table, sqn, set_bias, feat
+        pending.query_split = query_split
         pending.set_begin, pending.set_size, pending.set_off = set_begin, set_size, set_off
         pending.stream = torch.cuda.current_stream()
         pending.ready = torch.cuda.Event()
@@ -410,8 +429,11 @@ def proto_mask_features(cfg, ref_emb, ref_labels, prev_emb, prev_labels, cur_emb
     else:
         # the fp16-split correlation kernel (fp32-equivalent, device-side take-over to exact fp32), also for one frame per launch: with
         # hundreds of proxies (cfg3: 1158, cfg4: 1161) the exact-fp32 MFMA kernel is ten times slower; "fp32" asks for that kernel
-        ops.proxy_corr_min_batched([(query_flat, table, sqn, set_bias, feat)], set_begin, set_size, set_off, True,
-                                   "fp32" if (dense_precision or ops.DENSE_PRECISION) == "fp32" else "split")
+        if query_split is not None:
+            ops.proxy_corr_min_records([(query_flat, query_split, table, sqn, set_bias, feat)], set_begin, set_size, set_off, True)
+        else:
+            ops.proxy_corr_min_batched([(query_flat, table, sqn, set_bias, feat)], set_begin, set_size, set_off, True,
+                                       "fp32" if (dense_precision or ops.DENSE_PRECISION) == "fp32" else "split")
 
     # ---- previous-frame mask channel (aocnet.py:356 to_cat_previous_frame)
     feat[:, ch["prev_mask"]].copy_(prev_labels.permute(2, 0, 1))

@@ -204,8 +204,23 @@ class _CorrFrame(ctypes.Structure):
                 ("out", ctypes.c_void_p)]
 
 
+class _CorrFrameRec(ctypes.Structure):
+    """aoc_corr_frame_rec of include/aoc_hip.h."""
+    _fields_ = [("query", ctypes.c_void_p), ("query_rec", ctypes.c_void_p), ("query_sqnorm", ctypes.c_void_p), ("proxies", ctypes.c_void_p),
+                ("proxy_sqnorm", ctypes.c_void_p), ("set_bias", ctypes.c_void_p), ("out", ctypes.c_void_p)]
+
+
 CORR_PRECISION = {"split": 0, "fp32": 1}
 _corr_ws = {}
+
+
+def _corr_workspace(dev):
+    # the 256-byte flag workspace is only touched by kernels of one call, which are ordered on the call's stream: one per (device, stream)
+    key = (dev.index, _stream().value)
+    ws = _corr_ws.get(key)
+    if ws is None:
+        ws = _corr_ws[key] = torch.zeros(int(_lib.lib().aoc_proxy_corr_min_batched_workspace_bytes()), dtype=torch.uint8, device=dev)
+    return ws
 
 
 def proxy_corr_min_batched(frames, set_begin, set_size, set_out_offset, transform=True, precision="split"):
@@ -231,18 +246,55 @@ def proxy_corr_min_batched(frames, set_begin, set_size, set_out_offset, transfor
         keep.append((q, p, sq, b))
         arr[i] = _CorrFrame(q.data_ptr(), p.data_ptr(), sq.data_ptr() if sq is not None else None, b.data_ptr() if b is not None else None,
                             out.data_ptr())
-    dev = q0.device
     L = _lib.lib()
-    # the 256-byte flag workspace is only touched by kernels of this call, which are ordered on the call's stream: one per (device, stream)
-    key = (dev.index, _stream().value)
-    ws = _corr_ws.get(key)
-    if ws is None:
-        ws = _corr_ws[key] = torch.zeros(int(L.aoc_proxy_corr_min_batched_workspace_bytes()), dtype=torch.uint8, device=dev)
+    ws = _corr_workspace(q0.device)
     vp = ctypes.c_void_p
     _lib.check(L.aoc_proxy_corr_min_batched(ctypes.cast(arr, vp), len(frames), m, C, n_proxy, n_set, sb.ctypes.data_as(vp), ss.ctypes.data_as(vp),
                                             so.ctypes.data_as(vp), int(bool(transform)), CORR_PRECISION[precision], _p(ws), ws.numel(), _stream()),
                "aoc_proxy_corr_min_batched")
     return [f[4] for f in frames]
+
+
+def proxy_corr_min_records(frames, set_begin, set_size, set_out_offset, transform=True, prepare_only=False):
+    """aoc_proxy_corr_min_records: proxy_corr_min_batched with every frame's query handed over as the tile-major split records the dense
+    kernel consumes for the same frame.  frames: sequence of (query_flat [m, C], query_split (SplitRows, tiled), proxies, proxy_sqnorm or
+    None, set_bias or None, out)."""
+    q0, p0 = frames[0][0], frames[0][2]
+    m, C = q0.shape
+    n_proxy = p0.shape[0]
+    sb = np.ascontiguousarray(np.asarray(set_begin, dtype=np.int32))
+    ss = np.ascontiguousarray(np.asarray(set_size, dtype=np.int32))
+    so = np.ascontiguousarray(np.asarray(set_out_offset, dtype=np.int64))
+    n_set = sb.size
+    assert ss.size == n_set and so.size == n_set
+    arr = (_CorrFrameRec * len(frames))()
+    keep = []
+    for i, (q, qs, p, sq, b, out) in enumerate(frames):
+        q, p = _f32c(q), _f32c(p)
+        sq = _f32c(sq) if sq is not None else None
+        b = _f32c(b) if b is not None else None
+        _need_gpu(q, p, sq, b, out, qs.records, qs.sqnorm)
+        assert qs.tiled and qs.n == m, "the records kernel reads aoc_split_rows_tiled records of the whole query"
+        assert q.shape == (m, C) and p.shape == (n_proxy, C) and (b is None or b.numel() == n_set)
+        keep.append((q, p, sq, b))
+        arr[i] = _CorrFrameRec(q.data_ptr(), qs.records.data_ptr(), qs.sqnorm.data_ptr(), p.data_ptr(), sq.data_ptr() if sq is not None else None,
+                               b.data_ptr() if b is not None else None, out.data_ptr())
+    vp = ctypes.c_void_p
+    fn = _lib.lib().aoc_proxy_corr_min_records
+    dev = q0.device
+    n_frames = len(frames)
+    outs = [f[5] for f in frames]
+
+    def launch():
+        ws = _corr_workspace(dev)
+        _lib.check(fn(ctypes.cast(arr, vp), n_frames, m, C, n_proxy, n_set, sb.ctypes.data_as(vp), ss.ctypes.data_as(vp), so.ctypes.data_as(vp),
+                      int(bool(transform)), _p(ws), ws.numel(), _stream()), "aoc_proxy_corr_min_records")
+        return outs
+
+    launch.keep = (keep, frames)          # the tensors behind the raw pointers
+    if prepare_only:
+        return launch                     # bench.py: the argument marshalling stays outside the timed bracket
+    return launch()
 
 
 def dense_match_min(query_flat, pool, prep, obj_bias, out, out_pixel_stride, out_obj_stride, transform=True, float16=False):
@@ -264,17 +316,21 @@ def dense_match_min(query_flat, pool, prep, obj_bias, out, out_pixel_stride, out
 
 
 class SplitRows:
-    """fp16 split records of embedding rows (aoc_split_rows): records [n, 448] uint8, sqnorm [n], overflow flag [1]."""
-    __slots__ = ("records", "sqnorm", "overflow", "n")
+    """fp16 split records of embedding rows (aoc_split_rows): records [n, 448] uint8, sqnorm [n], overflow flag [1].  tiled: the records
+    in tile-major order (aoc_split_rows_tiled; [ceil(n / 32) * 32, 448] uint8) -- the query side of the dense and correlation kernels."""
+    __slots__ = ("records", "sqnorm", "overflow", "n", "tiled")
+
+    def __init__(self):
+        self.tiled = False
 
 
 def split_record_bytes(C):
     return int(_lib.lib().aoc_split_record_bytes(int(C)))
 
 
-def split_rows(x_flat, out=None, row0=0, overflow=None):
+def split_rows(x_flat, out=None, row0=0, overflow=None, tiled=False):
     """x [n, C] fp32 -> SplitRows.  With `out` (a SplitRows with capacity) the records are written at row `row0` of it
-    (the reference pool grows in place: only the appended frame is converted)."""
+    (the reference pool grows in place: only the appended frame is converted).  tiled: tile-major records of the whole x (a query)."""
     x_flat = _f32c(x_flat)
     _need_gpu(x_flat)
     n, C = x_flat.shape
@@ -282,6 +338,17 @@ def split_rows(x_flat, out=None, row0=0, overflow=None):
     if rb == 0:
         raise _lib.AocHipError(f"split records need C % 4 == 0 and C <= 100 (got {C})")
     dev = x_flat.device
+    if tiled:
+        assert out is None and row0 == 0
+        out = SplitRows()
+        out.tiled = True
+        out.records = torch.empty((n + 31) // 32 * 32, rb, dtype=torch.uint8, device=dev)
+        out.sqnorm = torch.empty(n, dtype=torch.float32, device=dev)
+        out.overflow = overflow if overflow is not None else torch.zeros(1, dtype=torch.int32, device=dev)
+        out.n = n
+        _lib.check(_lib.lib().aoc_split_rows_tiled(_p(x_flat), n, C, _p(out.records), _p(out.sqnorm), _p(out.overflow), _stream()),
+                   "aoc_split_rows_tiled")
+        return out
     if out is None:
         out = SplitRows()
         out.records = torch.empty(n, rb, dtype=torch.uint8, device=dev)
@@ -321,7 +388,9 @@ def dense_match_min_split(query_flat, query_split, pool, pool_split, prep, obj_b
     flag = pool_split.overflow
     if query_split.overflow.data_ptr() != flag.data_ptr():
         flag = torch.maximum(flag, query_split.overflow)
-    _lib.check(L.aoc_dense_match_min_split(_p(query_flat), _p(query_split.records), _p(query_split.sqnorm), m, C, _p(pool), _p(pool_split.records),
+    assert not pool_split.tiled
+    _lib.check(L.aoc_dense_match_min_split(_p(query_flat), _p(query_split.records), _p(query_split.sqnorm), int(query_split.tiled), m, C, _p(pool),
+                                           _p(pool_split.records),
                                            _p(flag), n, _p(prep.right_bits), _p(prep.wrong_bits), _p(prep.fg_rows), _p(prep.obj_rows),
                                            _p(prep.counts), _p(prep.obj_offsets), _p(obj_bias), n_obj, _p(out), int(out_pixel_stride),
                                            int(out_obj_stride), int(bool(transform)), _p(ws), ws.numel(), _stream()),
@@ -349,7 +418,7 @@ def dense_match(query_flat, pool, prep, obj_bias, out, out_pixel_stride, out_obj
     if pool_split is None:
         pool_split = split_rows(pool[:prep.n])
     if query_split is None:
-        query_split = split_rows(query_flat, overflow=pool_split.overflow)
+        query_split = split_rows(query_flat, overflow=pool_split.overflow, tiled=True)
     return dense_match_min_split(query_flat, query_split, pool, pool_split, prep, obj_bias, out, out_pixel_stride, out_obj_stride, transform)
 
 

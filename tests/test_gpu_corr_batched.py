@@ -51,6 +51,17 @@ def _case(rng, m, C, sizes, absent=(), n_frames=1, scale=0.3):
     return frames, sb, list(sizes)
 
 
+def _run_split(aoc, entry, dev_frames, sb, ss, so, transform=True):
+    """the fp16-split correlation through either entry point: fp32 queries (aoc_proxy_corr_min_batched) or the queries as tile-major
+    split records (aoc_proxy_corr_min_records)"""
+    if entry == "records":
+        rec = [(f[0], aoc.ops.split_rows(f[0], tiled=True), f[1], f[2], f[3], f[4]) for f in dev_frames]
+        aoc.ops.proxy_corr_min_records(rec, sb, ss, so, transform)
+    else:
+        aoc.ops.proxy_corr_min_batched(dev_frames, sb, ss, so, transform, "split")
+
+
+@pytest.mark.parametrize("entry", ["batched", "records"])
 @pytest.mark.parametrize("sizes,absent,m,n_frames", [
     ([16] * 8 + [1] * 4, (), 25773, 2),                  # cfg2 shape: 4 objects x (centroid, centroid_avg) + 4 k = 1 proxies
     ([8] * 6 + [16] * 6 + [32] * 6 + [1] * 3, (), 1000, 3),   # multi-level
@@ -58,7 +69,7 @@ def _case(rng, m, C, sizes, absent=(), n_frames=1, scale=0.3):
     ([16, 16, 16, 16, 1, 1], (3, 4, 5, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 65), 333, 1),   # absent proxies / whole absent set / absent k=1
     ([16] * 8 + [1] * 4, (), 31, 5),                     # fewer pixels than a tile
 ])
-def test_batched_split_vs_oracle(aoc, sizes, absent, m, n_frames):
+def test_batched_split_vs_oracle(aoc, sizes, absent, m, n_frames, entry):
     rng = np.random.RandomState(len(sizes) * 7 + m)
     C = 100
     frames, sb, ss = _case(rng, m, C, sizes, absent, n_frames)
@@ -69,7 +80,7 @@ def test_batched_split_vs_oracle(aoc, sizes, absent, m, n_frames):
         out = torch.full((n_set, m), -7.0, device="cuda")
         outs.append(out)
         dev_frames.append((q.cuda(), t.cuda(), sq.cuda(), bias.cuda(), out))
-    aoc.ops.proxy_corr_min_batched(dev_frames, sb, ss, so, True, "split")
+    _run_split(aoc, entry, dev_frames, sb, ss, so)
     ref32 = [torch.full((n_set, m), -7.0, device="cuda") for _ in frames]
     aoc.ops.proxy_corr_min_batched([(f[0], f[1], f[2], f[3], r) for f, r in zip(dev_frames, ref32)], sb, ss, so, True, "fp32")
     for (q, t, sq, bias), out, r32 in zip(frames, outs, ref32):
@@ -78,7 +89,8 @@ def test_batched_split_vs_oracle(aoc, sizes, absent, m, n_frames):
         np.testing.assert_allclose(r32.cpu().numpy(), want.numpy(), rtol=0, atol=ATOL)
 
 
-def test_batched_raw_distances_and_wide_range(aoc):
+@pytest.mark.parametrize("entry", ["batched", "records"])
+def test_batched_raw_distances_and_wide_range(aoc, entry):
     """transform = 0 (raw squared distances) on data with a wide dynamic range, against float64."""
     rng = np.random.RandomState(5)
     m, C = 2000, 100
@@ -87,7 +99,7 @@ def test_batched_raw_distances_and_wide_range(aoc):
     sb, ss = [0, 16, 32, 33, 34], [16, 16, 1, 1, 6]
     so = [s * m for s in range(5)]
     out = torch.empty(5, m, device="cuda")
-    aoc.ops.proxy_corr_min_batched([(torch.from_numpy(q).cuda(), torch.from_numpy(t).cuda(), None, None, out)], sb, ss, so, False, "split")
+    _run_split(aoc, entry, [(torch.from_numpy(q).cuda(), torch.from_numpy(t).cuda(), None, None, out)], sb, ss, so, False)
     q64, t64 = q.astype(np.float64), t.astype(np.float64)
     d = (q64 ** 2).sum(1)[:, None] + (t64 ** 2).sum(1)[None] - 2 * q64 @ t64.T
     want = np.stack([d[:, b:b + n].min(1) for b, n in zip(sb, ss)])
@@ -95,7 +107,8 @@ def test_batched_raw_distances_and_wide_range(aoc):
     assert float(np.max(np.abs(out.cpu().numpy() - want) / scale)) < 2e-6      # fp32-level relative error of a distance
 
 
-def test_batched_takeover_when_values_do_not_fit(aoc):
+@pytest.mark.parametrize("entry", ["batched", "records"])
+def test_batched_takeover_when_values_do_not_fit(aoc, entry):
     """|x| * 2^10 > 65000 somewhere: the device-side flag makes the exact-fp32 kernel recompute the launch (no host round trip)."""
     rng = np.random.RandomState(6)
     m, C = 500, 100
@@ -103,7 +116,7 @@ def test_batched_takeover_when_values_do_not_fit(aoc):
     frames[1][0][123, 7] = 80.0                                   # 80 * 1024 > 65000
     so = [s * m for s in range(3)]
     dev_frames = [(q.cuda(), t.cuda(), sq.cuda(), b.cuda(), torch.empty(3, m, device="cuda")) for q, t, sq, b in frames]
-    aoc.ops.proxy_corr_min_batched(dev_frames, sb, ss, so, True, "split")
+    _run_split(aoc, entry, dev_frames, sb, ss, so)
     ref = [torch.empty(3, m, device="cuda") for _ in frames]
     aoc.ops.proxy_corr_min_batched([(f[0], f[1], f[2], f[3], r) for f, r in zip(dev_frames, ref)], sb, ss, so, True, "fp32")
     for f, r in zip(dev_frames, ref):
@@ -127,3 +140,20 @@ def test_sets_beyond_the_lds_image_take_the_exact_kernel(aoc):
     dist = om.flattened_pairwise_distances(tab, tab.pow(2).sum(1), q, q.pow(2).sum(1))
     want = torch.stack([om.proto_transform(dist[:, b:b + n].min(1)[0], bias[i]) for i, (b, n) in enumerate(zip(sb, ss))])
     assert torch.allclose(out.cpu(), want, rtol=0, atol=5e-6)
+
+
+def test_tiled_records_are_the_row_major_records_reordered(aoc):
+    """aoc_split_rows_tiled writes exactly the chunks of aoc_split_rows, tile-major ([tile][plane][k-step][k-half][row % 32]); rows past n
+    are zero records; sqnorm and the overflow flag agree."""
+    rng = np.random.RandomState(11)
+    n, C = 1000 + 7, 100
+    x = torch.from_numpy((rng.randn(n, C) * 0.4).astype(np.float32)).cuda()
+    a = aoc.ops.split_rows(x)
+    b = aoc.ops.split_rows(x, tiled=True)
+    assert torch.equal(a.sqnorm, b.sqnorm) and int(b.overflow.item()) == 0
+    T = (n + 31) // 32
+    rows = torch.zeros(T * 32, 448, dtype=torch.uint8, device="cuda")
+    rows[:n] = a.records
+    # row-major chunk (plane p, k-step s, half h) of row r = bytes [(p * 14 + s * 2 + h) * 16, +16)
+    want = rows.view(T, 32, 2, 7, 2, 16).permute(0, 2, 3, 4, 1, 5).contiguous().view(T * 32, 448)
+    assert torch.equal(b.records, want)

@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--reps", type=int, default=30)
     ap.add_argument("--precision", default="split")
     ap.add_argument("--check", action="store_true", help="compare the split launch with the exact-fp32 one")
+    ap.add_argument("--records", action="store_true", help="aoc_proxy_corr_min_records: the queries as tile-major split records")
     args = ap.parse_args()
     cfg = syn.CONFIGS[args.config]
     levels = LEVELS[args.config]
@@ -47,6 +48,8 @@ def main():
                 ss.append(k)
                 so.append(o * stride + (ch["cluster"] + 2 * l + f) * hw)
     for o in range(O):
+        if os.environ.get("AOC_BENCH_NO_SINGLES"):     # developer switch: leave the k = 1 proxies out (timing experiments)
+            break
         sb.append(n_ad + o)
         ss.append(1)
         so.append(o * stride + ch["proxy"] * hw)
@@ -62,11 +65,16 @@ def main():
         bias = torch.zeros(n_set, device=dev)
         out = torch.empty(O, n_ch, cfg.h, cfg.w, device=dev)
         frames.append((q, table, sqn, bias, out))
+    splits = [ops.split_rows(f[0], tiled=True) for f in frames] if args.records else None
     algo = hw * C * 4 + (n_ad + O) * C * 4 + 4 * hw * n_set
     flops = 2.0 * hw * sum(ss) * C
     for b in [int(v) for v in args.batches.split(",")]:
         fr = frames[:b]
-        run = lambda: ops.proxy_corr_min_batched(fr, sb, ss, so, True, args.precision)
+        if args.records:
+            rfr = [(f[0], sp, f[1], f[2], f[3], f[4]) for f, sp in zip(fr, splits)]
+            run = lambda: ops.proxy_corr_min_records(rfr, sb, ss, so, True)
+        else:
+            run = lambda: ops.proxy_corr_min_batched(fr, sb, ss, so, True, args.precision)
         for _ in range(3):
             run()
         torch.cuda.synchronize()
@@ -79,7 +87,7 @@ def main():
         per = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(args.reps))
         ms = per[len(per) // 2]          # median call (the first use of fresh buffers costs tens of ms once)
         gbs = b * algo / (ms * 1e-3) / 1e9
-        line = dict(config=args.config, precision=args.precision, frames_per_launch=b, avg_launch_ms=round(ms, 4), us_per_frame=round(ms * 1e3 / b, 2),
+        line = dict(config=args.config, precision="split, query as records" if args.records else args.precision, frames_per_launch=b, avg_launch_ms=round(ms, 4), us_per_frame=round(ms * 1e3 / b, 2),
                     algorithmic_bytes_per_launch=b * algo, achieved_gbs=round(gbs, 1), frac_of_8TBs=round(gbs / 8000.0, 4),
                     algorithmic_tflops=round(b * flops / (ms * 1e-3) / 1e12, 2), n_set=n_set, proxies=n_ad + O,
                     per_call_ms_min_med_max=[round(per[0], 4), round(per[len(per) // 2], 4), round(per[-1], 4)])
