@@ -526,9 +526,12 @@ def cpu_baseline(cfg, mc, seed, gates, acts_cpu):
 
 # HBM-side traffic of the correlation kernel from committed rocprofv3 --pmc passes (separate FETCH_SIZE / WRITE_SIZE runs, FETCH doubled per the
 # gfx950 note of the micro-architecture guide); counters cannot be read inside the timed run
-TRAFFIC_OFFLINE = dict(file="profiles/r02_pmc_corr_cfg2_B16.txt", commit="16025a4", frames_per_launch=16, fetch_bytes=2 * 81.2e6, write_bytes=20.6e6,
-                       bytes_per_launch=183.0e6, algorithmic_bytes_per_launch=185.6e6, ratio=0.99,
-                       note="cfg2, 16 frames per launch: the kernel moves what the algorithm needs (no wasted re-reads); its deficit is on-chip")
+TRAFFIC_OFFLINE = dict(file="profiles/r03_pmc_corr_records_B16.txt", commit="see `git log -1 -- profiles/r03_pmc_corr_records_B16.txt`",
+                       kernel="proxy_corr_records_kernel", frames_per_launch=16, fetch_bytes=2 * 91.63e6, write_bytes=20.7e6,
+                       bytes_per_launch=204.0e6, algorithmic_bytes_per_launch=185.6e6, ratio=1.10,
+                       note="cfg2, 16 frames per launch: FETCH_SIZE x 2 (gfx950 counts 128-byte requests as 64) + WRITE_SIZE; the kernel reads the "
+                            "query as 448-byte split records where SURVEY 8d prices the fp32 rows (400 bytes): 1.10 x the algorithmic bytes, no "
+                            "re-reads; its deficit is on-chip (the matrix pipe, profiles/r03_corr_mfma_bound.txt)")
 
 
 def free_port():
