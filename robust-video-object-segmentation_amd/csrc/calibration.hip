@@ -1,6 +1,8 @@
 // Streaming kernels of the mask-calibration side: fg->bg min (AEM:9-23), k = 1 proxy pooling
 // (ATT:134-189), FiLM gate (ATT:12-17, CLB:81-84) and the conditioning-layer gate + pool (CL:23-43).
 // All of them are HBM-bound: one coalesced pass over the big operand, reductions in LDS/registers.
+#include <stdlib.h>
+
 #include "aoc_common.h"
 
 namespace {
@@ -290,7 +292,7 @@ __global__ __launch_bounds__(256) void channel_scale_kernel(const float *__restr
 // FiLM gate in one launch: every block first computes its plane's gain 1 + tanh(head[o,:].W[c,:] + b[c]) (a D-long
 // dot product, block-reduced), then streams its slice of the plane.  Saves the separate gain launch + round trip.
 __global__ __launch_bounds__(256) void film_scale_kernel(const float *__restrict__ x, const float *__restrict__ head, const float *__restrict__ weight,
-                                                          const float *__restrict__ bias, int D, int channels, int64_t hw, float *__restrict__ y) {
+                                                          const float *__restrict__ bias, int D, int channels, int64_t hw, float *__restrict__ y, int nt) {
     __shared__ float wsum[4];
     const int64_t plane = blockIdx.y;
     const int o = (int)(plane / channels), c = (int)(plane - (int64_t)o * channels);
@@ -338,7 +340,12 @@ __global__ __launch_bounds__(256) void film_scale_kernel(const float *__restrict
                 const int64_t i = i0 + u * nthreads;
                 if (i < body4) {
                     v[u].x *= g; v[u].y *= g; v[u].z *= g; v[u].w *= g;
-                    y4[i] = v[u];
+                    if (nt) {
+                        typedef float f32x4_t __attribute__((ext_vector_type(4)));
+                        __builtin_nontemporal_store(f32x4_t{v[u].x, v[u].y, v[u].z, v[u].w}, reinterpret_cast<f32x4_t *>(y4 + i));
+                    } else {
+                        y4[i] = v[u];
+                    }
                 }
             }
         }
@@ -1057,7 +1064,11 @@ int aoc_film_scale(const float *x, const float *head, const float *weight, const
     int bx = (int)((hw / 4 + 255) / 256);
     if (bx < 1) bx = 1;
     if (bx > 8) bx = 8;
-    hipLaunchKernelGGL(film_scale_kernel, dim3(bx, (unsigned)planes), dim3(256), 0, aoc_hip_stream(stream), x, head, weight, bias, head_dim, channels, hw, y);
+    // nontemporal stores: the gated activation is a pure stream-out, and every dirty line it would leave in the XCDs' L2s is written back at
+    // the next kernel boundary of ANY stream -- the k-means chain on the side stream has 125 of them per frame (bench: +2 % frames/s;
+    // AOC_FILM_NT=0 switches back)
+    static const int nt = getenv("AOC_FILM_NT") ? atoi(getenv("AOC_FILM_NT")) : 1;
+    hipLaunchKernelGGL(film_scale_kernel, dim3(bx, (unsigned)planes), dim3(256), 0, aoc_hip_stream(stream), x, head, weight, bias, head_dim, channels, hw, y, nt);
     AOC_RETURN_IF_LAUNCH_FAILED();
     return AOC_OK;
 }
