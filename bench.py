@@ -80,7 +80,7 @@ class HipEventPairs:
 
 class OpTimer:
     """HIP-event timing of every call of selected aoc_amd.ops functions on the stream they are launched on (torch's current stream).
-    Recording is switched on for the timed region only; the explicit ordering of the sequences' dense kernels is applied always (warm-up
+    Recording is switched on for the timed region only; the explicit ordering of the sequences' dense kernels (--dense-order) is applied always (warm-up
     and timed region schedule the same way)."""
 
     def __init__(self, names):
@@ -626,8 +626,11 @@ def main():
     ap.add_argument("--batch-corr", action="store_true",
                     help="ONE batched correlation launch per step for the frames of all in-flight sequences instead of one launch per sequence and "
                          "frame (measured slower with 2 sequences in flight: the shared launch makes the streams wait for each other every step)")
-    ap.add_argument("--no-dense-order", action="store_true",
-                    help="do not order the sequences' dense kernels explicitly (their live timing then includes queueing behind each other)")
+    ap.add_argument("--dense-order", action="store_true",
+                    help="order the in-flight sequences' dense kernels explicitly (one after the other: the kernel's live timing then excludes "
+                         "the time it shares the chip with the other sequence's dense kernel -- 0.24 instead of 0.22 of the fp16 peak -- at 2 % "
+                         "fewer frames/s: 325 against 332)")
+    ap.add_argument("--no-dense-order", action="store_true", help="(default since round 3; kept for old command lines)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="start a frame's k-means chain with the frame instead of as soon as its pool is final")
     ap.add_argument("--no-overlap", action="store_true", help="run the k-means branch on the main stream (no intra-frame stream overlap)")
@@ -800,7 +803,7 @@ def main():
     timer = OpTimer(["dense_match_min", "dense_match_min_split", "proxy_corr_min", "proxy_corr_min_batched", "proxy_corr_min_records", "kmeans_segmented",
                      "local_window_match",
                      "film_scale", "cond_gate_pool"])
-    timer.serialize_dense = not args.no_dense_order
+    timer.serialize_dense = bool(args.dense_order) and not args.no_dense_order
     timer.install(dict(dense_match_min=meta_dense, dense_match_min_split=meta_dense_split, proxy_corr_min=meta_proxy,
                        proxy_corr_min_batched=meta_proxy_batched, proxy_corr_min_records=meta_proxy_records, kmeans_segmented=meta_kmeans, film_scale=meta_film, cond_gate_pool=meta_cond))
     corr_stream = torch.cuda.Stream(device=dev) if batch_corr else None
@@ -954,7 +957,8 @@ def main():
                                      "added on chip (exactly the three-product value; same result as evaluating everything); frac prices the "
                                      "ALGORITHMIC fp32 flops (2 m n C) against the dense fp16 peak, pipe_frac the executed ones; avg_launch_ms = "
                                      "hipEvents recorded by the library immediately around the kernel while the other sequence's stream shares the "
-                                     "GPU; traffic (PMC FETCH/WRITE) is not measurable inside the run: the separate --pmc passes are under profiles/",
+                                     "GPU -- including, unless --dense-order is given, the other sequence's dense kernel (0.22 overlapping, 0.24 one "
+                                     "after the other, 0.31 alone); traffic (PMC FETCH/WRITE) is not measurable inside the run: the separate --pmc passes are under profiles/",
                                 op_avg_ms=k.get("op_avg_ms"))
                 if args.cu_reserve > 0:
                     # the kernel is launched on a stream whose CU mask leaves cu_reserve CUs to the k-means chains

@@ -55,6 +55,22 @@ ms = (time.perf_counter() - t0) / n * 1e3
 rows = sum(counts)
 print(f"k-means chain R={R} F={F} CUs={NCU or 'all'}: {ms:.3f} ms per chain ({ms / F:.3f} per frame), {rows} rows x {F} replicas", flush=True)
 
+NS = int(os.environ.get("KM_STREAMS", "0"))                # KM_STREAMS=n: n chains at a time, each on its own stream (do concurrent chains overlap?)
+if NS > 1:
+    sides = [torch.cuda.Stream(priority=-1) for _ in range(NS)]
+    def run_all():
+        for sd in sides:
+            hotpath.launch_cluster_proxies(mc, emb, lab, inits[0], sd)
+    for _ in range(2):
+        run_all()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        run_all()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / n * 1e3
+    print(f"  {NS} chains at a time on {NS} streams: {ms:.3f} ms per round = {ms / NS:.3f} ms per chain", flush=True)
+
 if os.environ.get("AOC_KM_PROF"):
     v = (ctypes.c_uint64 * 32)()
     aoc_amd._lib.lib().aoc_kmeans_chain_profile(v, 1)
