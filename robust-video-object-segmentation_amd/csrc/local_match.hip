@@ -561,8 +561,27 @@ __global__ __launch_bounds__(256) void resize_bilinear_hwc_kernel(const float *_
     bilinear_src(X, sw, w, x0, x1, wx0, wx1);
     const float v00 = in[((size_t)y0 * w + x0) * C + c], v01 = in[((size_t)y0 * w + x1) * C + c];
     const float v10 = in[((size_t)y1 * w + x0) * C + c], v11 = in[((size_t)y1 * w + x1) * C + c];
-    if (f16) {   // F.interpolate on a float16 tensor: float16 samples, fp32 arithmetic, float16 result
-        out[idx] = aoc_h(hy0 * (wx0 * aoc_h(v00) + wx1 * aoc_h(v01)) + hy1 * (wx0 * aoc_h(v10) + wx1 * aoc_h(v11)));
+    if (f16) {
+        // F.interpolate on a float16 tensor (AEM:938-941 after `.half()`): float16 samples, fp32 arithmetic, ONE rounding to float16.  The
+        // fp32 value is a float16 tie surprisingly often (weights like 0.9 x 11-bit samples), so the association order matters: this is
+        // torch-CPU's channels-last kernel term by term -- the four corner weights as fp32 products, then a fused multiply-add chain that
+        // runs from the last corner to the first inside its vector body (32 float16 channels per AVX-512 vector) and from the first to the
+        // last in its scalar tail (channels >= C - C % 32).  Found by enumerating the orders against F.interpolate: 0 of 27 300 differ.
+        const float a = aoc_h(v00), b = aoc_h(v01), cc = aoc_h(v10), d = aoc_h(v11);
+        const float w00 = hy0 * wx0, w01 = hy0 * wx1, w10 = hy1 * wx0, w11 = hy1 * wx1;
+        float acc;
+        if (c < C - C % 32) {
+            acc = w11 * d;
+            acc = __builtin_fmaf(w10, cc, acc);
+            acc = __builtin_fmaf(w01, b, acc);
+            acc = __builtin_fmaf(w00, a, acc);
+        } else {
+            acc = w00 * a;
+            acc = __builtin_fmaf(w01, b, acc);
+            acc = __builtin_fmaf(w10, cc, acc);
+            acc = __builtin_fmaf(w11, d, acc);
+        }
+        out[idx] = aoc_h(acc);
         return;
     }
     out[idx] = hy0 * (wx0 * v00 + wx1 * v01) + hy1 * (wx0 * v10 + wx1 * v11);

@@ -348,10 +348,13 @@ def test_local_atrous_golden(aoc, golden, name):
     np.testing.assert_allclose(out.cpu().numpy(), g["out"], rtol=0, atol=ATOL)
 
 
-def _f16_close(got, want, frac_exact=0.97, atol=1.2e-2):
-    """use_float16 mode: the reference's distances are float16 TENSORS; the device accumulates the same exact products in fp32 in another
-    order, which can move a float16 rounding of a norm / dot product by one float16 ulp of a value of O(1..10) (<= 2^-7), i.e. up to
-    about 4e-3 on an output after the sigmoid's slope <= 1/2.  Stated tolerance: >= 97 % of the outputs equal to 2e-6, all within 1.2e-2."""
+def _f16_close(got, want, frac_exact=0.999, atol=4e-3):
+    """use_float16 mode: the reference's distances are float16 TENSORS, so every step that rounds to float16 must round the same fp32 value.
+    Since round 3 the device reproduces torch-CPU's arithmetic where it matters -- the float16 bilinear resize term by term (its fp32 values
+    are float16 ties surprisingly often), dot products k-sequentially in fp32, squares rounded to float16 before they are summed -- and the
+    dense and local outputs equal the reference's own `.half()` code to 1.2e-7 on every element.  What is left is the summation order of a
+    dot product in the k = 1 proxy path (1 output of 2 880 off by one float16 ulp of a distance: 9e-4).  Stated tolerance: >= 99.9 % of the
+    outputs equal to 2e-6, all within 4e-3."""
     diff = np.abs(got - want)
     assert diff.max() <= atol, diff.max()
     assert np.mean(diff <= 2e-6) >= frac_exact, np.mean(diff <= 2e-6)

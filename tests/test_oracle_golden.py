@@ -309,10 +309,9 @@ def test_fullsize_cfg1_oracle(golden):
 
 
 # ------------------------------------------------------------------------------------------ use_float16=True (reference .half() paths)
-def _f16_close(got, want, frac_exact=0.97, atol=1.2e-2):
-    """float16-mode outputs: distances are float16 TENSORS in the reference, so a different fp32 summation order inside a dot product
-    or a norm can move a result by one float16 ulp of a distance of O(1..10) (up to 2^-7 = 0.0078, less than 1.2e-2 on the output after
-    the sigmoid's slope <= 1/2 ... bounded here generously).  Almost all elements agree to fp32 rounding."""
+def _f16_close(got, want, frac_exact=1.0, atol=2e-6):
+    """float16-mode outputs: distances are float16 TENSORS in the reference; the oracle restates its steps with the same torch-CPU operations
+    (same shapes, same memory formats), so it reproduces the reference's own `.half()` outputs on every element."""
     diff = np.abs(got - want)
     assert diff.max() <= atol, diff.max()
     assert np.mean(diff <= 2e-6) >= frac_exact, np.mean(diff <= 2e-6)
