@@ -154,6 +154,26 @@ def test_c_abi_rejects_bad_arguments_without_a_gpu():
     assert L.aoc_dense_match_min(p, 100, 100, p, ip, ip, 50, ip, p, 3, p, 1, 100, 1, p, 16, None) == WORKSPACE
     assert L.aoc_split_record_bytes(100) == 448 and L.aoc_split_record_bytes(104) == 0 and L.aoc_split_record_bytes(98) == 0
     assert L.aoc_dense_match_workspace_bytes(0, 5, 3) == 0
+    # tile-major records: whole 32-row tiles; the records correlation entry validates its frame table before anything is enqueued
+    assert L.aoc_split_rows_tiled_bytes(33, 100) == 64 * 448 and L.aoc_split_rows_tiled_bytes(32, 100) == 32 * 448
+    assert L.aoc_split_rows_tiled_bytes(10, 98) == 0
+    assert L.aoc_split_rows_tiled(None, 10, 100, p, p, ip, None) == INVALID
+    assert L.aoc_split_rows_tiled(p, 10, 98, p, p, ip, None) == UNSUPPORTED
+
+    class Frame(ctypes.Structure):
+        _fields_ = [(n, vp) for n in ("query", "query_rec", "query_sqnorm", "proxies", "proxy_sqnorm", "set_bias", "out")]
+    fr = (Frame * 1)(Frame(ctypes.addressof(dummy), ctypes.addressof(dummy), ctypes.addressof(dummy), ctypes.addressof(dummy), None, None,
+                           ctypes.addressof(dummy)))
+    fp = ctypes.cast(fr, vp)
+    i64 = (ctypes.c_int64 * 4)()
+    lp = ctypes.cast(i64, vp)
+    ws = (ctypes.c_char * 256)()
+    wp = ctypes.cast(ws, vp)
+    assert L.aoc_proxy_corr_min_records(fp, 1, 64, 96, 4, 1, ip, ip, lp, 1, wp, 256, None) == UNSUPPORTED      # records exist for C = 100 only
+    assert L.aoc_proxy_corr_min_records(fp, 1, 64, 100, 4, 1, ip, ip, lp, 1, None, 0, None) == WORKSPACE
+    assert L.aoc_proxy_corr_min_records(fp, 0, 64, 100, 4, 1, ip, ip, lp, 1, wp, 256, None) == INVALID
+    fr[0].query_rec = None
+    assert L.aoc_proxy_corr_min_records(fp, 1, 64, 100, 4, 1, ip, ip, lp, 1, wp, 256, None) == INVALID         # a frame without records
 
 
 def test_mirrors_refuse_to_run_under_autograd():
