@@ -189,7 +189,7 @@ class ClipWorkload:
     (ground-truth) label maps, R(t) = 1 + (t - 1) // MEM_EVERY -- exactly what the sequential loop with the reference's memory policy
     builds -- so every pool state exists from the start and the frames can be visited group by group in any order."""
 
-    def __init__(self, cfg, seed, device, mc, overlap=True, phase=0):
+    def __init__(self, cfg, seed, device, mc, overlap=True, phase=0, start=0):
         self.cfg, self.mc, self.dev = cfg, mc, device
         # the k-means branch (a long chain of small launches) runs on a high-priority side stream,
         # concurrently with the MFMA-bound dense matching on the main stream
@@ -231,6 +231,9 @@ class ClipWorkload:
         rot = (phase // 2) * 2 % len(order)
         order = order[rot:] + order[:rot]
         self.order = [t for g in order for t in groups[g]]
+        # `start`: position of the (cyclic) walk at which this sequence begins.  Sequences that start inside a group cross their group
+        # boundaries -- where a frame has to wait for a k-means chain that could not be enqueued ahead -- at different steps
+        self.start = start % len(self.order)
         self.group_first = {groups[g][0] for g in range(len(groups))}
         self.group_of = {t: g for g in range(len(groups)) for t in groups[g]}
         self.groups = groups
@@ -252,7 +255,7 @@ class ClipWorkload:
         return 1 + (t - 1) // self.mc.MEM_EVERY
 
     def reset(self):
-        self.pos = 0
+        self.pos = self.start
         self.dense_state["frames"] = 0
         self.dense_state.pop("ref_pool", None)
         self.cached_ahead = None
@@ -631,6 +634,9 @@ def main():
                          "the time it shares the chip with the other sequence's dense kernel -- 0.24 instead of 0.22 of the fp16 peak -- at 2 % "
                          "fewer frames/s: 325 against 332)")
     ap.add_argument("--no-dense-order", action="store_true", help="(default since round 3; kept for old command lines)")
+    ap.add_argument("--no-stagger", dest="stagger", action="store_false",
+                    help="start every in-flight sequence at a group boundary (default: sequence s starts s * MEM_EVERY / streams frames into its first group, "
+                         "so that the sequences need their un-prefetchable first-of-group k-means chains at different steps)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="start a frame's k-means chain with the frame instead of as soon as its pool is final")
     ap.add_argument("--no-overlap", action="store_true", help="run the k-means branch on the main stream (no intra-frame stream overlap)")
@@ -722,7 +728,7 @@ def main():
     n_streams = max(1, args.streams)
     # sequences are sharded over ranks: rank r owns sequences r*n_streams .. (+n_streams)
     workloads = [ClipWorkload(cfg, seed=1 + rank * n_streams + s, device=dev, mc=mc, overlap=not args.no_overlap,
-                              phase=s) for s in range(n_streams)]
+                              phase=s, start=(s * mc.MEM_EVERY) // n_streams if args.stagger else 0) for s in range(n_streams)]
     for wl in workloads:
         wl.chains = 1 if args.reuse_proxies else max(1, min(args.chains, mc.MEM_EVERY))
         wl.chain_plan = [int(x) for x in args.chain_plan.split(",")] if (args.chain_plan and not args.reuse_proxies) else None

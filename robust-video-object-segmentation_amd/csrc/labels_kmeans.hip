@@ -2066,10 +2066,15 @@ inline KsWorkspace ks_carve(void *workspace, int64_t cap, int n_seg, int kmax, i
 //             every doubling -- are summed literally, lanes = features (km_ordered_sum_kernel); larger clusters continue
 //             with the chunk-parallel integer folds and the serial stitch (their crossings are rare from there on);
 //   "ordered": literal sums only;   "scan": chunk-parallel pipeline only.   (AOC_KM_SUM, developer switch.)
-// 6 chunks = 3072 members: since the heads share a launch with the tail's chunk sums they are off the critical path up to about there,
-// and every chunk they take is one the fold / stitch kernels do not see (sweep 1 .. 8 at R = 6: 3.13, 3.03, 2.90, 2.89, 2.76, 2.78, 2.81,
-// 2.84 ms per chain; three frames per chain 5.13 -> 4.61 ms).  AOC_KM_HEAD_CHUNKS: developer switch.
-static const int KS_HEAD_CHUNKS = (getenv("AOC_KM_HEAD_CHUNKS") && atoi(getenv("AOC_KM_HEAD_CHUNKS")) > 0) ? atoi(getenv("AOC_KM_HEAD_CHUNKS")) : 6;
+// 12 chunks = 6144 members.  Alone, a chain is fastest at 5-6 chunks (sweep 1 .. 8 at R = 6: 3.13, 3.03, 2.90, 2.89, 2.76, 2.78, 2.81,
+// 2.84 ms per chain; 3.12 at 16): the heads share a launch with the tail's chunk sums and are off the critical path up to about
+// there.  In the bench, where the chains share the GPU with the other streams, what counts is the work a chain puts on the CUs, and the
+// literal heads (one adding wave per workgroup, a few cycles per member) are the cheapest way to sum a member: frames/s at
+// 2 / 3 / 4 / 6 / 8 / 10 / 12 / 16 / 24 / 32 / 64 chunks: cfg2 287 / 305 / 310 / 326 / 327 / 337 / 334 / 329 / 323 / 304 / 271, cfg3
+// 142 / 165 / 170 / 182 / 185 / 191 / 192 / 191 / 192 / 190 / 184.  AOC_KM_HEAD_CHUNKS: developer switch.  (A [4 members][feature] LDS layout
+// with one ds_read_b128 per four members shortens the adding wave's chain -- 3.0 -> 2.9 ms alone at 12 chunks -- but costs the seven
+// producer waves four ds_write_b32 per piece instead of one ds_write_b128: 1 % SLOWER in the bench, three runs each; not kept.)
+static const int KS_HEAD_CHUNKS = (getenv("AOC_KM_HEAD_CHUNKS") && atoi(getenv("AOC_KM_HEAD_CHUNKS")) > 0) ? atoi(getenv("AOC_KM_HEAD_CHUNKS")) : 12;
 constexpr int KC_INLINE_PREDICT_CHUNKS = 800;   // 409 600 rows per segment
 inline int ks_sum_mode() {
     static const int mode = [] {

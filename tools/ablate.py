@@ -27,10 +27,11 @@ if "local" in what:
     ops.local_window_match = fake_local
 if "corr" in what:
     ops.proxy_corr_min = lambda *a, **k: None
+    ops.proxy_corr_min_records = lambda *a, **k: None
+    ops.proxy_corr_min_batched = lambda *a, **k: None
 if "kmeans" in what:
     # keep the launch structure but run a single Lloyd iteration
-    hotpath.KMEANS_ITERS = 1
-    aoc.matching.KMEANS_ITERS = 1 if hasattr(aoc.matching, "KMEANS_ITERS") else None
+    hotpath.KMEANS_ITERS = int(os.environ.get("AOC_ABLATE_ITERS", "1"))
 if "gates" in what:
     orig = bench.frame_step
 
