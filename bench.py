@@ -613,8 +613,10 @@ def main():
                     help="keep the main streams off this many CUs (HIP CU mask) so the side-stream k-means chain always finds free CUs")
     ap.add_argument("--chains", type=int, default=3,
                     help="frames whose k-means is enqueued right after a pool update (1 = only the next frame; the others are batched into one chain)")
-    ap.add_argument("--chain-plan", default="",
-                    help="batch sizes of the k-means chains of a group of MEM_EVERY frames, e.g. 1,2,2 (overrides --chains)")
+    ap.add_argument("--chain-plan", default=None,
+                    help="batch sizes of the k-means chains of a group of MEM_EVERY frames, e.g. 1,2,2 (overrides --chains).  Default: 2,3 for cfg2 "
+                         "(340-342 frames/s against 332-334 with --chains 3, three runs each; cfg3 / cfg4 are 2 %% slower with it), none otherwise; "
+                         "'none' = the --chains schedule")
     ap.add_argument("--dump-timeline", default="", help="developer output: write the timed ops' (name, stream, start, end) to this JSON file")
     ap.add_argument("--chain-streams", type=int, default=1, help="side streams per sequence for its k-means chains (with --chain-plan: the batches of a group run side by side)")
     ap.add_argument("--chain-lead", type=int, default=1, help="with --chain-plan: batches enqueued ahead of the one in use")
@@ -727,11 +729,14 @@ def main():
     gates = hotpath.CalibrationGates(mc).to(dev)
     n_streams = max(1, args.streams)
     # sequences are sharded over ranks: rank r owns sequences r*n_streams .. (+n_streams)
+    chain_plan = args.chain_plan if args.chain_plan is not None else ("2,3" if args.config == "cfg2" else "")
+    if chain_plan == "none":
+        chain_plan = ""
     workloads = [ClipWorkload(cfg, seed=1 + rank * n_streams + s, device=dev, mc=mc, overlap=not args.no_overlap,
                               phase=s, start=(s * mc.MEM_EVERY) // n_streams if args.stagger else 0) for s in range(n_streams)]
     for wl in workloads:
         wl.chains = 1 if args.reuse_proxies else max(1, min(args.chains, mc.MEM_EVERY))
-        wl.chain_plan = [int(x) for x in args.chain_plan.split(",")] if (args.chain_plan and not args.reuse_proxies) else None
+        wl.chain_plan = [int(x) for x in chain_plan.split(",")] if (chain_plan and not args.reuse_proxies) else None
         wl.chain_lead = max(1, args.chain_lead)
         if wl.side is not None and args.chain_streams > 1:
             wl.sides = [wl.side] + [torch.cuda.Stream(device=dev, priority=-1) for _ in range(args.chain_streams - 1)]
@@ -1079,6 +1084,8 @@ def main():
                        "sequences_per_gpu": n_streams, "frames_per_step": n_streams, "sharding": "sequences over ranks, no data-path collective",
                        "intra_frame_overlap": ("none" if args.no_overlap else "k-means chain on a side HIP stream" +
                                                ("" if args.no_pipeline else ", enqueued as soon as the pool it depends on is final")),
+                       "kmeans_chain_batches": (f"the k-means of the {mc.MEM_EVERY} frames that see one pool state advance as chains of {chain_plan} frames" if chain_plan
+                                                else f"the frame that needs it first alone, the next {max(0, args.chains - 1)} batched into one chain"),
                        "correlation": ("ONE aoc_proxy_corr_min_records launch per step for the frames of all in-flight sequences" if batch_corr
                                        else "one aoc_proxy_corr_min_records launch (fp16-split kernel on the query's split records, one frame) per sequence and frame"),
                        "cu_reserve": (f"main streams masked off {args.cu_reserve} of {n_cu} CUs (hipExtStreamCreateWithCUMask), left to the side-stream "
