@@ -799,7 +799,7 @@ def main():
         m, npx = frames[0][0].shape[0], frames[0][2].shape[0]
         return dict(flops=2.0 * m * npx * C * len(frames), bytes=(m * C * 4 + npx * C * 4 + m * len(set_begin) * 4) * len(frames), frames=len(frames))
 
-    def meta_kmeans(pool, rows, seg_offsets, seg_k, init_rows, kmax, iters=20, rows_capacity=None):
+    def meta_kmeans(pool, rows, seg_offsets, seg_k, init_rows, kmax, iters=20, rows_capacity=None, n_rep=1):
         n = pool.shape[0]
         return dict(flops=2.0 * iters * n * kmax * C, bytes=float(iters) * n * C * 4 * 2 + n * 4)
 

@@ -125,6 +125,17 @@ int aoc_kmeans_segmented_ex(const float *pool, int64_t pool_rows, int C,
                             int64_t rows_capacity,
                             float *centroids, int32_t *labels, int32_t *cluster_counts,
                             void *workspace, size_t workspace_bytes, aoc_stream_t stream);
+/* The same for REPLICATED segment lists (aoc_kmeans_replicate / aoc_kmeans_replicate_levels): n_seg = n_rep * n_base segments, segment
+ * f * n_base + s lists the same rows, in the same order, as segment s (initial rows and cluster counts differ).  That is the k-means of
+ * several frames that see one pool state (AEM:268-276, eval_manager_mm.py:356-361) and of the cluster levels of BASELINE.json configs[2]
+ * in ONE chain; stating n_rep lets the assignment step fetch every pool row once per group of replicas instead of once per replica.
+ * Results are bit-identical to n_rep = 1 (= aoc_kmeans_segmented_ex), which is always a valid way to run the same lists. */
+int aoc_kmeans_segmented_rep(const float *pool, int64_t pool_rows, int C,
+                             const int32_t *rows, const int32_t *seg_offsets, const int32_t *seg_k,
+                             const int32_t *init_rows, int n_seg, int n_rep, int kmax, int iters,
+                             int64_t rows_capacity,
+                             float *centroids, int32_t *labels, int32_t *cluster_counts,
+                             void *workspace, size_t workspace_bytes, aoc_stream_t stream);
 int aoc_kmeans_segmented(const float *pool, int C,
                          const int32_t *rows, const int32_t *seg_offsets, const int32_t *seg_k,
                          const int32_t *init_rows, int n_seg, int kmax, int iters,

@@ -23,6 +23,7 @@ SIGNATURES = {
     "aoc_kmeans_workspace_bytes": (_sz, [_i64, _i, _i, _i]),
     "aoc_kmeans_segmented": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
     "aoc_kmeans_segmented_ex": (_i, [_vp, _i64, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "aoc_kmeans_segmented_rep": (_i, [_vp, _i64, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
     "aoc_prehead_workspace_bytes": (_sz, [_i, _i, _i, _i64]),
     "aoc_prehead": (_i, [_vp, _i, _i, _i64, _vp, _vp, _i, _i, _vp, _vp, _f, _vp, _i, _vp, _vp, _sz, _vp]),
     "aoc_cond_codes": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),

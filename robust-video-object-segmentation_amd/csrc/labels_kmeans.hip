@@ -861,6 +861,224 @@ __global__ __launch_bounds__(256, 2) void km_assign_mfma_kernel(const float *__r
     }
 }
 
+// The same assignment for REPLICATED segment lists (aoc_kmeans_replicate[_levels]: the k-means of several frames and / or cluster levels
+// that see the same pool advance as n_rep replicas of n_base segments with identical row lists, segment f * n_base + s0 = replica f of
+// base segment s0).  A work item = (group of up to n_grp replicas, base segment, 256-row block): the rows are fetched and staged ONCE
+// and multiplied against the code books of all replicas of the group, which sit side by side in LDS (the A operands are read from there
+// per (tile, replica) instead of living in registers).  Per replica the arithmetic -- and therefore every label, rank and histogram --
+// is exactly that of km_assign_mfma_kernel; what changes is the traffic: with F frames x L levels in a chain the single-replica kernel
+// streams the pool rows F * L times per Lloyd iteration.
+template <int TMAX, int KT>
+__global__ __launch_bounds__(256, 2) void km_assign_mfma_rep_kernel(const float *__restrict__ pool, int C, const int32_t *__restrict__ rows,
+                                                                  const int32_t *__restrict__ seg_off, const int32_t *__restrict__ seg_k, int n_base,
+                                                                  int n_rep, int n_grp, const float *__restrict__ centroids, int kmax,
+                                                                  int32_t *__restrict__ labels, uint16_t *__restrict__ rank16,
+                                                                  int32_t *__restrict__ hist, int nb_max, const float *__restrict__ rownorm) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int TP = (TMAX + 3) / 4 * 4;
+    constexpr int RS = 4 * TP + 4;
+    constexpr int NB4 = TP / 4;
+    constexpr int PIECES = (16 * TMAX + 63) / 64;
+    constexpr int c4 = TMAX;
+    constexpr int CB = KT * 16 * RS;                             // floats of one replica's code book image
+    constexpr int MAXG = 16;                                     // replicas per group (host: n_grp <= MAXG)
+    const int lane = aoc_lane(), wave = threadIdx.x >> 6;
+    const int j = lane & 15, g = lane >> 4;
+
+    float *cimg = lds;                                           // [n_grp][KT*16][RS]
+    float *lcn = cimg + (size_t)n_grp * CB;                      // [n_grp][KT*16]
+    float *wimg = lcn + (size_t)n_grp * KT * 16 + (size_t)wave * 16 * RS;
+    int32_t *wcnt = reinterpret_cast<int32_t *>(lcn + (size_t)n_grp * KT * 16 + (size_t)4 * 16 * RS);       // [4][kmax]
+    uint8_t *lab = reinterpret_cast<uint8_t *>(wcnt + 4 * kmax);                                             // [n_grp][256]
+    __shared__ int32_t lk[MAXG], lbeg[MAXG];
+
+    if (TP > c4) {
+        for (int idx = lane; idx < 16 * 4 * (TP - c4); idx += 64) {
+            const int rr = idx / (4 * (TP - c4)), rem = idx - rr * 4 * (TP - c4);
+            wimg[(size_t)rr * RS + (rem / (TP - c4)) * TP + c4 + rem % (TP - c4)] = 0.0f;
+        }
+        for (int idx = threadIdx.x; idx < n_grp * KT * 16 * 4 * (TP - c4); idx += 256) {
+            const int rr = idx / (4 * (TP - c4)), rem = idx - rr * 4 * (TP - c4);
+            cimg[(size_t)rr * RS + (rem / (TP - c4)) * TP + c4 + rem % (TP - c4)] = 0.0f;
+        }
+    }
+
+    constexpr int SEG_LDS = 128;
+    __shared__ int32_t lseg_off[SEG_LDS + 1], lseg_nb[SEG_LDS];
+    const bool seg_in_lds = n_base <= SEG_LDS;
+    if (seg_in_lds) {
+        for (int i = threadIdx.x; i <= n_base; i += 256) lseg_off[i] = seg_off[i];
+        __syncthreads();
+        for (int i = threadIdx.x; i < n_base; i += 256) lseg_nb[i] = (seg_k[i] > 0) ? (lseg_off[i + 1] - lseg_off[i] + 255) / 256 : 0;
+        __syncthreads();
+    }
+    int items_per_group = 0;
+    for (int s = 0; s < n_base; ++s)
+        items_per_group += seg_in_lds ? lseg_nb[s] : ((seg_k[s] > 0) ? (seg_off[s + 1] - seg_off[s] + 255) / 256 : 0);
+    const int n_groups = (n_rep + n_grp - 1) / n_grp;
+
+    int cur_seg = -1, cur_grp = -1, ng = 0, len = 0;
+    for (int w = blockIdx.x; items_per_group > 0; w += gridDim.x) {
+        const int gi = w / items_per_group;
+        if (gi >= n_groups) break;
+        int s = 0, bx = w - gi * items_per_group;
+        for (; s < n_base; ++s) {
+            const int nbs = seg_in_lds ? lseg_nb[s] : ((seg_k[s] > 0) ? (seg_off[s + 1] - seg_off[s] + 255) / 256 : 0);
+            if (bx < nbs) break;
+            bx -= nbs;
+        }
+        if (s >= n_base) break;
+        // ---- this item's rows (replica 0's lists: every replica lists the same rows in the same order)
+        constexpr int TPF = 2;
+        const int ibeg = seg_in_lds ? lseg_off[s] : seg_off[s], ilen = (seg_in_lds ? lseg_off[s + 1] : seg_off[s + 1]) - ibeg;
+        const int wave_row0 = bx * 256 + wave * 64;
+        float4 pv[TPF][PIECES];
+        const int my_p = min(wave_row0 + lane, ilen - 1);
+        const int my_id = rows[ibeg + max(my_p, 0)];
+        const float my_xs = rownorm[ibeg + max(my_p, 0)];
+        auto issue_tile = [&](int tile, float4 (&v)[PIECES]) {
+#pragma unroll
+            for (int i = 0; i < PIECES; ++i) {
+                const int idx = min(i * 64 + lane, 16 * c4 - 1);
+                const int rr = idx / c4, t = idx - rr * c4;
+                const int id = __shfl(my_id, tile * 16 + rr);
+                v[i] = reinterpret_cast<const float4 *>(pool + (size_t)id * C)[t];
+            }
+        };
+        auto write_tile = [&](int tile, const float4 (&v)[PIECES]) {
+#pragma unroll
+            for (int i = 0; i < PIECES; ++i) {
+                const int idx = i * 64 + lane;
+                if (idx < 16 * c4) {
+                    const int rr = idx / c4, t = idx - rr * c4;
+                    const bool in = wave_row0 + tile * 16 + rr < ilen;
+                    float *d = wimg + (size_t)rr * RS + t;
+                    d[0] = in ? v[i].x : 0.f; d[TP] = in ? v[i].y : 0.f; d[2 * TP] = in ? v[i].z : 0.f; d[3 * TP] = in ? v[i].w : 0.f;
+                }
+            }
+        };
+#pragma unroll
+        for (int t = 0; t < TPF; ++t) issue_tile(t, pv[t]);
+        if (s != cur_seg || gi != cur_grp) {
+            cur_seg = s;
+            cur_grp = gi;
+            ng = min(n_grp, n_rep - gi * n_grp);
+            len = ilen;
+            __syncthreads();                                   // previous users of cimg / lcn / lk are done
+            for (int r = 0; r < ng; ++r) {
+                const int sr = (gi * n_grp + r) * n_base + s;
+                const int kr = seg_k[sr];
+                const float *csrc = centroids + (size_t)sr * kmax * C;
+                float *ci = cimg + (size_t)r * CB;
+                for (int idx = threadIdx.x; idx < KT * 16 * c4; idx += 256) {
+                    const int cc = idx / c4, t = idx - cc * c4;
+                    const float4 v = (cc < kr) ? reinterpret_cast<const float4 *>(csrc + (size_t)cc * C)[t] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    float *d = ci + (size_t)cc * RS + t;
+                    d[0] = v.x; d[TP] = v.y; d[2 * TP] = v.z; d[3 * TP] = v.w;
+                }
+                if (threadIdx.x == 0) { lk[r] = kr; lbeg[r] = seg_off[sr]; }
+            }
+            __syncthreads();
+            // |c|^2 from the staged images (scipy code_sqr order: k = 0..C-1, multiply then add)
+            for (int idx = threadIdx.x; idx < ng * KT * 16; idx += 256) {
+                const int r = idx / (KT * 16), cc = idx - r * (KT * 16);
+                float nrm = INFINITY;
+                if (cc < lk[r]) {
+                    const float *im = cimg + (size_t)r * CB + (size_t)cc * RS;
+                    nrm = 0.0f;
+#pragma unroll
+                    for (int t = 0; t < TMAX; ++t) {
+#pragma unroll
+                        for (int kq = 0; kq < 4; ++kq) {
+                            const float v = im[kq * TP + t];
+                            const float prod = v * v;
+                            nrm = nrm + prod;
+                        }
+                    }
+                }
+                lcn[idx] = nrm;
+            }
+            __syncthreads();
+        }
+
+#pragma unroll
+        for (int tile = 0; tile < 4; ++tile) {
+            write_tile(tile, pv[tile % TPF]);
+            if (tile + TPF < 4) issue_tile(tile + TPF, pv[tile % TPF]);
+            const float *bs = wimg + (size_t)j * RS + g * TP;
+            float4 xb[NB4];
+#pragma unroll
+            for (int u = 0; u < NB4; ++u) xb[u] = *reinterpret_cast<const float4 *>(bs + 4 * u);
+            const int prow = wave_row0 + tile * 16 + j;
+            const float xs_l = __shfl(my_xs, tile * 16 + j);
+            const float xs = (prow < len) ? xs_l : 0.0f;
+#pragma unroll 1
+            for (int r = 0; r < ng; ++r) {
+                float low = INFINITY;
+                int arg = 0;
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt) {
+                    // A operands of replica r: lane (i = j, kq = g) holds c[16 kt + i][4t + kq]
+                    const float *st = cimg + (size_t)r * CB + (size_t)(kt * 16 + j) * RS + g * TP;
+                    float4 ca[NB4];
+#pragma unroll
+                    for (int u = 0; u < NB4; ++u) ca[u] = *reinterpret_cast<const float4 *>(st + 4 * u);
+                    const float4 cn4 = *reinterpret_cast<const float4 *>(lcn + (size_t)r * KT * 16 + kt * 16 + g * 4);
+                    const float cn[4] = {cn4.x, cn4.y, cn4.z, cn4.w};
+                    f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int u = 0; u < NB4; ++u) {
+                        const float aa[4] = {ca[u].x, ca[u].y, ca[u].z, ca[u].w};
+                        const float bb[4] = {xb[u].x, xb[u].y, xb[u].z, xb[u].w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (4 * u + e < TMAX) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aa[e], bb[e], acc, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float mm = -2.0f * acc[q];
+                        const float dist = (mm + xs) + cn[q];
+                        if (dist < low) { low = dist; arg = kt * 16 + g * 4 + q; }
+                    }
+                }
+#pragma unroll
+                for (int off = 16; off <= 32; off <<= 1) {
+                    const float d2 = __shfl_xor(low, off);
+                    const int a2 = __shfl_xor(arg, off);
+                    if (d2 < low || (d2 == low && a2 < arg)) { low = d2; arg = a2; }
+                }
+                const int mine = __shfl(arg, lane & 15);       // every lane: label of row (lane & 15) of this tile
+                if ((lane >> 4) == tile) lab[r * 256 + threadIdx.x] = (uint8_t)mine;      // read back by the same thread below
+            }
+        }
+        const int p = wave_row0 + lane;
+        const bool valid = p < len;
+        const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+        for (int r = 0; r < ng; ++r) {
+            const int kr = lk[r], beg = lbeg[r];
+            const int sr = (gi * n_grp + r) * n_base + s;
+            const int best = valid ? (int)lab[r * 256 + threadIdx.x] : -1;
+            if (valid) labels[beg + p] = best;
+            int rank = 0;
+            for (int kk = 0; kk < kr; ++kk) {
+                const unsigned long long mk = __ballot(best == kk);
+                if (best == kk) rank = __popcll(mk & lt);
+                if (lane == 0) wcnt[wave * kmax + kk] = __popcll(mk);
+            }
+            __syncthreads();
+            if (valid) {
+                int woff = 0;
+                for (int ww = 0; ww < wave; ++ww) woff += wcnt[ww * kmax + best];
+                rank16[beg + p] = (uint16_t)(woff + rank);
+            }
+            if ((int)threadIdx.x < kr)
+                hist[((size_t)sr * nb_max + bx) * kmax + threadIdx.x] =
+                    wcnt[threadIdx.x] + wcnt[kmax + threadIdx.x] + wcnt[2 * kmax + threadIdx.x] + wcnt[3 * kmax + threadIdx.x];
+            __syncthreads();                                   // wcnt is reused by the next replica / work item
+        }
+    }
+}
+
 // Segment lists replicated n_rep times (k-means of several frames that see the same pool, advanced together in the same
 // launches): rows_out[f * total + i] = rows[i], seg_off_out[f * n_seg + s] = f * total + seg_off[s], total = seg_off[n_seg].
 __global__ __launch_bounds__(256) void km_replicate_kernel(const int32_t *__restrict__ rows, const int32_t *__restrict__ seg_off,
@@ -2221,6 +2439,15 @@ int aoc_kmeans_segmented_ex(const float *pool, int64_t pool_rows, int C, const i
                             const int32_t *init_rows, int n_seg, int kmax, int iters, int64_t rows_capacity,
                             float *centroids, int32_t *labels, int32_t *cluster_counts,
                             void *workspace, size_t workspace_bytes, aoc_stream_t stream) {
+    return aoc_kmeans_segmented_rep(pool, pool_rows, C, rows, seg_offsets, seg_k, init_rows, n_seg, 1, kmax, iters, rows_capacity, centroids, labels,
+                                    cluster_counts, workspace, workspace_bytes, stream);
+}
+
+int aoc_kmeans_segmented_rep(const float *pool, int64_t pool_rows, int C, const int32_t *rows, const int32_t *seg_offsets, const int32_t *seg_k,
+                             const int32_t *init_rows, int n_seg, int n_rep, int kmax, int iters, int64_t rows_capacity,
+                             float *centroids, int32_t *labels, int32_t *cluster_counts,
+                             void *workspace, size_t workspace_bytes, aoc_stream_t stream) {
+    if (n_rep < 1 || (n_seg > 0 && n_seg % n_rep != 0)) return AOC_ERR_INVALID_ARG;
     if (!pool || !rows || !seg_offsets || !seg_k || !init_rows || !centroids || !labels || !cluster_counts || !workspace)
         return AOC_ERR_INVALID_ARG;
     if (C < 1 || n_seg < 1 || kmax < 1 || iters < 1 || rows_capacity < 1 || rows_capacity >= (1ll << 31)) return AOC_ERR_INVALID_ARG;
@@ -2260,12 +2487,42 @@ int aoc_kmeans_segmented_ex(const float *pool, int64_t pool_rows, int C, const i
         const int first = (it == 0);
         if (fast && !first && mfma_assign && C == 100 && kmax <= 64) {
             const int kt = (kmax + 15) / 16;
+            bool rep_done = false;
+            // replicated segment lists: the rows of a block are staged once for a group of replicas (km_assign_mfma_rep_kernel) as long as
+            // at least two code books fit next to the row images in half a CU's LDS
+            {
+                const size_t fixed = (size_t)4 * 16 * 116 * sizeof(float) + (size_t)4 * kmax * sizeof(int32_t);
+                const size_t per = ((size_t)kt * 16 * 116 + kt * 16) * sizeof(float) + 256;
+                const int fit = (int)std::min<size_t>(16, (78 * 1024 - fixed) / per);
+                static const bool rep_off = getenv("AOC_KM_ASSIGN_REP") && atoi(getenv("AOC_KM_ASSIGN_REP")) == 0;     // developer switch
+                if (n_rep > 1 && fit >= 2 && !rep_off) {
+                    const int n_groups = (n_rep + fit - 1) / fit;
+                    const int n_grp = (n_rep + n_groups - 1) / n_groups;
+                    const int n_base = n_seg / n_rep;
+                    const size_t rlds = fixed + (size_t)n_grp * per;
+                    const int64_t base_rows = std::min<int64_t>(rows_capacity / n_rep, seg_bound * n_base);
+                    const unsigned rgrid = (unsigned)std::min<int64_t>((base_rows / 256 + n_base) * n_groups, km_assign_grid_cap());
+#define AOC_KAR(KT)                                                                                                                                        \
+    do {                                                                                                                                                   \
+        static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(km_assign_mfma_rep_kernel<25, KT>),                                     \
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) == hipSuccess;                                  \
+        if (!ok) return AOC_ERR_LAUNCH;                                                                                                                    \
+        hipLaunchKernelGGL((km_assign_mfma_rep_kernel<25, KT>), dim3(rgrid), dim3(256), rlds, st, pool, C, rows, seg_offsets, seg_k, n_base, n_rep, n_grp, \
+                           centroids, kmax, labels, ws.rank16, ws.hist, ws.nb_max, rownorm);                                                               \
+    } while (0)
+                    if (kt == 1) AOC_KAR(1); else if (kt == 2) AOC_KAR(2); else if (kt == 3) AOC_KAR(3); else AOC_KAR(4);
+#undef AOC_KAR
+                    rep_done = true;
+                }
+            }
+            if (!rep_done) {
             const size_t alds = ((size_t)kt * 16 * 116 + kt * 16 + (size_t)4 * 16 * 116) * sizeof(float) + (size_t)4 * kmax * sizeof(int32_t);
             const unsigned pgrid = (unsigned)std::min<int64_t>(std::min<int64_t>(rows_capacity, seg_bound * n_seg) / 256 + n_seg, km_assign_grid_cap());    // persistent workgroups, several 256-row items each: the code book staging is paid once per workgroup
 #define AOC_KA(KT) hipLaunchKernelGGL((km_assign_mfma_kernel<25, KT>), dim3(pgrid), dim3(256), alds, st, pool, C, rows, seg_offsets, seg_k, n_seg, centroids, \
                                       kmax, labels, ws.rank16, ws.hist, ws.nb_max, rownorm)
             if (kt == 1) AOC_KA(1); else if (kt == 2) AOC_KA(2); else if (kt == 3) AOC_KA(3); else AOC_KA(4);
 #undef AOC_KA
+            }
         } else if (fast) {
             if (C <= 100)
                 hipLaunchKernelGGL(km_assign_rank_kernel<25>, agrid, dim3(256), lds_fast, st, pool, C, rows, seg_offsets, seg_k, centroids, kmax, labels,

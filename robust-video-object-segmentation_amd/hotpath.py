@@ -116,7 +116,7 @@ def launch_cluster_proxies_batch(cfg, ref_emb, ref_labels, init_rows_list, side_
         cap = prep.obj_rows.numel()
         rows_f, off_f, k_f = ops.kmeans_replicate_levels(prep.obj_rows, prep.obj_offsets, O, F * L, levels, rows_capacity=cap)
         init = init_rows_list[0] if F == 1 else torch.cat([r.reshape(L * O, kmax) for r in init_rows_list], dim=0)
-        cen, lab, _ = ops.kmeans_segmented(pool, rows_f, off_f, k_f, init.reshape(F * L * O, kmax), kmax, KMEANS_ITERS, rows_capacity=F * L * cap)
+        cen, lab, _ = ops.kmeans_segmented(pool, rows_f, off_f, k_f, init.reshape(F * L * O, kmax), kmax, KMEANS_ITERS, rows_capacity=F * L * cap, n_rep=F * L)
         proxies, psq = ops.build_proxies(pool, prep.fg_rows, off_f, k_f, lab, cen)          # [F*L*O, 2, kmax, C]
         for f in range(F):
             out = ClusterProxiesAhead()

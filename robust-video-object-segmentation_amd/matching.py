@@ -136,7 +136,7 @@ def cluster_proxies(pool, labels_flat, cluster_num=DEFAULT_CLUSTER_NUM, init_row
     cap = prep.obj_rows.numel()
     init_dev = torch.from_numpy(rows_host).to(dev)
     rows, offs, seg_k_dev = ops.kmeans_replicate_levels(prep.obj_rows, prep.obj_offsets, n_obj, L, levels, rows_capacity=cap)
-    centroids, labels, ccounts = ops.kmeans_segmented(pool, rows, offs, seg_k_dev, init_dev, kmax, iters, rows_capacity=L * cap)
+    centroids, labels, ccounts = ops.kmeans_segmented(pool, rows, offs, seg_k_dev, init_dev, kmax, iters, rows_capacity=L * cap, n_rep=L)
     proxies, sqnorm = ops.build_proxies(pool, prep.fg_rows, offs, seg_k_dev, labels, centroids)
     return dict(prep=prep, levels=levels, seg_k=seg_k if multi else seg_k[0], init_rows=drawn if multi else drawn[0], seg_offsets=offs,
                 centroids=centroids, labels=labels, cluster_counts=ccounts, proxies=proxies, proxy_sqnorm=sqnorm, counts=counts)

@@ -106,8 +106,9 @@ def kmeans_plan(counts, n_seg, cluster_num):
 
 
 # ------------------------------------------------------------------------------------------ k-means
-def kmeans_segmented(pool, rows, seg_offsets, seg_k, init_rows, kmax, iters=20, rows_capacity=None):
+def kmeans_segmented(pool, rows, seg_offsets, seg_k, init_rows, kmax, iters=20, rows_capacity=None, n_rep=1):
     """Segmented k-means, bit-identical to scipy kmeans2 (see include/aoc_hip.h).
+    n_rep > 1: the segment lists are n_rep replicas of n_seg / n_rep base segments (kmeans_replicate[_levels]).
     Returns (centroids [S,kmax,C], labels [rows_capacity], cluster_counts [S,kmax])."""
     pool = _f32c(pool)
     _need_gpu(pool, rows, seg_offsets, seg_k, init_rows)
@@ -121,9 +122,9 @@ def kmeans_segmented(pool, rows, seg_offsets, seg_k, init_rows, kmax, iters=20, 
     ccounts = torch.empty(n_seg, kmax, dtype=torch.int32, device=dev)
     ws = _ws(L.aoc_kmeans_workspace_bytes(cap, n_seg, kmax, C), dev)
     init_rows = init_rows.to(torch.int32).contiguous()
-    _lib.check(L.aoc_kmeans_segmented_ex(_p(pool), pool.shape[0], C, _p(rows), _p(seg_offsets), _p(seg_k), _p(init_rows), n_seg, kmax,
-                                         int(iters), cap, _p(centroids), _p(labels), _p(ccounts), _p(ws), ws.numel(), _stream()),
-               "aoc_kmeans_segmented_ex")
+    _lib.check(L.aoc_kmeans_segmented_rep(_p(pool), pool.shape[0], C, _p(rows), _p(seg_offsets), _p(seg_k), _p(init_rows), n_seg, int(n_rep), kmax,
+                                          int(iters), cap, _p(centroids), _p(labels), _p(ccounts), _p(ws), ws.numel(), _stream()),
+               "aoc_kmeans_segmented_rep")
     return centroids, labels, ccounts
 
 
