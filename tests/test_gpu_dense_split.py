@@ -187,6 +187,48 @@ def test_batched_cluster_chains_equal_single_chains(aoc):
         assert torch.equal(b.sqn[:n], s.sqn[:n])
 
 
+@pytest.mark.parametrize("levels,n_frames", [([16], 3), ([8, 16, 32], 1), ([8, 16, 32], 3), ([32], 7), ([64], 2)])
+def test_replica_fused_assignment_is_bit_identical(aoc, levels, n_frames):
+    """aoc_kmeans_segmented_rep (the rows of a block fetched once per GROUP of replicas: 6 / 3 / 1 code books per group at K <= 16 / 32 / 64,
+    so 7 replicas at K = 32 run as groups of 3 + 3 + 1 and K = 64 falls back to one replica per launch item) against the same replicated
+    lists run with n_rep = 1: labels, code books and cluster sizes of all 20 Lloyd iterations' final state are equal bit for bit."""
+    syn, ops = aoc.synthetic, aoc.ops
+    cfg = syn.CONFIGS["cfg1"]
+    clip = syn.make_clip(cfg, 21, frames=11)
+    R, O = 3, cfg.n_obj
+    idx = [0, 5, 10]
+    pool = torch.from_numpy(clip["emb"][idx]).cuda().reshape(-1, cfg.c)
+    lab = torch.from_numpy(np.stack([syn.one_hot(clip["lab"][i], O) for i in idx])).cuda().reshape(-1, O)
+    prep = ops.label_prep(lab)
+    counts = prep.counts.cpu().numpy()
+    L, F, kmax = len(levels), n_frames, max(levels)
+    cap = prep.obj_rows.numel()
+    rows_f, off_f, k_f = ops.kmeans_replicate_levels(prep.obj_rows, prep.obj_offsets, O, F * L, levels, rows_capacity=cap)
+    init = np.zeros((F * L * O, kmax), np.int32)
+    for f in range(F):
+        for li, k in enumerate(levels):
+            rows = syn.kmeans_init_rows(1000 + 17 * f + li, [int(c) for c in counts[:O]], k)
+            for o, r in enumerate(rows):
+                if r is not None:
+                    init[(f * L + li) * O + o, :len(r)] = r
+    init = torch.from_numpy(init).cuda()
+    fused = ops.kmeans_segmented(pool, rows_f, off_f, k_f, init, kmax, 20, rows_capacity=F * L * cap, n_rep=F * L)
+    plain = ops.kmeans_segmented(pool, rows_f, off_f, k_f, init, kmax, 20, rows_capacity=F * L * cap, n_rep=1)
+    torch.cuda.synchronize()
+    n_rows = int(off_f[-1].item())
+    assert torch.equal(fused[1][:n_rows], plain[1][:n_rows])
+    kk = k_f.cpu().numpy()
+    for s in range(F * L * O):
+        assert torch.equal(fused[0][s, :kk[s]], plain[0][s, :kk[s]])
+        assert torch.equal(fused[2][s, :kk[s]], plain[2][s, :kk[s]])
+    # and replicas with the same level and initial rows would agree with each other: replica 0 against a single-replica call
+    one = ops.kmeans_replicate_levels(prep.obj_rows, prep.obj_offsets, O, L, levels, rows_capacity=cap)
+    single = ops.kmeans_segmented(pool, one[0], one[1], one[2], init[:L * O], kmax, 20, rows_capacity=L * cap, n_rep=1)
+    torch.cuda.synchronize()
+    for s in range(L * O):
+        assert torch.equal(fused[0][s, :kk[s]], single[0][s, :kk[s]])
+
+
 def test_reused_proxies_accuracy(aoc):
     """NON-PARITY mode: adaptive proxies computed once for a pool and reused for later frames that see the
     same pool, instead of re-clustering with fresh initial rows.  The cluster channels then differ from the reference's by

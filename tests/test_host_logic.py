@@ -160,6 +160,11 @@ def test_c_abi_rejects_bad_arguments_without_a_gpu():
     assert L.aoc_split_rows_tiled(None, 10, 100, p, p, ip, None) == INVALID
     assert L.aoc_split_rows_tiled(p, 10, 98, p, p, ip, None) == UNSUPPORTED
 
+    # replicated segment lists: the replica count has to divide the segment count
+    assert L.aoc_kmeans_segmented_rep(p, 10, 100, ip, ip, ip, ip, 6, 4, 16, 20, 100, p, ip, ip, p, 16, None) == INVALID
+    assert L.aoc_kmeans_segmented_rep(p, 10, 100, ip, ip, ip, ip, 6, 0, 16, 20, 100, p, ip, ip, p, 16, None) == INVALID
+    assert L.aoc_kmeans_segmented_rep(p, 10, 100, ip, ip, ip, ip, 6, 3, 16, 20, 100, p, ip, ip, p, 16, None) == WORKSPACE
+
     class Frame(ctypes.Structure):
         _fields_ = [(n, vp) for n in ("query", "query_rec", "query_sqnorm", "proxies", "proxy_sqnorm", "set_bias", "out")]
     fr = (Frame * 1)(Frame(ctypes.addressof(dummy), ctypes.addressof(dummy), ctypes.addressof(dummy), ctypes.addressof(dummy), None, None,
