@@ -2184,7 +2184,15 @@ __global__ __launch_bounds__((OS_NPROD + 1) * 64) void km_heads_chunk_sums_kerne
     const int n_head = kmax * n_seg * os_groups_dev(C);
     const int b = blockIdx.x;
     if (b < n_head) {
-        const int j = b % kmax, s = (b / kmax) % n_seg, grp = b / (kmax * n_seg);
+        // XCD-aware ids: workgroups are dealt round-robin to the 8 XCDs, each with its own L2.  The feature groups of ONE cluster read
+        // neighbouring 112-byte pieces of the same member rows (pieces straddle 64-byte sectors: ~700 bytes fetched per 400-byte row when
+        // every piece comes through a different L2); their ids differ by 8, so they run on the same XCD at about the same time and share
+        // the sectors.  Blocks of 8 clusters x groups; the last block may hold fewer clusters.
+        const int n_cl = kmax * n_seg, groups = os_groups_dev(C);
+        const int blk = b / (8 * groups), rem = b - blk * (8 * groups);
+        const int pc = min(8, n_cl - blk * 8);
+        const int grp = rem / pc, c = blk * 8 + rem - grp * pc;
+        const int j = c % kmax, s = c / kmax;
         os_ordered_sum_body<MODE>(j, s, grp, os_lds, pool, pool_bytes, C, seg_off, seg_k, counts, cbase, moff, kmax, dst, member_cap, head_state);
         return;
     }
