@@ -1438,11 +1438,20 @@ __global__ __launch_bounds__(256) void km_chunk_fold_kernel(const float *__restr
                                                              const int32_t *__restrict__ owner_cluster, const int32_t *__restrict__ owner_local,
                                                              int8_t *__restrict__ cexp, int32_t *__restrict__ cinc0, int32_t *__restrict__ cinc1,
                                                              int start_chunk, const float *__restrict__ csum, const int32_t *__restrict__ cchunk,
-                                                             const float *__restrict__ head_state) {
+                                                             const float *__restrict__ head_state, int n_chunks_grid, int n_groups) {
     __shared__ float tile[2][64 * KC_G_LD];
     __shared__ uint32_t loffs[KS_CHUNK];
     __shared__ int lexp[KC_FG];
-    const int chunk = blockIdx.x, grp = blockIdx.y;
+    // 1-D grid, XCD-aware: the feature groups of ONE chunk read neighbouring 80-byte pieces of the same member rows; with ids that differ
+    // by 8 they run on the same XCD at about the same time and share the 64-byte sectors in its L2 (workgroups are dealt round-robin to
+    // the XCDs).  Blocks of 8 chunks x n_groups; the last block may hold fewer chunks.
+    int chunk, grp;
+    {
+        const int b = blockIdx.x, blk = b / (8 * n_groups), rem = b - blk * (8 * n_groups);
+        const int pc = min(8, n_chunks_grid - blk * 8);
+        grp = rem / pc;
+        chunk = blk * 8 + rem - grp * pc;
+    }
     const int oc = owner_cluster[chunk];
     if (oc < 0) return;
     if (owner_local[chunk] < start_chunk) return;
@@ -1815,8 +1824,20 @@ __global__ __launch_bounds__(64) void km_sum_scan_kernel(const float *__restrict
                                                           const uint32_t *__restrict__ moff, int kmax, float *__restrict__ dst,
                                                           const int32_t *__restrict__ cchunk, const int8_t *__restrict__ cexp,
                                                           const int32_t *__restrict__ cinc0, const int32_t *__restrict__ cinc1,
-                                                          int start_chunk, const float *__restrict__ head_state) {
-    const int s = blockIdx.z, j = blockIdx.y, q = blockIdx.x;
+                                                          int start_chunk, const float *__restrict__ head_state, int n_seg_grid) {
+    // 1-D grid, XCD-aware: the C / NF waves of ONE cluster each read 4 NF bytes of the same member rows (the chunks whose summaries do
+    // not apply); with ids that differ by 8 they run on one XCD and fetch every 64-byte sector once instead of once per XCD.  Blocks of 8
+    // clusters x n_q waves; the last block may hold fewer clusters.
+    int s, j, q;
+    {
+        const int n_q = C / NF, n_cl = kmax * n_seg_grid;
+        const int b = blockIdx.x, blk = b / (8 * n_q), rem = b - blk * (8 * n_q);
+        const int pc = min(8, n_cl - blk * 8);
+        q = rem / pc;
+        const int c = blk * 8 + rem - q * pc;
+        j = c % kmax;
+        s = c / kmax;
+    }
     if (j >= seg_k[s]) return;
     const int cnt = counts[s * kmax + j];
     if (start_chunk > 0 && cnt <= start_chunk * KS_CHUNK) return;       // finished by km_ordered_sum_kernel
@@ -2352,13 +2373,13 @@ inline void ks_launch_sums(hipStream_t st, const float *pool, uint32_t pool_byte
         const bool inline_predict = !sep_predict && ws.seg_chunks_max <= KC_INLINE_PREDICT_CHUNKS;
         if (!inline_predict)
             hipLaunchKernelGGL(km_chunk_predict_kernel, dim3(kmax, n_seg), dim3(128), 0, st, seg_k, counts, ws.cchunk, ws.csum, kmax, C, ws.cexp, start, ws.head);
-        hipLaunchKernelGGL(km_chunk_fold_kernel, dim3(ws.nch_cap, (C + KC_FG - 1) / KC_FG), dim3(256), 0, st, pool, C, seg_offsets, counts, ws.cbase, ws.moff,
+        hipLaunchKernelGGL(km_chunk_fold_kernel, dim3((unsigned)ws.nch_cap * ((C + KC_FG - 1) / KC_FG)), dim3(256), 0, st, pool, C, seg_offsets, counts, ws.cbase, ws.moff,
                            kmax, ws.owner_cluster, ws.owner_local, ws.cexp, ws.cinc0, ws.cinc1, start, inline_predict ? ws.csum : (const float *)nullptr,
-                           ws.cchunk, ws.head);
+                           ws.cchunk, ws.head, ws.nch_cap, (C + KC_FG - 1) / KC_FG);
     }
     static const int nf = getenv("AOC_KS_NF") ? atoi(getenv("AOC_KS_NF")) : 1;       // features per stitch wave (developer switch)
-#define AOC_KSS(NF) hipLaunchKernelGGL((km_sum_scan_kernel<MODE, NF>), dim3(C / NF, kmax, n_seg), dim3(64), 0, st, pool, pool_bytes, C, seg_offsets, seg_k, \
-                                       counts, ws.cbase, ws.moff, kmax, dst, ws.cchunk, ws.cexp, ws.cinc0, ws.cinc1, start, ws.head)
+#define AOC_KSS(NF) hipLaunchKernelGGL((km_sum_scan_kernel<MODE, NF>), dim3((unsigned)(C / NF) * kmax * n_seg), dim3(64), 0, st, pool, pool_bytes, C, seg_offsets, seg_k, \
+                                       counts, ws.cbase, ws.moff, kmax, dst, ws.cchunk, ws.cexp, ws.cinc0, ws.cinc1, start, ws.head, n_seg)
     if (nf == 4) AOC_KSS(4); else if (nf == 2) AOC_KSS(2); else AOC_KSS(1);
 #undef AOC_KSS
 }
