@@ -895,38 +895,49 @@ __global__ __launch_bounds__(64) void cond_codes_kernel(const float *__restrict_
 // DynamicPreHead (decoding_module.py:228-240: 1x1 conv -> GroupNorm -> ReLU on the [O, 24, h, w] proto-mask tensor) fused with
 // the concatenation of aocnet.py:362 (current-frame embedding || pre-head output -> [O, C + E, h, w]).
 constexpr int PH_MAX_IN = 32, PH_MAX_OUT = 128, PH_PIX = 256;
-// pass 1: per (object, pixel chunk) partial sums of y and y^2 per GroupNorm group (y = W x + b), in double
-__global__ __launch_bounds__(PH_PIX) void prehead_stats_kernel(const float *__restrict__ feat, int n_in, int64_t hw, const float *__restrict__ w,
+// pass 1: per (object, pixel chunk) partial sums of y and y^2 per GroupNorm group (y = W x + b), in double.
+// N_IN > 0: the input channel count as a compile-time constant (24 / 26 / 28 = 22 + 2 x levels proto-mask channels): the 1x1 convolution is
+// a fully unrolled FMA chain in the same order as the generic form (N_IN = 0: runtime count, every FMA behind a scalar branch -- 2 048
+// branches per pixel at 28 -> 64 channels, which is what made this kernel and the next take ~100 us each on a 145 x 261 map).  The groups'
+// wave sums are all formed first and combined behind ONE barrier (they were 16 x 2 barriers); the order of every addition is unchanged.
+constexpr int PH_MAX_GROUPS = 32;
+template <int N_IN>
+__global__ __launch_bounds__(PH_PIX) void prehead_stats_kernel(const float *__restrict__ feat, int n_in_rt, int64_t hw, const float *__restrict__ w,
                                                                 const float *__restrict__ b, int n_out, int group_size, int n_chunks,
                                                                 double *__restrict__ partial) {
     __shared__ float lw[PH_MAX_OUT * PH_MAX_IN + PH_MAX_OUT];
-    __shared__ double wred[PH_PIX / 64][2];
+    __shared__ double wred[PH_MAX_GROUPS][PH_PIX / 64][2];
+    const int n_in = N_IN > 0 ? N_IN : n_in_rt;
+    constexpr int NK = N_IN > 0 ? N_IN : PH_MAX_IN;
     const int o = blockIdx.y;
     for (int i = threadIdx.x; i < n_out * n_in; i += blockDim.x) lw[i] = w[i];
     for (int i = threadIdx.x; i < n_out; i += blockDim.x) lw[n_out * n_in + i] = b[i];
     __syncthreads();
     const int64_t p = (int64_t)blockIdx.x * PH_PIX + threadIdx.x;
-    float x[PH_MAX_IN];
+    float x[NK];
 #pragma unroll
-    for (int k = 0; k < PH_MAX_IN; ++k) x[k] = (k < n_in && p < hw) ? feat[((size_t)o * n_in + k) * hw + p] : 0.0f;
+    for (int k = 0; k < NK; ++k) x[k] = (k < n_in && p < hw) ? feat[((size_t)o * n_in + k) * hw + p] : 0.0f;
     const int n_groups = n_out / group_size;
-    for (int g = 0; g < n_groups; ++g) {
-        float s1 = 0.0f, s2 = 0.0f;
-        for (int c = g * group_size; c < (g + 1) * group_size; ++c) {
-            float y = lw[n_out * n_in + c];
+    for (int g0 = 0; g0 < n_groups; g0 += PH_MAX_GROUPS) {
+        const int g1 = min(n_groups, g0 + PH_MAX_GROUPS);
+        for (int g = g0; g < g1; ++g) {
+            float s1 = 0.0f, s2 = 0.0f;
+            for (int c = g * group_size; c < (g + 1) * group_size; ++c) {
+                float y = lw[n_out * n_in + c];
 #pragma unroll
-            for (int k = 0; k < PH_MAX_IN; ++k)
-                if (k < n_in) y = __builtin_fmaf(lw[c * n_in + k], x[k], y);
-            if (p < hw) { s1 += y; s2 += y * y; }
+                for (int k = 0; k < NK; ++k)
+                    if (N_IN > 0 || k < n_in) y = __builtin_fmaf(lw[c * n_in + k], x[k], y);
+                if (p < hw) { s1 += y; s2 += y * y; }
+            }
+            double d1 = (double)s1, d2 = (double)s2;
+            for (int off = 32; off > 0; off >>= 1) { d1 += __shfl_xor(d1, off); d2 += __shfl_xor(d2, off); }
+            if (aoc_lane() == 0) { wred[g - g0][threadIdx.x >> 6][0] = d1; wred[g - g0][threadIdx.x >> 6][1] = d2; }
         }
-        double d1 = (double)s1, d2 = (double)s2;
-        for (int off = 32; off > 0; off >>= 1) { d1 += __shfl_xor(d1, off); d2 += __shfl_xor(d2, off); }
-        if (aoc_lane() == 0) { wred[threadIdx.x >> 6][0] = d1; wred[threadIdx.x >> 6][1] = d2; }
         __syncthreads();
-        if (threadIdx.x == 0) {
+        if ((int)threadIdx.x < g1 - g0) {
             double t1 = 0.0, t2 = 0.0;
-            for (int wv = 0; wv < PH_PIX / 64; ++wv) { t1 += wred[wv][0]; t2 += wred[wv][1]; }
-            double *dst = partial + (((size_t)o * n_groups + g) * n_chunks + blockIdx.x) * 2;
+            for (int wv = 0; wv < PH_PIX / 64; ++wv) { t1 += wred[threadIdx.x][wv][0]; t2 += wred[threadIdx.x][wv][1]; }
+            double *dst = partial + (((size_t)o * n_groups + g0 + threadIdx.x) * n_chunks + blockIdx.x) * 2;
             dst[0] = t1; dst[1] = t2;
         }
         __syncthreads();
@@ -948,12 +959,15 @@ __global__ __launch_bounds__(64) void prehead_finalize_kernel(const double *__re
     }
 }
 // pass 3: out[o, C + c, p] = relu((y - mean) * rstd * gamma_c + beta_c); out[o, k, p] = emb[p, k] for k < C
-__global__ __launch_bounds__(PH_PIX) void prehead_apply_kernel(const float *__restrict__ feat, int n_in, int64_t hw, const float *__restrict__ w,
+template <int N_IN>
+__global__ __launch_bounds__(PH_PIX) void prehead_apply_kernel(const float *__restrict__ feat, int n_in_rt, int64_t hw, const float *__restrict__ w,
                                                                 const float *__restrict__ b, int n_out, int group_size,
                                                                 const float *__restrict__ gamma, const float *__restrict__ beta,
                                                                 const float *__restrict__ stats, const float *__restrict__ emb, int C,
                                                                 float *__restrict__ out) {
     __shared__ float lw[PH_MAX_OUT * PH_MAX_IN + PH_MAX_OUT];
+    const int n_in = N_IN > 0 ? N_IN : n_in_rt;
+    constexpr int NK = N_IN > 0 ? N_IN : PH_MAX_IN;
     const int o = blockIdx.y;
     for (int i = threadIdx.x; i < n_out * n_in; i += blockDim.x) lw[i] = w[i];
     for (int i = threadIdx.x; i < n_out; i += blockDim.x) lw[n_out * n_in + i] = b[i];
@@ -965,15 +979,15 @@ __global__ __launch_bounds__(PH_PIX) void prehead_apply_kernel(const float *__re
         const float *e = emb + (size_t)p * C;
         for (int k = 0; k < C; ++k) dst[(size_t)k * hw] = e[k];          // aocnet.py:188,362: the embedding, expanded over the objects
     }
-    float x[PH_MAX_IN];
+    float x[NK];
 #pragma unroll
-    for (int k = 0; k < PH_MAX_IN; ++k) x[k] = (k < n_in) ? feat[((size_t)o * n_in + k) * hw + p] : 0.0f;
+    for (int k = 0; k < NK; ++k) x[k] = (k < n_in) ? feat[((size_t)o * n_in + k) * hw + p] : 0.0f;
     const int n_groups = n_out / group_size;
     for (int c = 0; c < n_out; ++c) {
         float y = lw[n_out * n_in + c];
 #pragma unroll
-        for (int k = 0; k < PH_MAX_IN; ++k)
-            if (k < n_in) y = __builtin_fmaf(lw[c * n_in + k], x[k], y);
+        for (int k = 0; k < NK; ++k)
+            if (N_IN > 0 || k < n_in) y = __builtin_fmaf(lw[c * n_in + k], x[k], y);
         const int g = c / group_size;
         const float mean = stats[((size_t)o * n_groups + g) * 2], rstd = stats[((size_t)o * n_groups + g) * 2 + 1];
         const float v = (y - mean) * rstd * gamma[c] + beta[c];
@@ -1196,10 +1210,16 @@ int aoc_prehead(const float *feat, int n_obj, int n_in, int64_t hw, const float 
     const int n_chunks = (int)((hw + PH_PIX - 1) / PH_PIX);
     double *partial = static_cast<double *>(workspace);
     float *stats = reinterpret_cast<float *>(static_cast<char *>(workspace) + aoc_align_up((size_t)n_obj * n_groups * n_chunks * 2 * sizeof(double), 256));
-    hipLaunchKernelGGL(prehead_stats_kernel, dim3(n_chunks, n_obj), dim3(PH_PIX), 0, st, feat, n_in, hw, weight, bias, n_out, group_size, n_chunks, partial);
-    hipLaunchKernelGGL(prehead_finalize_kernel, dim3(n_obj * n_groups), dim3(64), 0, st, partial, n_chunks, (double)group_size * (double)hw, eps, stats);
-    hipLaunchKernelGGL(prehead_apply_kernel, dim3(n_chunks, n_obj), dim3(PH_PIX), 0, st, feat, n_in, hw, weight, bias, n_out, group_size, gamma, beta, stats,
-                       emb_hwc, C, out);
+#define AOC_PH(NI)                                                                                                                                        \
+    do {                                                                                                                                                  \
+        hipLaunchKernelGGL(prehead_stats_kernel<NI>, dim3(n_chunks, n_obj), dim3(PH_PIX), 0, st, feat, n_in, hw, weight, bias, n_out, group_size, n_chunks, partial); \
+        hipLaunchKernelGGL(prehead_finalize_kernel, dim3(n_obj * n_groups), dim3(64), 0, st, partial, n_chunks, (double)group_size * (double)hw, eps, stats);         \
+        hipLaunchKernelGGL(prehead_apply_kernel<NI>, dim3(n_chunks, n_obj), dim3(PH_PIX), 0, st, feat, n_in, hw, weight, bias, n_out, group_size, gamma, beta, stats, \
+                           emb_hwc, C, out);                                                                                                               \
+    } while (0)
+    // the proto-mask tensor has 22 + 2 x levels channels (aocnet.py:341-358): compile-time channel counts for one to three levels
+    if (n_in == 24) AOC_PH(24); else if (n_in == 26) AOC_PH(26); else if (n_in == 28) AOC_PH(28); else AOC_PH(0);
+#undef AOC_PH
     AOC_RETURN_IF_LAUNCH_FAILED();
     return AOC_OK;
 }
