@@ -137,6 +137,43 @@ __global__ __launch_bounds__(256) void jf_match_kernel(const uint32_t *__restric
     if (threadIdx.x < 4 * 16 && lc[threadIdx.x] != 0) atomicAdd(&counts[3 * 16 + threadIdx.x], lc[threadIdx.x]);
 }
 
+// The same on a 32 x 8 pixel tile whose bits (+ a halo of r pixels, zeros outside the image) are staged in LDS once: a boundary pixel's disk
+// of (2 r + 1)^2 probes then reads LDS instead of global memory (r = 8 at 480p: 289 probes per boundary pixel).  r <= JF_R_LDS.
+constexpr int JF_TW = 32, JF_TH = 8, JF_R_LDS = 32;
+__global__ __launch_bounds__(256) void jf_match_tile_kernel(const uint32_t *__restrict__ bits, int H, int W, int n_obj, int r, int32_t *__restrict__ counts) {
+    extern __shared__ uint32_t jf_tile[];            // [(JF_TH + 2 r)][(JF_TW + 2 r)]
+    __shared__ int32_t lc[4 * 16];
+    if (threadIdx.x < 4 * 16) lc[threadIdx.x] = 0;
+    const int tw = JF_TW + 2 * r, th = JF_TH + 2 * r;
+    const int x0 = blockIdx.x * JF_TW - r, y0 = blockIdx.y * JF_TH - r;
+    for (int i = threadIdx.x; i < tw * th; i += 256) {
+        const int ty = i / tw, tx = i - ty * tw;
+        const int yy = y0 + ty, xx = x0 + tx;
+        jf_tile[i] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? bits[(size_t)yy * W + xx] : 0u;
+    }
+    __syncthreads();
+    const int lx = threadIdx.x & (JF_TW - 1), ly = threadIdx.x / JF_TW;
+    const int x = blockIdx.x * JF_TW + lx, y = blockIdx.y * JF_TH + ly;
+    const uint32_t here = (x < W && y < H) ? jf_tile[(ly + r) * tw + lx + r] : 0u;
+    uint32_t near = 0;
+    if (here != 0) {
+        for (int dy = -r; dy <= r; ++dy) {
+            const uint32_t *row = jf_tile + (ly + r + dy) * tw + lx + r;
+            for (int dx = -r; dx <= r; ++dx)
+                if (dx * dx + dy * dy <= r * r) near |= row[dx];               // skimage.morphology.disk(r); outside the image: zeros
+        }
+    }
+    if (__ballot(here != 0) != 0ull) {
+        const uint32_t pb = here & 0xffffu, gb = here >> 16, ngt = near >> 16, npr = near & 0xffffu;
+        jf_count(lc, 0, n_obj, pb & ngt);
+        jf_count(lc, 1, n_obj, gb & npr);
+        jf_count(lc, 2, n_obj, pb);
+        jf_count(lc, 3, n_obj, gb);
+    }
+    __syncthreads();
+    if (threadIdx.x < 4 * 16 && lc[threadIdx.x] != 0) atomicAdd(&counts[3 * 16 + threadIdx.x], lc[threadIdx.x]);
+}
+
 // One wave: lane o scores object o (its seven counters are seven independent loads instead of a single thread's serial walk: 67 -> ~5 us);
 // the per-object values are then added in the order 1 .. n_obj - 1, as the oracle adds them, and the counters are zeroed for the next frame.
 __global__ __launch_bounds__(64) void jf_finalize_kernel(int32_t *__restrict__ counts, int n_obj, double *__restrict__ accum) {
@@ -187,7 +224,11 @@ int aoc_mask_jf_accumulate(const int32_t *pred, const int32_t *gt, int H, int W,
     if (!workspace_is_clean && hipMemsetAsync(counts, 0, 7 * 16 * sizeof(int32_t), st) != hipSuccess) return AOC_ERR_LAUNCH;
     const unsigned nb = (unsigned)(((size_t)H * W + 255) / 256);
     hipLaunchKernelGGL(jf_boundary_kernel, dim3(nb), dim3(256), 0, st, pred, gt, H, W, n_obj, bits, counts);
-    hipLaunchKernelGGL(jf_match_kernel, dim3(nb), dim3(256), 0, st, bits, H, W, n_obj, bound_pix, counts);
+    if (bound_pix <= JF_R_LDS)
+        hipLaunchKernelGGL(jf_match_tile_kernel, dim3((W + JF_TW - 1) / JF_TW, (H + JF_TH - 1) / JF_TH), dim3(256),
+                           (size_t)(JF_TW + 2 * bound_pix) * (JF_TH + 2 * bound_pix) * sizeof(uint32_t), st, bits, H, W, n_obj, bound_pix, counts);
+    else
+        hipLaunchKernelGGL(jf_match_kernel, dim3(nb), dim3(256), 0, st, bits, H, W, n_obj, bound_pix, counts);
     hipLaunchKernelGGL(jf_finalize_kernel, dim3(1), dim3(64), 0, st, counts, n_obj, accum);
     AOC_RETURN_IF_LAUNCH_FAILED();
     return AOC_OK;
