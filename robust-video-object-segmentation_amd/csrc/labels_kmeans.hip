@@ -906,15 +906,21 @@ __global__ __launch_bounds__(256, 2) void km_assign_mfma_rep_kernel(const float 
     constexpr int SEG_LDS = 128;
     __shared__ int32_t lseg_off[SEG_LDS + 1], lseg_nb[SEG_LDS];
     const bool seg_in_lds = n_base <= SEG_LDS;
+    // a base segment is walked if ANY replica clusters it (the cluster counts may differ per replica; a replica with K = 0 is skipped below)
+    auto seg_live = [&](int i) -> bool {
+        bool any = false;
+        for (int f = 0; f < n_rep; ++f) any |= seg_k[f * n_base + i] > 0;
+        return any;
+    };
     if (seg_in_lds) {
         for (int i = threadIdx.x; i <= n_base; i += 256) lseg_off[i] = seg_off[i];
         __syncthreads();
-        for (int i = threadIdx.x; i < n_base; i += 256) lseg_nb[i] = (seg_k[i] > 0) ? (lseg_off[i + 1] - lseg_off[i] + 255) / 256 : 0;
+        for (int i = threadIdx.x; i < n_base; i += 256) lseg_nb[i] = seg_live(i) ? (lseg_off[i + 1] - lseg_off[i] + 255) / 256 : 0;
         __syncthreads();
     }
     int items_per_group = 0;
     for (int s = 0; s < n_base; ++s)
-        items_per_group += seg_in_lds ? lseg_nb[s] : ((seg_k[s] > 0) ? (seg_off[s + 1] - seg_off[s] + 255) / 256 : 0);
+        items_per_group += seg_in_lds ? lseg_nb[s] : (seg_live(s) ? (seg_off[s + 1] - seg_off[s] + 255) / 256 : 0);
     const int n_groups = (n_rep + n_grp - 1) / n_grp;
 
     int cur_seg = -1, cur_grp = -1, ng = 0, len = 0;
@@ -923,7 +929,7 @@ __global__ __launch_bounds__(256, 2) void km_assign_mfma_rep_kernel(const float 
         if (gi >= n_groups) break;
         int s = 0, bx = w - gi * items_per_group;
         for (; s < n_base; ++s) {
-            const int nbs = seg_in_lds ? lseg_nb[s] : ((seg_k[s] > 0) ? (seg_off[s + 1] - seg_off[s] + 255) / 256 : 0);
+            const int nbs = seg_in_lds ? lseg_nb[s] : (seg_live(s) ? (seg_off[s + 1] - seg_off[s] + 255) / 256 : 0);
             if (bx < nbs) break;
             bx -= nbs;
         }
@@ -1056,6 +1062,7 @@ __global__ __launch_bounds__(256, 2) void km_assign_mfma_rep_kernel(const float 
         const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
         for (int r = 0; r < ng; ++r) {
             const int kr = lk[r], beg = lbeg[r];
+            if (kr <= 0) continue;                             // this replica does not cluster the segment (wave- and block-uniform)
             const int sr = (gi * n_grp + r) * n_base + s;
             const int best = valid ? (int)lab[r * 256 + threadIdx.x] : -1;
             if (valid) labels[beg + p] = best;
