@@ -1445,7 +1445,7 @@ __global__ __launch_bounds__(256) void km_chunk_fold_kernel(const float *__restr
                                                              const int32_t *__restrict__ owner_cluster, const int32_t *__restrict__ owner_local,
                                                              int8_t *__restrict__ cexp, int32_t *__restrict__ cinc0, int32_t *__restrict__ cinc1,
                                                              int start_chunk, const float *__restrict__ csum, const int32_t *__restrict__ cchunk,
-                                                             const float *__restrict__ head_state, int n_chunks_grid, int n_groups) {
+                                                             const float *__restrict__ head_state, int n_chunks_grid, int n_groups, int xcd_aware) {
     __shared__ float tile[2][64 * KC_G_LD];
     __shared__ uint32_t loffs[KS_CHUNK];
     __shared__ int lexp[KC_FG];
@@ -1458,6 +1458,7 @@ __global__ __launch_bounds__(256) void km_chunk_fold_kernel(const float *__restr
         const int pc = min(8, n_chunks_grid - blk * 8);
         grp = rem / pc;
         chunk = blk * 8 + rem - grp * pc;
+        if (!xcd_aware) { chunk = b % n_chunks_grid; grp = b / n_chunks_grid; }
     }
     const int oc = owner_cluster[chunk];
     if (oc < 0) return;
@@ -1831,7 +1832,7 @@ __global__ __launch_bounds__(64) void km_sum_scan_kernel(const float *__restrict
                                                           const uint32_t *__restrict__ moff, int kmax, float *__restrict__ dst,
                                                           const int32_t *__restrict__ cchunk, const int8_t *__restrict__ cexp,
                                                           const int32_t *__restrict__ cinc0, const int32_t *__restrict__ cinc1,
-                                                          int start_chunk, const float *__restrict__ head_state, int n_seg_grid) {
+                                                          int start_chunk, const float *__restrict__ head_state, int n_seg_grid, int xcd_aware) {
     // 1-D grid, XCD-aware: the C / NF waves of ONE cluster each read 4 NF bytes of the same member rows (the chunks whose summaries do
     // not apply); with ids that differ by 8 they run on one XCD and fetch every 64-byte sector once instead of once per XCD.  Blocks of 8
     // clusters x n_q waves; the last block may hold fewer clusters.
@@ -1841,7 +1842,8 @@ __global__ __launch_bounds__(64) void km_sum_scan_kernel(const float *__restrict
         const int b = blockIdx.x, blk = b / (8 * n_q), rem = b - blk * (8 * n_q);
         const int pc = min(8, n_cl - blk * 8);
         q = rem / pc;
-        const int c = blk * 8 + rem - q * pc;
+        int c = blk * 8 + rem - q * pc;
+        if (!xcd_aware) { q = b % n_q; c = b / n_q; }
         j = c % kmax;
         s = c / kmax;
     }
@@ -2206,7 +2208,7 @@ __global__ __launch_bounds__((OS_NPROD + 1) * 64) void km_heads_chunk_sums_kerne
                                                                                    const uint32_t *__restrict__ moff, int kmax, int n_seg, float *__restrict__ dst,
                                                                                    int member_cap, float *__restrict__ head_state,
                                                                                    const int32_t *__restrict__ owner_cluster, const int32_t *__restrict__ owner_local,
-                                                                                   float *__restrict__ csum, int start_chunk) {
+                                                                                   float *__restrict__ csum, int start_chunk, int xcd_aware) {
     __shared__ __attribute__((aligned(16))) float os_lds[2 * OS_BATCH * OS_LD];
     static_assert(sizeof(float) * 2 * OS_BATCH * OS_LD >= sizeof(uint32_t) * KS_CHUNK + sizeof(float4) * 256, "the chunk role's buffers fit the head role's");
     const int n_head = kmax * n_seg * os_groups_dev(C);
@@ -2219,7 +2221,8 @@ __global__ __launch_bounds__((OS_NPROD + 1) * 64) void km_heads_chunk_sums_kerne
         const int n_cl = kmax * n_seg, groups = os_groups_dev(C);
         const int blk = b / (8 * groups), rem = b - blk * (8 * groups);
         const int pc = min(8, n_cl - blk * 8);
-        const int grp = rem / pc, c = blk * 8 + rem - grp * pc;
+        int grp = rem / pc, c = blk * 8 + rem - grp * pc;
+        if (!xcd_aware) { c = b % n_cl; grp = b / n_cl; }       // developer switch AOC_KM_XCD=0: the group-major order of before
         const int j = c % kmax, s = c / kmax;
         os_ordered_sum_body<MODE>(j, s, grp, os_lds, pool, pool_bytes, C, seg_off, seg_k, counts, cbase, moff, kmax, dst, member_cap, head_state);
         return;
@@ -2328,6 +2331,10 @@ inline KsWorkspace ks_carve(void *workspace, int64_t cap, int n_seg, int kmax, i
 // 142 / 165 / 170 / 182 / 185 / 191 / 192 / 191 / 192 / 190 / 184.  AOC_KM_HEAD_CHUNKS: developer switch.  (A [4 members][feature] LDS layout
 // with one ds_read_b128 per four members shortens the adding wave's chain -- 3.0 -> 2.9 ms alone at 12 chunks -- but costs the seven
 // producer waves four ds_write_b32 per piece instead of one ds_write_b128: 1 % SLOWER in the bench, three runs each; not kept.)
+inline int km_xcd_aware() {
+    static const int on = !(getenv("AOC_KM_XCD") && atoi(getenv("AOC_KM_XCD")) == 0);       // developer switch (counter comparisons)
+    return on;
+}
 static const int KS_HEAD_CHUNKS = (getenv("AOC_KM_HEAD_CHUNKS") && atoi(getenv("AOC_KM_HEAD_CHUNKS")) > 0) ? atoi(getenv("AOC_KM_HEAD_CHUNKS")) : 12;
 constexpr int KC_INLINE_PREDICT_CHUNKS = 800;   // 409 600 rows per segment
 inline int ks_sum_mode() {
@@ -2356,7 +2363,7 @@ inline void ks_launch_sums(hipStream_t st, const float *pool, uint32_t pool_byte
     if (merged) {
         hipLaunchKernelGGL(km_heads_chunk_sums_kernel<MODE>, dim3(kmax * n_seg * os_groups(C) + ws.nch_cap), dim3((OS_NPROD + 1) * 64), 0, st, pool, pool_bytes, C,
                            seg_offsets, seg_k, counts, ws.cbase, ws.moff, kmax, n_seg, dst, KS_HEAD_CHUNKS * KS_CHUNK, ws.head, ws.owner_cluster, ws.owner_local,
-                           ws.csum, start);
+                           ws.csum, start, km_xcd_aware());
     } else if (mode != 0) {
         const int cap = (mode == 2 || mode == 3) ? KS_HEAD_CHUNKS * KS_CHUNK : 0;
         hipLaunchKernelGGL(km_ordered_sum_kernel<MODE>, dim3(kmax, n_seg, os_groups(C)), dim3((OS_NPROD + 1) * 64), 0, st, pool, pool_bytes, C, seg_offsets,
@@ -2382,11 +2389,11 @@ inline void ks_launch_sums(hipStream_t st, const float *pool, uint32_t pool_byte
             hipLaunchKernelGGL(km_chunk_predict_kernel, dim3(kmax, n_seg), dim3(128), 0, st, seg_k, counts, ws.cchunk, ws.csum, kmax, C, ws.cexp, start, ws.head);
         hipLaunchKernelGGL(km_chunk_fold_kernel, dim3((unsigned)ws.nch_cap * ((C + KC_FG - 1) / KC_FG)), dim3(256), 0, st, pool, C, seg_offsets, counts, ws.cbase, ws.moff,
                            kmax, ws.owner_cluster, ws.owner_local, ws.cexp, ws.cinc0, ws.cinc1, start, inline_predict ? ws.csum : (const float *)nullptr,
-                           ws.cchunk, ws.head, ws.nch_cap, (C + KC_FG - 1) / KC_FG);
+                           ws.cchunk, ws.head, ws.nch_cap, (C + KC_FG - 1) / KC_FG, km_xcd_aware());
     }
     static const int nf = getenv("AOC_KS_NF") ? atoi(getenv("AOC_KS_NF")) : 1;       // features per stitch wave (developer switch)
 #define AOC_KSS(NF) hipLaunchKernelGGL((km_sum_scan_kernel<MODE, NF>), dim3((unsigned)(C / NF) * kmax * n_seg), dim3(64), 0, st, pool, pool_bytes, C, seg_offsets, seg_k, \
-                                       counts, ws.cbase, ws.moff, kmax, dst, ws.cchunk, ws.cexp, ws.cinc0, ws.cinc1, start, ws.head, n_seg)
+                                       counts, ws.cbase, ws.moff, kmax, dst, ws.cchunk, ws.cexp, ws.cinc0, ws.cinc1, start, ws.head, n_seg, km_xcd_aware())
     if (nf == 4) AOC_KSS(4); else if (nf == 2) AOC_KSS(2); else AOC_KSS(1);
 #undef AOC_KSS
 }
