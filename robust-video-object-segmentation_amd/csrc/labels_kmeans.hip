@@ -2215,9 +2215,10 @@ __global__ __launch_bounds__((OS_NPROD + 1) * 64) void km_heads_chunk_sums_kerne
     const int b = blockIdx.x;
     if (b < n_head) {
         // XCD-aware ids: workgroups are dealt round-robin to the 8 XCDs, each with its own L2.  The feature groups of ONE cluster read
-        // neighbouring 112-byte pieces of the same member rows (pieces straddle 64-byte sectors: ~700 bytes fetched per 400-byte row when
-        // every piece comes through a different L2); their ids differ by 8, so they run on the same XCD at about the same time and share
-        // the sectors.  Blocks of 8 clusters x groups; the last block may hold fewer clusters.
+        // neighbouring 112-byte pieces of the same member rows; their ids differ by 8, so they run on the same XCD at about the same time
+        // and find each other's lines in its L2 (bench: cfg2 +1.3 %, cfg3 +6 %; FETCH_SIZE of this kernel alone only drops 3 % -- at the
+        // fabric it was already near one pass over the rows per replica, profiles/r03_pmc_kmeans_R6_F3.txt).  Blocks of 8 clusters x
+        // groups; the last block may hold fewer clusters.
         const int n_cl = kmax * n_seg, groups = os_groups_dev(C);
         const int blk = b / (8 * groups), rem = b - blk * (8 * groups);
         const int pc = min(8, n_cl - blk * 8);
