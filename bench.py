@@ -651,9 +651,10 @@ def main():
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the short cfg3 / cfg4 regions and the fixed-set sequence-sharded evaluation (strong scaling) that the default line carries")
     ap.add_argument("--strong-scale", type=float, default=0.12, help="share of the 537-sequence evaluation set used for the strong-scaling figure (64 sequences)")
-    ap.add_argument("--eval-lanes", type=int, default=6,
-                    help="sequences in flight per rank in the closed evaluation loop, each on its own HIP stream (one MI355X, 65-sequence set: "
-                         "2 / 3 / 4 / 5 / 6 / 8 / 10 lanes = 158 / 165 / 174 / 176 / 181 / 174 / 176 frames/s)")
+    ap.add_argument("--eval-lanes", type=int, default=4,
+                    help="sequences in flight per rank in the closed evaluation loop, each on its own HIP stream (one MI355X, 16-sequence set at the "
+                         "end of round 3: 2 / 3 / 4 / 5 / 6 / 8 / 10 lanes = 226 / 241 / 245-251 / 242 / 239 / 234 / 225 frames/s; with the slower "
+                         "kernels of the round's first half six lanes were best: 158 / 165 / 174 / 176 / 181 / 174 / 176)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
