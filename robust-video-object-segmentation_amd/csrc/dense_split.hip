@@ -168,8 +168,12 @@ __global__ __launch_bounds__(256) void split_plan_kernel(const int32_t *__restri
         sq = __builtin_fmaxf(sq, __shfl_xor(sq, d));
         ln = __builtin_fmaxf(ln, __shfl_xor(ln, d));
     }
-    if (aoc_lane() == 0 && sq > 0.0f) atomicMax(pmax_bits, __float_as_uint(sq));
-    if (aoc_lane() == 0 && ln > 0.0f) atomicMax(pmax_bits - 2, __float_as_uint(ln));      // gate[1]: largest lo-plane norm
+    // one atomic per wave only while the wave can still raise the maximum (thousands of atomics on two addresses serialise: most of this
+    // kernel's 64 us): a relaxed device-scope read first, the atomic only if the wave's value is larger than what is already there
+    if (aoc_lane() == 0 && sq > 0.0f && __float_as_uint(sq) > __hip_atomic_load(pmax_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+        atomicMax(pmax_bits, __float_as_uint(sq));
+    if (aoc_lane() == 0 && ln > 0.0f && __float_as_uint(ln) > __hip_atomic_load(pmax_bits - 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+        atomicMax(pmax_bits - 2, __float_as_uint(ln));      // gate[1]: largest lo-plane norm
     if (e == 0 && overflow && *overflow) atomicOr(gate, 1);
     const int64_t t = e / SP_TILE;
     const int i = (int)(e - t * SP_TILE);

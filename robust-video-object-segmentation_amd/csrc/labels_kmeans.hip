@@ -640,6 +640,34 @@ __global__ __launch_bounds__(256) void km_assign_rank_kernel(const float *__rest
             wcnt[threadIdx.x] + wcnt[kmax + threadIdx.x] + wcnt[2 * kmax + threadIdx.x] + wcnt[3 * kmax + threadIdx.x];
 }
 
+// |x|^2 of every listed row, scipy's order (sequential multiply-then-add over the channels; the library is compiled with -ffp-contract=off),
+// for the rows [0, seg_off[n_seg_limit]) of the packed lists: with it the matrix-pipe assignment below also serves the FIRST Lloyd iteration
+// (km_assign_rank_kernel computed the norms on the fly there, one pass over the rows per replica).
+__global__ __launch_bounds__(256) void km_rownorm_kernel(const float *__restrict__ pool, int C, const int32_t *__restrict__ rows,
+                                                          const int32_t *__restrict__ seg_off, int n_seg_limit, float *__restrict__ rownorm) {
+    const int total = seg_off[n_seg_limit];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const float4 *xr = reinterpret_cast<const float4 *>(pool + (size_t)rows[i] * C);
+    const int c4 = C >> 2;
+    float xs = 0.0f;
+    for (int t0 = 0; t0 < c4; t0 += 5) {                     // five 16-byte loads in flight, then their 20 additions in channel order
+        float4 v[5];
+#pragma unroll
+        for (int u = 0; u < 5; ++u) v[u] = xr[min(t0 + u, c4 - 1)];
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {
+            if (t0 + u < c4) {
+                float p0 = v[u].x * v[u].x; xs = xs + p0;
+                float p1 = v[u].y * v[u].y; xs = xs + p1;
+                float p2 = v[u].z * v[u].z; xs = xs + p2;
+                float p3 = v[u].w * v[u].w; xs = xs + p3;
+            }
+        }
+    }
+    rownorm[i] = xs;
+}
+
 // Assignment on the fp32 matrix pipe (iterations 2..20; the first one also produces the row norms and uses the
 // kernel above).  v_mfma_f32_16x16x4_f32 accumulates each output as one k-ordered fmaf chain -- the OpenBLAS order
 // scipy's vq sees -- so labels stay bit-identical while the rows are fetched with coalesced 16-byte loads instead of
@@ -2527,9 +2555,20 @@ int aoc_kmeans_segmented_rep(const float *pool, int64_t pool_rows, int C, const 
     const size_t lds = ((size_t)kmax * C + kmax) * sizeof(float);
     const size_t lds_fast = lds + (size_t)4 * kmax * sizeof(int32_t);
     const int nf = (C + 63) / 64;
+    const bool use_mfma = fast && mfma_assign && C == 100 && kmax <= 64;
+    if (use_mfma) {
+        // row norms up front (replicated lists whose assignment is fused: replica 0's entries are the ones read), so that the first iteration
+        // takes the matrix-pipe kernel as well
+        const size_t per_r = ((size_t)((kmax + 15) / 16) * 16 * 116 + ((kmax + 15) / 16) * 16) * sizeof(float) + 256;
+        const size_t fixed_r = (size_t)4 * 16 * 116 * sizeof(float) + (size_t)4 * kmax * sizeof(int32_t);
+        const bool rep_path = n_rep > 1 && (78 * 1024 - fixed_r) / per_r >= 2 && !(getenv("AOC_KM_ASSIGN_REP") && atoi(getenv("AOC_KM_ASSIGN_REP")) == 0);
+        const int lim = rep_path ? n_seg / n_rep : n_seg;
+        const int64_t bound = rep_path ? std::min<int64_t>(rows_capacity / n_rep + 1, rows_capacity) : rows_capacity;
+        hipLaunchKernelGGL(km_rownorm_kernel, dim3((unsigned)((bound + 255) / 256)), dim3(256), 0, st, pool, C, rows, seg_offsets, lim, rownorm);
+    }
     for (int it = 0; it < iters; ++it) {
         const int first = (it == 0);
-        if (fast && !first && mfma_assign && C == 100 && kmax <= 64) {
+        if (use_mfma) {
             const int kt = (kmax + 15) / 16;
             bool rep_done = false;
             // replicated segment lists: the rows of a block are staged once for a group of replicas (km_assign_mfma_rep_kernel) as long as
