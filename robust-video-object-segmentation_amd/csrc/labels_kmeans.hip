@@ -2352,7 +2352,8 @@ inline KsWorkspace ks_carve(void *workspace, int64_t cap, int n_seg, int kmax, i
 //             every doubling -- are summed literally, lanes = features (km_ordered_sum_kernel); larger clusters continue
 //             with the chunk-parallel integer folds and the serial stitch (their crossings are rare from there on);
 //   "ordered": literal sums only;   "scan": chunk-parallel pipeline only.   (AOC_KM_SUM, developer switch.)
-// 12 chunks = 6144 members.  Alone, a chain is fastest at 5-6 chunks (sweep 1 .. 8 at R = 6: 3.13, 3.03, 2.90, 2.89, 2.76, 2.78, 2.81,
+// 20 chunks = 10240 members (12 until the sum kernels' XCD-aware ids; after them, three runs each at 12 / 20 / 28 chunks: cfg2 360.3 / 359.7 / 356.0,
+// cfg3 208.5 / 212.6 / 211.1, closed evaluation loop 246 / 251 / 239).  Alone, a chain is fastest at 5-6 chunks (sweep 1 .. 8 at R = 6: 3.13, 3.03, 2.90, 2.89, 2.76, 2.78, 2.81,
 // 2.84 ms per chain; 3.12 at 16): the heads share a launch with the tail's chunk sums and are off the critical path up to about
 // there.  In the bench, where the chains share the GPU with the other streams, what counts is the work a chain puts on the CUs, and the
 // literal heads (one adding wave per workgroup, a few cycles per member) are the cheapest way to sum a member: frames/s at
@@ -2364,7 +2365,7 @@ inline int km_xcd_aware() {
     static const int on = !(getenv("AOC_KM_XCD") && atoi(getenv("AOC_KM_XCD")) == 0);       // developer switch (counter comparisons)
     return on;
 }
-static const int KS_HEAD_CHUNKS = (getenv("AOC_KM_HEAD_CHUNKS") && atoi(getenv("AOC_KM_HEAD_CHUNKS")) > 0) ? atoi(getenv("AOC_KM_HEAD_CHUNKS")) : 12;
+static const int KS_HEAD_CHUNKS = (getenv("AOC_KM_HEAD_CHUNKS") && atoi(getenv("AOC_KM_HEAD_CHUNKS")) > 0) ? atoi(getenv("AOC_KM_HEAD_CHUNKS")) : 20;
 constexpr int KC_INLINE_PREDICT_CHUNKS = 800;   // 409 600 rows per segment
 inline int ks_sum_mode() {
     static const int mode = [] {
