@@ -1006,6 +1006,15 @@ def main():
         cond_roof = hbm_roof("cond_gate_pool", "cond_scores / cond_kth_largest / cond_masked_gap (aoc_cond_gate_pool)",
                              "in-run average over the 4 conditioning blocks; algorithmic bytes O C H W 4 = ONE read of z (SURVEY 8d); the op reads z twice "
                              "(scores, masked pooling) around the exact k-th-largest selection")
+        calib_pmc = dict(file="profiles/r03_pmc_calibration_cfg2.txt", commit="see `git log -1 -- profiles/r03_pmc_calibration_cfg2.txt`")
+        if film_roof is not None:
+            film_roof["traffic_offline"] = dict(calib_pmc, shape=[4, 256, 121, 213], algorithmic_bytes=211.1e6, fetch_bytes=121.8e6, write_bytes=105.8e6, ratio=1.08,
+                                                note="the kernel alone (tools/pmc_calib.sh): FETCH_SIZE x 2 + WRITE_SIZE against one read + one write of the planes")
+        if cond_roof is not None:
+            cond_roof["traffic_offline"] = dict(calib_pmc, shape=[4, 256, 121, 213], algorithmic_bytes=105.6e6, fetch_bytes=104.8e6 + 107.4e6 + 5.0e6,
+                                                write_bytes=4.1e6, ratio=2.1,
+                                                note="the op alone: the scores pass and the masked pooling read z once each (104.8 + 107.4 MB), the score "
+                                                     "reduction, three radix-select passes and the codes move < 2 MB each; nothing is re-read")
         corr_name = next((k for k in ("proxy_corr_min_records", "proxy_corr_min_batched") if k in kernels), "proxy_corr_min")
         corr = kernels.get(corr_name)
         corr_roof = None
