@@ -77,6 +77,8 @@ class HotPathBackend:
         self.dense_precision = dense_precision
         self._heads = {}
         self.ahead = bool(ahead)               # False: the per-frame reference-API path (label prep + count read-back + chain on the frame's stream)
+        import os
+        self.chain_plan = [int(x) for x in os.environ.get("AOC_EVAL_CHAIN_PLAN", "1").split(",") if x.strip()] or [1]   # developer switch
         self.side = None
 
     def _head(self, n_ch):
@@ -152,9 +154,18 @@ class HotPathBackend:
                     if k > 0:
                         rows[li * O + i, :k] = self.rng.permutation(int(counts[i]))[:k]
             inits.append(torch.from_numpy(rows).to(self.device, non_blocking=True))
-        out = [self.hot.launch_cluster_proxies(mc, ref_emb, ref_lab, inits[0], self.side)]
-        if n > 1:
-            out += self.hot.launch_cluster_proxies_batch(mc, ref_emb, ref_lab, inits[1:], self.side)
+        out, i = [], 0
+        for b in self.chain_plan:                            # batch sizes of the chains of one pool state (default: the first frame's alone)
+            if i >= n:
+                break
+            part = inits[i:i + b]
+            out += ([self.hot.launch_cluster_proxies(mc, ref_emb, ref_lab, part[0], self.side)] if len(part) == 1
+                    else self.hot.launch_cluster_proxies_batch(mc, ref_emb, ref_lab, part, self.side))
+            i += len(part)
+        if i < n:
+            rest = inits[i:]
+            out += ([self.hot.launch_cluster_proxies(mc, ref_emb, ref_lab, rest[0], self.side)] if len(rest) == 1
+                    else self.hot.launch_cluster_proxies_batch(mc, ref_emb, ref_lab, rest, self.side))
         self._ahead = out
 
     @torch.no_grad()
