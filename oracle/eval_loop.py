@@ -2,9 +2,12 @@
 networks/engine/eval_manager_mm.py:196-361 for the single-scale, no-flip configuration, with
 networks/layers/shannon_entropy.py:10-13 and the label-map preparation of networks/aoc/aocnet.py:128-133,151.
 
-PARITY UNPINNED by the reference: eval_manager_mm.py is not importable in the build container (cv2 / torchvision /
-dataloaders) and ships no tests; shannon_entropy.py imports matplotlib at module level.  The statements below follow the
-cited lines one by one; the arithmetic is torch CPU fp32 like the reference's (on its device).
+PINNED by the reference itself: ``tests/golden/make_golden_r4.py`` imports eval_manager_mm.py unmodified (the modules it imports
+that need cv2 / torchvision / the datasets are empty stand-ins, ``Tensor.cuda`` is the identity), runs ``Evaluator.evaluating`` on mock
+sequences with a recording mock model and stores what the model is handed every frame -- which embeddings are in the pool, every
+confident reference mask incl. the label 125, the previous mask -- and the label maps it saves (``tests/golden/eval_loop_*.npz``;
+``tests/test_oracle_golden.py::test_eval_loop_bookkeeping_vs_reference``).  The entropy map has its own golden
+(``shannon_entropy.npz``).  The arithmetic is torch CPU fp32 like the reference's (on its device).
 """
 import numpy as np
 import torch

@@ -1,9 +1,11 @@
 """CPU restatement of the matching half of ``AOCNet.before_seghead_process`` (TEST INFRASTRUCTURE ONLY).
 
-Reference: /root/reference/AOC-Net/complete_project/AOCNet/networks/aoc/aocnet.py:141-358 (eval branch,
-batch size 1).  The module itself cannot be imported (missing ``networks.p2t``), so the
-call order and the channel order are restated from the source and every callee is the oracle function
-that IS pinned by golden vectors.  Parity of this orchestration is therefore pinned through its parts.
+Reference: /root/reference/AOC-Net/complete_project/AOCNet/networks/aoc/aocnet.py:114-372 (eval branch, batch size 1).
+PINNED by the reference itself: ``tests/golden/make_golden_r4.py`` imports aocnet.py unmodified (its one missing import,
+``networks.p2t.decoding_module``, is aliased to the reference's own ``networks/aoc/decoding_module.py``), calls
+``AOCNet.before_seghead_process`` on a mock ``self`` and records the 24-channel tensor handed to ``DynamicPreHead``, the prehead's
+output and the attention head handed to the decoder (``tests/golden/frame_*.npz``; ``tests/test_oracle_golden.py::
+test_frame_orchestration_vs_reference``).  Every callee is the oracle function that is pinned by its own golden vectors.
 """
 import torch
 
@@ -50,3 +52,27 @@ def proto_mask_features(ref_emb, ref_labels, prev_emb, prev_labels, cur_emb, dis
         l_bg = om.foreground2background(resh, O).permute(0, 4, 2, 3, 1).squeeze(-1)                 # aocnet.py:351-353
         pre = torch.cat([pre, l_bg, g_bg], 1)                                                       # aocnet.py:358
     return pre, head
+
+
+def before_seghead_process_eval(ref_emb, ref_labels_full, prev_emb, prev_label_full, cur_emb, n_obj, bg_bias, fg_bias, prehead=None,
+                                multi_local_distance=(2, 4, 6, 8, 10, 12), epsilon=1e-5, matching_background=True, init_rows=None):
+    """aocnet.py:114-372 as forward_for_eval drives it (batch 1), from the FULL-RESOLUTION integer label maps.
+
+    ref_emb [R,h,w,C]; ref_labels_full [R,H,W] int (125 = uncertain, matches no object); prev_emb / cur_emb [h,w,C];
+    prev_label_full [H,W]; ``prehead`` = dict(conv_w, conv_b, gn_w, gn_b, groups, eps) or None.
+    Returns (pre_to_cat [O,24,h,w], attention_head [O,4C], prehead output [O,E,h,w] or None)."""
+    from .eval_loop import label_onehot_nearest
+    R, h, w, C = ref_emb.shape
+    ref_labels = torch.stack([label_onehot_nearest(ref_labels_full[r], h, w, n_obj) for r in range(R)])       # aocnet.py:127-131, 192
+    prev_labels = label_onehot_nearest(prev_label_full, h, w, n_obj)                                          # aocnet.py:133-134, 151
+    # aocnet.py:143-146: background bias for object 0, the foreground bias for every other object
+    dis_bias = torch.cat([torch.as_tensor(bg_bias, dtype=torch.float32).reshape(1),
+                          torch.as_tensor(fg_bias, dtype=torch.float32).reshape(1).expand(n_obj - 1)]) if n_obj > 1 else \
+        torch.as_tensor(bg_bias, dtype=torch.float32).reshape(1)
+    pre, head = proto_mask_features(ref_emb, ref_labels, prev_emb, prev_labels, cur_emb, dis_bias, multi_local_distance, epsilon,
+                                    matching_background, init_rows)
+    out = None
+    if prehead is not None:
+        out = ocal.dynamic_prehead(pre, prehead["conv_w"], prehead["conv_b"], prehead["gn_w"], prehead["gn_b"], prehead["groups"],
+                                   prehead["eps"])                                                            # aocnet.py:360
+    return pre, head, out

@@ -340,3 +340,51 @@ def test_local_atrous(golden, name):
                             int(g["atrous_rate"]), bool(g["float16"]), bool(g["down"]))
     assert tuple(out.shape) == g["out"].shape
     np.testing.assert_allclose(out.numpy(), g["out"], **TOL)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Round 4: the per-frame orchestration (f-1) and the eval-loop bookkeeping (f-2) against the reference ITSELF
+# (tests/golden/make_golden_r4.py: AOCNet.before_seghead_process and Evaluator.evaluating run unmodified on mock objects).
+from golden_cases import FRAME_CASES, check_eval_loop, frame_inputs  # noqa: E402  (tests/golden_cases.py)
+
+
+@pytest.mark.parametrize("name", FRAME_CASES)
+def test_frame_orchestration_vs_reference(golden, name):
+    """oracle/hotpath.py against aocnet.py:114-372 executed by the reference: label prep from full-resolution maps (nearest resize,
+    label 125, an object absent from a reference frame), bias assembly, call order under ONE RandomState stream, the channel order of
+    the 24 (17 without MODEL_MATCHING_BACKGROUND) proto-mask channels, DynamicPreHead, the attention head."""
+    from oracle import hotpath as oh
+    g = golden(name)
+    np.random.seed(int(g["seed"]))
+    pre, head, out = oh.before_seghead_process_eval(**frame_inputs(g))
+    assert tuple(pre.shape) == g["pre_to_cat"].shape == (int(g["n_obj"]), 24 if g["background"] else 17, *g["in_cur"].shape[:2])
+    np.testing.assert_allclose(pre.numpy(), g["pre_to_cat"], **TOL)
+    np.testing.assert_allclose(head.numpy(), g["attention_head"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(out.numpy(), g["prehead_out"], rtol=1e-4, atol=2e-5)
+    # the previous-frame mask channel IS what the decoder is handed as to_cat_previous_frame (aocnet.py:152,356,367)
+    assert np.array_equal(pre[:, 16:17].numpy(), g["seghead_prev_mask"])
+
+
+def test_frame_goldens_hold_what_they_claim(golden):
+    g = golden("frame_R2_O3_absent_unc")
+    assert (g["ref_labels_full"] == 125).sum() > 0 and not (g["ref_labels_full"][1] == 2).any() and (g["ref_labels_full"][0] == 2).any()
+    g = golden("frame_R3_O4_bias")
+    assert g["in_ref"].shape[0] == 3 and int(g["km_calls"]) == 4 and float(g["bg_bias"]) != float(g["fg_bias"]) != 0.0
+    assert golden("frame_R2_O3_nobg")["pre_to_cat"].shape[1] == 17
+
+
+@pytest.mark.parametrize("name", ["eval_loop_join_obj3", "eval_loop_mem3"])
+def test_eval_loop_bookkeeping_vs_reference(golden, name):
+    """oracle/eval_loop.py::MemoryPolicy against Evaluator.evaluating executed by the reference (recording mock model)."""
+    from oracle import eval_loop as oe
+    g = golden(name)
+    check_eval_loop(g, oe.MemoryPolicy(mem_every=int(g["mem_every"]), unc_ratio=float(g["unc_ratio"])))
+
+
+def test_eval_loop_goldens_hold_what_they_claim(golden):
+    g = golden("eval_loop_join_obj3")
+    assert int(g["n_frames"]) >= 12 and int(g["mem_every"]) == 5
+    assert g["f13_ref_frames"].tolist() == [0, 5, 7, 10]                       # MEM_EVERY frames and the frame that carries ground truth
+    assert (g["f13_ref_masks"] == 125).any()                                   # uncertain pixels reach the model as label 125
+    assert not (g["saved_labels"][:6] == 3).any() and (g["saved_labels"][6] == 3).any()      # object 3 joins at frame 7
+    assert not (g["saved_labels"] == 4).any() and g["probs"].shape[1] == 5                   # channel 4: a label never seen in any ground truth
