@@ -685,10 +685,9 @@ def main():
     n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
     if args.cu_reserve >= n_cu:
         args.cu_reserve = 0
-    if args.cu_reserve > 0:
-        os.environ.setdefault("AOC_DENSE_CUS", str(n_cu - args.cu_reserve))   # the dense kernel sizes its grid in whole rounds of CUs
-        os.environ.setdefault("AOC_CORR_CUS", str(n_cu - args.cu_reserve))
     aoc_amd._lib.lib()
+    if args.cu_reserve > 0:
+        aoc_amd.ops.set_stream_cus(n_cu - args.cu_reserve)   # the matrix kernels size their grids in whole rounds of the CUs their stream may use
 
     def barrier():
         torch.cuda.synchronize()
@@ -763,8 +762,7 @@ def main():
         if rc != 0 or not handle.value:
             print(f"bench: hipExtStreamCreateWithCUMask failed ({rc}); running without the CU reservation", file=sys.stderr)
             args.cu_reserve = 0
-            os.environ.pop("AOC_DENSE_CUS", None)
-            os.environ.pop("AOC_CORR_CUS", None)
+            aoc_amd.ops.set_stream_cus(0)
             return torch.cuda.Stream(device=dev)
         return torch.cuda.ExternalStream(handle.value, device=dev)
 

@@ -143,18 +143,6 @@ int aoc_kmeans_segmented(const float *pool, int C,
                          float *centroids, int32_t *labels, int32_t *cluster_counts,
                          void *workspace, size_t workspace_bytes, aoc_stream_t stream);
 
-/* With C = 100, kmax <= 64 and n_seg <= 128 (every configuration of the model) the whole call -- the one kmeans2() of AEM:276 -- is ONE
- * persistent launch: the Lloyd iterations are phases of a resident grid separated by grid barriers (kmeans_persistent.hip).  The grid
- * must be resident as a whole; aoc_kmeans_set_grid states how many workgroups (of 256 threads) a chain may take -- e.g. what fits the
- * CUs a caller leaves to its k-means streams -- 0 = default (one per CU, capped by the occupancy of the kernel).  Process-wide. */
-int aoc_kmeans_set_grid(int workgroups);
-/* Developer counters of the persistent chain (only filled when the process runs with AOC_KM_PROF=w+1): what workgroup w spent, in ticks
- * of the 100 MHz wall clock, in [0] row norms, [1] assignment, [3] fold, [5] merge, [7] stitch, [2][4][6][8] the grid barrier behind
- * each, [9] chains, [12][13] fold steps / general steps of its first thread, [16..] sections inside a phase.  Host pointer to 32 values. */
-int aoc_kmeans_chain_profile(unsigned long long *out32_host, int reset);
-/* The same per workgroup, for the last chain (16 slots of ticks per workgroup, indexed as above; [10][11] = prefix phase and its barrier). */
-int aoc_kmeans_chain_profile_workgroups(unsigned int *out_host, int n_workgroups);
-
 /* The reference's second proxy set, AEM:280: for every non-empty cluster j of segment s the mean of
  * the rows  fg[p], p in {segment-local indices with label == j}  of the GLOBAL kept-row array (the
  * reference indexes the wrong array; reproduced as is).  Also emits the squared norms of both
@@ -332,6 +320,11 @@ int aoc_dense_match_min_split(const float *query, const void *query_rec, const f
  * since the last reset (synchronises the device): out4[0] (reference tile, query tile) pairs tested with one fp16 product,
  * out4[1] pairs rescored with all three products, out4[2] reference tiles with at least one rescoring, out4[3] reference tiles. */
 int aoc_dense_prune_stats(uint64_t *out4, int reset);
+
+/* How many CUs the streams that launch the matrix kernels (dense matching, batched correlation) may use -- a caller that runs them under a
+ * HIP CU mask says so here and the kernels size their grids in whole rounds of that many CUs; 0 (default) = every CU of the device.
+ * Process-wide, may be changed between calls.  (The library itself never reads the environment.) */
+int aoc_set_stream_cus(int n_cus);
 
 /* Measurement probe: the NEXT aoc_dense_match_min / aoc_dense_match_min_split call made by the calling thread records
  * `start` immediately before and `stop` immediately after its matrix kernel (dense_match_partial_kernel /

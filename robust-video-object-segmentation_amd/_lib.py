@@ -9,7 +9,14 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-SO_PATH = os.path.join(CSRC, "libaoc_hip.so")
+RELEASE_SO = os.path.join(CSRC, "libaoc_hip.so")
+DEV_SO = os.path.join(CSRC, "libaoc_hip_dev.so")
+# AOC_LIB_VARIANT=dev (read HERE, in Python, never by the library): load the development build, the only one that knows the
+# developer switches of tools/README.md (timing experiments, alternative kernels).  The release library ignores the environment.
+VARIANT = os.environ.get("AOC_LIB_VARIANT", "release")
+if VARIANT not in ("release", "dev"):
+    raise ImportError(f"AOC_LIB_VARIANT={VARIANT!r}: 'release' or 'dev'")
+SO_PATH = DEV_SO if VARIANT == "dev" else RELEASE_SO
 
 _vp, _i, _i64, _sz, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_size_t, ctypes.c_float
 
@@ -34,9 +41,6 @@ SIGNATURES = {
     "aoc_label_onehot_nearest": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "aoc_mask_jf_workspace_bytes": (_sz, [_i, _i]),
     "aoc_mask_jf_accumulate": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _sz, _i, _vp, _vp]),
-    "aoc_kmeans_set_grid": (_i, [_i]),
-    "aoc_kmeans_chain_profile": (_i, [_vp, _i]),
-    "aoc_kmeans_chain_profile_workgroups": (_i, [_vp, _i]),
     "aoc_kmeans_replicate": (_i, [_vp, _vp, _vp, _i, _i, _i64, _vp, _vp, _vp, _vp]),
     "aoc_kmeans_replicate_levels": (_i, [_vp, _vp, _i, _i, _vp, _i, _i64, _vp, _vp, _vp, _vp]),
     "aoc_build_proxies_workspace_bytes": (_sz, [_i64, _i, _i]),
@@ -50,6 +54,7 @@ SIGNATURES = {
     "aoc_dense_match_min_f16": (_i, [_vp, _i64, _i, _vp, _vp, _vp, _i64, _vp, _vp, _i, _vp, _i64, _i64, _i, _vp, _sz, _vp]),
     "aoc_proxy_corr_min_f16": (_i, [_vp, _i64, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _i64, _i, _vp]),
     "aoc_dense_match_set_probe": (_i, [_vp, _vp]),
+    "aoc_set_stream_cus": (_i, [_i]),
     "aoc_split_record_bytes": (_sz, [_i]),
     "aoc_split_rows": (_i, [_vp, _i64, _i, _vp, _vp, _vp, _vp]),
     "aoc_split_rows_tiled_bytes": (_sz, [_i64, _i]),
@@ -90,11 +95,14 @@ class AocHipError(RuntimeError):
     pass
 
 
-def build(force=False):
-    """hipcc --offload-arch=gfx950 build of csrc/*.hip -> csrc/libaoc_hip.so (in-tree)."""
+def build(force=False, dev=True):
+    """hipcc --offload-arch=gfx950 build of csrc/*.hip -> csrc/libaoc_hip.so (in-tree) and, with dev=True, the development
+    build csrc/libaoc_hip_dev.so (-DAOC_DEV: the same sources with the developer switches compiled in)."""
     if force:
         subprocess.check_call(["make", "-s", "-C", CSRC, "clean"])
     subprocess.check_call(["make", "-s", "-j4", "-C", CSRC])
+    if dev:
+        subprocess.check_call(["make", "-s", "-j4", "-C", CSRC, "DEV=1"])
     return SO_PATH
 
 

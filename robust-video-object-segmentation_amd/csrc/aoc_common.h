@@ -71,14 +71,17 @@ int aoc_dense_match_min_gated(const float *query, int64_t m, int C, const float 
 struct AocDenseProbe { hipEvent_t start, stop; };
 AocDenseProbe aoc_take_dense_probe();
 
-// persistent k-means chain (kmeans_persistent.hip): the Lloyd iterations of one aoc_kmeans_segmented_ex call in ONE launch
-bool aoc_kp_supported(int C, int n_seg, int kmax);
-size_t aoc_kp_workspace_bytes(int64_t rows_capacity, int n_seg, int kmax);
-int aoc_kp_chain(const float *pool, const int32_t *rows, const int32_t *seg_offsets, const int32_t *seg_k, int n_seg, int kmax, int iters,
-                 int64_t rows_capacity, float *centroids, int32_t *labels, int32_t *cluster_counts, float *rownorm, void *workspace, hipStream_t st);
+// Developer switches (timing experiments, alternative kernels, some of which produce WRONG results on purpose) only exist in the
+// development build (`make DEV=1` -> libaoc_hip_dev.so, -DAOC_DEV).  The release library never reads the environment: a stray
+// variable cannot change a result or a kernel choice.  tests/test_host_logic.py checks that no switch name is in the release binary.
+#include <stdlib.h>
+#ifdef AOC_DEV
+#define AOC_DEV_ENV(name) getenv(name)
+#define AOC_DEV_ENV_INT(name, dflt) (getenv(name) ? atoi(getenv(name)) : (dflt))
+#else
+#define AOC_DEV_ENV(name) (static_cast<const char *>(nullptr))      /* the switch's name is not even in the binary */
+#define AOC_DEV_ENV_INT(name, dflt) (dflt)
+#endif
 
-// record pipeline for the ordered sums of the launch-per-phase k-means (kmeans_records.hip)
-bool aoc_kr_supported(int C, int kmax);
-size_t aoc_kr_workspace_bytes(int64_t rows_capacity, int n_seg, int kmax);
-int aoc_kr_sums(const float *pool, const int32_t *seg_offsets, const int32_t *seg_k, const int32_t *counts, const int32_t *cbase, const uint32_t *moff,
-                int n_seg, int kmax, int64_t rows_capacity, int64_t seg_bound, float *centroids, void *workspace, hipStream_t st);
+// CUs the launching stream may use (aoc_set_stream_cus; 0 = all CUs of the device).  Defined in dense_split.hip.
+int aoc_stream_cus();

@@ -1097,7 +1097,7 @@ int aoc_film_scale(const float *x, const float *head, const float *weight, const
     // nontemporal stores: the gated activation is a pure stream-out, and every dirty line it would leave in the XCDs' L2s is written back at
     // the next kernel boundary of ANY stream -- the k-means chain on the side stream has 125 of them per frame (bench: +2 % frames/s;
     // AOC_FILM_NT=0 switches back)
-    static const int nt = getenv("AOC_FILM_NT") ? atoi(getenv("AOC_FILM_NT")) : 1;
+    static const int nt = AOC_DEV_ENV_INT("AOC_FILM_NT", 1);
     hipLaunchKernelGGL(film_scale_kernel, dim3(bx, (unsigned)planes), dim3(256), 0, aoc_hip_stream(stream), x, head, weight, bias, head_dim, channels, hw, y, nt);
     AOC_RETURN_IF_LAUNCH_FAILED();
     return AOC_OK;

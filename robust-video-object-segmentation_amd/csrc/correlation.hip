@@ -532,7 +532,7 @@ inline int dense_nsplit(int64_t m, int na) {
     // rounds of 256 CUs (tail effect); among near-equal fills prefer MORE, shorter blocks: CUs then free up
     // often, which lets the latency-bound kernels of other streams (k-means chain) interleave with this one.
     const int64_t row_blocks = (m + 16 * DM_NW * na - 1) / (16 * DM_NW * na);
-    static const int max_rounds = getenv("AOC_DENSE_ROUNDS") ? atoi(getenv("AOC_DENSE_ROUNDS")) : 4;
+    static const int max_rounds = AOC_DEV_ENV_INT("AOC_DENSE_ROUNDS", 4);
     int best = 1;
     double best_eff = 0.0;
     for (int k = 1; k <= max_rounds; ++k) {

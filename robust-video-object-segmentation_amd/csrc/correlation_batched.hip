@@ -671,11 +671,11 @@ __global__ __launch_bounds__(NW * 64, 4) void proxy_corr_records_kernel(AocCorrR
 }
 
 inline int cb_n_cus() {
+    const int set = aoc_stream_cus();                                         // CUs the launching stream may use (aoc_set_stream_cus: HIP CU mask)
+    if (set > 0) return set;
     static int n = 0;
     if (n == 0) {
-        const char *e = getenv("AOC_CORR_CUS");                               // CUs the launching stream may use (HIP CU mask)
-        if (e && atoi(e) > 0) n = atoi(e);
-        else {
+        {
             int dev = 0, v = 0;
             if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
             else n = 256;
@@ -755,7 +755,7 @@ int cb_run(const aoc_corr_frame *frames_host, const AocCorrRecFrame *rec_host, i
                 AocCorrRecFrames rf;
                 rf.n = fr.n;
                 for (int f = 0; f < fr.n; ++f) rf.f[f] = rec_host[f0 + f];
-                static const int dbg_r = getenv("AOC_CORR_DEBUG") ? atoi(getenv("AOC_CORR_DEBUG")) : 0;
+                static const int dbg_r = AOC_DEV_ENV_INT("AOC_CORR_DEBUG", 0);
                 const bool col0_r = tab.t[0].kind == 1;
                 if (grid > 2 * (int64_t)n_cu) grid = 2 * (int64_t)n_cu;
 #define AOC_CR(N, COL)                                                                                                                  \
@@ -783,7 +783,7 @@ int cb_run(const aoc_corr_frame *frames_host, const AocCorrRecFrame *rec_host, i
                 return hipGetLastError() == hipSuccess ? AOC_OK : AOC_ERR_LAUNCH;
             }
             if (grid > n_cu) grid = n_cu;
-            static const int dbg = getenv("AOC_CORR_DEBUG") ? atoi(getenv("AOC_CORR_DEBUG")) : 0;   // developer switch: 2 = no tile loads, 4 = no conversion (timing experiments; wrong results)
+            static const int dbg = AOC_DEV_ENV_INT("AOC_CORR_DEBUG", 0);   // developer switch: 2 = no tile loads, 4 = no conversion (timing experiments; wrong results)
             const bool col0 = tab.t[0].kind == 1;
 #define AOC_CB(N, COL)                                                                                                                  \
     do {                                                                                                                                \

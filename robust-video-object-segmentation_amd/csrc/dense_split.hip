@@ -13,6 +13,8 @@
 // This kernel only runs when (a) every scaled value fits fp16 and (b) every kept reference pixel is right for
 // exactly one object; both facts are device flags, and the exact-fp32 kernels of correlation.hip take over on
 // the same stream otherwise (each side checks the flag itself: no host round trip).
+#include <atomic>
+
 #include "aoc_common.h"
 
 namespace {
@@ -32,7 +34,6 @@ constexpr int SP_TILE = 32;                    // reference pixels per MFMA tile
 constexpr int SP_NB = 4;                       // tiles per staged chunk
 constexpr int SP_NW = 8;                       // waves per block
 constexpr int SP_NQ = 2;                       // 32-pixel query tiles per wave (stationary B operands in registers)
-constexpr int SP_ROWS_PER_BLOCK = SP_NW * SP_NQ * 32;
 
 static_assert(SP_NORM_SLOT + 4 <= SP_K && SP_NORM_SLOT / 16 == SP_KS - 1 && (SP_NORM_SLOT % 16) + 4 <= 8, "norm slots live in the low half of the last k-step");
 
@@ -569,7 +570,7 @@ __global__ __launch_bounds__(256) void dense_split_finalize_kernel(const uint32_
 inline int split_waves() {
     // developer switch AOC_DENSE_WAVES=4: workgroups of 4 waves (256 query pixels), one wave per SIMD -- half of every CU's register file stays
     // free for the other streams' kernels, and no CU mask is needed; the default (8) fills the CUs it runs on
-    static const int nw = (getenv("AOC_DENSE_WAVES") && atoi(getenv("AOC_DENSE_WAVES")) == 4) ? 4 : 8;
+    static const int nw = AOC_DEV_ENV_INT("AOC_DENSE_WAVES", 8) == 4 ? 4 : 8;
     return nw;
 }
 inline int split_nsplit(int64_t m) {
@@ -578,9 +579,9 @@ inline int split_nsplit(int64_t m) {
     // at most two rounds of workgroups (developer switch AOC_DENSE_ROUNDS): fewer splits share their bounds sooner (in-run launch 1.43 /
     // 1.50 / 1.56 ms at 1 / 2 / 4 rounds), but with one round the other streams' kernels wait for a whole dense launch before a CU
     // comes free: bench 320 / 324 / 320 frames/s
-    static const int max_rounds = getenv("AOC_DENSE_ROUNDS") ? atoi(getenv("AOC_DENSE_ROUNDS")) : 2;
+    static const int max_rounds = AOC_DEV_ENV_INT("AOC_DENSE_ROUNDS", 2);
     // CUs the launching stream may use (256 unless the caller runs it under a HIP CU mask and says so)
-    static const int n_cu = (getenv("AOC_DENSE_CUS") && atoi(getenv("AOC_DENSE_CUS")) > 0) ? atoi(getenv("AOC_DENSE_CUS")) : 256;
+    const int n_cu = aoc_stream_cus() > 0 ? aoc_stream_cus() : 256;
     int best = 1;
     double best_eff = 0.0;
     for (int k = 1; k <= max_rounds; ++k) {
@@ -687,7 +688,7 @@ int aoc_dense_match_min_split(const float *query, const void *query_rec, const f
         hipFuncSetAttribute(reinterpret_cast<const void *>(dense_prune_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
     if (!lds_ok) return AOC_ERR_LAUNCH;
     const AocDenseProbe probe = aoc_take_dense_probe();
-    static const int dbg = getenv("AOC_DENSE_DEBUG") ? atoi(getenv("AOC_DENSE_DEBUG")) : 0;       // developer switch: timing experiments only
+    static const int dbg = AOC_DEV_ENV_INT("AOC_DENSE_DEBUG", 0);       // developer switch: timing experiments only
     if (probe.start) (void)hipEventRecord(probe.start, st);
     if (nw == 4)
         hipLaunchKernelGGL(dense_prune_kernel<4>, grid, dim3(4 * 64), lds, st, static_cast<const uint4 *>(query_rec), query_sqnorm, m,
@@ -702,6 +703,13 @@ int aoc_dense_match_min_split(const float *query, const void *query_rec, const f
     // exact-fp32 kernels: run only when the gate is set
     return aoc_dense_match_min_gated(query, m, C, pool, fg_rows, counts + n_obj, n, wrong_bits, obj_bias, n_obj, out, out_pixel_stride,
                                      out_obj_stride, transform, w.fp32_ws, w.fp32_bytes, w.gate, stream);
+}
+
+static std::atomic<int> g_stream_cus{0};
+int aoc_set_stream_cus(int n_cus) {
+    if (n_cus < 0) return AOC_ERR_INVALID_ARG;
+    g_stream_cus.store(n_cus, std::memory_order_relaxed);
+    return AOC_OK;
 }
 
 // Developer counters of the coarse-then-rescore kernel, summed over all launches since the last reset:
@@ -719,3 +727,5 @@ int aoc_dense_prune_stats(uint64_t *out4, int reset) {
 }
 
 }  // extern "C"
+
+int aoc_stream_cus() { return g_stream_cus.load(std::memory_order_relaxed); }

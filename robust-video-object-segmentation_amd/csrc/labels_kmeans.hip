@@ -2308,8 +2308,6 @@ struct KsWorkspace {
     int8_t *cexp;
     uint32_t *cflag;          // per (chunk, feature group): local sums published (km_chunk_scanfold_kernel)
     int seg_chunks_max;       // no segment (hence no cluster) has more chunks than this
-    void *kr_ws = nullptr;    // workspace of the record pipeline (kmeans_records.hip), when the call has one
-    int64_t kr_cap = 0, kr_seg_bound = 0;
 };
 inline int ks_chunk_capacity(int64_t cap, int n_seg, int kmax) { return (int)(cap / KS_CHUNK) + n_seg * (kmax + 1) + 2; }
 inline size_t ks_workspace_bytes(int64_t cap, int n_seg, int kmax) {
@@ -2362,17 +2360,16 @@ inline KsWorkspace ks_carve(void *workspace, int64_t cap, int n_seg, int kmax, i
 // with one ds_read_b128 per four members shortens the adding wave's chain -- 3.0 -> 2.9 ms alone at 12 chunks -- but costs the seven
 // producer waves four ds_write_b32 per piece instead of one ds_write_b128: 1 % SLOWER in the bench, three runs each; not kept.)
 inline int km_xcd_aware() {
-    static const int on = !(getenv("AOC_KM_XCD") && atoi(getenv("AOC_KM_XCD")) == 0);       // developer switch (counter comparisons)
+    static const int on = AOC_DEV_ENV_INT("AOC_KM_XCD", 1) != 0;       // developer switch (counter comparisons)
     return on;
 }
-static const int KS_HEAD_CHUNKS = (getenv("AOC_KM_HEAD_CHUNKS") && atoi(getenv("AOC_KM_HEAD_CHUNKS")) > 0) ? atoi(getenv("AOC_KM_HEAD_CHUNKS")) : 20;
+static const int KS_HEAD_CHUNKS = AOC_DEV_ENV_INT("AOC_KM_HEAD_CHUNKS", 20) > 0 ? AOC_DEV_ENV_INT("AOC_KM_HEAD_CHUNKS", 20) : 20;
 constexpr int KC_INLINE_PREDICT_CHUNKS = 800;   // 409 600 rows per segment
 inline int ks_sum_mode() {
     static const int mode = [] {
-        const char *e = getenv("AOC_KM_SUM");
+        const char *e = AOC_DEV_ENV("AOC_KM_SUM");
         if (e && strcmp(e, "scan") == 0) return 0;
         if (e && strcmp(e, "ordered") == 0) return 1;
-        if (e && strcmp(e, "records") == 0) return 3;
         return 2;
     }();
     return mode;
@@ -2381,21 +2378,16 @@ template <int MODE>
 inline void ks_launch_sums(hipStream_t st, const float *pool, uint32_t pool_bytes, int C, const int32_t *seg_offsets, const int32_t *seg_k,
                            const int32_t *counts, const KsWorkspace &ws, int kmax, int n_seg, float *dst) {
     const int mode = ks_sum_mode();
-    if (MODE == 0 && mode == 3 && ws.kr_ws && aoc_kr_supported(C, kmax)) {
-        // "records": chunk-parallel exact sums with verified records on the member lists (kmeans_records.hip)
-        aoc_kr_sums(pool, seg_offsets, seg_k, counts, ws.cbase, ws.moff, n_seg, kmax, ws.kr_cap, ws.kr_seg_bound, dst, ws.kr_ws, st);
-        return;
-    }
-    const int start = (mode == 2 || mode == 3) ? KS_HEAD_CHUNKS : 0;
-    static const bool fused = getenv("AOC_KM_FUSED") && atoi(getenv("AOC_KM_FUSED")) == 1;
-    static const bool split_heads = getenv("AOC_KM_HEADS") && strcmp(getenv("AOC_KM_HEADS"), "kernel") == 0;   // developer switch: heads and chunk sums as two launches
-    const bool merged = (mode == 2 || mode == 3) && !(fused && C <= KC_FG * 8) && !split_heads;
+    const int start = (mode == 2) ? KS_HEAD_CHUNKS : 0;
+    static const bool fused = AOC_DEV_ENV_INT("AOC_KM_FUSED", 0) == 1;
+    static const bool split_heads = AOC_DEV_ENV("AOC_KM_HEADS") && strcmp(AOC_DEV_ENV("AOC_KM_HEADS"), "kernel") == 0;   // developer switch: heads and chunk sums as two launches
+    const bool merged = (mode == 2) && !(fused && C <= KC_FG * 8) && !split_heads;
     if (merged) {
         hipLaunchKernelGGL(km_heads_chunk_sums_kernel<MODE>, dim3(kmax * n_seg * os_groups(C) + ws.nch_cap), dim3((OS_NPROD + 1) * 64), 0, st, pool, pool_bytes, C,
                            seg_offsets, seg_k, counts, ws.cbase, ws.moff, kmax, n_seg, dst, KS_HEAD_CHUNKS * KS_CHUNK, ws.head, ws.owner_cluster, ws.owner_local,
                            ws.csum, start, km_xcd_aware());
     } else if (mode != 0) {
-        const int cap = (mode == 2 || mode == 3) ? KS_HEAD_CHUNKS * KS_CHUNK : 0;
+        const int cap = (mode == 2) ? KS_HEAD_CHUNKS * KS_CHUNK : 0;
         hipLaunchKernelGGL(km_ordered_sum_kernel<MODE>, dim3(kmax, n_seg, os_groups(C)), dim3((OS_NPROD + 1) * 64), 0, st, pool, pool_bytes, C, seg_offsets,
                            seg_k, counts, ws.cbase, ws.moff, kmax, dst, cap, ws.head);
         if (mode == 1) return;
@@ -2413,7 +2405,7 @@ inline void ks_launch_sums(hipStream_t st, const float *pool, uint32_t pool_byte
                                ws.owner_local, ws.csum, start);
         // the binade prediction runs inside the fold kernel (every workgroup re-adds its cluster's earlier chunk sums: quadratic in the
         // chunks of a cluster, so only while a cluster cannot have more than KC_INLINE_PREDICT_CHUNKS); AOC_KM_PREDICT=kernel: separate launch
-        static const bool sep_predict = getenv("AOC_KM_PREDICT") && strcmp(getenv("AOC_KM_PREDICT"), "kernel") == 0;
+        static const bool sep_predict = AOC_DEV_ENV("AOC_KM_PREDICT") && strcmp(AOC_DEV_ENV("AOC_KM_PREDICT"), "kernel") == 0;
         const bool inline_predict = !sep_predict && ws.seg_chunks_max <= KC_INLINE_PREDICT_CHUNKS;
         if (!inline_predict)
             hipLaunchKernelGGL(km_chunk_predict_kernel, dim3(kmax, n_seg), dim3(128), 0, st, seg_k, counts, ws.cchunk, ws.csum, kmax, C, ws.cexp, start, ws.head);
@@ -2421,7 +2413,7 @@ inline void ks_launch_sums(hipStream_t st, const float *pool, uint32_t pool_byte
                            kmax, ws.owner_cluster, ws.owner_local, ws.cexp, ws.cinc0, ws.cinc1, start, inline_predict ? ws.csum : (const float *)nullptr,
                            ws.cchunk, ws.head, ws.nch_cap, (C + KC_FG - 1) / KC_FG, km_xcd_aware());
     }
-    static const int nf = getenv("AOC_KS_NF") ? atoi(getenv("AOC_KS_NF")) : 1;       // features per stitch wave (developer switch)
+    static const int nf = AOC_DEV_ENV_INT("AOC_KS_NF", 1);       // features per stitch wave (developer switch)
 #define AOC_KSS(NF) hipLaunchKernelGGL((km_sum_scan_kernel<MODE, NF>), dim3((unsigned)(C / NF) * kmax * n_seg), dim3(64), 0, st, pool, pool_bytes, C, seg_offsets, seg_k, \
                                        counts, ws.cbase, ws.moff, kmax, dst, ws.cchunk, ws.cexp, ws.cinc0, ws.cinc1, start, ws.head, n_seg, km_xcd_aware())
     if (nf == 4) AOC_KSS(4); else if (nf == 2) AOC_KSS(2); else AOC_KSS(1);
@@ -2429,7 +2421,7 @@ inline void ks_launch_sums(hipStream_t st, const float *pool, uint32_t pool_byte
 }
 
 inline int km_assign_grid_cap() {
-    static const int cap = getenv("AOC_KM_ASSIGN_GRID") ? atoi(getenv("AOC_KM_ASSIGN_GRID")) : 512;      // developer switch (measured: 128 .. 512 within 3 %)
+    static const int cap = AOC_DEV_ENV_INT("AOC_KM_ASSIGN_GRID", 512);      // developer switch (measured: 128 .. 512 within 3 %)
     return cap > 0 ? cap : 512;
 }
 
@@ -2480,24 +2472,10 @@ int aoc_kmeans_plan(const int32_t *counts, int n_seg, int cluster_num, int32_t *
     return AOC_OK;
 }
 
-// the launch-per-phase pipeline's share of the workspace (the persistent chain's tables follow it)
-static size_t km_launches_workspace_bytes(int64_t rows_capacity, int n_seg, int kmax) {
-    return aoc_align_up((size_t)n_seg * kmax * sizeof(float), 256) + aoc_align_up(ks_workspace_bytes(rows_capacity, n_seg, kmax), 256);
-}
-// AOC_KM_CHAIN=persistent: the whole call as ONE persistent launch (kmeans_persistent.hip).  Bit-identical (the k-means tests are re-run
-// with it), but measured slower than the launch-per-phase pipeline so far: opt-in.
-static bool km_chain_enabled() {
-    static const bool on = getenv("AOC_KM_CHAIN") && strcmp(getenv("AOC_KM_CHAIN"), "persistent") == 0;
-    return on;
-}
-
 size_t aoc_kmeans_workspace_bytes(int64_t rows_capacity, int n_seg, int kmax, int C) {
+    (void)C;
     if (rows_capacity < 0 || n_seg < 1 || kmax < 1) return 0;
-    size_t b = km_launches_workspace_bytes(rows_capacity, n_seg, kmax);
-    // the alternative pipelines' tables only when this process has asked for them (their switches are read once per process)
-    if (km_chain_enabled() && aoc_kp_supported(C, n_seg, kmax)) b += aoc_kp_workspace_bytes(rows_capacity, n_seg, kmax);
-    if (ks_sum_mode() == 3 && aoc_kr_supported(C, kmax)) b += aoc_kr_workspace_bytes(rows_capacity, n_seg, kmax);
-    return b;
+    return aoc_align_up((size_t)n_seg * kmax * sizeof(float), 256) + aoc_align_up(ks_workspace_bytes(rows_capacity, n_seg, kmax), 256);
 }
 
 int aoc_kmeans_segmented(const float *pool, int C, const int32_t *rows, const int32_t *seg_offsets, const int32_t *seg_k,
@@ -2536,22 +2514,10 @@ int aoc_kmeans_segmented_rep(const float *pool, int64_t pool_rows, int C, const 
     // scan-sum pipeline: rows addressed by 32-bit byte offsets through a bounds-checked buffer descriptor
     const bool fast = (C % 4) == 0 && C <= 128 && pool_rows > 0 && (uint64_t)pool_rows * C * 4 < 0xFFFFFF00ull;
     const uint32_t pool_bytes = fast ? (uint32_t)((uint64_t)pool_rows * C * 4) : 0u;
-    static const bool mfma_assign = !(getenv("AOC_KM_ASSIGN") && strcmp(getenv("AOC_KM_ASSIGN"), "valu") == 0);   // developer switch
+    static const bool mfma_assign = !(AOC_DEV_ENV("AOC_KM_ASSIGN") && strcmp(AOC_DEV_ENV("AOC_KM_ASSIGN"), "valu") == 0);   // developer switch
 
     hipLaunchKernelGGL(km_init_kernel, dim3(kmax, n_seg), dim3(64), 0, st, pool, C, rows, seg_offsets, seg_k, init_rows, kmax,
                        centroids, cnorm, cluster_counts);
-    if (fast && ks_sum_mode() == 3 && aoc_kr_supported(C, kmax)) {
-        ws.kr_ws = static_cast<char *>(workspace) + km_launches_workspace_bytes(rows_capacity, n_seg, kmax) +
-                   ((km_chain_enabled() && aoc_kp_supported(C, n_seg, kmax)) ? aoc_kp_workspace_bytes(rows_capacity, n_seg, kmax) : 0);
-        ws.kr_cap = rows_capacity;
-        ws.kr_seg_bound = seg_bound;
-    }
-    // one persistent launch for all iterations (kmeans_persistent.hip), where asked for and applicable
-    if (fast && km_chain_enabled() && aoc_kp_supported(C, n_seg, kmax)) {
-        AOC_RETURN_IF_LAUNCH_FAILED();
-        return aoc_kp_chain(pool, rows, seg_offsets, seg_k, n_seg, kmax, iters, rows_capacity, centroids, labels, cluster_counts, rownorm,
-                            static_cast<char *>(workspace) + km_launches_workspace_bytes(rows_capacity, n_seg, kmax), st);
-    }
     const dim3 agrid((unsigned)((seg_bound + 255) / 256), (unsigned)n_seg);
     const size_t lds = ((size_t)kmax * C + kmax) * sizeof(float);
     const size_t lds_fast = lds + (size_t)4 * kmax * sizeof(int32_t);
@@ -2562,7 +2528,7 @@ int aoc_kmeans_segmented_rep(const float *pool, int64_t pool_rows, int C, const 
         // takes the matrix-pipe kernel as well
         const size_t per_r = ((size_t)((kmax + 15) / 16) * 16 * 116 + ((kmax + 15) / 16) * 16) * sizeof(float) + 256;
         const size_t fixed_r = (size_t)4 * 16 * 116 * sizeof(float) + (size_t)4 * kmax * sizeof(int32_t);
-        const bool rep_path = n_rep > 1 && (78 * 1024 - fixed_r) / per_r >= 2 && !(getenv("AOC_KM_ASSIGN_REP") && atoi(getenv("AOC_KM_ASSIGN_REP")) == 0);
+        const bool rep_path = n_rep > 1 && (78 * 1024 - fixed_r) / per_r >= 2 && AOC_DEV_ENV_INT("AOC_KM_ASSIGN_REP", 1) != 0;
         const int lim = rep_path ? n_seg / n_rep : n_seg;
         const int64_t bound = rep_path ? std::min<int64_t>(rows_capacity / n_rep + 1, rows_capacity) : rows_capacity;
         hipLaunchKernelGGL(km_rownorm_kernel, dim3((unsigned)((bound + 255) / 256)), dim3(256), 0, st, pool, C, rows, seg_offsets, lim, rownorm);
@@ -2578,7 +2544,7 @@ int aoc_kmeans_segmented_rep(const float *pool, int64_t pool_rows, int C, const 
                 const size_t fixed = (size_t)4 * 16 * 116 * sizeof(float) + (size_t)4 * kmax * sizeof(int32_t);
                 const size_t per = ((size_t)kt * 16 * 116 + kt * 16) * sizeof(float) + 256;
                 const int fit = (int)std::min<size_t>(16, (78 * 1024 - fixed) / per);
-                static const bool rep_off = getenv("AOC_KM_ASSIGN_REP") && atoi(getenv("AOC_KM_ASSIGN_REP")) == 0;     // developer switch
+                static const bool rep_off = AOC_DEV_ENV_INT("AOC_KM_ASSIGN_REP", 1) == 0;     // developer switch
                 if (n_rep > 1 && fit >= 2 && !rep_off) {
                     const int n_groups = (n_rep + fit - 1) / fit;
                     const int n_grp = (n_rep + n_groups - 1) / n_groups;

@@ -650,7 +650,7 @@ int aoc_local_window_match_ex(const float *query, const float *prev, const uint3
                        (size_t)4 * 16 * n_radii * n_obj * sizeof(float);
     if (lds > 150 * 1024) return AOC_ERR_UNSUPPORTED;
     hipStream_t st = aoc_hip_stream(stream);
-    static const char *which = getenv("AOC_LOCAL_KERNEL");            // developer switch: "row" / "block" = the LDS-image kernels
+    static const char *which = AOC_DEV_ENV("AOC_LOCAL_KERNEL");            // developer switch: "row" / "block" = the LDS-image kernels
     // register-operand kernel (no LDS image): C == 100 / 128
     if ((C == 100 || C == 128) && !(which && (strcmp(which, "row") == 0 || strcmp(which, "block") == 0))) {
         const dim3 rgrid((W + 7) / 8, (H + 1) / 2);
@@ -666,7 +666,7 @@ int aoc_local_window_match_ex(const float *query, const float *prev, const uint3
     {
         const int TPc = (C == 100) ? 28 : 32, RSc = 4 * TPc + 4;
         const size_t lds_row = ((size_t)4 * ((size_t)NG * 16 * RSc + 2 * NG * 16) + 32 + (size_t)4 * 16 * n_radii * n_obj) * sizeof(float);
-        static const bool use_row = !(getenv("AOC_LOCAL_KERNEL") && strcmp(getenv("AOC_LOCAL_KERNEL"), "block") == 0);   // developer switch
+        static const bool use_row = !(AOC_DEV_ENV("AOC_LOCAL_KERNEL") && strcmp(AOC_DEV_ENV("AOC_LOCAL_KERNEL"), "block") == 0);   // developer switch
         if (use_row && (C == 100 || C == 128) && R <= 16 && lds_row <= 150 * 1024) {
             const dim3 rgrid((W + 15) / 16, H);
             if (C == 100)

@@ -403,6 +403,12 @@ def dense_match_min_split(query_flat, query_split, pool, pool_split, prep, obj_b
 DENSE_PRECISION = os.environ.get("AOC_DENSE_PRECISION", "split")
 
 
+def set_stream_cus(n_cus):
+    """aoc_set_stream_cus: how many CUs the streams that launch the matrix kernels may use (a caller that runs them under a HIP CU mask
+    says so; 0 = every CU of the device)."""
+    _lib.check(_lib.lib().aoc_set_stream_cus(int(n_cus)), "aoc_set_stream_cus")
+
+
 def dense_match(query_flat, pool, prep, obj_bias, out, out_pixel_stride, out_obj_stride, transform=True, precision=None,
                 query_split=None, pool_split=None):
     """Dense matching front door: picks the split-fp16 entry point when the shape supports it (C % 4 == 0, C <= 100,

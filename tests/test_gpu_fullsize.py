@@ -224,28 +224,17 @@ def test_cfg4_full_size_kmeans_and_dense(aoc):
 
 
 def test_kmeans_bit_exact_with_the_single_pass_tail():
-    """AOC_KM_FUSED=1 (km_chunk_scanfold_kernel: chunk sums, look-back and folds in one launch) is read once per process, so the bit-exactness
-    tests of the k-means pipeline are re-run in a child process with the switch set."""
+    """AOC_KM_FUSED=1 (km_chunk_scanfold_kernel: chunk sums, look-back and folds in one launch) is a developer switch of the DEVELOPMENT build
+    (libaoc_hip_dev.so, AOC_LIB_VARIANT=dev), read once per process: the bit-exactness tests of the k-means pipeline are re-run in a child
+    process with that library and the switch set."""
     import os, subprocess, sys
     if not torch.cuda.is_available():
         pytest.skip("needs an MI355X")
     here = os.path.dirname(os.path.abspath(__file__))
-    env = dict(os.environ, AOC_KM_FUSED="1")
-    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.join(here, "test_gpu_fullsize.py"), os.path.join(here, "test_gpu_parity.py"),
-                        "-k", "kmeans and not single_pass and not persistent"], env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-
-
-@pytest.mark.parametrize("switch", [("AOC_KM_CHAIN", "persistent"), ("AOC_KM_SUM", "records")])
-def test_kmeans_bit_exact_with_the_persistent_chain(switch):
-    """AOC_KM_CHAIN=persistent (kmeans_persistent.hip: the Lloyd iterations of a call as phases of ONE resident launch) and AOC_KM_SUM=records
-    (kmeans_records.hip: the same chunk-parallel exact sums, verified by a stitch, as kernels of the launch pipeline on its member lists) are
-    read once per process: the bit-exactness tests of the k-means pipeline are re-run in a child process with the switch set."""
-    import os, subprocess, sys
-    if not torch.cuda.is_available():
-        pytest.skip("needs an MI355X")
-    here = os.path.dirname(os.path.abspath(__file__))
-    env = dict(os.environ, **{switch[0]: switch[1]})
+    import aoc_amd
+    if not os.path.exists(aoc_amd._lib.DEV_SO):
+        pytest.skip("development build not present (make DEV=1)")
+    env = dict(os.environ, AOC_KM_FUSED="1", AOC_LIB_VARIANT="dev")
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.join(here, "test_gpu_fullsize.py"), os.path.join(here, "test_gpu_parity.py"),
                         "-k", "kmeans and not single_pass and not persistent"], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

@@ -132,3 +132,16 @@ def test_memory_policy_vs_reference_loop(aoc, golden, name):
     model every frame: pool membership, every confident reference mask incl. 125, the previous mask, the saved label maps."""
     g = golden(name)
     check_eval_loop(g, aoc.eval_loop.MemoryPolicy(mem_every=int(g["mem_every"]), unc_ratio=float(g["unc_ratio"])), to_dev=lambda t: t.cuda())
+
+
+def test_release_library_ignores_developer_switches():
+    """The wrong-result developer switches of the development build (AOC_DENSE_DEBUG, AOC_CORR_DEBUG, ...) set in the environment of a
+    process that loads the RELEASE library change nothing: the golden parity tests of the kernels they used to reach pass unchanged."""
+    import os, subprocess, sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, AOC_DENSE_DEBUG="7", AOC_CORR_DEBUG="6", AOC_KR_DEBUG="1", AOC_KM_SUM="scan", AOC_KM_ASSIGN="valu", AOC_LOCAL_KERNEL="block",
+               AOC_DENSE_CUS="8", AOC_CORR_CUS="8", AOC_KM_CHAIN="persistent")
+    env.pop("AOC_LIB_VARIANT", None)
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.join(here, "test_gpu_round4.py"), "-k", "orchestrated_frame"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

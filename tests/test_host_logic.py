@@ -28,6 +28,36 @@ def test_library_exports_every_declared_symbol():
     assert b"gfx950" in lib.aoc_version()
 
 
+DEV_SWITCH = re.compile(rb"AOC_[A-Z][A-Z0-9_]{2,}")
+
+
+def _dynamic_imports(path):
+    out = subprocess.run(["nm", "-D", "--undefined-only", path], capture_output=True, text=True, check=True).stdout
+    return {l.split()[-1].split("@")[0] for l in out.splitlines() if l.strip()}
+
+
+def test_release_library_never_reads_the_environment():
+    """Release hygiene: libaoc_hip.so has no developer switch -- it does not import getenv and none of the switch names
+    (AOC_*_DEBUG, AOC_KM_*, ...) is in the binary, so a stray environment variable cannot change a result or a kernel choice.
+    The development build (make DEV=1, loaded only with AOC_LIB_VARIANT=dev) is the one that knows them."""
+    rel = aoc_amd._lib.RELEASE_SO
+    blob = open(rel, "rb").read()
+    names = {m.group(0).decode() for m in DEV_SWITCH.finditer(blob)} - {"AOC_OK"}
+    names = {n for n in names if not n.startswith(("AOC_ERR", "AOC_MAX", "AOC_RETURN"))}
+    assert not names, f"environment switch names in the release library: {sorted(names)}"
+    assert "getenv" not in _dynamic_imports(rel) and "secure_getenv" not in _dynamic_imports(rel)
+    dev = aoc_amd._lib.DEV_SO
+    if os.path.exists(dev):
+        dblob = open(dev, "rb").read()
+        for n in (b"AOC_CORR_DEBUG", b"AOC_DENSE_DEBUG", b"AOC_KM_FUSED"):
+            assert n in dblob
+        assert "getenv" in _dynamic_imports(dev)
+    srcs = os.path.join(ROOT, "robust-video-object-segmentation_amd", "csrc")
+    for f in os.listdir(srcs):
+        if f.endswith((".hip", ".h")) and f != "aoc_common.h":
+            assert "getenv(" not in open(os.path.join(srcs, f)).read(), f"{f}: use AOC_DEV_ENV / AOC_DEV_ENV_INT (aoc_common.h)"
+
+
 def test_reference_signatures_are_kept():
     """Positional order and defaults of the reference API."""
     m = aoc_amd.matching

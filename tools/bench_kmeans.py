@@ -70,19 +70,3 @@ if NS > 1:
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / n * 1e3
     print(f"  {NS} chains at a time on {NS} streams: {ms:.3f} ms per round = {ms / NS:.3f} ms per chain", flush=True)
-
-if os.environ.get("AOC_KM_PROF"):
-    v = (ctypes.c_uint64 * 32)()
-    aoc_amd._lib.lib().aoc_kmeans_chain_profile(v, 1)
-    chains = max(int(v[9]), 1)
-    print("  assign sections (thread 0, us per chain): " + ", ".join(f"{n} {v[24 + i] / chains / 100:.1f}" for i, n in enumerate(["setup+codebook", "row commit (wait)", "mfma+argmin", "chunk sums", "sync", "prefix"])))
-    print("  fold sections (thread 0, us per chain): " + ", ".join(f"{n} {v[16 + i] / chains / 100:.1f}" for i, n in enumerate(["base", "block setup", "predict", "init", "members", "finish"])))
-    print(f"  stitch (thread 0, per chain): head setup {v[14] / chains / 100:.1f} us, head adds {v[15] / chains / 100:.1f} us, parts {v[22] / chains / 100:.1f} us; parts walked {v[23] / chains:.0f}, record steps {v[30] / chains:.0f}, stuck*1000+expansions {v[31] / chains:.0f}")
-    print(f"  fold (wave 0): member steps {v[12] / chains:.0f} per chain, general step {v[13] / chains:.0f}")
-    order = [(0, "norms"), (1, "assign"), (2, "bar"), (10, "prefix"), (11, "bar"), (3, "fold"), (4, "bar"), (5, "merge"), (6, "bar"), (7, "stitch"), (8, "bar")]
-    print("  per chain (one workgroup, us): " + ", ".join(f"{n} {v[i] / chains / 100:.1f}" for i, n in order) + f"  [{chains} chains]")
-    G = int(os.environ.get("AOC_KM_GRID", "256"))
-    w = (ctypes.c_uint32 * (G * 16))()
-    aoc_amd._lib.lib().aoc_kmeans_chain_profile_workgroups(w, G)
-    a = np.array(w, dtype=np.float64).reshape(G, 16) / 100.0
-    print("  over the workgroups, last chain (us: min / mean / max): " + ", ".join(f"{n} {a[:, i].min():.0f}/{a[:, i].mean():.0f}/{a[:, i].max():.0f}" for i, n in order[1:]))

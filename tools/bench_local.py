@@ -68,6 +68,7 @@ def main():
     for k in args.kernels.split(","):
         env = dict(os.environ)
         env["AOC_LOCAL_KERNEL"] = k
+        env["AOC_LIB_VARIANT"] = "dev"            # library-level switches only exist in the development build
         dump = "/tmp/bench_local_%s.npy" % k
         subprocess.run([sys.executable, os.path.abspath(__file__), "--config", args.config, "--child", dump], env=env, check=True)
         o = np.load(dump)

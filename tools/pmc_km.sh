@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp
 for xcd in 1 0; do
   for ctr in FETCH_SIZE WRITE_SIZE; do
     rm -rf /tmp/pmc_km
-    AOC_KM_XCD=$xcd rocprofv3 --kernel-trace --pmc $ctr -d /tmp/pmc_km -o pmc --output-format csv -- python $GRAFT_REPO_ROOT/tools/bench_kmeans.py $R $F > /tmp/pmc_km.log 2>&1
+    AOC_LIB_VARIANT=dev AOC_KM_XCD=$xcd rocprofv3 --kernel-trace --pmc $ctr -d /tmp/pmc_km -o pmc --output-format csv -- python $GRAFT_REPO_ROOT/tools/bench_kmeans.py $R $F > /tmp/pmc_km.log 2>&1
     python3 - "$xcd" "$ctr" <<'PY'
 import csv, glob, collections, sys
 f = glob.glob("/tmp/pmc_km/**/*counter_collection.csv", recursive=True)
