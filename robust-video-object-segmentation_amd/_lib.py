@@ -17,6 +17,8 @@ VARIANT = os.environ.get("AOC_LIB_VARIANT", "release")
 if VARIANT not in ("release", "dev"):
     raise ImportError(f"AOC_LIB_VARIANT={VARIANT!r}: 'release' or 'dev'")
 SO_PATH = DEV_SO if VARIANT == "dev" else RELEASE_SO
+if os.environ.get("AOC_LIB_FILE"):          # developer override (python side): an experimental build of the library, by file name in csrc/
+    SO_PATH = os.path.join(CSRC, os.environ["AOC_LIB_FILE"])
 
 _vp, _i, _i64, _sz, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_size_t, ctypes.c_float
 

@@ -1189,57 +1189,108 @@ constexpr int KS_CHUNK = 64 * KS_T;
 __host__ __device__ __forceinline__ int ks_seg_chunk_base(int seg_beg, int s, int kmax) { return seg_beg / KS_CHUNK + s * (kmax + 1); }
 __host__ __device__ __forceinline__ int ks_seg_chunk_region(int len, int kmax) { return len / KS_CHUNK + kmax + 1; }
 
-// one block per segment: exclusive scan of the block histograms per cluster, cluster sizes and bases, plus the
-// chunk table of the segment (chunk base per cluster; owner cluster / local index per chunk id, -1 = unused)
-__global__ __launch_bounds__(1024) void km_blockscan_kernel(const int32_t *__restrict__ seg_off, const int32_t *__restrict__ seg_k,
-                                                             const int32_t *__restrict__ hist, int32_t *__restrict__ blockoff, int nb_max,
-                                                             int kmax, int32_t *__restrict__ counts, int32_t *__restrict__ cbase,
-                                                             int32_t *__restrict__ cchunk, int32_t *__restrict__ owner_cluster,
-                                                             int32_t *__restrict__ owner_local, int nch_cap,
-                                                             uint32_t *__restrict__ cflag) {
-    __shared__ int32_t ltot[AOC_MAX_CLUSTERS];
+// Block offsets, cluster sizes, chunk table AND the ordered member lists in ONE launch (round 3: km_blockscan_kernel on one workgroup per
+// segment, then km_scatter_kernel -- two latency floors per Lloyd iteration).  A workgroup owns KSS_BLOCKS consecutive 256-row blocks of
+// one segment.  The per-block histograms of the WHOLE segment are final when this kernel starts (the assignment kernel wrote them), so every
+// workgroup adds up, per cluster, the blocks in front of its own range (its exclusive offsets) and all blocks (cluster sizes -> cluster bases)
+// itself: nb x kmax integers per workgroup from L2 (38 KB at 600 blocks x 16 clusters; the quadratic total stays below 2 % of one pass over the
+// pool rows because a workgroup covers 2048 rows), lanes = clusters x block strides, no inter-workgroup dependency.  Workgroup 0 of a
+// segment also publishes what the sum kernels read: cluster sizes, cluster bases, and the segment's chunk table (chunk base per cluster; owner
+// cluster / local index per chunk id, -1 = unused).  Member position = segment begin + cluster base + offset of the row's block + stable rank
+// inside the block -- the same formula as before, so the lists are identical.
+//   moff[pos] = byte offset of the member's pool row.  rows_local != nullptr: proxy construction, AEM:280 -- the GLOBAL kept-row array at
+//   the LOCAL index p.
+constexpr int KSS_BLOCKS = 8;
+__global__ __launch_bounds__(256) void km_scan_scatter_kernel(const int32_t *__restrict__ rows, const int32_t *__restrict__ rows_local,
+                                                               const int32_t *__restrict__ seg_off, const int32_t *__restrict__ seg_k, int n_seg,
+                                                               const int32_t *__restrict__ labels, const uint16_t *__restrict__ rank16,
+                                                               const int32_t *__restrict__ hist, int nb_max, int kmax, uint32_t row_bytes,
+                                                               uint32_t *__restrict__ moff, int32_t *__restrict__ counts, int32_t *__restrict__ cbase,
+                                                               int32_t *__restrict__ cchunk, int32_t *__restrict__ owner_cluster,
+                                                               int32_t *__restrict__ owner_local, int nch_cap, uint32_t *__restrict__ cflag) {
+    __shared__ int32_t part[2][256];                               // [before my range | whole segment][stride group x cluster]
+    __shared__ int32_t lpre[AOC_MAX_CLUSTERS], ltot[AOC_MAX_CLUSTERS], lbase[AOC_MAX_CLUSTERS];
+    __shared__ int32_t loff[KSS_BLOCKS][AOC_MAX_CLUSTERS];
     __shared__ int32_t lchunk[AOC_MAX_CLUSTERS + 1];
-    const int s = blockIdx.x;
+    const int s = blockIdx.y;
     const int k = seg_k[s];
     const int beg = seg_off[s];
     const int len = seg_off[s + 1] - beg;
-    const int nb = (len + 255) / 256;
-    const int lane = aoc_lane(), wave = threadIdx.x >> 6;
-    for (int kk = wave; kk < kmax; kk += 16) {
-        int carry = 0;
+    const int b0 = blockIdx.x * KSS_BLOCKS;
+    const bool first = blockIdx.x == 0;
+    if (!first && (k <= 0 || b0 * 256 >= len)) return;
+    const int nb = (k > 0) ? (len + 255) / 256 : 0;
+    // ---- per cluster: blocks in front of this workgroup's range, and all blocks.  kp = clusters rounded up to a power of two (<= 64)
+    int kp = 1;
+    while (kp < kmax) kp <<= 1;
+    const int groups = 256 / kp;
+    {
+        const int kk = threadIdx.x & (kp - 1), g = threadIdx.x / kp;
+        int pre = 0, tot = 0;
         if (kk < k) {
-            for (int base = 0; base < nb; base += 64) {
-                const int b = base + lane;
-                const int v = (b < nb) ? hist[((size_t)s * nb_max + b) * kmax + kk] : 0;
-                int incl = v;
-                for (int o = 1; o < 64; o <<= 1) {
-                    int t = __shfl_up(incl, o);
-                    if (lane >= o) incl += t;
+            const int32_t *hp = hist + (size_t)s * nb_max * kmax + kk;
+            // eight independent loads in flight per round (clamped index, select afterwards: no exec-masked regions)
+            for (int bb = g; bb < nb; bb += 8 * groups) {
+                int v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = hp[(size_t)min(bb + u * groups, nb - 1) * kmax];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int b = bb + u * groups;
+                    const int w = (b < nb) ? v[u] : 0;
+                    tot += w;
+                    pre += (b < b0) ? w : 0;
                 }
-                if (b < nb) blockoff[((size_t)s * nb_max + b) * kmax + kk] = carry + incl - v;
-                carry += __shfl(incl, 63);
             }
         }
-        if (lane == 0) { counts[s * kmax + kk] = carry; ltot[kk] = carry; }
+        part[0][threadIdx.x] = pre;
+        part[1][threadIdx.x] = tot;
     }
     __syncthreads();
-    const int cb = ks_seg_chunk_base(beg, s, kmax);
-    // this segment initialises every chunk id up to the next segment's base (the last one up to the capacity)
-    const int region = ((s + 1 < (int)gridDim.x) ? ks_seg_chunk_base(seg_off[s + 1], s + 1, kmax) : nch_cap) - cb;
+    if ((int)threadIdx.x < kmax) {
+        int pre = 0, tot = 0;
+        for (int g = 0; g < groups; ++g) {
+            pre += part[0][g * kp + threadIdx.x];
+            tot += part[1][g * kp + threadIdx.x];
+        }
+        lpre[threadIdx.x] = pre;
+        ltot[threadIdx.x] = tot;
+    }
+    __syncthreads();
     if (threadIdx.x == 0) {
+        const int cb = ks_seg_chunk_base(beg, s, kmax);
         int off = 0, ch = 0;
         for (int kk = 0; kk < kmax; ++kk) {
-            cbase[s * kmax + kk] = off;
-            off += ltot[kk];
+            lbase[kk] = off;
             lchunk[kk] = ch;
-            if (cchunk) cchunk[s * kmax + kk] = cb + ch;
+            if (first) {
+                counts[s * kmax + kk] = ltot[kk];
+                cbase[s * kmax + kk] = off;
+                if (cchunk) cchunk[s * kmax + kk] = cb + ch;
+            }
+            off += ltot[kk];
             ch += (ltot[kk] + KS_CHUNK - 1) / KS_CHUNK;
         }
         lchunk[kmax] = ch;
     }
+    // offsets of this workgroup's blocks: a serial walk over at most KSS_BLOCKS histograms per cluster
+    if ((int)threadIdx.x < k) {
+        int hv[KSS_BLOCKS];
+#pragma unroll
+        for (int i = 0; i < KSS_BLOCKS; ++i) hv[i] = hist[((size_t)s * nb_max + min(b0 + i, nb - 1)) * kmax + threadIdx.x];
+        int run = lpre[threadIdx.x];
+#pragma unroll
+        for (int i = 0; i < KSS_BLOCKS; ++i) {
+            loff[i][threadIdx.x] = run;
+            run += (b0 + i < nb) ? hv[i] : 0;
+        }
+    }
     __syncthreads();
-    if (owner_cluster) {
-        for (int i = threadIdx.x; i < region; i += blockDim.x) {
+    if (first && owner_cluster) {
+        // this segment initialises every chunk id up to the next segment's base (the last one up to the capacity)
+        const int cb = ks_seg_chunk_base(beg, s, kmax);
+        const int region = ((s + 1 < n_seg) ? ks_seg_chunk_base(seg_off[s + 1], s + 1, kmax) : nch_cap) - cb;
+        for (int i = threadIdx.x; i < region; i += 256) {
             int oc = -1, ol = 0;
             if (i < lchunk[kmax]) {
                 int kk = 0;
@@ -1255,25 +1306,22 @@ __global__ __launch_bounds__(1024) void km_blockscan_kernel(const int32_t *__res
             }
         }
     }
-}
-
-// ordered member lists: moff[seg_beg + cbase[label] + blockoff + rank] = byte offset of the member's pool row.
-// rows_local != nullptr: proxy construction, AEM:280 -- the GLOBAL kept-row array at the LOCAL index p.
-__global__ __launch_bounds__(256) void km_scatter_kernel(const int32_t *__restrict__ rows, const int32_t *__restrict__ rows_local,
-                                                          const int32_t *__restrict__ seg_off, const int32_t *__restrict__ seg_k,
-                                                          const int32_t *__restrict__ labels, const uint16_t *__restrict__ rank16,
-                                                          const int32_t *__restrict__ blockoff, const int32_t *__restrict__ cbase, int nb_max,
-                                                          int kmax, uint32_t row_bytes, uint32_t *__restrict__ moff) {
-    const int s = blockIdx.y;
-    if (seg_k[s] <= 0) return;
-    const int beg = seg_off[s];
-    const int len = seg_off[s + 1] - beg;
-    const int p = blockIdx.x * 256 + threadIdx.x;
-    if (p >= len) return;
-    const int lab = labels[beg + p];
-    const int pos = beg + cbase[s * kmax + lab] + blockoff[((size_t)s * nb_max + blockIdx.x) * kmax + lab] + (int)rank16[beg + p];
-    const int row = rows_local ? rows_local[p] : rows[beg + p];
-    moff[pos] = (uint32_t)row * row_bytes;
+    if (k <= 0) return;
+    // ---- the member lists of this workgroup's rows: all loads of the KSS_BLOCKS rounds are independent
+    int lab[KSS_BLOCKS], rk[KSS_BLOCKS], row[KSS_BLOCKS];
+    const int32_t *rsrc = rows_local ? rows_local : rows + beg;
+#pragma unroll
+    for (int i = 0; i < KSS_BLOCKS; ++i) {
+        const int p = min((b0 + i) * 256 + (int)threadIdx.x, len - 1);
+        lab[i] = labels[beg + p];
+        rk[i] = (int)rank16[beg + p];
+        row[i] = rsrc[p];
+    }
+#pragma unroll
+    for (int i = 0; i < KSS_BLOCKS; ++i) {
+        const int p = (b0 + i) * 256 + threadIdx.x;
+        if (p < len) moff[beg + lbase[lab[i]] + loff[i][lab[i]] + rk[i]] = (uint32_t)row[i] * row_bytes;
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2217,6 +2265,184 @@ __device__ __forceinline__ void os_ordered_sum_body(int j, int s, int grp, float
         }
     }
 }
+// ------------------------------------------------------------------------------------------
+// The same literal sums with the rows travelling by LDS-DMA (round 4): one consumer wave + two producer waves per (cluster, feature group).
+// The eight-wave version above keeps its row pieces "in flight across the barriers" only on paper: hipcc cannot count vmcnt across the
+// loop's branches and drains every load in front of every barrier (s_waitcnt vmcnt(0)), so each batch of 128 members costs one full memory
+// round trip -- 6.4 ns per member, 66 us for a 10 240-member head at any depth, although the adding wave itself only needs ~3 ns (one
+// ds_read2_b32 per two members and one dependent v_add_f32 per member, at ~4 cycles per issue slot).  Here nothing the compiler sees is a
+// vector-memory operation: member offsets and row pieces travel by global_load_lds (asm statements hipcc neither counts nor drains) and
+// the producers do their own vmcnt arithmetic.  Per step (128 members) a producer (64 of the members each):
+//      s_waitcnt vmcnt((D-1) * 8)  -> what it issued D steps ago has landed: its half of batch b and its member offsets of batch b + D
+//      s_barrier                   -> batch b belongs to the consumer, batch b - 1's ring slot is free
+//      issue the offsets of batch b + 2D (one 256-byte transfer) and its rows of batch b + D (seven 1 KiB transfers whose source
+//      addresses come from the landed offsets, read back from LDS)
+// A transfer costs its issuing wave 60-100 cycles (MI355X_MICROARCH.md), i.e. ~700 per step and producer against the consumer's ~770
+// (the single-wave form of this kernel, everything on the adding wave, was measured SLOWER than the old one for exactly that reason: 75
+// against 66 us).  Indices past the cluster's end are clamped to its last member (valid addresses, uniform operation counts); the last
+// batch adds +0.0f for them exactly as the zero rows of the version above did.  LDS rows are unpadded (112 B): transfer k of a producer
+// fills slots [64 k, 64 k + 64) of its half lane-linearly, slot j = piece j % 7 of member j / 7.
+#ifndef AOC_OD_NPROD
+#define AOC_OD_NPROD 3
+#endif
+#ifndef AOC_OD_DEPTH
+#define AOC_OD_DEPTH 2
+#endif
+constexpr int OD_NPROD = AOC_OD_NPROD;                         // producer waves
+constexpr int OD_HALF = 64;                                    // members per producer and step
+constexpr int OD_BATCH = OD_NPROD * OD_HALF;                   // members per step
+constexpr int OD_DEPTH = AOC_OD_DEPTH;                         // batches of row pieces in flight
+constexpr int OD_NB = OD_DEPTH + 1;                            // ring slots (rows and offsets)
+constexpr int OD_LD = OS_FP * 4;                               // 28 floats per member
+constexpr int OD_BATCH_BYTES = OD_BATCH * OD_LD * 4;           // 14336
+constexpr int OD_RING_FLOATS = OD_NB * OD_BATCH * OD_LD;
+constexpr int OD_OPS = OS_FP + 1;                              // vector-memory operations per producer and step
+constexpr int OD_LDS_FLOATS = OD_RING_FLOATS + OD_NB * OD_BATCH;
+static_assert(OD_DEPTH * OD_OPS < 64 && OD_NPROD >= 1 && OD_NPROD <= 3, "vmcnt is a 6-bit counter; the launch has four waves");
+
+__device__ __forceinline__ void od_glds4(const void *gsrc, uint32_t lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void od_glds16(uint32_t byte_off, const void *base, uint32_t lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(byte_off), "s"(base), "s"(lds_dst) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void od_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void od_barrier() {
+    __builtin_amdgcn_s_waitcnt(0xc07f);                        // lgkmcnt(0): this wave's LDS reads of the slot it gives up have returned
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+template <int MODE>
+__device__ __forceinline__ void os_head_dma_body(int j, int s, int grp, float *__restrict__ os_lds, const float *__restrict__ pool, int C,
+                                                 const int32_t *__restrict__ seg_off, const int32_t *__restrict__ seg_k,
+                                                 const int32_t *__restrict__ counts, const int32_t *__restrict__ cbase,
+                                                 const uint32_t *__restrict__ moff, int kmax, float *__restrict__ dst, int member_cap,
+                                                 float *__restrict__ head_state) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = aoc_lane();
+    if (wave > OD_NPROD) return;                               // the launch is 256 wide for the chunk-sum role
+    if (j >= seg_k[s]) return;
+    const int oc = s * kmax + j;
+    const int cnt_all = counts[oc];
+    const int f0 = grp * OS_FP * 4;
+    const int nfeat = min(OS_FP * 4, C - f0);
+    float *out = ((MODE == 0) ? dst + (size_t)oc * C : dst + (((size_t)s * 2 + 1) * kmax + j) * C) + f0;
+    if (cnt_all == 0) {
+        if (MODE == 1 && (int)threadIdx.x < nfeat) out[threadIdx.x] = 0.0f;
+        return;
+    }
+    const bool head_only = member_cap > 0 && cnt_all > member_cap;
+    const int cnt = head_only ? member_cap : cnt_all;
+    const int nb = (cnt + OD_BATCH - 1) / OD_BATCH;
+    auto wrap = [](int x) { return x >= OD_NB ? x - OD_NB : x; };
+
+    if (wave == 0) {
+        // ---- consumer: the sequential float32 sum, lanes = features
+        const bool active = lane < nfeat;
+        const float *col = os_lds + (active ? lane : 0);
+        float sum = 0.0f;
+        int slot = 0;
+        for (int b = 0; b < nb; ++b) {
+            od_barrier();                                      // batch b has landed (the producers waited for it before arriving)
+            const float *t = col + slot * (OD_BATCH * OD_LD);
+            // groups of OD_G members, the next group's LDS reads issued in front of this group's additions (two register sets): the
+            // adding chain never waits for an LDS round trip (left to itself hipcc issues 18 reads, waits, adds 18: 9 cycles per member)
+            constexpr int OD_G = 32, NG = OD_BATCH / OD_G;
+            const int rem = (b + 1 < nb) ? OD_BATCH : cnt - b * OD_BATCH;
+            float xa[OD_G], xb[OD_G];
+#pragma unroll
+            for (int u = 0; u < OD_G; ++u) xa[u] = t[u * OD_LD];
+#pragma unroll
+            for (int g = 0; g < NG; g += 2) {
+                if (g + 1 < NG) {
+#pragma unroll
+                    for (int u = 0; u < OD_G; ++u) xb[u] = t[((g + 1) * OD_G + u) * OD_LD];
+                }
+                if (rem >= (g + 1) * OD_G) {
+#pragma unroll
+                    for (int u = 0; u < OD_G; ++u) sum = sum + xa[u];
+                } else {
+#pragma unroll
+                    for (int u = 0; u < OD_G; ++u) sum = sum + (g * OD_G + u < rem ? xa[u] : 0.0f);
+                }
+                if (g + 2 < NG) {
+#pragma unroll
+                    for (int u = 0; u < OD_G; ++u) xa[u] = t[((g + 2) * OD_G + u) * OD_LD];
+                }
+                if (g + 1 < NG) {
+                    if (rem >= (g + 2) * OD_G) {
+#pragma unroll
+                        for (int u = 0; u < OD_G; ++u) sum = sum + xb[u];
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < OD_G; ++u) sum = sum + ((g + 1) * OD_G + u < rem ? xb[u] : 0.0f);
+                    }
+                }
+            }
+            slot = wrap(slot + 1);
+        }
+        if (active) {
+            if (head_only) head_state[(size_t)oc * C + f0 + lane] = sum;
+            else out[lane] = sum / (float)cnt;
+        }
+        return;
+    }
+
+    // ---- producers: p = 0 / 1 owns members [64 p, 64 p + 64) of every batch
+    const int p = wave - 1;
+    const uint32_t *list = moff + seg_off[s] + cbase[oc];
+    const uint32_t lds_base = (uint32_t)reinterpret_cast<uintptr_t>(os_lds);
+    const uint32_t offs_base = lds_base + OD_RING_FLOATS * 4 + (uint32_t)p * (OD_HALF * 4);
+    const uint32_t *offs = reinterpret_cast<const uint32_t *>(os_lds + OD_RING_FLOATS) + p * OD_HALF;
+    // transfer plan of this lane: slot i * 64 + lane of the producer's half = (member, piece); pieces past the row's end (last group)
+    // repeat the group's first
+    const int npiece = min(OS_FP, (C >> 2) - grp * OS_FP);
+    int prow[OS_FP];
+    uint32_t pbyte[OS_FP];
+#pragma unroll
+    for (int i = 0; i < OS_FP; ++i) {
+        const int idx = i * 64 + lane;
+        prow[i] = idx / OS_FP;
+        const int piece = idx - prow[i] * OS_FP;
+        pbyte[i] = (uint32_t)(grp * OS_FP + (piece < npiece ? piece : 0)) * 16u;
+    }
+    auto issue_offs = [&](int b, int slot) {                   // this producer's member offsets of batch b -> offsets slot
+        od_glds4(list + min(b * OD_BATCH + p * OD_HALF + lane, cnt - 1), offs_base + (uint32_t)slot * (OD_BATCH * 4));
+    };
+    auto issue_rows = [&](int slot) {                          // its rows of the batch whose offsets sit in `slot` -> ring slot `slot`
+        const uint32_t *o = offs + slot * OD_BATCH;
+        uint32_t src[OS_FP];
+#pragma unroll
+        for (int i = 0; i < OS_FP; ++i) src[i] = o[prow[i]] + pbyte[i];
+        const uint32_t d = lds_base + (uint32_t)slot * OD_BATCH_BYTES + (uint32_t)p * (OD_HALF * OD_LD * 4);
+#pragma unroll
+        for (int i = 0; i < OS_FP; ++i) od_glds16(src[i], pool, d + (uint32_t)i * 1024u);
+    };
+    // prologue: offsets of batches 0 .. D-1 (drained once), then D steps' worth of transfers in the steady-state order
+#pragma unroll
+    for (int x = 0; x < OD_DEPTH; ++x) issue_offs(x, x);
+    od_wait_vm<0>();
+#pragma unroll
+    for (int i = 0; i < OD_DEPTH; ++i) {
+        issue_offs(OD_DEPTH + i, wrap(OD_DEPTH + i));
+        issue_rows(i);
+    }
+    int slot = 0;                                              // ring slot of batch b
+    for (int b = 0; b < nb; ++b) {
+        od_wait_vm<(OD_DEPTH - 1) * OD_OPS>();                  // this producer's rows of batch b and offsets of batch b + D have landed
+        od_barrier();
+        const int slot_d = wrap(slot + OD_DEPTH);              // slot of batch b + D (= of batch b - 1: consumed)
+        issue_offs(b + 2 * OD_DEPTH, wrap(slot_d + OD_DEPTH)); // = slot of batch b + D - 1, whose offsets the last step used
+        issue_rows(slot_d);
+        slot = wrap(slot + 1);
+    }
+    od_wait_vm<0>();                                           // nothing may still be travelling into this workgroup's LDS when it ends
+}
 template <int MODE>
 __global__ __launch_bounds__((OS_NPROD + 1) * 64) void km_ordered_sum_kernel(const float *__restrict__ pool, uint32_t pool_bytes, int C,
                                                                               const int32_t *__restrict__ seg_off, const int32_t *__restrict__ seg_k,
@@ -2229,15 +2455,15 @@ __global__ __launch_bounds__((OS_NPROD + 1) * 64) void km_ordered_sum_kernel(con
 // The literal heads and the any-order sums of the tail chunks only depend on the member lists, not on each other: ONE launch, the
 // first kmax * n_seg * groups workgroups take the heads (the long ones, dispatched first), the others one tail chunk each (on the
 // first four of their eight waves; the LDS allocation of the head role is reused).
-template <int MODE>
-__global__ __launch_bounds__((OS_NPROD + 1) * 64) void km_heads_chunk_sums_kernel(const float *__restrict__ pool, uint32_t pool_bytes, int C,
+template <int MODE, bool DMA>
+__global__ __launch_bounds__(DMA ? 256 : (OS_NPROD + 1) * 64) void km_heads_chunk_sums_kernel(const float *__restrict__ pool, uint32_t pool_bytes, int C,
                                                                                    const int32_t *__restrict__ seg_off, const int32_t *__restrict__ seg_k,
                                                                                    const int32_t *__restrict__ counts, const int32_t *__restrict__ cbase,
                                                                                    const uint32_t *__restrict__ moff, int kmax, int n_seg, float *__restrict__ dst,
                                                                                    int member_cap, float *__restrict__ head_state,
                                                                                    const int32_t *__restrict__ owner_cluster, const int32_t *__restrict__ owner_local,
                                                                                    float *__restrict__ csum, int start_chunk, int xcd_aware) {
-    __shared__ __attribute__((aligned(16))) float os_lds[2 * OS_BATCH * OS_LD];
+    __shared__ __attribute__((aligned(16))) float os_lds[DMA ? (OD_LDS_FLOATS > 2 * OS_BATCH * OS_LD ? OD_LDS_FLOATS : 2 * OS_BATCH * OS_LD) : 2 * OS_BATCH * OS_LD];
     static_assert(sizeof(float) * 2 * OS_BATCH * OS_LD >= sizeof(uint32_t) * KS_CHUNK + sizeof(float4) * 256, "the chunk role's buffers fit the head role's");
     const int n_head = kmax * n_seg * os_groups_dev(C);
     const int b = blockIdx.x;
@@ -2253,7 +2479,8 @@ __global__ __launch_bounds__((OS_NPROD + 1) * 64) void km_heads_chunk_sums_kerne
         int grp = rem / pc, c = blk * 8 + rem - grp * pc;
         if (!xcd_aware) { c = b % n_cl; grp = b / n_cl; }       // developer switch AOC_KM_XCD=0: the group-major order of before
         const int j = c % kmax, s = c / kmax;
-        os_ordered_sum_body<MODE>(j, s, grp, os_lds, pool, pool_bytes, C, seg_off, seg_k, counts, cbase, moff, kmax, dst, member_cap, head_state);
+        if (DMA) os_head_dma_body<MODE>(j, s, grp, os_lds, pool, C, seg_off, seg_k, counts, cbase, moff, kmax, dst, member_cap, head_state);
+        else os_ordered_sum_body<MODE>(j, s, grp, os_lds, pool, pool_bytes, C, seg_off, seg_k, counts, cbase, moff, kmax, dst, member_cap, head_state);
         return;
     }
     if (threadIdx.x >= 256) return;
@@ -2298,7 +2525,7 @@ __global__ __launch_bounds__(64) void km_proxy_finish_kernel(const float *__rest
 struct KsWorkspace {
     float *rownorm;
     uint16_t *rank16;
-    int32_t *hist, *blockoff, *counts, *cbase;
+    int32_t *hist, *counts, *cbase;
     uint32_t *moff;
     int nb_max;
     // chunk summaries
@@ -2313,7 +2540,7 @@ inline int ks_chunk_capacity(int64_t cap, int n_seg, int kmax) { return (int)(ca
 inline size_t ks_workspace_bytes(int64_t cap, int n_seg, int kmax) {
     const size_t nb = (size_t)(cap + 255) / 256 + 1;
     const size_t nch = (size_t)ks_chunk_capacity(cap, n_seg, kmax);
-    return aoc_align_up((size_t)cap * 4, 256) + aoc_align_up((size_t)cap * 2, 256) + 2 * aoc_align_up((size_t)n_seg * nb * kmax * 4, 256) +
+    return aoc_align_up((size_t)cap * 4, 256) + aoc_align_up((size_t)cap * 2, 256) + aoc_align_up((size_t)n_seg * nb * kmax * 4, 256) +
            3 * aoc_align_up((size_t)n_seg * kmax * 4, 256) + aoc_align_up(((size_t)cap + 64) * 4, 256) + 2 * aoc_align_up(nch * 4, 256) +
            3 * aoc_align_up(nch * AOC_MAX_CHANNELS / 2 * 4, 256) + aoc_align_up(nch * AOC_MAX_CHANNELS / 2, 256) +
            aoc_align_up((size_t)n_seg * kmax * (AOC_MAX_CHANNELS / 2) * 4, 256) + aoc_align_up(nch * 8 * 4, 256);
@@ -2327,7 +2554,6 @@ inline KsWorkspace ks_carve(void *workspace, int64_t cap, int n_seg, int kmax, i
     w.rownorm = reinterpret_cast<float *>(p); p += aoc_align_up((size_t)cap * 4, 256);
     w.rank16 = reinterpret_cast<uint16_t *>(p); p += aoc_align_up((size_t)cap * 2, 256);
     w.hist = reinterpret_cast<int32_t *>(p); p += aoc_align_up((size_t)n_seg * nb * kmax * 4, 256);
-    w.blockoff = reinterpret_cast<int32_t *>(p); p += aoc_align_up((size_t)n_seg * nb * kmax * 4, 256);
     w.counts = reinterpret_cast<int32_t *>(p); p += aoc_align_up((size_t)n_seg * kmax * 4, 256);
     w.cbase = reinterpret_cast<int32_t *>(p); p += aoc_align_up((size_t)n_seg * kmax * 4, 256);
     w.cchunk = reinterpret_cast<int32_t *>(p); p += aoc_align_up((size_t)n_seg * kmax * 4, 256);
@@ -2383,9 +2609,17 @@ inline void ks_launch_sums(hipStream_t st, const float *pool, uint32_t pool_byte
     static const bool split_heads = AOC_DEV_ENV("AOC_KM_HEADS") && strcmp(AOC_DEV_ENV("AOC_KM_HEADS"), "kernel") == 0;   // developer switch: heads and chunk sums as two launches
     const bool merged = (mode == 2) && !(fused && C <= KC_FG * 8) && !split_heads;
     if (merged) {
-        hipLaunchKernelGGL(km_heads_chunk_sums_kernel<MODE>, dim3(kmax * n_seg * os_groups(C) + ws.nch_cap), dim3((OS_NPROD + 1) * 64), 0, st, pool, pool_bytes, C,
-                           seg_offsets, seg_k, counts, ws.cbase, ws.moff, kmax, n_seg, dst, KS_HEAD_CHUNKS * KS_CHUNK, ws.head, ws.owner_cluster, ws.owner_local,
-                           ws.csum, start, km_xcd_aware());
+        // literal heads on one wave per (cluster, feature group) with LDS-DMA row transfers (os_head_dma_body); developer switch
+        // AOC_KM_HEADS_DMA=0: the eight-wave producer / consumer version of rounds 2-3
+        static const bool dma = AOC_DEV_ENV_INT("AOC_KM_HEADS_DMA", 1) != 0;
+        if (dma)
+            hipLaunchKernelGGL((km_heads_chunk_sums_kernel<MODE, true>), dim3(kmax * n_seg * os_groups(C) + ws.nch_cap), dim3(256), 0, st, pool, pool_bytes, C,
+                               seg_offsets, seg_k, counts, ws.cbase, ws.moff, kmax, n_seg, dst, KS_HEAD_CHUNKS * KS_CHUNK, ws.head, ws.owner_cluster, ws.owner_local,
+                               ws.csum, start, km_xcd_aware());
+        else
+            hipLaunchKernelGGL((km_heads_chunk_sums_kernel<MODE, false>), dim3(kmax * n_seg * os_groups(C) + ws.nch_cap), dim3((OS_NPROD + 1) * 64), 0, st, pool, pool_bytes, C,
+                               seg_offsets, seg_k, counts, ws.cbase, ws.moff, kmax, n_seg, dst, KS_HEAD_CHUNKS * KS_CHUNK, ws.head, ws.owner_cluster, ws.owner_local,
+                               ws.csum, start, km_xcd_aware());
     } else if (mode != 0) {
         const int cap = (mode == 2) ? KS_HEAD_CHUNKS * KS_CHUNK : 0;
         hipLaunchKernelGGL(km_ordered_sum_kernel<MODE>, dim3(kmax, n_seg, os_groups(C)), dim3((OS_NPROD + 1) * 64), 0, st, pool, pool_bytes, C, seg_offsets,
@@ -2519,6 +2753,7 @@ int aoc_kmeans_segmented_rep(const float *pool, int64_t pool_rows, int C, const 
     hipLaunchKernelGGL(km_init_kernel, dim3(kmax, n_seg), dim3(64), 0, st, pool, C, rows, seg_offsets, seg_k, init_rows, kmax,
                        centroids, cnorm, cluster_counts);
     const dim3 agrid((unsigned)((seg_bound + 255) / 256), (unsigned)n_seg);
+    const dim3 sgrid((unsigned)((seg_bound + 256 * KSS_BLOCKS - 1) / (256 * KSS_BLOCKS)), (unsigned)n_seg);
     const size_t lds = ((size_t)kmax * C + kmax) * sizeof(float);
     const size_t lds_fast = lds + (size_t)4 * kmax * sizeof(int32_t);
     const int nf = (C + 63) / 64;
@@ -2582,10 +2817,9 @@ int aoc_kmeans_segmented_rep(const float *pool, int64_t pool_rows, int C, const 
                                    ws.rank16, ws.hist, ws.nb_max, rownorm, first);
         }
         if (fast) {
-            hipLaunchKernelGGL(km_blockscan_kernel, dim3(n_seg), dim3(1024), 0, st, seg_offsets, seg_k, ws.hist, ws.blockoff, ws.nb_max, kmax,
-                               cluster_counts, ws.cbase, ws.cchunk, ws.owner_cluster, ws.owner_local, ws.nch_cap, ws.cflag);
-            hipLaunchKernelGGL(km_scatter_kernel, agrid, dim3(256), 0, st, rows, (const int32_t *)nullptr, seg_offsets, seg_k, labels, ws.rank16,
-                               ws.blockoff, ws.cbase, ws.nb_max, kmax, (uint32_t)C * 4u, ws.moff);
+            hipLaunchKernelGGL(km_scan_scatter_kernel, sgrid, dim3(256), 0, st, rows, (const int32_t *)nullptr, seg_offsets, seg_k, n_seg, labels, ws.rank16,
+                               ws.hist, ws.nb_max, kmax, (uint32_t)C * 4u, ws.moff, cluster_counts, ws.cbase, ws.cchunk, ws.owner_cluster, ws.owner_local,
+                               ws.nch_cap, ws.cflag);
             ks_launch_sums<0>(st, pool, pool_bytes, C, seg_offsets, seg_k, cluster_counts, ws, kmax, n_seg, centroids);
             continue;
         }
@@ -2655,10 +2889,10 @@ int aoc_build_proxies(const float *pool, int64_t pool_rows, int C, const int32_t
         KsWorkspace ws = ks_carve(workspace, rows_capacity, n_seg, kmax, seg_bound);
         const dim3 agrid((unsigned)((seg_bound + 255) / 256), (unsigned)n_seg);
         hipLaunchKernelGGL(km_rank_only_kernel, agrid, dim3(256), 0, st, seg_offsets, seg_k, labels, kmax, ws.rank16, ws.hist, ws.nb_max);
-        hipLaunchKernelGGL(km_blockscan_kernel, dim3(n_seg), dim3(1024), 0, st, seg_offsets, seg_k, ws.hist, ws.blockoff, ws.nb_max, kmax, ws.counts, ws.cbase,
-                           ws.cchunk, ws.owner_cluster, ws.owner_local, ws.nch_cap, ws.cflag);
-        hipLaunchKernelGGL(km_scatter_kernel, agrid, dim3(256), 0, st, (const int32_t *)nullptr, fg_rows, seg_offsets, seg_k, labels, ws.rank16,
-                           ws.blockoff, ws.cbase, ws.nb_max, kmax, (uint32_t)C * 4u, ws.moff);
+        const dim3 sgrid((unsigned)((seg_bound + 256 * KSS_BLOCKS - 1) / (256 * KSS_BLOCKS)), (unsigned)n_seg);
+        hipLaunchKernelGGL(km_scan_scatter_kernel, sgrid, dim3(256), 0, st, (const int32_t *)nullptr, fg_rows, seg_offsets, seg_k, n_seg, labels, ws.rank16,
+                           ws.hist, ws.nb_max, kmax, (uint32_t)C * 4u, ws.moff, ws.counts, ws.cbase, ws.cchunk, ws.owner_cluster, ws.owner_local,
+                           ws.nch_cap, ws.cflag);
         ks_launch_sums<1>(st, pool, (uint32_t)((uint64_t)pool_rows * C * 4), C, seg_offsets, seg_k, ws.counts, ws, kmax, n_seg, proxies);
         hipLaunchKernelGGL(km_proxy_finish_kernel, grid, dim3(64), 0, st, centroids, seg_k, ws.counts, kmax, C, proxies, proxy_sqnorm);
         AOC_RETURN_IF_LAUNCH_FAILED();
