@@ -376,6 +376,43 @@ int aoc_resize_bilinear_planes(const float *in, int P, int h, int w, float *out,
 int aoc_resize_nearest_bits(const uint32_t *in, int h, int w, uint32_t *out, int H, int W,
                             aoc_stream_t stream);
 
+/* ---- round 4: fused per-frame launches (each replaces several of the calls above and computes the same expressions term by term, so
+ * the outputs equal theirs bit for bit; hotpath.proto_mask_features and aoc_frame_enqueue both use them) ---------------------------- */
+
+/* aoc_resize_bilinear_planes with one more level of output addressing: plane p = (group, outer, inner), groups of
+ * outer_count * inner_count planes land out_group_stride apart (the two local-matching results of a frame -> two channel ranges of the
+ * proto-mask tensor, aocnet.py:355, in one launch). */
+int aoc_resize_bilinear_planes_grouped(const float *in, int P, int h, int w, float *out, int H, int W, int inner_count, int outer_count,
+                                       int64_t out_group_stride, int64_t out_outer_stride, int64_t out_plane_stride, int64_t out_pixel_stride,
+                                       aoc_stream_t stream);
+
+/* local_matching AND local_matching_proxy (AEM:968-1156 as aocnet.py:255,328 calls them: same query, same label bits, fp32, atrous rate 1)
+ * in one launch: out_a from prev_a (the previous frame's embedding), out_b from prev_b (its per-pixel proxy map). */
+int aoc_local_window_match_pair(const float *query, const float *prev_a, const float *prev_b, const uint32_t *right_bits, int H, int W, int C,
+                                const int32_t *radii_host, int n_radii, const float *obj_bias, int n_obj, float *out_a, float *out_b,
+                                int transform, aoc_stream_t stream);
+
+/* The half-resolution operands of both local matchings (AEM:938-941 with MODEL_LOCAL_DOWNSAMPLE) in one launch:
+ *   q2, p2 [H2, W2, C]  = aoc_resize_bilinear_hwc of cur_emb / prev_emb [h, w, C]
+ *   pm2    [H2, W2, C]  = aoc_resize_bilinear_hwc of aoc_label_mix(prev_labels [h*w, n_obj], prev_pos [n_obj, C])   (aocnet.py:325)
+ *   bits2  [H2 * W2]    = aoc_resize_nearest_bits of aoc_label_bits(prev_labels)
+ * Optional small tables filled by the same launch (NULL / 0 = off): set_bias_out [n_pair_sets + n_obj] = the per-set bias table of the
+ * correlation launch (set s < n_pair_sets belongs to object (s / 2) % n_obj, set n_pair_sets + o to object o); two float copies
+ * copy_dst_x[0 .. n_copy_x) = copy_src_x[..] (the pooled reference heads into the k = 1 rows of the proxy table). */
+int aoc_local_prep(const float *cur_emb, const float *prev_emb, const float *prev_labels, const float *prev_pos, int h, int w, int C, int n_obj,
+                   float *q2, float *p2, float *pm2, uint32_t *bits2, int H2, int W2,
+                   const float *obj_bias, int n_pair_sets, float *set_bias_out,
+                   const float *copy_src_a, float *copy_dst_a, int n_copy_a, const float *copy_src_b, float *copy_dst_b, int n_copy_b,
+                   aoc_stream_t stream);
+
+/* The tail of a frame's proto-mask tensor feat [n_obj, n_ch, hw] (object stride obj_stride floats) in one launch, aocnet.py:349-358:
+ * channels [ch_local_bg, +n_local) = foreground2background of [ch_local, +n_local), channel ch_global_bg = foreground2background of
+ * ch_global, channel ch_prev_mask = prev_labels [hw, n_obj] transposed; head [n_obj, 4 C] = (ref_pos | ref_neg | prev_pos | prev_neg),
+ * ATT:188.  A channel index < 0 / head == NULL switches that part off. */
+int aoc_proto_finish(float *feat, int n_obj, int64_t hw, int64_t obj_stride, int ch_local, int n_local, int ch_local_bg, int ch_global, int ch_global_bg,
+                     int ch_prev_mask, const float *prev_labels, const float *ref_pos, const float *ref_neg, const float *prev_pos, const float *prev_neg,
+                     int C, float *head, aoc_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * foreground2background, AEM:9-23: the reference concatenates the OTHER objects' maps along dim 1
  * and reduces that dim, so  out[o, 0, x] = min over o' != o and over channels c of dis[o', c, x].

@@ -72,6 +72,10 @@ SIGNATURES = {
     "aoc_resize_bilinear_planes": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _i64, _i64, _i64, _vp]),
     "aoc_resize_nearest_bits": (_i, [_vp, _i, _i, _vp, _i, _i, _vp]),
     "aoc_fg2bg_min": (_i, [_vp, _i, _i, _i64, _i64, _vp, _i64, _vp]),
+    "aoc_resize_bilinear_planes_grouped": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _i, _i64, _i64, _i64, _i64, _vp]),
+    "aoc_local_window_match_pair": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _vp]),
+    "aoc_local_prep": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp]),
+    "aoc_proto_finish": (_i, [_vp, _i, _i64, _i64, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "aoc_masked_mean_pool_workspace_bytes": (_sz, [_i, _i64, _i, _i]),
     "aoc_masked_mean_pool": (_i, [_vp, _vp, _i, _i64, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _sz, _vp]),
     "aoc_film_gain": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),

@@ -25,6 +25,41 @@ __global__ __launch_bounds__(256) void fg2bg_kernel(const float *__restrict__ di
     for (int o = 0; o < n_obj; ++o) out[(size_t)o * out_obj_stride + i] = (o == arg) ? m2 : m1;   // min over the OTHER objects
 }
 
+// The tail of a frame's proto-mask tensor in ONE launch (aocnet.py:349-358): the background maps of the local-matching channels and of
+// the dense channel (two fg2bg_kernel passes: min over the OTHER objects; a single object keeps its own map, AEM:10-11), the previous-frame
+// mask channel, and the attention head [O, 4C] = (ref_pos | ref_neg | prev_pos | prev_neg) (ATT:188).  feat is [O, n_ch, hw] with object
+// stride obj_stride; channel indices < 0 switch a part off.
+__global__ __launch_bounds__(256) void proto_finish_kernel(float *__restrict__ feat, int n_obj, int64_t hw, int64_t obj_stride, int ch_local, int n_local,
+                                                           int ch_local_bg, int ch_global, int ch_global_bg, int ch_prev, const float *__restrict__ prev_labels,
+                                                           const float *__restrict__ ref_pos, const float *__restrict__ ref_neg,
+                                                           const float *__restrict__ prev_pos, const float *__restrict__ prev_neg, int C,
+                                                           float *__restrict__ head) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (head && i < (int64_t)n_obj * 4 * C) {
+        const int o = (int)(i / (4 * C)), r = (int)(i - (int64_t)o * 4 * C), part = r / C, c = r - part * C;
+        const float *src = part == 0 ? ref_pos : part == 1 ? ref_neg : part == 2 ? prev_pos : prev_neg;
+        head[i] = src[(size_t)o * C + c];
+    }
+    auto fg2bg = [&](const float *dis, float *out, int64_t idx) {
+        if (n_obj == 1) { out[idx] = dis[idx]; return; }
+        float m1 = INFINITY, m2 = INFINITY;
+        int arg = -1;
+        for (int o = 0; o < n_obj; ++o) {
+            float v = INFINITY;
+            v = fminf(v, dis[(size_t)o * obj_stride + idx]);
+            if (v < m1) { m2 = m1; m1 = v; arg = o; }
+            else if (v < m2) { m2 = v; }
+        }
+        for (int o = 0; o < n_obj; ++o) out[(size_t)o * obj_stride + idx] = (o == arg) ? m2 : m1;
+    };
+    if (ch_local_bg >= 0 && i < (int64_t)n_local * hw) fg2bg(feat + (size_t)ch_local * hw, feat + (size_t)ch_local_bg * hw, i);
+    if (i < hw) {
+        if (ch_global_bg >= 0) fg2bg(feat + (size_t)ch_global * hw, feat + (size_t)ch_global_bg * hw, i);
+        if (ch_prev >= 0)
+            for (int o = 0; o < n_obj; ++o) feat[(size_t)o * obj_stride + (size_t)ch_prev * hw + i] = prev_labels[(size_t)i * n_obj + o];
+    }
+}
+
 // ------------------------------------------------------------------------------------------ pooling
 constexpr int MP_PIX = 128;      // pixels per block
 constexpr int MP_OMAX = 32;
@@ -1022,6 +1057,20 @@ int aoc_fg2bg_min(const float *dis, int n_obj, int n_ch, int64_t inner, int64_t 
     if (!dis || !out || n_obj < 2 || n_ch < 1 || inner < 1 || dis_obj_stride < n_ch * inner || out_obj_stride < inner) return AOC_ERR_INVALID_ARG;
     hipLaunchKernelGGL(fg2bg_kernel, dim3((unsigned)((inner + 255) / 256)), dim3(256), 0, aoc_hip_stream(stream), dis, n_obj, n_ch, inner,
                        dis_obj_stride, out, out_obj_stride);
+    AOC_RETURN_IF_LAUNCH_FAILED();
+    return AOC_OK;
+}
+
+int aoc_proto_finish(float *feat, int n_obj, int64_t hw, int64_t obj_stride, int ch_local, int n_local, int ch_local_bg, int ch_global, int ch_global_bg,
+                     int ch_prev_mask, const float *prev_labels, const float *ref_pos, const float *ref_neg, const float *prev_pos, const float *prev_neg,
+                     int C, float *head, aoc_stream_t stream) {
+    if (!feat || n_obj < 1 || hw < 1 || obj_stride < hw || n_local < 0) return AOC_ERR_INVALID_ARG;
+    if (ch_prev_mask >= 0 && !prev_labels) return AOC_ERR_INVALID_ARG;
+    if (head && (!ref_pos || !ref_neg || !prev_pos || !prev_neg || C < 1)) return AOC_ERR_INVALID_ARG;
+    int64_t span = hw > (int64_t)n_local * hw ? hw : (int64_t)n_local * hw;
+    if (head && span < (int64_t)n_obj * 4 * C) span = (int64_t)n_obj * 4 * C;
+    hipLaunchKernelGGL(proto_finish_kernel, dim3((unsigned)((span + 255) / 256)), dim3(256), 0, aoc_hip_stream(stream), feat, n_obj, hw, obj_stride, ch_local,
+                       n_local, ch_local_bg, ch_global, ch_global_bg, ch_prev_mask, prev_labels, ref_pos, ref_neg, prev_pos, prev_neg, C, head);
     AOC_RETURN_IF_LAUNCH_FAILED();
     return AOC_OK;
 }

@@ -374,11 +374,16 @@ __global__ __launch_bounds__(256) void local_window_row_kernel(const float *__re
 // (candidate row, group) items with the next item's loads in flight under the current item's MFMAs (two register buffers, loop
 // unrolled by two).
 template <int TMAX>
-__global__ __launch_bounds__(256) void local_window_reg_kernel(const float *__restrict__ query, const float *__restrict__ prev,
+__global__ __launch_bounds__(256) void local_window_reg_kernel(const float *__restrict__ query, const float *__restrict__ prev_a,
                                                                 const uint32_t *__restrict__ right_bits, int H, int W,
                                                                 LocalRadii radii, const float *__restrict__ obj_bias, int n_obj,
-                                                                float *__restrict__ out, int transform, int rate, int f16) {
+                                                                float *__restrict__ out_a, int transform, int rate, int f16,
+                                                                const float *__restrict__ prev_b, float *__restrict__ out_b) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    // gridDim.z == 2 (aoc_local_window_match_pair): the same query against a second previous-frame map (aocnet.py:328, the per-pixel proxy
+    // map) in the same launch
+    const float *__restrict__ prev = blockIdx.z ? prev_b : prev_a;
+    float *__restrict__ out = blockIdx.z ? out_b : out_a;
     constexpr int C = 4 * TMAX;
     constexpr int NP = TMAX / 4;                        // float4 pieces per lane
     constexpr bool TAIL = (TMAX % 4) != 0;              // TMAX = 25: one more channel per lane (16 NP + g)
@@ -590,7 +595,7 @@ __global__ __launch_bounds__(256) void resize_bilinear_hwc_kernel(const float *_
 __global__ __launch_bounds__(256) void resize_bilinear_planes_kernel(const float *__restrict__ in, int P, int h, int w,
                                                                       float *__restrict__ out, int H, int W, float sh, float sw,
                                                                       int inner_count, int64_t outer_stride, int64_t plane_stride,
-                                                                      int64_t pixel_stride) {
+                                                                      int64_t pixel_stride, int outer_count, int64_t group_stride) {
     const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t total = (int64_t)P * H * W;
     if (idx >= total) return;
@@ -604,7 +609,71 @@ __global__ __launch_bounds__(256) void resize_bilinear_planes_kernel(const float
     const float *ip = in + (size_t)p * h * w;
     const float v00 = ip[(size_t)y0 * w + x0], v01 = ip[(size_t)y0 * w + x1];
     const float v10 = ip[(size_t)y1 * w + x0], v11 = ip[(size_t)y1 * w + x1];
-    out[(p / inner_count) * outer_stride + (p % inner_count) * plane_stride + ((int64_t)Y * W + X) * pixel_stride] = hy0 * (wx0 * v00 + wx1 * v01) + hy1 * (wx0 * v10 + wx1 * v11);
+    // plane p = (group, outer, inner): groups of outer_count * inner_count planes land group_stride apart (two local-matching results ->
+    // two channel ranges of the proto-mask tensor in one launch)
+    const int po = p / inner_count;
+    out[(po / outer_count) * group_stride + (po % outer_count) * outer_stride + (p % inner_count) * plane_stride + ((int64_t)Y * W + X) * pixel_stride] = hy0 * (wx0 * v00 + wx1 * v01) + hy1 * (wx0 * v10 + wx1 * v11);
+}
+
+__global__ __launch_bounds__(256) void local_prep_kernel(const float *__restrict__ cur, const float *__restrict__ prev, const float *__restrict__ lab,
+                                                          const float *__restrict__ rows, int h, int w, int C, int n_obj, float *__restrict__ q2,
+                                                          float *__restrict__ p2, float *__restrict__ pm2, uint32_t *__restrict__ bits2, int H, int W,
+                                                          float sh, float sw, float nsh, float nsw, const float *__restrict__ obj_bias, int n_pair_sets,
+                                                          float *__restrict__ set_bias_out, const float *__restrict__ csa, float *__restrict__ cda, int nca,
+                                                          const float *__restrict__ csb, float *__restrict__ cdb, int ncb) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // the small tables first (any thread range will do: they only depend on this launch's inputs)
+    if (set_bias_out && idx < n_pair_sets + n_obj) {
+        const int o = idx < n_pair_sets ? (int)((idx >> 1) % n_obj) : (int)(idx - n_pair_sets);
+        set_bias_out[idx] = obj_bias ? obj_bias[o] : 0.0f;
+    }
+    if (idx < nca) cda[idx] = csa[idx];
+    if (idx < ncb) cdb[idx] = csb[idx];
+    const int64_t total = (int64_t)H * W * C;
+    if (idx >= total) return;
+    const int c = (int)(idx % C);
+    const int64_t pix = idx / C;
+    const int X = (int)(pix % W), Y = (int)(pix / W);
+    int y0, y1, x0, x1;
+    float hy0, hy1, wx0, wx1;
+    bilinear_src(Y, sh, h, y0, y1, hy0, hy1);
+    bilinear_src(X, sw, w, x0, x1, wx0, wx1);
+    const size_t p00 = (size_t)y0 * w + x0, p01 = (size_t)y0 * w + x1, p10 = (size_t)y1 * w + x0, p11 = (size_t)y1 * w + x1;
+    {
+        const float v00 = cur[p00 * C + c], v01 = cur[p01 * C + c], v10 = cur[p10 * C + c], v11 = cur[p11 * C + c];
+        q2[idx] = hy0 * (wx0 * v00 + wx1 * v01) + hy1 * (wx0 * v10 + wx1 * v11);
+    }
+    {
+        const float v00 = prev[p00 * C + c], v01 = prev[p01 * C + c], v10 = prev[p10 * C + c], v11 = prev[p11 * C + c];
+        p2[idx] = hy0 * (wx0 * v00 + wx1 * v01) + hy1 * (wx0 * v10 + wx1 * v11);
+    }
+    {
+        // label_mix_kernel's sum at the four corners (objects in order), then the bilinear expression
+        float v00 = 0.0f, v01 = 0.0f, v10 = 0.0f, v11 = 0.0f;
+        for (int o = 0; o < n_obj; ++o) {
+            const float r = rows[(size_t)o * C + c];
+            v00 += lab[p00 * n_obj + o] * r;
+            v01 += lab[p01 * n_obj + o] * r;
+            v10 += lab[p10 * n_obj + o] * r;
+            v11 += lab[p11 * n_obj + o] * r;
+        }
+        pm2[idx] = hy0 * (wx0 * v00 + wx1 * v01) + hy1 * (wx0 * v10 + wx1 * v11);
+    }
+    if (c == 0) {
+        // label_bits_kernel at the nearest source pixel (torch nearest: floor(dst * in / out))
+        const int sy = min((int)floorf((float)Y * nsh), h - 1);
+        const int sx = min((int)floorf((float)X * nsw), w - 1);
+        const float *l = lab + ((size_t)sy * w + sx) * n_obj;
+        uint32_t right = 0;
+        float sum = 0.0f;
+        for (int o = 0; o < n_obj; ++o) {
+            const float v = l[o];
+            sum += v;
+            if (v > 0.9f) right |= 1u << o;
+        }
+        if (sum > 0.9f) right |= AOC_ROW_KEPT_BIT;
+        bits2[pix] = right;
+    }
 }
 
 __global__ __launch_bounds__(256) void resize_nearest_bits_kernel(const uint32_t *__restrict__ in, int h, int w,
@@ -627,9 +696,31 @@ int aoc_local_window_match(const float *query, const float *prev, const uint32_t
     return aoc_local_window_match_ex(query, prev, right_bits, H, W, C, radii_host, n_radii, obj_bias, n_obj, out, transform, 1, 0, stream);
 }
 
+static int local_window_match_impl(const float *query, const float *prev, const uint32_t *right_bits, int H, int W, int C,
+                                   const int32_t *radii_host, int n_radii, const float *obj_bias, int n_obj,
+                                   float *out, int transform, int atrous_rate, int float16, aoc_stream_t stream, const float *prev2, float *out2);
+
 int aoc_local_window_match_ex(const float *query, const float *prev, const uint32_t *right_bits, int H, int W, int C,
                               const int32_t *radii_host, int n_radii, const float *obj_bias, int n_obj,
                               float *out, int transform, int atrous_rate, int float16, aoc_stream_t stream) {
+    return local_window_match_impl(query, prev, right_bits, H, W, C, radii_host, n_radii, obj_bias, n_obj, out, transform, atrous_rate, float16, stream,
+                                   nullptr, nullptr);
+}
+
+int aoc_local_window_match_pair(const float *query, const float *prev_a, const float *prev_b, const uint32_t *right_bits, int H, int W, int C,
+                                const int32_t *radii_host, int n_radii, const float *obj_bias, int n_obj, float *out_a, float *out_b,
+                                int transform, aoc_stream_t stream) {
+    if (!prev_b || !out_b) return AOC_ERR_INVALID_ARG;
+    if (C == 100 || C == 128)      // the register-operand kernel takes both maps as one launch (grid z)
+        return local_window_match_impl(query, prev_a, right_bits, H, W, C, radii_host, n_radii, obj_bias, n_obj, out_a, transform, 1, 0, stream, prev_b, out_b);
+    const int rc = local_window_match_impl(query, prev_a, right_bits, H, W, C, radii_host, n_radii, obj_bias, n_obj, out_a, transform, 1, 0, stream, nullptr, nullptr);
+    if (rc != AOC_OK) return rc;
+    return local_window_match_impl(query, prev_b, right_bits, H, W, C, radii_host, n_radii, obj_bias, n_obj, out_b, transform, 1, 0, stream, nullptr, nullptr);
+}
+
+static int local_window_match_impl(const float *query, const float *prev, const uint32_t *right_bits, int H, int W, int C,
+                                   const int32_t *radii_host, int n_radii, const float *obj_bias, int n_obj,
+                                   float *out, int transform, int atrous_rate, int float16, aoc_stream_t stream, const float *prev2, float *out2) {
     if (!query || !prev || !right_bits || !radii_host || !out) return AOC_ERR_INVALID_ARG;
     if (H < 1 || W < 1 || C < 4 || n_radii < 1 || n_obj < 1 || atrous_rate < 1) return AOC_ERR_INVALID_ARG;
     if ((C & 3) || C > 128 || n_radii > LM_MAX_RADII || n_obj > AOC_MAX_OBJECTS) return AOC_ERR_UNSUPPORTED;
@@ -652,13 +743,13 @@ int aoc_local_window_match_ex(const float *query, const float *prev, const uint3
     hipStream_t st = aoc_hip_stream(stream);
     static const char *which = AOC_DEV_ENV("AOC_LOCAL_KERNEL");            // developer switch: "row" / "block" = the LDS-image kernels
     // register-operand kernel (no LDS image): C == 100 / 128
-    if ((C == 100 || C == 128) && !(which && (strcmp(which, "row") == 0 || strcmp(which, "block") == 0))) {
-        const dim3 rgrid((W + 7) / 8, (H + 1) / 2);
+    if ((C == 100 || C == 128) && (prev2 || !(which && (strcmp(which, "row") == 0 || strcmp(which, "block") == 0)))) {
+        const dim3 rgrid((W + 7) / 8, (H + 1) / 2, prev2 ? 2 : 1);
         const size_t lds_reg = (32 + (size_t)4 * 16 * n_radii * n_obj) * sizeof(float);
         if (C == 100)
-            hipLaunchKernelGGL(local_window_reg_kernel<25>, rgrid, dim3(256), lds_reg, st, query, prev, right_bits, H, W, radii, obj_bias, n_obj, out, transform, rate, f16);
+            hipLaunchKernelGGL(local_window_reg_kernel<25>, rgrid, dim3(256), lds_reg, st, query, prev, right_bits, H, W, radii, obj_bias, n_obj, out, transform, rate, f16, prev2, out2);
         else
-            hipLaunchKernelGGL(local_window_reg_kernel<32>, rgrid, dim3(256), lds_reg, st, query, prev, right_bits, H, W, radii, obj_bias, n_obj, out, transform, rate, f16);
+            hipLaunchKernelGGL(local_window_reg_kernel<32>, rgrid, dim3(256), lds_reg, st, query, prev, right_bits, H, W, radii, obj_bias, n_obj, out, transform, rate, f16, prev2, out2);
         AOC_RETURN_IF_LAUNCH_FAILED();
         return AOC_OK;
     }
@@ -705,10 +796,42 @@ int aoc_resize_bilinear_hwc_ex(const float *in, int h, int w, int C, float *out,
 
 int aoc_resize_bilinear_planes(const float *in, int P, int h, int w, float *out, int H, int W, int inner_count,
                                int64_t out_outer_stride, int64_t out_plane_stride, int64_t out_pixel_stride, aoc_stream_t stream) {
-    if (!in || !out || P < 1 || h < 1 || w < 1 || H < 1 || W < 1 || inner_count < 1) return AOC_ERR_INVALID_ARG;
+    return aoc_resize_bilinear_planes_grouped(in, P, h, w, out, H, W, inner_count, P > 0 && inner_count > 0 ? (P + inner_count - 1) / inner_count : 1, 0,
+                                              out_outer_stride, out_plane_stride, out_pixel_stride, stream);
+}
+
+int aoc_resize_bilinear_planes_grouped(const float *in, int P, int h, int w, float *out, int H, int W, int inner_count, int outer_count,
+                                       int64_t out_group_stride, int64_t out_outer_stride, int64_t out_plane_stride, int64_t out_pixel_stride,
+                                       aoc_stream_t stream) {
+    if (!in || !out || P < 1 || h < 1 || w < 1 || H < 1 || W < 1 || inner_count < 1 || outer_count < 1) return AOC_ERR_INVALID_ARG;
     const int64_t total = (int64_t)P * H * W;
     hipLaunchKernelGGL(resize_bilinear_planes_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, aoc_hip_stream(stream), in, P, h, w,
-                       out, H, W, align_corners_scale(h, H), align_corners_scale(w, W), inner_count, out_outer_stride, out_plane_stride, out_pixel_stride);
+                       out, H, W, align_corners_scale(h, H), align_corners_scale(w, W), inner_count, out_outer_stride, out_plane_stride, out_pixel_stride,
+                       outer_count, out_group_stride);
+    AOC_RETURN_IF_LAUNCH_FAILED();
+    return AOC_OK;
+}
+
+// The half-resolution operands of both local matchings in ONE launch (aocnet.py:255, 325-337 with MODEL_LOCAL_DOWNSAMPLE; AEM:938-941):
+// q2 / p2 = bilinear (align_corners) down-samples of the current and the previous frame's embedding, pm2 = the same of the per-pixel proxy
+// map matmul(prev label, prev_head_pos) (never materialised at full resolution), bits2 = the nearest-neighbour down-sample of the previous
+// frame's "right for object o" bit mask.  Every value is computed by the expressions of aoc_resize_bilinear_hwc / aoc_label_mix /
+// aoc_label_bits / aoc_resize_nearest_bits, term by term: the outputs equal those four calls' bit for bit.  The launch also fills small
+// per-frame tables when asked to: the per-set bias table of the correlation launch (set s < n_pair_sets belongs to object (s / 2) % n_obj,
+// the others to s - n_pair_sets) and copies of `n_copy` floats (the pooled reference heads into the k = 1 rows of the proxy table).
+int aoc_local_prep(const float *cur_emb, const float *prev_emb, const float *prev_labels, const float *prev_pos, int h, int w, int C, int n_obj,
+                   float *q2, float *p2, float *pm2, uint32_t *bits2, int H2, int W2,
+                   const float *obj_bias, int n_pair_sets, float *set_bias_out,
+                   const float *copy_src_a, float *copy_dst_a, int n_copy_a, const float *copy_src_b, float *copy_dst_b, int n_copy_b,
+                   aoc_stream_t stream) {
+    if (!cur_emb || !prev_emb || !prev_labels || !prev_pos || !q2 || !p2 || !pm2 || !bits2) return AOC_ERR_INVALID_ARG;
+    if (h < 1 || w < 1 || C < 1 || n_obj < 1 || H2 < 1 || W2 < 1 || n_pair_sets < 0 || n_copy_a < 0 || n_copy_b < 0) return AOC_ERR_INVALID_ARG;
+    if (n_obj > AOC_MAX_OBJECTS) return AOC_ERR_UNSUPPORTED;
+    const int64_t total = (int64_t)H2 * W2 * C;
+    hipLaunchKernelGGL(local_prep_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, aoc_hip_stream(stream), cur_emb, prev_emb, prev_labels,
+                       prev_pos, h, w, C, n_obj, q2, p2, pm2, bits2, H2, W2, align_corners_scale(h, H2), align_corners_scale(w, W2),
+                       (float)h / (float)H2, (float)w / (float)W2, obj_bias, n_pair_sets, set_bias_out, copy_src_a, copy_dst_a, n_copy_a, copy_src_b,
+                       copy_dst_b, n_copy_b);
     AOC_RETURN_IF_LAUNCH_FAILED();
     return AOC_OK;
 }

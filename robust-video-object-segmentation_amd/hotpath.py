@@ -312,18 +312,17 @@ def proto_mask_features(cfg, ref_emb, ref_labels, prev_emb, prev_labels, cur_emb
             sqn[:n_ad].fill_(float("inf"))       # nothing labelled -> every cluster feature is 1
 
     cached = dense_state.get("ref_pool") if dense_state is not None else None
+    k1_copies = []
     if cached is not None and cached[0] == R:
         # the pooled reference heads are a function of the pool alone (ATT:155-170): unchanged since the last frame
         _, ref_pos, ref_neg, ref_sq = cached
-        table[n_ad:].copy_(ref_pos)
-        sqn[n_ad:].copy_(ref_sq)
+        k1_copies = [(ref_pos, table[n_ad:]), (ref_sq, sqn[n_ad:])]       # into the k = 1 rows of this frame's proxy table (by the local-prep launch)
     else:
         ref_pos, ref_neg = ops.masked_mean_pool(ref_emb.reshape(R, hw, C), ref_labels.reshape(R, hw, O), cfg.MODEL_EPSILON, pixel_major=True,
                                                 out_pos=table[n_ad:], out_pos_sqnorm=sqn[n_ad:])
         if dense_state is not None:
             dense_state["ref_pool"] = (R, ref_pos.clone(), ref_neg, sqn[n_ad:].clone())
     prev_pos, prev_neg = ops.masked_mean_pool(prev_emb.reshape(1, hw, C), prev_labels.reshape(1, hw, O), cfg.MODEL_EPSILON, pixel_major=True)
-    attention_head = torch.cat([ref_pos, ref_neg, prev_pos, prev_neg], dim=1)          # ATT:188, [O, 4C]
 
     # ---- dense pixel-level matching, AEM:688-817 -> channel 0
     pool_split = None
@@ -367,19 +366,21 @@ def proto_mask_features(cfg, ref_emb, ref_labels, prev_emb, prev_labels, cur_emb
     # ---- local matching against the previous frame and against its per-pixel proxy map (aocnet.py:255,325-337)
     radii = list(cfg.MODEL_MULTI_LOCAL_DISTANCE)
     prev_flat_labels = prev_labels.reshape(hw, O)
-    right_prev, _ = ops.label_bits(prev_flat_labels, want_wrong=False)
-    proxy_map = ops.label_mix(prev_flat_labels, prev_pos).view(h, w, C)                # aocnet.py:325
     if cfg.MODEL_LOCAL_DOWNSAMPLE:
+        # one launch for the three bilinear down-samples, the (never materialised) proxy map and the label bits; one for both matchings;
+        # one for both up-samples into their channel ranges
         H2, W2 = int(h / 2) + 1, int(w / 2) + 1
-        q2 = ops.resize_bilinear_hwc(cur_emb, H2, W2)
-        p2 = ops.resize_bilinear_hwc(prev_emb, H2, W2)
-        pm2 = ops.resize_bilinear_hwc(proxy_map, H2, W2)
-        bits2 = ops.resize_nearest_bits(right_prev, h, w, H2, W2)
+        q2, p2, pm2, bits2 = ops.local_prep(cur_emb, prev_emb, prev_flat_labels, prev_pos, H2, W2, copies=k1_copies)
+        k1_copies = []
+        lf = ops.local_window_match_pair(q2, p2, pm2, bits2, radii, bias, O, True)          # [2, O, nl, H2, W2]
+        ops.resize_bilinear_planes_grouped(lf.view(2 * O * nl, H2, W2), h, w, base[ch["local"] * hw:], nl, O, (ch["local_proxy"] - ch["local"]) * hw,
+                                           obj_stride, hw, 1)
     else:
-        H2, W2, q2, p2, pm2, bits2 = h, w, cur_emb, prev_emb, proxy_map, right_prev
-    for key, prev_map in (("local", p2), ("local_proxy", pm2)):
-        lf = ops.local_window_match(q2, prev_map, bits2, radii, bias, O, True)        # [O, nl, H2, W2]
-        ops.resize_bilinear_planes(lf.view(O * nl, H2, W2), h, w, base[ch[key] * hw:], hw, 1, inner_count=nl, out_outer_stride=obj_stride)
+        right_prev, _ = ops.label_bits(prev_flat_labels, want_wrong=False)
+        proxy_map = ops.label_mix(prev_flat_labels, prev_pos).view(h, w, C)                # aocnet.py:325
+        for key, prev_map in (("local", prev_emb), ("local_proxy", proxy_map)):
+            lf = ops.local_window_match(cur_emb, prev_map, right_prev, radii, bias, O, True)        # [O, nl, h, w]
+            ops.resize_bilinear_planes(lf.view(O * nl, h, w), h, w, base[ch[key] * hw:], hw, 1, inner_count=nl, out_outer_stride=obj_stride)
 
     # ---- one correlation launch: cluster (2 sets / object / level) + k = 1 proxy (1 set / object), AEM:316-319 + matching.py:2653
     set_begin, set_size, set_off, set_obj = [], [], [], []
@@ -417,6 +418,8 @@ def proto_mask_features(cfg, ref_emb, ref_labels, prev_emb, prev_labels, cur_emb
             dense_state["set_bias"] = (bkey, set_bias)
     if cluster_ahead is not None:
         torch.cuda.current_stream().wait_event(cluster_ahead.done_event)   # join: the proxy table is complete
+    for src, dst in k1_copies:                        # (no local-prep launch took them along)
+        dst.copy_(src)
     pending = None
     if defer_correlation:
         pending = PendingCorrelation()
@@ -435,20 +438,12 @@ def proto_mask_features(cfg, ref_emb, ref_labels, prev_emb, prev_labels, cur_emb
             ops.proxy_corr_min_batched([(query_flat, table, sqn, set_bias, feat)], set_begin, set_size, set_off, True,
                                        "fp32" if (dense_precision or ops.DENSE_PRECISION) == "fp32" else "split")
 
-    # ---- previous-frame mask channel (aocnet.py:356 to_cat_previous_frame)
-    feat[:, ch["prev_mask"]].copy_(prev_labels.permute(2, 0, 1))
-
     if dense_done is not None:
         torch.cuda.current_stream().wait_event(dense_done)           # join: channel 0 (dense) is complete
-    # ---- background maps, AEM:9-23 (aocnet.py:349-353)
-    if cfg.MODEL_MATCHING_BACKGROUND and O > 1:
-        ops.fg2bg_min(base[ch["local"] * hw:], O, out=base[ch["local_bg"] * hw:], dis_obj_stride=obj_stride, out_obj_stride=obj_stride,
-                      n_ch=1, inner=nl * hw)
-        ops.fg2bg_min(base[ch["global_fg"] * hw:], O, out=base[ch["global_bg"] * hw:], dis_obj_stride=obj_stride, out_obj_stride=obj_stride,
-                      n_ch=1, inner=hw)
-    elif cfg.MODEL_MATCHING_BACKGROUND:
-        feat[:, ch["local_bg"]:ch["local_bg"] + nl].copy_(feat[:, ch["local"]:ch["local"] + nl])     # AEM:10-11
-        feat[:, ch["global_bg"]].copy_(feat[:, ch["global_fg"]])
+    # ---- previous-frame mask channel (aocnet.py:356), background maps (AEM:9-23, aocnet.py:349-353) and the attention head (ATT:188) in one launch
+    bg = cfg.MODEL_MATCHING_BACKGROUND
+    attention_head = ops.proto_finish(feat, hw, obj_stride, ch["local"], nl, ch["local_bg"] if bg else -1, ch["global_fg"], ch["global_bg"] if bg else -1,
+                                      ch["prev_mask"], prev_flat_labels, ref_pos.contiguous(), ref_neg.contiguous(), prev_pos, prev_neg)
     return feat, attention_head, dict(cluster=cp, prev_pos=prev_pos, ref_pos=ref_pos, pending_correlation=pending)
 
 

@@ -472,6 +472,75 @@ def local_window_match(query, prev, right_bits, radii, obj_bias, n_obj, transfor
     return out
 
 
+def local_prep(cur_emb, prev_emb, prev_labels_flat, prev_pos, H2, W2, obj_bias=None, n_pair_sets=0, set_bias_out=None, copies=()):
+    """aoc_local_prep: the half-resolution operands of both local matchings in one launch -> (q2, p2, pm2 [H2, W2, C], bits2 [H2 * W2]).
+    copies: up to two (src, dst) float tensor pairs copied by the same launch; set_bias_out [n_pair_sets + O] is filled from obj_bias."""
+    cur_emb, prev_emb, prev_labels_flat, prev_pos = _f32c(cur_emb), _f32c(prev_emb), _f32c(prev_labels_flat), _f32c(prev_pos)
+    _need_gpu(cur_emb, prev_emb, prev_labels_flat, prev_pos, obj_bias, set_bias_out)
+    h, w, C = cur_emb.shape
+    n_obj = prev_labels_flat.shape[-1]
+    dev = cur_emb.device
+    q2 = torch.empty(H2, W2, C, dtype=torch.float32, device=dev)
+    p2, pm2 = torch.empty_like(q2), torch.empty_like(q2)
+    bits2 = torch.empty(H2 * W2, dtype=torch.int32, device=dev)
+    cp = [(None, None, 0), (None, None, 0)]
+    for i, (src, dst) in enumerate(copies):
+        assert src.is_contiguous() and dst.is_contiguous() and src.dtype == dst.dtype == torch.float32 and src.numel() == dst.numel()
+        cp[i] = (src, dst, src.numel())
+    if obj_bias is not None:
+        obj_bias = _f32c(obj_bias)
+    _lib.check(_lib.lib().aoc_local_prep(_p(cur_emb), _p(prev_emb), _p(prev_labels_flat), _p(prev_pos), h, w, C, n_obj, _p(q2), _p(p2), _p(pm2), _p(bits2),
+                                         int(H2), int(W2), _p(obj_bias), int(n_pair_sets), _p(set_bias_out), _p(cp[0][0]), _p(cp[0][1]), cp[0][2],
+                                         _p(cp[1][0]), _p(cp[1][1]), cp[1][2], _stream()), "aoc_local_prep")
+    return q2, p2, pm2, bits2
+
+
+def local_window_match_pair(query, prev_a, prev_b, right_bits, radii, obj_bias, n_obj, transform=True):
+    """aoc_local_window_match_pair -> [2, n_obj, len(radii), H, W]: local matching against prev_a and prev_b in one launch."""
+    query, prev_a, prev_b = _f32c(query), _f32c(prev_a), _f32c(prev_b)
+    _need_gpu(query, prev_a, prev_b, right_bits)
+    H, W, C = query.shape
+    radii = np.ascontiguousarray(np.asarray(radii, dtype=np.int32))
+    out = torch.empty(2, n_obj, radii.size, H, W, dtype=torch.float32, device=query.device)
+    if obj_bias is not None:
+        obj_bias = _f32c(obj_bias)
+    _lib.check(_lib.lib().aoc_local_window_match_pair(_p(query), _p(prev_a), _p(prev_b), _p(right_bits), H, W, C, radii.ctypes.data_as(ctypes.c_void_p),
+                                                      int(radii.size), _p(obj_bias), n_obj, _p(out[0]), _p(out[1]), int(bool(transform)), _stream()),
+               "aoc_local_window_match_pair")
+    return out
+
+
+def resize_bilinear_planes_grouped(x, H, W, out, inner_count, outer_count, group_stride, outer_stride, plane_stride, pixel_stride=1):
+    """aoc_resize_bilinear_planes_grouped: x [P, h, w], plane p = (group, outer, inner) -> strided destination."""
+    x = _f32c(x)
+    _need_gpu(x, out)
+    P, h, w = x.shape
+    _lib.check(_lib.lib().aoc_resize_bilinear_planes_grouped(_p(x), P, h, w, _p(out), H, W, int(inner_count), int(outer_count), int(group_stride),
+                                                             int(outer_stride), int(plane_stride), int(pixel_stride), _stream()),
+               "aoc_resize_bilinear_planes_grouped")
+    return out
+
+
+def proto_finish(feat, hw, obj_stride, ch_local, n_local, ch_local_bg, ch_global, ch_global_bg, ch_prev_mask, prev_labels_flat,
+                 ref_pos=None, ref_neg=None, prev_pos=None, prev_neg=None):
+    """aoc_proto_finish: background channels, previous-mask channel and (when the four pooled heads are given) the attention head
+    [O, 4C] of one frame in one launch.  Returns the head (or None)."""
+    _need_gpu(feat, prev_labels_flat, ref_pos, ref_neg, prev_pos, prev_neg)
+    n_obj = feat.shape[0]
+    head, C = None, 0
+    if ref_pos is not None:
+        C = ref_pos.shape[1]
+        head = torch.empty(n_obj, 4 * C, dtype=torch.float32, device=feat.device)
+        for t in (ref_pos, ref_neg, prev_pos, prev_neg):
+            assert t.is_contiguous() and t.shape == (n_obj, C)
+    if prev_labels_flat is not None:
+        prev_labels_flat = _f32c(prev_labels_flat)
+    _lib.check(_lib.lib().aoc_proto_finish(_p(feat), n_obj, int(hw), int(obj_stride), int(ch_local), int(n_local), int(ch_local_bg), int(ch_global),
+                                           int(ch_global_bg), int(ch_prev_mask), _p(prev_labels_flat), _p(ref_pos), _p(ref_neg), _p(prev_pos), _p(prev_neg),
+                                           int(C), _p(head), _stream()), "aoc_proto_finish")
+    return head
+
+
 # ------------------------------------------------------------------------------------------ calibration side
 def fg2bg_min(dis, n_obj, out=None, dis_obj_stride=None, out_obj_stride=None, n_ch=None, inner=None):
     """dis [O, c, ...] -> [O, 1, ...]: min over the other objects and over dim 1 (AEM:18-20).
