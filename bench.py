@@ -158,6 +158,19 @@ class OpTimer:
 
             setattr(ops, n, wrapped)
 
+    def frame_probes(self):
+        """Six raw events for aoc_frame_enqueue's probe slots (dense op, correlation launch, local-matching launch) + the dense kernel probe."""
+        self.kernel_probe.arm()
+        return [self._event() for _ in range(6)]
+
+    def frame_done(self, probes, n, m, n_proxy):
+        st = ops._stream().value
+        for name, (a, b), args in (("dense_match_min_split", probes[0:2], ("dense", m, n)), ("proxy_corr_min_records", probes[2:4], ("corr", m, n_proxy)),
+                                   ("local_window_match", probes[4:6], None)):
+            self.records[name].append((a, b))
+            self.streams.setdefault(name, []).append(st)
+            self.meta[name].append(self.frame_meta(*args) if args else None)
+
     def summary(self):
         out = {}
         for n in self.names:
@@ -247,6 +260,9 @@ class ClipWorkload:
         self.reuse_proxies = False                         # non-parity mode: one k-means per pool state
         self.bank = None                                   # non-parity mode: hotpath.IncrementalProxyBank (one clustering per pool FRAME)
         self.cached_ahead = None
+        self.runner = None                                 # hotpath.FrameRunner: one C call per frame (aoc_frame_enqueue); None = the Python orchestrator
+        self.timer = None
+        self.pool_gen = 0
         self.r_hist = {}
         self.count_r = False
         self.reset()
@@ -256,6 +272,8 @@ class ClipWorkload:
 
     def reset(self):
         self.pos = self.start
+        if self.runner is not None:
+            self.runner.reset()
         self.dense_state["frames"] = 0
         self.dense_state.pop("ref_pool", None)
         self.cached_ahead = None
@@ -293,6 +311,9 @@ class ClipWorkload:
         (eval_manager_mm.py:309-312): that frame's split records are converted again and nothing that depends on the pool may have
         been enqueued earlier."""
         if self.t in self.group_first:
+            self.pool_gen += 1
+            if self.runner is not None:
+                self.runner.pool_changed(self.R - 1)
             self.dense_state["frames"] = min(self.dense_state.get("frames", 0), self.R - 1)
             self.dense_state.pop("ref_pool", None)
             self.cached_ahead = None
@@ -322,6 +343,9 @@ class ClipWorkload:
             t = t_of[R]
             self.dense_state["frames"] = 0
             self.dense_state.pop("ref_pool", None)
+            self.pool_gen += 1
+            if self.runner is not None:
+                self.runner.reset()
             ref_emb, ref_lab = self.pool_emb[:R], self.pool_lab[:R]
             init = self.init_rows[t][0]
             ev = torch.cuda.Event()
@@ -330,6 +354,8 @@ class ClipWorkload:
                 ahead = hotpath.launch_cluster_proxies(self.mc, ref_emb, ref_lab, init, self.side, wait_event=ev)
                 for nb in (sorted({b for b in self.chain_plan if b > 1}) if self.chain_plan else range(2, self.chains)):   # batched chains of every size the run can ask for
                     hotpath.launch_cluster_proxies_batch(self.mc, ref_emb, ref_lab, [init] * nb, self.side, wait_event=ev)
+                if self.runner is not None and dense_precision == "split" and self.dense_stream is None:
+                    feat, head = self.runner(ref_emb, ref_lab, self.emb[t - 1], self.lab[t - 1], self.emb[t], self.bias, ahead, pool_key=self.pool_gen)
                 feat, head, _ = hotpath.proto_mask_features(self.mc, ref_emb, ref_lab, self.emb[t - 1], self.lab[t - 1], self.emb[t], self.bias,
                                                             cluster_ahead=ahead, dense_state=self.dense_state, dense_precision=dense_precision,
                                                             dense_stream=self.dense_stream)
@@ -417,9 +443,18 @@ def frame_step(wl, gates, acts, dense_precision="split", pipeline=True, defer_co
                 launch_chains(wl, done=t)                   # keeps one batch of lead (no-op when it is already enqueued)
         elif not wl.reuse_proxies and nxt and nxt[0] not in wl.ahead:
             wl.ahead[nxt[0]] = hotpath.launch_cluster_proxies(wl.mc, ref_emb, ref_lab, wl.init_rows[nxt[0]][0], wl.side, wait_event=wl.pool_event)
-        feat, head, aux = hotpath.proto_mask_features(wl.mc, ref_emb, ref_lab, wl.emb[t - 1], wl.lab[t - 1], wl.emb[t], wl.bias,
-                                                      cluster_ahead=ahead, dense_state=wl.dense_state, dense_precision=dense_precision,
-                                                      dense_stream=wl.dense_stream, defer_correlation=defer_corr)
+        if wl.runner is not None and dense_precision == "split" and wl.dense_stream is None and not defer_corr:
+            # ONE C call for the frame (aoc_frame_enqueue); the op timings the line reports come from events the call records itself
+            tm = wl.timer
+            probes = tm.frame_probes() if (tm is not None and tm.enabled) else None
+            feat, head = wl.runner(ref_emb, ref_lab, wl.emb[t - 1], wl.lab[t - 1], wl.emb[t], wl.bias, ahead, pool_key=wl.pool_gen, probes=probes)
+            if probes is not None:
+                tm.frame_done(probes, ref_emb.shape[0] * ref_emb.shape[1] * ref_emb.shape[2], wl.emb[t].shape[0] * wl.emb[t].shape[1], ahead.table.shape[0])
+            aux = dict(pending_correlation=None)
+        else:
+            feat, head, aux = hotpath.proto_mask_features(wl.mc, ref_emb, ref_lab, wl.emb[t - 1], wl.lab[t - 1], wl.emb[t], wl.bias,
+                                                          cluster_ahead=ahead, dense_state=wl.dense_state, dense_precision=dense_precision,
+                                                          dense_stream=wl.dense_stream, defer_correlation=defer_corr)
     else:
         feat, head, aux = hotpath.proto_mask_features(wl.mc, ref_emb, ref_lab, wl.emb[t - 1], wl.lab[t - 1], wl.emb[t], wl.bias,
                                                       cluster_state=dict(init_rows=wl.init_rows[t][0]), side_stream=wl.side,
@@ -639,6 +674,9 @@ def main():
     ap.add_argument("--no-stagger", dest="stagger", action="store_false",
                     help="start every in-flight sequence at a group boundary (default: sequence s starts s * MEM_EVERY / streams frames into its first group, "
                          "so that the sequences need their un-prefetchable first-of-group k-means chains at different steps)")
+    ap.add_argument("--python-frames", action="store_true",
+                    help="drive every frame through hotpath.proto_mask_features (the individual C entry points, ~45 ctypes calls per frame) instead of ONE "
+                         "aoc_frame_enqueue call per frame (default since round 4; bit-identical results)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="start a frame's k-means chain with the frame instead of as soon as its pool is final")
     ap.add_argument("--no-overlap", action="store_true", help="run the k-means branch on the main stream (no intra-frame stream overlap)")
@@ -743,6 +781,8 @@ def main():
         wl.reuse_proxies = args.reuse_proxies
         if args.incremental_proxies:
             wl.enable_incremental()
+        if not args.python_frames and not args.incremental_proxies and hotpath.FrameRunner.supported(mc, cfg.c, cfg.n_obj):
+            wl.runner = hotpath.FrameRunner(mc, cfg.h, cfg.w, cfg.c, cfg.n_obj, wl.rmax, dev)
     acts = make_activations(gates, cfg.n_obj, cfg.h, cfg.w, dev, seed=7)
 
     def make_main_stream():
@@ -813,6 +853,14 @@ def main():
     timer = OpTimer(["dense_match_min", "dense_match_min_split", "proxy_corr_min", "proxy_corr_min_batched", "proxy_corr_min_records", "kmeans_segmented",
                      "local_window_match",
                      "film_scale", "cond_gate_pool"])
+    def frame_meta(kind, m, n):
+        if kind == "dense":
+            return dict(flops=2.0 * m * n * C, bytes=(m + n) * C * 4 + n * 4 + m * O * 4)
+        n_set = 2 * len(mc.cluster_levels) * O + O
+        return dict(flops=2.0 * m * n * C, bytes=m * C * 4 + n * C * 4 + m * n_set * 4, frames=1)
+    timer.frame_meta = frame_meta
+    for wl in workloads:
+        wl.timer = timer
     timer.serialize_dense = bool(args.dense_order) and not args.no_dense_order
     timer.install(dict(dense_match_min=meta_dense, dense_match_min_split=meta_dense_split, proxy_corr_min=meta_proxy,
                        proxy_corr_min_batched=meta_proxy_batched, proxy_corr_min_records=meta_proxy_records, kmeans_segmented=meta_kmeans, film_scale=meta_film, cond_gate_pool=meta_cond))
@@ -1111,6 +1159,8 @@ def main():
                                       "per-frame code books (hotpath.IncrementalProxyBank)" if args.incremental_proxies else
                                       "NON-PARITY: adaptive proxies reused until the pool changes (one k-means per MEM_EVERY frames)"
                                       if args.reuse_proxies else "reference: the pool is re-clustered for every frame with that frame's initial rows"),
+                       "frame_call": ("ONE aoc_frame_enqueue call per frame (the counterpart of the single before_seghead_process call, aocnet.py:114)"
+                                      if workloads[0].runner is not None else "hotpath.proto_mask_features: the individual C entry points, ~45 ctypes calls per frame"),
                        "dense_precision": ("fp16-split products (hi*hi + hi*lo + lo*hi), fp32 accumulate: fp32-equivalent; exact-fp32 take-over "
                                            "on overflow / soft labels" if args.dense == "split" else "exact fp32 MFMA")},
             "host_enqueue_ms_per_step": round(host_enqueue_s / args.steps * 1e3, 3),

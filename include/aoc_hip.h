@@ -315,6 +315,19 @@ int aoc_dense_match_min_split(const float *query, const void *query_rec, const f
                               const float *obj_bias, int n_obj,
                               float *out, int64_t out_pixel_stride, int64_t out_obj_stride,
                               int transform, void *workspace, size_t workspace_bytes, aoc_stream_t stream);
+/* The same call for a caller that keeps `workspace` across the frames that see ONE pool state (same pool rows, labels and records):
+ * reuse_plan = 0 builds the plan (object-pure tile lists, norm maxima, one-hot check: a function of the pool alone) and leaves it in the
+ * workspace; reuse_plan = 1 skips the plan kernel and both memsets (the finalize kernel of every call leaves the per-pixel bounds zeroed)
+ * and only refreshes the gate from the sticky overflow flag.  Results are identical to aoc_dense_match_min_split. */
+int aoc_dense_match_min_split_cached(const float *query, const void *query_rec, const float *query_sqnorm, int query_rec_tiled,
+                              int64_t m, int C, const float *pool, const void *pool_rec,
+                              const int32_t *overflow_flag, int64_t n,
+                              const uint32_t *right_bits, const uint32_t *wrong_bits,
+                              const int32_t *fg_rows, const int32_t *obj_rows,
+                              const int32_t *counts, const int32_t *obj_offsets,
+                              const float *obj_bias, int n_obj,
+                              float *out, int64_t out_pixel_stride, int64_t out_obj_stride,
+                              int transform, void *workspace, size_t workspace_bytes, int reuse_plan, aoc_stream_t stream);
 
 /* Developer counters of the coarse-then-rescore kernel behind aoc_dense_match_min_split, summed over all launches of the process
  * since the last reset (synchronises the device): out4[0] (reference tile, query tile) pairs tested with one fp16 product,
@@ -548,6 +561,56 @@ size_t aoc_mask_jf_workspace_bytes(int H, int W);
 int aoc_mask_jf_accumulate(const int32_t *pred, const int32_t *gt, int H, int W, int n_obj, int bound_pix,
                            void *workspace, size_t workspace_bytes, int workspace_is_clean, double *accum,
                            aoc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * One frame as ONE call: the counterpart of AOCNet.before_seghead_process (networks/aoc/aocnet.py:114-372, eval branch, batch 1) up to the
+ * tensor handed to DynamicPreHead (aocnet.py:355-358) and the attention head (aocnet.py:297), enqueued on `stream` without any host
+ * synchronisation.  It issues the kernels of the individual entry points above (results bit-identical to calling them one by one, which
+ * is what hotpath.proto_mask_features does) out of ONE caller-owned device workspace per sequence, and keeps across the frames of a sequence
+ * what only depends on the reference pool: its fp16 split records (append-only pool: only new frames are converted), the pooled reference
+ * heads (ATT:155-170) and the dense kernel's plan -- keyed by pool_key.
+ *
+ * Covered configuration: C = 100, <= 16 objects, fp32 matching (MODEL_FLOAT16_MATCHING = False), MODEL_LOCAL_DOWNSAMPLE = True, atrous rates 1
+ * (configs/resnet101_aocnet.py); anything else returns AOC_ERR_UNSUPPORTED (use the individual entry points).
+ *
+ * The adaptive proxies (k-means chain, AEM:252-286: aoc_label_prep, aoc_kmeans_replicate_levels, aoc_kmeans_segmented_rep,
+ * aoc_build_proxies) only depend on the pool and are produced by the caller on ANOTHER stream, ahead of the frame; this call gets the label
+ * prep arrays, the proxy table they are written to, and two hipEvent_t: it waits for prep_ready before reading the label prep and for
+ * proxies_ready in front of the correlation launch (NULL = already ordered on `stream`).
+ *
+ * Output channels of feat [n_obj, n_ch, h, w], n_ch = aoc_frame_channels(): global(1) | cluster (centroid, centroid_avg) per level |
+ * proxy(1) | local(n_radii) | local_proxy(n_radii) | prev_mask(1) [| local_bg(n_radii) | global_bg(1)]. */
+typedef struct aoc_frame_desc {
+    int32_t h, w, C, n_obj;          /* map size, embedding width, objects incl. background */
+    int32_t R, R_capacity;           /* pool frames this frame sees / the workspace was sized for */
+    int32_t n_radii, radii[8];       /* MODEL_MULTI_LOCAL_DISTANCE */
+    int32_t n_levels, levels[8];     /* cluster_num per level (AEM:232; one level: {16}) */
+    int32_t kmax;                    /* max(levels): proxy slots per (level, object, set) in the table */
+    int32_t matching_background;     /* MODEL_MATCHING_BACKGROUND */
+    int32_t n_adaptive;              /* = n_levels * n_obj * 2 * kmax rows of the proxy table in front of the n_obj k = 1 rows */
+    float epsilon;                   /* MODEL_EPSILON */
+    int64_t pool_key;                /* != 0; changes whenever the pool's content changes (append-only pool: R) */
+    const float *ref_emb;            /* [R * h * w, C]   reference pool, resident, append-only */
+    const float *ref_labels;         /* [R * h * w, n_obj] float 0 / 1 */
+    const float *prev_emb, *prev_labels, *cur_emb;     /* [h * w, C], [h * w, n_obj], [h * w, C] */
+    const float *dis_bias;           /* [n_obj] */
+    const uint32_t *right_bits, *wrong_bits;           /* aoc_label_prep(ref_labels) */
+    const int32_t *fg_rows, *obj_rows, *counts, *obj_offsets;
+    float *proxy_table;              /* [n_adaptive + n_obj, C]: adaptive rows by the k-means chain, k = 1 rows by this call */
+    float *proxy_sqnorm;             /* [n_adaptive + n_obj] */
+    void *prep_ready, *proxies_ready;                  /* hipEvent_t or NULL */
+    float *feat;                     /* [n_obj, n_ch, h, w] */
+    float *head;                     /* [n_obj, 4 C] */
+    void *probe[6];                  /* measurement only, hipEvent_t or NULL: recorded on `stream` immediately before / after the dense matching
+                                        op [0][1], the correlation launch [2][3], the local-matching launch [4][5] */
+} aoc_frame_desc;
+/* Host-side record of what the workspace holds; caller-owned, zero-initialised when a sequence starts (the library keeps no state). */
+typedef struct aoc_seq_state {
+    int64_t initialised, records_frames, ref_pool_key, plan_key, plan_rows;
+} aoc_seq_state;
+int aoc_frame_channels(int n_radii, int n_levels, int matching_background);
+size_t aoc_frame_workspace_bytes(int h, int w, int C, int n_obj, int R_capacity, int n_radii, int n_levels);
+int aoc_frame_enqueue(const aoc_frame_desc *desc, aoc_seq_state *state, void *workspace, size_t workspace_bytes, aoc_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -65,6 +65,11 @@ SIGNATURES = {
     "aoc_dense_prune_stats": (_i, [_vp, _i]),
     "aoc_dense_match_min_split": (_i, [_vp, _vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i64, _i64, _i,
                                        _vp, _sz, _vp]),
+    "aoc_dense_match_min_split_cached": (_i, [_vp, _vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i64, _i64, _i,
+                                              _vp, _sz, _i, _vp]),
+    "aoc_frame_channels": (_i, [_i, _i, _i]),
+    "aoc_frame_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i]),
+    "aoc_frame_enqueue": (_i, [_vp, _vp, _vp, _sz, _vp]),
     "aoc_local_window_match": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp]),
     "aoc_resize_bilinear_hwc": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _vp]),
     "aoc_resize_bilinear_hwc_ex": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _vp]),

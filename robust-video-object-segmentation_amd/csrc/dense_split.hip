@@ -534,7 +534,9 @@ __global__ __launch_bounds__(NW * 64, 1) void dense_prune_kernel(const uint4 *__
 }
 
 // out[i,o] = f( min(own_o, 5e4 + min_{o' != o} own_o') ), own_o = |q_i|^2 - 2^-19 max-accumulator (+inf: no pixel of o)
-__global__ __launch_bounds__(256) void dense_split_finalize_kernel(const uint32_t *__restrict__ gbest, int64_t m, int n_obj,
+// (every word of gbest it reads is zeroed again: a caller that keeps the workspace across the frames of one pool state -- aoc_dense_match_min_split_cached
+// -- starts the next frame without a memset)
+__global__ __launch_bounds__(256) void dense_split_finalize_kernel(uint32_t *__restrict__ gbest, int64_t m, int n_obj,
                                                                     const int32_t *__restrict__ counts, const int32_t *__restrict__ gate,
                                                                     const float *__restrict__ q2, const float *__restrict__ obj_bias,
                                                                     float *__restrict__ out, int64_t pstride, int64_t ostride, int transform) {
@@ -549,6 +551,7 @@ __global__ __launch_bounds__(256) void dense_split_finalize_kernel(const uint32_
         own[o] = INFINITY;
         if (o < n_obj && counts[o] > 0) {
             own[o] = qq + SP_UNSCALE * ord_dec(gbest[(size_t)row * n_obj + o]);
+            gbest[(size_t)row * n_obj + o] = 0u;
             n_kept += counts[o];
         }
     }
@@ -565,6 +568,12 @@ __global__ __launch_bounds__(256) void dense_split_finalize_kernel(const uint32_
             out[row * pstride + o * ostride] = v;
         }
     }
+}
+
+// reused plan (aoc_dense_match_min_split_cached): the plan's gate already holds "a kept row is not one-hot | overflow at plan time"; the
+// overflow word is sticky and may have been raised by a later query
+__global__ void split_gate_refresh_kernel(const int32_t *__restrict__ overflow, int32_t *__restrict__ gate) {
+    if (*overflow) atomicOr(gate, 1);
 }
 
 inline int split_waves() {
@@ -664,6 +673,16 @@ int aoc_dense_match_min_split(const float *query, const void *query_rec, const f
                               const uint32_t *wrong_bits, const int32_t *fg_rows, const int32_t *obj_rows, const int32_t *counts,
                               const int32_t *obj_offsets, const float *obj_bias, int n_obj, float *out, int64_t out_pixel_stride,
                               int64_t out_obj_stride, int transform, void *workspace, size_t workspace_bytes, aoc_stream_t stream) {
+    return aoc_dense_match_min_split_cached(query, query_rec, query_sqnorm, query_rec_tiled, m, C, pool, pool_rec, overflow_flag, n, right_bits, wrong_bits,
+                                            fg_rows, obj_rows, counts, obj_offsets, obj_bias, n_obj, out, out_pixel_stride, out_obj_stride, transform, workspace,
+                                            workspace_bytes, 0, stream);
+}
+
+int aoc_dense_match_min_split_cached(const float *query, const void *query_rec, const float *query_sqnorm, int query_rec_tiled, int64_t m, int C, const float *pool,
+                                     const void *pool_rec, const int32_t *overflow_flag, int64_t n, const uint32_t *right_bits,
+                                     const uint32_t *wrong_bits, const int32_t *fg_rows, const int32_t *obj_rows, const int32_t *counts,
+                                     const int32_t *obj_offsets, const float *obj_bias, int n_obj, float *out, int64_t out_pixel_stride,
+                                     int64_t out_obj_stride, int transform, void *workspace, size_t workspace_bytes, int reuse_plan, aoc_stream_t stream) {
     if (!query || !query_rec || !query_sqnorm || !pool || !pool_rec || !overflow_flag || !right_bits || !wrong_bits || !fg_rows ||
         !obj_rows || !counts || !obj_offsets || !out || !workspace)
         return AOC_ERR_INVALID_ARG;
@@ -672,12 +691,18 @@ int aoc_dense_match_min_split(const float *query, const void *query_rec, const f
     if (workspace_bytes < aoc_dense_match_split_workspace_bytes(m, n, n_obj)) return AOC_ERR_WORKSPACE;
     hipStream_t st = aoc_hip_stream(stream);
     const SplitWs w = split_carve(workspace, m, n, n_obj);
-    if (hipMemsetAsync(w.gate, 0, 16, st) != hipSuccess) return AOC_ERR_LAUNCH;
-    if (hipMemsetAsync(w.gbest, 0, (size_t)m * n_obj * sizeof(uint32_t), st) != hipSuccess) return AOC_ERR_LAUNCH;
-    const int64_t plan_threads = w.tile_capacity * SP_TILE > n ? w.tile_capacity * SP_TILE : n;
-    hipLaunchKernelGGL(split_plan_kernel, dim3((unsigned)((plan_threads + 255) / 256)), dim3(256), 0, st, obj_rows, counts, obj_offsets, n_obj, n,
-                       right_bits, wrong_bits, overflow_flag, static_cast<const uint4 *>(pool_rec), w.tile_capacity, w.tile_rows, w.tile_obj,
-                       w.n_tiles, w.gate, w.pmax);
+    if (reuse_plan) {
+        // same pool rows, labels and records as the call that built the plan in this workspace: tile lists, norm maxima and the one-hot check
+        // stand; gbest was left clean by that call's finalize kernel
+        hipLaunchKernelGGL(split_gate_refresh_kernel, dim3(1), dim3(1), 0, st, overflow_flag, w.gate);
+    } else {
+        if (hipMemsetAsync(w.gate, 0, 16, st) != hipSuccess) return AOC_ERR_LAUNCH;
+        if (hipMemsetAsync(w.gbest, 0, (size_t)m * n_obj * sizeof(uint32_t), st) != hipSuccess) return AOC_ERR_LAUNCH;
+        const int64_t plan_threads = w.tile_capacity * SP_TILE > n ? w.tile_capacity * SP_TILE : n;
+        hipLaunchKernelGGL(split_plan_kernel, dim3((unsigned)((plan_threads + 255) / 256)), dim3(256), 0, st, obj_rows, counts, obj_offsets, n_obj, n,
+                           right_bits, wrong_bits, overflow_flag, static_cast<const uint4 *>(pool_rec), w.tile_capacity, w.tile_rows, w.tile_obj,
+                           w.n_tiles, w.gate, w.pmax);
+    }
     const int ns = split_nsplit(m);
     const int nw = split_waves();
     const int64_t rpb = (int64_t)nw * SP_NQ * 32;

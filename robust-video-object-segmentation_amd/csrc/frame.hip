@@ -1,0 +1,210 @@
+// One frame of the matching path as ONE call: the counterpart of AOCNet.before_seghead_process (aocnet.py:114-372) up to the proto-mask
+// tensor and the attention head, on the caller's stream, out of one caller-owned workspace per sequence.
+//
+// The reference's own entry point for this work is a single Python method call per frame; until round 3 this library was driven through
+// ~60 ctypes calls per frame (argument marshalling, ~40 torch allocations), 2.4-3.4 ms of host time per two-frame step.  aoc_frame_enqueue
+// issues the same kernels the Python orchestrator (hotpath.proto_mask_features) issues, through the same C entry points, so the results
+// are bit-identical by construction (tests/test_gpu_frame.py: torch.equal); what it adds is state kept across the frames of a sequence:
+//   * the fp16 split records of the (append-only) reference pool: only frames that joined since the last call are converted;
+//   * the pooled reference heads (ATT:155-170), a function of the pool alone;
+//   * the dense kernel's plan (object-pure tile lists, norm maxima, one-hot check), also a function of the pool alone: 4 of 5 frames skip
+//     the plan kernel and both memsets (aoc_dense_match_min_split_cached);
+// keyed by desc->pool_key, which the caller changes whenever the pool's content changes.
+//
+// The adaptive proxies of the frame (k-means chain, AEM:252-286) are produced on ANOTHER stream (they only depend on the pool): the caller
+// hands over the proxy table they are written to and two events; this call waits for `prep_ready` before it reads the label prep and for
+// `proxies_ready` in front of the correlation launch.
+#include <algorithm>
+
+#include "aoc_common.h"
+
+namespace {
+
+struct FrameWs {
+    // persistent across the frames of a sequence
+    int32_t *overflow;            // sticky fp16-overflow flag of the split records (zeroed once)
+    char *corr_ws;                // 256-byte flag workspace of the correlation launch (zeroed once)
+    char *pool_rec;               // [R_capacity * hw, 448]
+    float *pool_sq;               // [R_capacity * hw]
+    float *ref_pos, *ref_neg, *ref_sq;
+    char *dense_ws;
+    size_t dense_bytes;
+    // per frame (stream-ordered scratch)
+    float *prev_pos, *prev_neg, *set_bias;
+    char *q_rec;
+    float *q_sq;
+    float *q2, *p2, *pm2, *lf;
+    uint32_t *bits2;
+    char *pool_ws;
+    size_t pool_ws_bytes;
+    size_t total, init_bytes;
+};
+
+inline FrameWs frame_carve(void *base, int h, int w, int C, int n_obj, int R_cap, int n_radii, int n_set) {
+    FrameWs f;
+    char *p = static_cast<char *>(base);
+    size_t off = 0;
+    auto take = [&](size_t bytes) { char *r = p ? p + off : nullptr; off += aoc_align_up(bytes, 256); return r; };
+    const int64_t hw = (int64_t)h * w, n_cap = hw * R_cap;
+    const int H2 = h / 2 + 1, W2 = w / 2 + 1;
+    f.overflow = reinterpret_cast<int32_t *>(take(256));
+    f.corr_ws = take(aoc_proxy_corr_min_batched_workspace_bytes());
+    f.init_bytes = off;                                     // [0, init_bytes) is zeroed when a sequence starts
+    f.pool_rec = take((size_t)n_cap * aoc_split_record_bytes(C));
+    f.pool_sq = reinterpret_cast<float *>(take((size_t)n_cap * sizeof(float)));
+    f.ref_pos = reinterpret_cast<float *>(take((size_t)n_obj * C * sizeof(float)));
+    f.ref_neg = reinterpret_cast<float *>(take((size_t)n_obj * C * sizeof(float)));
+    f.ref_sq = reinterpret_cast<float *>(take((size_t)n_obj * sizeof(float)));
+    f.dense_bytes = aoc_dense_match_split_workspace_bytes(hw, n_cap, n_obj);
+    f.dense_ws = take(f.dense_bytes);
+    f.prev_pos = reinterpret_cast<float *>(take((size_t)n_obj * C * sizeof(float)));
+    f.prev_neg = reinterpret_cast<float *>(take((size_t)n_obj * C * sizeof(float)));
+    f.set_bias = reinterpret_cast<float *>(take((size_t)(n_set > 0 ? n_set : 1) * sizeof(float)));
+    f.q_rec = take(aoc_split_rows_tiled_bytes(hw, C));
+    f.q_sq = reinterpret_cast<float *>(take((size_t)hw * sizeof(float)));
+    const size_t half = (size_t)H2 * W2 * C * sizeof(float);
+    f.q2 = reinterpret_cast<float *>(take(half));
+    f.p2 = reinterpret_cast<float *>(take(half));
+    f.pm2 = reinterpret_cast<float *>(take(half));
+    f.lf = reinterpret_cast<float *>(take((size_t)2 * n_obj * n_radii * H2 * W2 * sizeof(float)));
+    f.bits2 = reinterpret_cast<uint32_t *>(take((size_t)H2 * W2 * sizeof(uint32_t)));
+    f.pool_ws_bytes = std::max(aoc_masked_mean_pool_workspace_bytes(R_cap, hw, n_obj, C), aoc_masked_mean_pool_workspace_bytes(1, hw, n_obj, C));
+    f.pool_ws = take(f.pool_ws_bytes);
+    f.total = off;
+    return f;
+}
+
+inline int frame_sets(const aoc_frame_desc *d) { return 2 * d->n_levels * d->n_obj + d->n_obj; }
+
+}  // namespace
+
+extern "C" {
+
+int aoc_frame_channels(int n_radii, int n_levels, int matching_background) {
+    if (n_radii < 1 || n_levels < 1) return 0;
+    return 2 + 2 * n_levels + 2 * n_radii + 1 + (matching_background ? n_radii + 1 : 0);       // aocnet.py:43-46 (+ 2 per further level)
+}
+
+size_t aoc_frame_workspace_bytes(int h, int w, int C, int n_obj, int R_capacity, int n_radii, int n_levels) {
+    if (h < 1 || w < 1 || C < 1 || n_obj < 1 || R_capacity < 1 || n_radii < 1 || n_levels < 1) return 0;
+    if (aoc_split_record_bytes(C) == 0) return 0;
+    return frame_carve(nullptr, h, w, C, n_obj, R_capacity, n_radii, 2 * n_levels * n_obj + n_obj).total;
+}
+
+int aoc_frame_enqueue(const aoc_frame_desc *d, aoc_seq_state *state, void *workspace, size_t workspace_bytes, aoc_stream_t stream) {
+    if (!d || !state || !workspace) return AOC_ERR_INVALID_ARG;
+    if (!d->ref_emb || !d->ref_labels || !d->prev_emb || !d->prev_labels || !d->cur_emb || !d->dis_bias || !d->right_bits || !d->wrong_bits ||
+        !d->fg_rows || !d->obj_rows || !d->counts || !d->obj_offsets || !d->proxy_table || !d->proxy_sqnorm || !d->feat || !d->head)
+        return AOC_ERR_INVALID_ARG;
+    if (d->h < 1 || d->w < 1 || d->n_obj < 1 || d->R < 1 || d->R > d->R_capacity || d->n_radii < 1 || d->n_radii > 8 || d->n_levels < 1 ||
+        d->n_levels > 8 || d->kmax < 1 || d->pool_key == 0)
+        return AOC_ERR_INVALID_ARG;
+    // the configuration this call covers (everything else goes through the individual entry points): C = 100 split records, <= 16 objects,
+    // half-resolution local matching (MODEL_LOCAL_DOWNSAMPLE), fp32 matching
+    if (d->C != 100 || d->n_obj > 16 || aoc_split_record_bytes(d->C) == 0) return AOC_ERR_UNSUPPORTED;
+    const int h = d->h, w = d->w, C = d->C, O = d->n_obj, R = d->R, nl = d->n_radii, L = d->n_levels, kmax = d->kmax;
+    const int64_t hw = (int64_t)h * w, n = hw * R;
+    const int n_set = frame_sets(d);
+    const int n_ad = L * O * 2 * kmax;
+    if (d->n_adaptive != n_ad) return AOC_ERR_INVALID_ARG;
+    if (workspace_bytes < aoc_frame_workspace_bytes(h, w, C, O, d->R_capacity, nl, L)) return AOC_ERR_WORKSPACE;
+    const FrameWs f = frame_carve(workspace, h, w, C, O, d->R_capacity, nl, n_set);
+    hipStream_t st = aoc_hip_stream(stream);
+    const int H2 = h / 2 + 1, W2 = w / 2 + 1;
+    const int n_ch = aoc_frame_channels(nl, L, d->matching_background);
+    const int64_t obj_stride = (int64_t)n_ch * hw;
+    // channel layout, aocnet.py:355-358
+    const int c2 = 2 * L;
+    const int ch_global = 0, ch_cluster = 1, ch_proxy = 1 + c2, ch_local = 2 + c2, ch_local_proxy = 2 + c2 + nl, ch_prev = 2 + c2 + 2 * nl;
+    const int ch_local_bg = d->matching_background ? 3 + c2 + 2 * nl : -1, ch_global_bg = d->matching_background ? 3 + c2 + 3 * nl : -1;
+    int rc;
+#define AOC_TRY(call) do { rc = (call); if (rc != AOC_OK) return rc; } while (0)
+    auto mark = [&](int i) { if (d->probe[i]) (void)hipEventRecord(static_cast<hipEvent_t>(d->probe[i]), st); };
+
+    if (!state->initialised) {
+        if (hipMemsetAsync(workspace, 0, f.init_bytes, st) != hipSuccess) return AOC_ERR_LAUNCH;
+        state->initialised = 1;
+        state->records_frames = 0;
+        state->ref_pool_key = 0;
+        state->plan_key = 0;
+    }
+    if (d->prep_ready && hipStreamWaitEvent(st, static_cast<hipEvent_t>(d->prep_ready), 0) != hipSuccess) return AOC_ERR_LAUNCH;
+
+    // ---- k = 1 proxies (ATT:155-189): the pooled reference heads once per pool state, the previous frame's every frame
+    if (state->ref_pool_key != d->pool_key) {
+        AOC_TRY(aoc_masked_mean_pool(d->ref_emb, d->ref_labels, R, hw, C, O, 1, d->epsilon, f.ref_pos, f.ref_neg, f.ref_sq, f.pool_ws, f.pool_ws_bytes, stream));
+        state->ref_pool_key = d->pool_key;
+    }
+    AOC_TRY(aoc_masked_mean_pool(d->prev_emb, d->prev_labels, 1, hw, C, O, 1, d->epsilon, f.prev_pos, f.prev_neg, nullptr, f.pool_ws, f.pool_ws_bytes, stream));
+
+    // ---- half-resolution operands of the local matchings + the per-set bias table + the k = 1 rows of this frame's proxy table
+    AOC_TRY(aoc_local_prep(d->cur_emb, d->prev_emb, d->prev_labels, f.prev_pos, h, w, C, O, f.q2, f.p2, f.pm2, f.bits2, H2, W2, d->dis_bias, 2 * L * O,
+                           f.set_bias, f.ref_pos, d->proxy_table + (size_t)n_ad * C, O * C, f.ref_sq, d->proxy_sqnorm + n_ad, O, stream));
+
+    // ---- split records: pool frames that joined since the last call, and the query (tile-major)
+    if (state->records_frames > R) state->records_frames = 0;             // the pool restarted: the caller should have reset the state
+    if (state->records_frames < R) {
+        const int64_t r0 = state->records_frames * hw;
+        AOC_TRY(aoc_split_rows(d->ref_emb + (size_t)r0 * C, n - r0, C, f.pool_rec + (size_t)r0 * aoc_split_record_bytes(C), f.pool_sq + r0, f.overflow, stream));
+        state->records_frames = R;
+    }
+    AOC_TRY(aoc_split_rows_tiled(d->cur_emb, hw, C, f.q_rec, f.q_sq, f.overflow, stream));
+
+    // ---- dense pixel-level matching -> channel 0 (the plan is kept across the frames of one pool state)
+    {
+        const int reuse = state->plan_key == d->pool_key && state->plan_rows == n;
+        mark(0);
+        AOC_TRY(aoc_dense_match_min_split_cached(d->cur_emb, f.q_rec, f.q_sq, 1, hw, C, d->ref_emb, f.pool_rec, f.overflow, n, d->right_bits, d->wrong_bits,
+                                                 d->fg_rows, d->obj_rows, d->counts, d->obj_offsets, d->dis_bias, O, d->feat + (size_t)ch_global * hw, 1,
+                                                 obj_stride, 1, f.dense_ws, f.dense_bytes, reuse, stream));
+        mark(1);
+        state->plan_key = d->pool_key;
+        state->plan_rows = n;
+    }
+
+    // ---- both local matchings and their up-samples into the two channel ranges
+    mark(4);
+    AOC_TRY(aoc_local_window_match_pair(f.q2, f.p2, f.pm2, f.bits2, H2, W2, C, d->radii, nl, d->dis_bias, O, f.lf, f.lf + (size_t)O * nl * H2 * W2, 1, stream));
+    mark(5);
+    AOC_TRY(aoc_resize_bilinear_planes_grouped(f.lf, 2 * O * nl, H2, W2, d->feat + (size_t)ch_local * hw, h, w, nl, O, (int64_t)(ch_local_proxy - ch_local) * hw,
+                                               obj_stride, hw, 1, stream));
+
+    // ---- one correlation launch: cluster sets (2 per object and level) + the k = 1 set of every object
+    {
+        int32_t sb[2 * 8 * 16 + 16], ss[2 * 8 * 16 + 16];
+        int64_t so[2 * 8 * 16 + 16];
+        int s = 0;
+        for (int l = 0; l < L; ++l)
+            for (int o = 0; o < O; ++o)
+                for (int t = 0; t < 2; ++t, ++s) {
+                    sb[s] = ((l * O + o) * 2 + t) * kmax;
+                    ss[s] = d->levels[l];                                   // slots beyond the sticky K carry norm = +inf
+                    so[s] = (int64_t)o * obj_stride + (int64_t)(ch_cluster + 2 * l + t) * hw;
+                }
+        for (int o = 0; o < O; ++o, ++s) {
+            sb[s] = n_ad + o;
+            ss[s] = 1;
+            so[s] = (int64_t)o * obj_stride + (int64_t)ch_proxy * hw;
+        }
+        if (d->proxies_ready && hipStreamWaitEvent(st, static_cast<hipEvent_t>(d->proxies_ready), 0) != hipSuccess) return AOC_ERR_LAUNCH;
+        aoc_corr_frame_rec fr;
+        fr.query = d->cur_emb;
+        fr.query_rec = f.q_rec;
+        fr.query_sqnorm = f.q_sq;
+        fr.proxies = d->proxy_table;
+        fr.proxy_sqnorm = d->proxy_sqnorm;
+        fr.set_bias = f.set_bias;
+        fr.out = d->feat;
+        mark(2);
+        AOC_TRY(aoc_proxy_corr_min_records(&fr, 1, hw, C, n_ad + O, n_set, sb, ss, so, 1, f.corr_ws, aoc_proxy_corr_min_batched_workspace_bytes(), stream));
+        mark(3);
+    }
+
+    // ---- background maps, previous-mask channel, attention head
+    AOC_TRY(aoc_proto_finish(d->feat, O, hw, obj_stride, ch_local, nl, ch_local_bg, ch_global, ch_global_bg, ch_prev, d->prev_labels, f.ref_pos, f.ref_neg,
+                             f.prev_pos, f.prev_neg, C, d->head, stream));
+#undef AOC_TRY
+    return AOC_OK;
+}
+
+}  // extern "C"

@@ -76,6 +76,7 @@ class HotPathBackend:
         self.device = device
         self.dense_precision = dense_precision
         self._heads = {}
+        self._runners = {}
         self.ahead = bool(ahead)               # False: the per-frame reference-API path (label prep + count read-back + chain on the frame's stream)
         import os
         self.chain_plan = [int(x) for x in os.environ.get("AOC_EVAL_CHAIN_PLAN", "1").split(",") if x.strip()] or [1]   # developer switch
@@ -108,6 +109,15 @@ class HotPathBackend:
         self._pool_lab = torch.empty(cap, spec.h, spec.w, spec.n_obj, dtype=torch.float32, device=self.device)
         self._pool_R = 0
         self._ahead = []
+        # ONE C call per frame (aoc_frame_enqueue) where the configuration allows: its workspace is kept per map size / object count
+        self.runner = None
+        if self.ahead and self.dense_precision in (None, "split") and self.hot.FrameRunner.supported(self.mc, 100, spec.n_obj):
+            wcap = (cap + 3) // 4 * 4                      # few distinct workspace sizes per lane
+            key = (spec.h, spec.w, spec.n_obj, tuple(spec.levels), wcap)
+            if key not in self._runners:
+                self._runners[key] = self.hot.FrameRunner(self.mc, spec.h, spec.w, 100, spec.n_obj, wcap, self.device)
+            self.runner = self._runners[key]
+            self.runner.reset()
         if self.ahead and self.side is None:
             self.side = torch.cuda.Stream(self.device, priority=-1)
 
@@ -176,8 +186,11 @@ class HotPathBackend:
         if self.ahead and (changed or not self._ahead):
             self._launch_ahead(ref_emb, ref_lab)
         ahead = self._ahead.pop(0) if self._ahead else None
-        feat, _, _ = self.hot.proto_mask_features(self.mc, ref_emb, ref_lab, prev_emb, prev_lab, emb, self.bias, dense_precision=self.dense_precision,
-                                                  dense_state=self.dense_state, rng=self.rng, cluster_ahead=ahead)
+        if self.runner is not None and ahead is not None and ref_emb.shape[0] <= self.runner.call.cap:
+            feat, _ = self.runner(ref_emb, ref_lab, prev_emb, prev_lab, emb, self.bias, ahead, pool_key=ref_emb.shape[0])
+        else:
+            feat, _, _ = self.hot.proto_mask_features(self.mc, ref_emb, ref_lab, prev_emb, prev_lab, emb, self.bias, dense_precision=self.dense_precision,
+                                                      dense_state=self.dense_state, rng=self.rng, cluster_ahead=ahead)
         pre, wv = self._head(feat.shape[1])
         y = pre(feat)                                                          # [O, 64, h, w]
         ch = self.hot.channel_slices(self.mc)

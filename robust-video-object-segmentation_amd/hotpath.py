@@ -447,6 +447,43 @@ def proto_mask_features(cfg, ref_emb, ref_labels, prev_emb, prev_labels, cur_emb
     return feat, attention_head, dict(cluster=cp, prev_pos=prev_pos, ref_pos=ref_pos, pending_correlation=pending)
 
 
+class FrameRunner:
+    """The frames of ONE sequence through aoc_frame_enqueue (one C call per frame: the counterpart of the single before_seghead_process call of
+    aocnet.py:114): same arguments as proto_mask_features with ``cluster_ahead`` (the adaptive proxies come from launch_cluster_proxies[_batch]
+    on a side stream), same results bit for bit.  Owns the sequence's device workspace (split records of the pool, pooled reference heads and
+    the dense kernel's plan are kept across frames); ``reset()`` when a new sequence starts in it."""
+
+    def __init__(self, cfg, h, w, C, n_obj, capacity_frames, device):
+        if not FrameRunner.supported(cfg, C, n_obj):
+            raise NotImplementedError("aoc_frame_enqueue does not cover this configuration: use proto_mask_features")
+        self.cfg = cfg
+        self.call = ops.FrameCall(h, w, C, n_obj, capacity_frames, cfg.MODEL_MULTI_LOCAL_DISTANCE, cfg.cluster_levels, cfg.MODEL_MATCHING_BACKGROUND,
+                                  cfg.MODEL_EPSILON, device)
+
+    @staticmethod
+    def supported(cfg, C, n_obj):
+        return ops.FrameCall.supported(C, n_obj, cfg.MODEL_LOCAL_DOWNSAMPLE, cfg.MODEL_FLOAT16_MATCHING, len(cfg.MODEL_MULTI_LOCAL_DISTANCE), len(cfg.cluster_levels))
+
+    def reset(self):
+        self.call.reset()
+
+    def pool_changed(self, valid_frames):
+        """The pool's content beyond its first `valid_frames` frames was replaced (a benchmark that revisits pool states): their split records are
+        converted again by the next frame.  An append-only pool never needs this."""
+        st = self.call.state
+        st.records_frames = min(int(st.records_frames), int(valid_frames))
+
+    def __call__(self, ref_emb, ref_labels, prev_emb, prev_labels, cur_emb, dis_bias, cluster_ahead, pool_key=None, probes=None):
+        a = cluster_ahead
+        assert a is not None and a.cluster_sets is None and a.R == ref_emb.shape[0], "FrameRunner takes the ClusterProxiesAhead of this frame's pool"
+        O = ref_labels.shape[-1]
+        bias = _bias_vec(dis_bias, O, cur_emb.device)
+        main = torch.cuda.current_stream()
+        for t in (a.table, a.sqn, a.prep.right_bits, a.prep.wrong_bits, a.prep.fg_rows, a.prep.obj_rows, a.prep.counts, a.prep.obj_offsets):
+            t.record_stream(main)
+        return self.call(ref_emb, ref_labels, prev_emb, prev_labels, cur_emb, bias, a.prep, a.table, a.sqn, a.prep_event, a.done_event, pool_key, probes)
+
+
 class DynamicPreHead(nn.Module):
     """decoding_module.py:228-240 (1x1 conv -> GroupNorm(embed_dim / 4) -> ReLU) on the HIP library, with the reference's
     parameter names (``conv``, ``bn``).  ``forward(x)`` mirrors the reference; ``forward(x, cur_emb)`` also performs the

@@ -541,6 +541,90 @@ def proto_finish(feat, hw, obj_stride, ch_local, n_local, ch_local_bg, ch_global
     return head
 
 
+class _FrameDesc(ctypes.Structure):
+    """aoc_frame_desc of include/aoc_hip.h."""
+    _fields_ = [("h", ctypes.c_int32), ("w", ctypes.c_int32), ("C", ctypes.c_int32), ("n_obj", ctypes.c_int32),
+                ("R", ctypes.c_int32), ("R_capacity", ctypes.c_int32),
+                ("n_radii", ctypes.c_int32), ("radii", ctypes.c_int32 * 8),
+                ("n_levels", ctypes.c_int32), ("levels", ctypes.c_int32 * 8),
+                ("kmax", ctypes.c_int32), ("matching_background", ctypes.c_int32), ("n_adaptive", ctypes.c_int32), ("epsilon", ctypes.c_float),
+                ("pool_key", ctypes.c_int64),
+                ("ref_emb", ctypes.c_void_p), ("ref_labels", ctypes.c_void_p), ("prev_emb", ctypes.c_void_p), ("prev_labels", ctypes.c_void_p),
+                ("cur_emb", ctypes.c_void_p), ("dis_bias", ctypes.c_void_p),
+                ("right_bits", ctypes.c_void_p), ("wrong_bits", ctypes.c_void_p), ("fg_rows", ctypes.c_void_p), ("obj_rows", ctypes.c_void_p),
+                ("counts", ctypes.c_void_p), ("obj_offsets", ctypes.c_void_p),
+                ("proxy_table", ctypes.c_void_p), ("proxy_sqnorm", ctypes.c_void_p), ("prep_ready", ctypes.c_void_p), ("proxies_ready", ctypes.c_void_p),
+                ("feat", ctypes.c_void_p), ("head", ctypes.c_void_p), ("probe", ctypes.c_void_p * 6)]
+
+
+class _SeqState(ctypes.Structure):
+    """aoc_seq_state of include/aoc_hip.h."""
+    _fields_ = [("initialised", ctypes.c_int64), ("records_frames", ctypes.c_int64), ("ref_pool_key", ctypes.c_int64), ("plan_key", ctypes.c_int64),
+                ("plan_rows", ctypes.c_int64)]
+
+
+class FrameCall:
+    """aoc_frame_enqueue for the frames of ONE sequence: owns the sequence's device workspace and host state record.
+    supported(...) says whether the one-call path covers a configuration (otherwise hotpath.proto_mask_features drives the individual calls)."""
+
+    @staticmethod
+    def supported(C, n_obj, local_downsample, float16_matching, n_radii, n_levels):
+        return C == 100 and n_obj <= 16 and bool(local_downsample) and not float16_matching and n_radii <= 8 and n_levels <= 8 and DENSE_PRECISION == "split"
+
+    def __init__(self, h, w, C, n_obj, capacity_frames, radii, levels, matching_background, epsilon, device):
+        L = _lib.lib()
+        self.h, self.w, self.C, self.n_obj, self.cap = int(h), int(w), int(C), int(n_obj), int(capacity_frames)
+        self.n_ch = int(L.aoc_frame_channels(len(radii), len(levels), int(bool(matching_background))))
+        nbytes = int(L.aoc_frame_workspace_bytes(self.h, self.w, self.C, self.n_obj, self.cap, len(radii), len(levels)))
+        if nbytes == 0:
+            raise _lib.AocHipError("aoc_frame_workspace_bytes: unsupported configuration")
+        self.ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        self.state = _SeqState()
+        d = self.desc = _FrameDesc()
+        d.h, d.w, d.C, d.n_obj, d.R_capacity = self.h, self.w, self.C, self.n_obj, self.cap
+        d.n_radii, d.n_levels, d.kmax = len(radii), len(levels), max(levels)
+        for i, r in enumerate(radii):
+            d.radii[i] = int(r)
+        for i, k in enumerate(levels):
+            d.levels[i] = int(k)
+        d.matching_background = int(bool(matching_background))
+        d.n_adaptive = len(levels) * self.n_obj * 2 * max(levels)
+        d.epsilon = float(epsilon)
+        self.device = device
+
+    def reset(self):
+        """A new sequence starts in this workspace (eval_manager_mm.py:376-382)."""
+        ctypes.memset(ctypes.byref(self.state), 0, ctypes.sizeof(self.state))
+
+    def __call__(self, ref_emb, ref_labels, prev_emb, prev_labels, cur_emb, dis_bias, prep, table, sqn, prep_event=None, done_event=None, pool_key=None,
+                 probes=None):
+        """ref_emb [R, h, w, C] / ref_labels [R, h, w, O] contiguous fp32 views of the resident pool; prep = LabelPrep of ref_labels; table / sqn = this
+        frame's proxy table (adaptive rows written by the k-means chain).  Returns (feat [O, n_ch, h, w], head [O, 4C])."""
+        _need_gpu(ref_emb, ref_labels, prev_emb, prev_labels, cur_emb, dis_bias, table, sqn)
+        for t in (ref_emb, ref_labels, prev_emb, prev_labels, cur_emb, dis_bias, table, sqn):
+            assert t.dtype == torch.float32 and t.is_contiguous(), "aoc_frame_enqueue takes contiguous float32 tensors"
+        R = ref_emb.shape[0]
+        d = self.desc
+        assert R <= self.cap and tuple(cur_emb.shape) == (self.h, self.w, self.C) and ref_labels.shape[-1] == self.n_obj and dis_bias.numel() == self.n_obj
+        assert table.shape[0] == d.n_adaptive + self.n_obj and prep.n == R * self.h * self.w
+        feat = torch.empty(self.n_obj, self.n_ch, self.h, self.w, dtype=torch.float32, device=self.device)
+        head = torch.empty(self.n_obj, 4 * self.C, dtype=torch.float32, device=self.device)
+        d.R = R
+        d.pool_key = int(R if pool_key is None else pool_key)
+        d.ref_emb, d.ref_labels, d.prev_emb, d.prev_labels, d.cur_emb = ref_emb.data_ptr(), ref_labels.data_ptr(), prev_emb.data_ptr(), prev_labels.data_ptr(), cur_emb.data_ptr()
+        d.dis_bias = dis_bias.data_ptr()
+        d.right_bits, d.wrong_bits, d.fg_rows, d.obj_rows = prep.right_bits.data_ptr(), prep.wrong_bits.data_ptr(), prep.fg_rows.data_ptr(), prep.obj_rows.data_ptr()
+        d.counts, d.obj_offsets = prep.counts.data_ptr(), prep.obj_offsets.data_ptr()
+        d.proxy_table, d.proxy_sqnorm = table.data_ptr(), sqn.data_ptr()
+        d.prep_ready = prep_event.cuda_event if prep_event is not None else None
+        d.proxies_ready = done_event.cuda_event if done_event is not None else None
+        d.feat, d.head = feat.data_ptr(), head.data_ptr()
+        for i in range(6):                      # measurement only: raw hipEvent_t handles (bench.py)
+            d.probe[i] = probes[i] if probes is not None else None
+        _lib.check(_lib.lib().aoc_frame_enqueue(ctypes.byref(d), ctypes.byref(self.state), _p(self.ws), self.ws.numel(), _stream()), "aoc_frame_enqueue")
+        return feat, head
+
+
 # ------------------------------------------------------------------------------------------ calibration side
 def fg2bg_min(dis, n_obj, out=None, dis_obj_stride=None, out_obj_stride=None, n_ch=None, inner=None):
     """dis [O, c, ...] -> [O, 1, ...]: min over the other objects and over dim 1 (AEM:18-20).

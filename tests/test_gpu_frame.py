@@ -1,0 +1,97 @@
+"""aoc_frame_enqueue (ONE C call per frame, include/aoc_hip.h; hotpath.FrameRunner) against the Python-orchestrated path
+(hotpath.proto_mask_features driving the individual entry points): the same kernels out of one persistent workspace per sequence, so the
+proto-mask tensor and the attention head must be EQUAL bit for bit -- over a sequence whose pool grows (split records appended, pooled
+reference heads and the dense plan rebuilt exactly when the pool changes), with the k-means chains on a side stream."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def aoc():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    import aoc_amd
+    aoc_amd._lib.lib()
+    return aoc_amd
+
+
+def _init_rows_dev(syn, seed, counts, levels, n_obj):
+    kmax = max(levels)
+    rows = np.zeros((len(levels) * n_obj, kmax), np.int32)
+    for li, k in enumerate(levels):
+        for o, r in enumerate(syn.kmeans_init_rows(seed + li, counts, k)):
+            if r is not None:
+                rows[li * n_obj + o, :len(r)] = r
+    return torch.from_numpy(rows).cuda()
+
+
+@pytest.mark.parametrize("cfg_name,levels,background", [("tiny", None, True), ("tiny", [8, 16, 32], True), ("tiny", None, False), ("cfg1", None, True)])
+def test_frame_call_equals_python_orchestration(aoc, cfg_name, levels, background):
+    syn, hot = aoc.synthetic, aoc.hotpath
+    cfg = syn.CONFIGS[cfg_name]
+    T = 9 if cfg_name == "tiny" else 4
+    clip = syn.make_clip(cfg, 21, frames=T)
+    O, h, w, C = cfg.n_obj, cfg.h, cfg.w, cfg.c
+    mc = hot.MatchingConfig(CLUSTER_LEVELS=levels, MODEL_MATCHING_BACKGROUND=background, MEM_EVERY=3)
+    emb = torch.from_numpy(clip["emb"]).cuda()
+    lab = torch.from_numpy(np.stack([syn.one_hot(l, O) for l in clip["lab"]])).cuda()
+    bias = torch.tensor([0.25, -0.5, 0.125, 0.0, 0.3, -0.1][:O]).cuda()
+    assert hot.FrameRunner.supported(mc, C, O)
+    runner = hot.FrameRunner(mc, h, w, C, O, capacity_frames=4, device=emb.device)
+    side = torch.cuda.Stream()
+    dense_state = {}
+    pool_ids = [0]
+    for t in range(1, T):
+        ref_emb, ref_lab = emb[pool_ids].contiguous(), lab[pool_ids].contiguous()
+        counts = [int(ref_lab[..., o].sum().item()) for o in range(O)]
+        init = _init_rows_dev(syn, 100 + t, counts, mc.cluster_levels, O)
+        ahead = hot.launch_cluster_proxies(mc, ref_emb, ref_lab, init, side)
+        feat_c, head_c = runner(ref_emb, ref_lab, emb[t - 1], lab[t - 1], emb[t], bias, ahead)
+        feat_c, head_c = feat_c.clone(), head_c.clone()
+        feat_p, head_p, _ = hot.proto_mask_features(mc, ref_emb, ref_lab, emb[t - 1], lab[t - 1], emb[t], bias, cluster_ahead=ahead, dense_state=dense_state)
+        torch.cuda.synchronize()
+        assert feat_c.shape == feat_p.shape == (O, mc.proto_channels, h, w)
+        assert torch.equal(feat_c, feat_p), f"frame {t}: proto-mask tensor differs (max {float((feat_c - feat_p).abs().max())})"
+        assert torch.equal(head_c, head_p), f"frame {t}: attention head differs"
+        if t % 3 == 0 and len(pool_ids) < 4:
+            pool_ids.append(t)                      # the pool grows: new split records, new pooled heads, new dense plan
+    assert len(pool_ids) >= 3 or cfg_name != "tiny"
+    # a second sequence in the same workspace
+    runner.reset()
+    ref_emb, ref_lab = emb[[2]].contiguous(), lab[[2]].contiguous()
+    counts = [int(ref_lab[..., o].sum().item()) for o in range(O)]
+    ahead = hot.launch_cluster_proxies(mc, ref_emb, ref_lab, _init_rows_dev(syn, 7, counts, mc.cluster_levels, O), side)
+    feat_c, head_c = runner(ref_emb, ref_lab, emb[2], lab[2], emb[3], bias, ahead)
+    feat_p, head_p, _ = hot.proto_mask_features(mc, ref_emb, ref_lab, emb[2], lab[2], emb[3], bias, cluster_ahead=ahead)
+    assert torch.equal(feat_c, feat_p) and torch.equal(head_c, head_p)
+
+
+def test_frame_call_vs_reference_golden(aoc, golden):
+    """The one-call path against the tensors the reference's own before_seghead_process produced (tests/golden/make_golden_r4.py)."""
+    from golden_cases import FRAME_CASES
+    hot, ops = aoc.hotpath, aoc.ops
+    for name in FRAME_CASES:
+        g = golden(name)
+        n_obj = int(g["n_obj"])
+        h, w = g["in_cur"].shape[:2]
+        mc = hot.MatchingConfig(MODEL_MATCHING_BACKGROUND=bool(g["background"]))
+        dev = lambda a, dt=None: (torch.from_numpy(np.ascontiguousarray(a)) if dt is None else torch.from_numpy(np.ascontiguousarray(a)).to(dt)).cuda()
+        ref_lab = torch.stack([ops.label_onehot_nearest(dev(l, torch.int32), h, w, n_obj) for l in g["ref_labels_full"]])
+        prev_lab = ops.label_onehot_nearest(dev(g["prev_label_full"], torch.int32), h, w, n_obj)
+        ref_emb = dev(g["in_ref"])
+        # the initial rows scipy drew in the reference run (recorded per kmeans2 call, one per object)
+        rows = np.zeros((n_obj, 16), np.int32)
+        for i in range(int(g["km_calls"])):
+            r = g[f"km{i}_rows"]
+            rows[i, :len(r)] = r
+        assert int(g["km_calls"]) == n_obj
+        ahead = hot.launch_cluster_proxies(mc, ref_emb, ref_lab, torch.from_numpy(rows).cuda())
+        runner = hot.FrameRunner(mc, h, w, 100, n_obj, ref_emb.shape[0], ref_emb.device)
+        b = torch.full((n_obj,), float(g["fg_bias"]))
+        b[0] = float(g["bg_bias"])
+        feat, head = runner(ref_emb, ref_lab, dev(g["in_prev"]), prev_lab, dev(g["in_cur"]), b.cuda(), ahead)
+        np.testing.assert_allclose(feat.cpu().numpy(), g["pre_to_cat"], rtol=0, atol=5e-6)
+        np.testing.assert_allclose(head.cpu().numpy(), g["attention_head"], rtol=1e-5, atol=1e-6)
