@@ -475,7 +475,7 @@ def _block_weights(mod):
             "mlp_w": sd["mlp_layer.weight"], "mlp_b": sd["mlp_layer.bias"]}
 
 
-DENSE_SUBSAMPLE = 16
+DENSE_SUBSAMPLE = 1              # --cpu-dense-subsample
 CPU_BASELINE_R = 6             # pool frames of the CPU sample: the clip's average is 6.4
 
 
@@ -564,7 +564,9 @@ def cpu_baseline(cfg, mc, seed, gates, acts_cpu):
 
 # HBM-side traffic of the correlation kernel from committed rocprofv3 --pmc passes (separate FETCH_SIZE / WRITE_SIZE runs, FETCH doubled per the
 # gfx950 note of the micro-architecture guide); counters cannot be read inside the timed run
-TRAFFIC_OFFLINE = dict(file="profiles/r03_pmc_corr_records_B16.txt", commit="see `git log -1 -- profiles/r03_pmc_corr_records_B16.txt`",
+
+
+TRAFFIC_OFFLINE = dict(file="profiles/r03_pmc_corr_records_B16.txt", commit="4c8b1fb", source="constants copied from the committed file, not measured in this run",
                        kernel="proxy_corr_records_kernel", frames_per_launch=16, fetch_bytes=2 * 91.63e6, write_bytes=20.7e6,
                        bytes_per_launch=204.0e6, algorithmic_bytes_per_launch=185.6e6, ratio=1.10,
                        note="cfg2, 16 frames per launch: FETCH_SIZE x 2 (gfx950 counts 128-byte requests as 64) + WRITE_SIZE; the kernel reads the "
@@ -611,6 +613,17 @@ def correlation_roofline(cfg, mc, dev, batches=(1, 4, 16, 32), reps=20):
         frames.append((q, table, table.pow(2).sum(1), torch.zeros(n_set, device=dev), torch.empty(O, mc.proto_channels, cfg.h, cfg.w, device=dev)))
     algo = hw * C * 4 + (n_ad + O) * C * 4 + 4 * hw * n_set
     splits = [ops.split_rows(f[0], tiled=True) for f in frames]           # what the product path has made for the dense kernel anyway
+    # the conversion of one frame's query into tile-major split records (aoc_split_rows_tiled): shared with the dense kernel in the product, i.e.
+    # outside the correlation launch; timed here so that the line can also state the bracket that includes it
+    e0 = [torch.cuda.Event(enable_timing=True) for _ in range(reps)]
+    e1 = [torch.cuda.Event(enable_timing=True) for _ in range(reps)]
+    torch.cuda.synchronize()
+    for i in range(reps):
+        e0[i].record()
+        ops.split_rows(frames[0][0], tiled=True)
+        e1[i].record()
+    torch.cuda.synchronize()
+    split_ms = float(np.median([e0[i].elapsed_time(e1[i]) for i in range(reps)]))
     out = []
     for b in batches:
         launch = ops.proxy_corr_min_records([(f[0], sp, f[1], f[2], f[3], f[4]) for f, sp in zip(frames[:b], splits)], sb, ss, so, True,
@@ -628,7 +641,8 @@ def correlation_roofline(cfg, mc, dev, batches=(1, 4, 16, 32), reps=20):
         ms = float(np.median([ev0[i].elapsed_time(ev1[i]) for i in range(reps)]))
         gbs = b * algo / (ms * 1e-3) / 1e9
         out.append(dict(frames_per_launch=b, avg_launch_ms=round(ms, 4), algorithmic_bytes_per_launch=b * algo, achieved=round(gbs, 1),
-                        frac=round(gbs / PEAK_HBM_GBS, 4)))
+                        frac=round(gbs / PEAK_HBM_GBS, 4), query_split_ms_per_frame=round(split_ms, 4),
+                        frac_including_query_split=round(b * algo / ((ms + b * split_ms) * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)))
     return out
 
 
@@ -642,6 +656,9 @@ def main():
     ap.add_argument("--dense", default="split", choices=["split", "fp32"],
                     help="dense-matching arithmetic: fp16-split products with fp32 accumulate (fp32-equivalent) or exact-fp32 MFMA")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-dense-subsample", type=int, default=1,
+                    help="cpu_baseline: time the dense branch of the oracle on every N-th query pixel and scale by N (default 1 = the whole frame, ~22 s "
+                         "on 32 threads; rounds 1-3 used 16)")
     ap.add_argument("--exact-steps", type=int, default=10,
                     help="steps of the informational second region with the exact-fp32 dense kernel (reported as exact_fp32_dense_run; 0 = skip)")
     ap.add_argument("--cu-reserve", type=int, default=32,
@@ -694,6 +711,8 @@ def main():
                          "end of round 3: 2 / 3 / 4 / 5 / 6 / 8 / 10 lanes = 226 / 241 / 245-251 / 242 / 239 / 234 / 225 frames/s; with the slower "
                          "kernels of the round's first half six lanes were best: 158 / 165 / 174 / 176 / 181 / 174 / 176)")
     args = ap.parse_args()
+    global DENSE_SUBSAMPLE
+    DENSE_SUBSAMPLE = max(1, args.cpu_dense_subsample)
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # one process per GPU over RCCL: re-launch under torch.distributed.run
@@ -1032,7 +1051,7 @@ def main():
                            avg_launch_ms=km["avg_ms"], algorithmic_bytes_per_launch=km["avg_bytes"],
                            note="a dependent chain of ~120 launches whose ordered float32 sums are latency-bound by construction; the in-run "
                                 "figure spans the time the chain shares the GPU with the other streams",
-                           traffic_offline=dict(file="profiles/r03_pmc_kmeans_R6_F3.txt", commit="see `git log -1 -- profiles/r03_pmc_kmeans_R6_F3.txt`",
+                           traffic_offline=dict(file="profiles/r03_pmc_kmeans_R6_F3.txt", commit="5fc6454", source="constants copied from the committed file, not measured in this run",
                                                 workload="three frames per chain, R = 6 pool frames (61.9 MB of pool rows), per Lloyd iteration",
                                                 fetch_bytes_per_iteration=368.0e6, rows_bytes=61.9e6, reads_per_frame_and_iteration=round(368.0 / 3 / 61.9, 2),
                                                 note="FETCH_SIZE x 2 (gfx950 counts 128-byte requests as 64) summed over the six kernels of an iteration: "
@@ -1052,7 +1071,7 @@ def main():
         cond_roof = hbm_roof("cond_gate_pool", "cond_scores / cond_kth_largest / cond_masked_gap (aoc_cond_gate_pool)",
                              "in-run average over the 4 conditioning blocks; algorithmic bytes O C H W 4 = ONE read of z (SURVEY 8d); the op reads z twice "
                              "(scores, masked pooling) around the exact k-th-largest selection")
-        calib_pmc = dict(file="profiles/r03_pmc_calibration_cfg2.txt", commit="see `git log -1 -- profiles/r03_pmc_calibration_cfg2.txt`")
+        calib_pmc = dict(file="profiles/r03_pmc_calibration_cfg2.txt", commit="3c2da86", source="constants copied from the committed file, not measured in this run")
         if film_roof is not None:
             film_roof["traffic_offline"] = dict(calib_pmc, shape=[4, 256, 121, 213], algorithmic_bytes=211.1e6, fetch_bytes=121.8e6, write_bytes=105.8e6, ratio=1.08,
                                                 note="the kernel alone (tools/pmc_calib.sh): FETCH_SIZE x 2 + WRITE_SIZE against one read + one write of the planes")
@@ -1087,7 +1106,7 @@ def main():
             br = ", ".join(f"{k} {v:.2f}" for k, v in tm.items())
             cpu = dict(value=round(1.0 / (t_match + t_cal), 5), unit="frames/s", cores=threads, kind="port",
                        sample=f"1 frame of {cfg.name} with R={CPU_BASELINE_R} pool frames (the clip's average is 6.4): matching {t_match:.2f} s "
-                              f"[{br}; dense timed on every {DENSE_SUBSAMPLE}th query pixel and scaled x{DENSE_SUBSAMPLE}] + calibration gates "
+                              f"[{br}; dense branch on {'every query pixel' if DENSE_SUBSAMPLE == 1 else f'every {DENSE_SUBSAMPLE}th query pixel, scaled x{DENSE_SUBSAMPLE}'}] + calibration gates "
                               f"{t_cal:.2f} s (each distinct gate shape timed once x its count); torch CPU fp32 + C k-means oracle, {threads} threads")
             # parity spot check of a frame (R = 1) on the GPU: every branch against the oracle, and a surrogate
             # mask (argmin over objects of the dense-matching channel) on the sub-sampled pixels
@@ -1126,6 +1145,19 @@ def main():
         top_roof = None
         if corr_roof is not None:
             top_roof = dict(corr_roof)
+            iso = {r["frames_per_launch"]: r for r in corr_roof.get("isolated", [])}
+            own = iso.get(top_roof["frames_per_launch"])
+            if own is not None:
+                # the KERNEL's own figure at the product's frames per launch: event pair around the launch on an otherwise idle GPU (no time
+                # queued behind other streams' kernels); the in-run bracket, which measures the schedule as much as the kernel, moves to `in_run`
+                top_roof["in_run"] = dict(achieved=corr_roof["achieved"], frac=corr_roof["frac"], avg_launch_ms=corr_roof["avg_launch_ms"],
+                                          note="event pair around the launch inside the timed region: also spans the time the launch waits for CUs "
+                                               "behind the other streams' kernels")
+                top_roof.update(achieved=own["achieved"], frac=own["frac"], avg_launch_ms=own["avg_launch_ms"],
+                                frac_including_query_split=own["frac_including_query_split"],
+                                note="the kernel alone at the product's frames per launch (one): latency regime -- 11.6 MB cannot fill the chip; "
+                                     "`isolated_best_*` = the same kernel fed 16-32 frames per launch; bound by the matrix pipe with three fp16 products "
+                                     "per fp32-equivalent product (DESIGN 4.1b), the 0.60 bar of north_star is NOT met")
             top_roof["traffic"] = None
             top_roof["traffic_offline"] = TRAFFIC_OFFLINE
         value = metrics["frames"] / elapsed_max
