@@ -1141,6 +1141,16 @@ def main():
                                        workload=j["config"]["workload"], host_enqueue_ms_per_step=j["host_enqueue_ms_per_step"])
                 except Exception as e:                      # the headline must not depend on the extras
                     other[name] = dict(error=repr(e)[:200])
+        # SURVEY 8(d) "reported separately": plain-PyTorch random-weight ResNet101-DeepLabv3+ in front of the hot path (tools/backbone_e2e.py; the
+        # backbone is out of scope -- this only says what share of an image-level frame the hot path is)
+        e2e = None
+        if world == 1 and not args.no_extras and args.config == "cfg2":
+            try:
+                r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "backbone_e2e.py")],
+                                   capture_output=True, text=True, timeout=420)
+                e2e = json.loads(r.stdout.strip().splitlines()[-1])
+            except Exception as e:
+                e2e = dict(error=repr(e)[:200])
         # the graded kernel first (north_star: the correlation kernel against the HBM roofline), the matrix kernel as roofline_dense
         top_roof = None
         if corr_roof is not None:
@@ -1199,7 +1209,7 @@ def main():
             "exact_fp32_dense_run": exact,
             "roofline": top_roof if top_roof is not None else roofline, "roofline_dense": roofline, "roofline_correlation_kernel": corr_roof,
             "roofline_kmeans_chain": km_roof, "roofline_film_scale": film_roof,
-            "roofline_cond_gate_pool": cond_roof, "strong_scaling": strong, "other_configs": other, "cpu_baseline": cpu, "parity": parity, "kernels": kernels,
+            "roofline_cond_gate_pool": cond_roof, "strong_scaling": strong, "other_configs": other, "image_level_end_to_end": e2e, "cpu_baseline": cpu, "parity": parity, "kernels": kernels,
         }
         print(json.dumps(line), flush=True)
     if world > 1:
