@@ -980,11 +980,21 @@ def main():
             tot = eval_runner.eval_sharded(specs, rank, world, dev, barrier=barrier, lanes=max(1, args.eval_lanes))
             barrier()
         secs = float(tot["loop_seconds_max"])
+        # like for like with `value`: the same closed loop over DAVIS-17-like sequences only (121x213 maps, K = 16, 1-3 objects: the cfg2 shape; the
+        # mixed set above is 95 % YouTube-VOS-like sequences with three cluster levels, whose orchestrated figure is other_configs.cfg3)
+        dspecs = eval_runner.make_sequence_set("davis17", scale=max(args.strong_scale, 0.27), seed=0)
+        with torch.no_grad():
+            dtot = eval_runner.eval_sharded(dspecs, rank, world, dev, barrier=barrier, lanes=max(1, args.eval_lanes))
+            barrier()
+        davis = dict(value=round(dtot["frames"] / float(dtot["loop_seconds_max"]), 3), unit="frames/s", sequences=int(dtot["sequences"]), frames=int(dtot["frames"]),
+                     mean_objects_incl_background=round(float(np.mean([sp.n_obj for sp in dspecs])), 2),
+                     note="closed evaluation loop (reference-API path incl. read-out, soft-max at image resolution, memory policy, J/F on the device) on the "
+                          "cfg2-shaped part of the set: compare with `value` (orchestrated matching + calibration gates, 4 objects incl. background)")
         strong = dict(metric="frames/sec, sequence-sharded evaluation of a fixed set (strong scaling)", value=round(tot["frames"] / secs, 3), unit="frames/s",
                       n_gpus=world, sequences=int(tot["sequences"]), frames=int(tot["frames"]), objects=int(tot["objects"]),
                       loop_seconds_max=round(secs, 4), rank_seconds_mean=round(float(tot["rank_seconds_mean"]), 4),
                       imbalance=round(float(tot["imbalance"]), 4), planned_imbalance=round(float(tot["planned_imbalance"]), 4),
-                      mean_j=tot["mean_j"], mean_f=tot["mean_f"], lanes_per_rank=max(1, args.eval_lanes),
+                      mean_j=tot["mean_j"], mean_f=tot["mean_f"], lanes_per_rank=max(1, args.eval_lanes), closed_loop_davis17_like=davis,
                       workload=f"{len(specs)} synthetic sequences = {args.strong_scale:g} of the 30 DAVIS-17-val-like (121x213, K=16) + 507 YouTube-VOS-19-like "
                                "(145x261, K in {8,16,32}) set; closed loop (matching -> DynamicPreHead -> linear read-out -> soft-max -> memory policy) through "
                                "the reference-API path; the set does not depend on the number of ranks",

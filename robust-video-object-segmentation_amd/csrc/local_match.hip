@@ -572,6 +572,10 @@ __global__ __launch_bounds__(256) void resize_bilinear_hwc_kernel(const float *_
         // torch-CPU's channels-last kernel term by term -- the four corner weights as fp32 products, then a fused multiply-add chain that
         // runs from the last corner to the first inside its vector body (32 float16 channels per AVX-512 vector) and from the first to the
         // last in its scalar tail (channels >= C - C % 32).  Found by enumerating the orders against F.interpolate: 0 of 27 300 differ.
+        // NB this is the association order of torch-CPU on an AVX-512 host -- the machine the golden vectors were generated on (and the CPU
+        // oracle runs on) -- not of the reference's CUDA run, which evaluates h0 (w0 a + w1 b) + h1 (w0 c + w1 d); an AVX2 host vectorises 16
+        // float16 lanes and moves the body / tail boundary.  The float16 mode is therefore pinned to one float16 ulp of any of these orders
+        // (tests: 2e-6 on the generating host's goldens, one ulp = 4e-3 stated in DESIGN 2 as the cross-host tolerance).
         const float a = aoc_h(v00), b = aoc_h(v01), cc = aoc_h(v10), d = aoc_h(v11);
         const float w00 = hy0 * wx0, w01 = hy0 * wx1, w10 = hy1 * wx0, w11 = hy1 * wx1;
         float acc;

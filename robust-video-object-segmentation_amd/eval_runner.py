@@ -108,7 +108,7 @@ class HotPathBackend:
         self._pool_emb = torch.empty(cap, spec.h, spec.w, 100, dtype=torch.float32, device=self.device)
         self._pool_lab = torch.empty(cap, spec.h, spec.w, spec.n_obj, dtype=torch.float32, device=self.device)
         self._pool_R = 0
-        self._ahead = []
+        self._ahead, self._ahead_rng = [], []
         # ONE C call per frame (aoc_frame_enqueue) where the configuration allows: its workspace is kept per map size / object count
         self.runner = None
         if self.ahead and self.dense_precision in (None, "split") and self.hot.FrameRunner.supported(self.mc, 100, spec.n_obj):
@@ -150,13 +150,18 @@ class HotPathBackend:
         O = spec.n_obj
         prep = ops.label_prep(ref_lab.reshape(-1, O))
         counts = prep.counts.cpu().numpy()
-        self._ahead = []
+        if self._ahead and self._ahead_rng:
+            # chains enqueued for a pool that changed earlier than predicted (a later frame carried ground truth) are dropped: their initial
+            # rows go back into the stream, so that the draws stay those of the per-frame path (and of the reference: one kmeans2 per frame)
+            self.rng.set_state(self._ahead_rng[0])
+        self._ahead, self._ahead_rng = [], []
         if int(counts[O]) == 0:
             return                                           # nothing labelled: the per-frame path handles it (AEM:588-589)
         levels = mc.cluster_levels
         kmax = max(levels)
         inits = []
         for _ in range(n):
+            self._ahead_rng.append(self.rng.get_state())
             rows = np.zeros((len(levels) * O, kmax), np.int32)
             for li, k in enumerate(levels):
                 for i in range(O):
@@ -186,6 +191,8 @@ class HotPathBackend:
         if self.ahead and (changed or not self._ahead):
             self._launch_ahead(ref_emb, ref_lab)
         ahead = self._ahead.pop(0) if self._ahead else None
+        if ahead is not None and self._ahead_rng:
+            self._ahead_rng.pop(0)
         if self.runner is not None and ahead is not None and ref_emb.shape[0] <= self.runner.call.cap:
             feat, _ = self.runner(ref_emb, ref_lab, prev_emb, prev_lab, emb, self.bias, ahead, pool_key=ref_emb.shape[0])
         else:

@@ -183,16 +183,18 @@ def test_bench_two_ranks_on_one_gpu_over_gloo():
 
 
 @pytest.mark.gpu
-def test_chains_ahead_equal_the_per_frame_reference_api_path():
+@pytest.mark.parametrize("levels,n_obj", [((16,), 3), ((8, 16, 32), 4)])
+def test_chains_ahead_equal_the_per_frame_reference_api_path(levels, n_obj):
     """HotPathBackend(ahead=True) reads the row counts once per pool state, draws the initial rows of the frames that will see that pool
-    in the reference's order and enqueues their k-means chains ahead on a side stream; the predicted label maps must equal those of the
-    per-frame path (label prep + read-back + chain on every frame) bit for bit."""
+    in the reference's order and enqueues their k-means chains ahead on a side stream, and every frame is ONE aoc_frame_enqueue call; the
+    predicted label maps must equal those of the per-frame path (label prep + read-back + chain on every frame, Python-orchestrated
+    individual entry points) bit for bit -- single- and multi-level proxies."""
     import torch
     from aoc_amd import eval_runner as er
     if not torch.cuda.is_available():
         pytest.skip("needs an MI355X")
     dev = torch.device("cuda", 0)
-    spec = er.SequenceSpec("davis-like", 41, 57, 3, 14, seed=5, levels=(16,), mem_every=5)
+    spec = er.SequenceSpec("davis-like", 41, 57, n_obj, 14, seed=5, levels=levels, mem_every=5)
     data = er.load_sequence(spec, dev)
     outs = []
     for ahead in (False, True):
