@@ -1055,19 +1055,18 @@ def main():
         km = kernels.get("kmeans_segmented")
         km_roof = None
         if km and "gbs" in km:
-            km_roof = dict(kernel="aoc_kmeans_segmented_rep (20 Lloyd iterations of the 2 or 3 frames that share a chain: replica-fused assignment, block scan, "
-                                  "scatter, literal heads + chunk sums, fold, stitch)", bound="hbm",
+            km_roof = dict(kernel="aoc_kmeans_segmented_rep (20 Lloyd iterations of the 2 or 3 frames that share a chain: replica-fused assignment, block scan + "
+                                  "scatter, literal heads (LDS-DMA) + chunk sums, fold, stitch: five launches per iteration)", bound="hbm",
                            achieved=km["gbs"], peak=PEAK_HBM_GBS, unit="GB/s", frac=round(km["gbs"] / PEAK_HBM_GBS, 4),
                            avg_launch_ms=km["avg_ms"], algorithmic_bytes_per_launch=km["avg_bytes"],
-                           note="a dependent chain of ~120 launches whose ordered float32 sums are latency-bound by construction; the in-run "
+                           note="a dependent chain of ~105 launches whose ordered float32 sums are latency-bound by construction; the in-run "
                                 "figure spans the time the chain shares the GPU with the other streams",
-                           traffic_offline=dict(file="profiles/r03_pmc_kmeans_R6_F3.txt", commit="5fc6454", source="constants copied from the committed file, not measured in this run",
+                           traffic_offline=dict(file="profiles/r04_pmc_kmeans_R6_F3.txt", commit="d729f67", source="constants copied from the committed file, not measured in this run",
                                                 workload="three frames per chain, R = 6 pool frames (61.9 MB of pool rows), per Lloyd iteration",
-                                                fetch_bytes_per_iteration=368.0e6, rows_bytes=61.9e6, reads_per_frame_and_iteration=round(368.0 / 3 / 61.9, 2),
-                                                note="FETCH_SIZE x 2 (gfx950 counts 128-byte requests as 64) summed over the six kernels of an iteration: "
-                                                     "1.98 passes over the rows per frame and iteration (assignment 0.34: one pass for three replicas; "
-                                                     "heads + chunk sums 1.03; fold 0.47; stitch 0.11); 528 MB = 2.84 before the replica-fused assignment "
-                                                     "and the XCD-aware grids of the sum kernels"))
+                                                fetch_bytes_per_iteration=338.0e6, rows_bytes=61.9e6, reads_per_frame_and_iteration=round(338.0 / 3 / 61.9, 2),
+                                                note="FETCH_SIZE x 2 (gfx950 counts 128-byte requests as 64) summed over the five kernels of an iteration: "
+                                                     "1.82 passes over the rows per frame and iteration (assignment 0.34: one pass for three replicas; "
+                                                     "heads + chunk sums 1.03; fold 0.36; stitch 0.06; scan + scatter 0.03); round 3: 1.98, round 2: 2.84"))
 
         def hbm_roof(name, kernel, note):
             kk = kernels.get(name)
