@@ -158,6 +158,22 @@ class OpTimer:
 
             setattr(ops, n, wrapped)
 
+    def gate_probes(self, gates, acts):
+        plan = gates.plan(0, 0)
+        return [[self._event(), self._event(), self._event() if name.startswith("CLB") else None, self._event() if name.startswith("CLB") else None]
+                for (name, *_r) in plan]
+
+    def gates_done(self, probes, gates, acts):
+        st = ops._stream().value
+        for (name, *_r), p, x in zip(gates.plan(0, 0), probes, acts):
+            self.records["film_scale"].append((p[0], p[1]))
+            self.streams.setdefault("film_scale", []).append(st)
+            self.meta["film_scale"].append(dict(flops=float(x.numel()), bytes=2.0 * x.numel() * 4))
+            if p[2] is not None:
+                self.records["cond_gate_pool"].append((p[2], p[3]))
+                self.streams.setdefault("cond_gate_pool", []).append(st)
+                self.meta["cond_gate_pool"].append(dict(flops=2.0 * x.numel(), bytes=1.0 * x.numel() * 4))
+
     def frame_probes(self):
         """Six raw events for aoc_frame_enqueue's probe slots (dense op, correlation launch, local-matching launch) + the dense kernel probe."""
         self.kernel_probe.arm()
@@ -260,6 +276,7 @@ class ClipWorkload:
         self.reuse_proxies = False                         # non-parity mode: one k-means per pool state
         self.bank = None                                   # non-parity mode: hotpath.IncrementalProxyBank (one clustering per pool FRAME)
         self.cached_ahead = None
+        self.batch_gates = False                           # the gates of a frame as ONE C call (aoc_gates_enqueue)
         self.runner = None                                 # hotpath.FrameRunner: one C call per frame (aoc_frame_enqueue); None = the Python orchestrator
         self.timer = None
         self.pool_gen = 0
@@ -459,7 +476,14 @@ def frame_step(wl, gates, acts, dense_precision="split", pipeline=True, defer_co
         feat, head, aux = hotpath.proto_mask_features(wl.mc, ref_emb, ref_lab, wl.emb[t - 1], wl.lab[t - 1], wl.emb[t], wl.bias,
                                                       cluster_state=dict(init_rows=wl.init_rows[t][0]), side_stream=wl.side,
                                                       dense_state=wl.dense_state, dense_precision=dense_precision, defer_correlation=defer_corr)
-    outs = gates(acts, head)
+    if wl.batch_gates:
+        tm = wl.timer
+        gp = tm.gate_probes(gates, acts) if (tm is not None and tm.enabled) else None
+        outs = gates.forward_batched(acts, head, slot=id(wl), probes=gp)
+        if gp is not None:
+            tm.gates_done(gp, gates, acts)
+    else:
+        outs = gates(acts, head)
     wl.advance()                                           # the walk moves on (a new group = a new pool state starts here)
     if wl.bank is None and wl.side is not None and pipeline and wl.t not in wl.ahead and not (wl.reuse_proxies and wl.cached_ahead is not None and wl.cached_ahead.R == wl.R):
         launch_chains(wl)                                  # the next frame's pool is final now: its chain starts under the other sequences' work
@@ -802,6 +826,7 @@ def main():
             wl.enable_incremental()
         if not args.python_frames and not args.incremental_proxies and hotpath.FrameRunner.supported(mc, cfg.c, cfg.n_obj):
             wl.runner = hotpath.FrameRunner(mc, cfg.h, cfg.w, cfg.c, cfg.n_obj, wl.rmax, dev)
+        wl.batch_gates = not args.python_frames
     acts = make_activations(gates, cfg.n_obj, cfg.h, cfg.w, dev, seed=7)
 
     def make_main_stream():

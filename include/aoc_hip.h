@@ -612,6 +612,27 @@ int aoc_frame_channels(int n_radii, int n_levels, int matching_background);
 size_t aoc_frame_workspace_bytes(int h, int w, int C, int n_obj, int R_capacity, int n_radii, int n_levels);
 int aoc_frame_enqueue(const aoc_frame_desc *desc, aoc_seq_state *state, void *workspace, size_t workspace_bytes, aoc_stream_t stream);
 
+/* The modulation gates of CalibrationDecoding.forward (decoding_module.py:96-149, 162-210) as ONE call: a list of gate descriptors, every
+ * gate issuing exactly the launches of its module mirror (outputs bit-identical to attention.IA_gate / conditioning_layer.conditioning_block).
+ *   kind 0  IA_gate (ATT:7-17):                       y = x * (1 + tanh(head W^T + b)),                     W [channels, head_dim]
+ *   kind 1  IA gate with the extended head (decoding_module.py:126-130): head' = (head | sum_o GAP(x) - GAP(x)), W [channels, head_dim + channels]
+ *   kind 2  conditioning_block (CLB:50-86):  W = mlp_layer.weight [channels, 2 channels + head_dim]; phi = CL_1.phi_layer; w1..b3 = the
+ *           mlp_layer of CL_1 / CL_2 / CL_3; k_rank = int(beta * H * W) (CL:32)
+ * x, y [n_obj, channels, hw]; head [n_obj, head_dim]; the scratch of all gates comes out of one workspace (stream-ordered reuse). */
+typedef struct aoc_gate_desc {
+    int32_t kind, channels, k_rank, reserved;
+    int64_t hw;
+    const float *x;
+    float *y;
+    const float *w, *b;
+    const float *phi_w, *phi_b, *w1, *b1, *w2, *b2, *w3, *b3;
+    void *probe[4];                  /* measurement only, hipEvent_t or NULL: recorded immediately before / after the gate's aoc_film_scale [0][1]
+                                        and its aoc_cond_gate_pool_ex [2][3] */
+} aoc_gate_desc;
+size_t aoc_gates_workspace_bytes(const aoc_gate_desc *gates, int n_gates, int n_obj, int head_dim);
+int aoc_gates_enqueue(const aoc_gate_desc *gates, int n_gates, const float *head, int n_obj, int head_dim, void *workspace, size_t workspace_bytes,
+                      aoc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

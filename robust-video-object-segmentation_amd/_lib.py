@@ -70,6 +70,8 @@ SIGNATURES = {
     "aoc_frame_channels": (_i, [_i, _i, _i]),
     "aoc_frame_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i]),
     "aoc_frame_enqueue": (_i, [_vp, _vp, _vp, _sz, _vp]),
+    "aoc_gates_workspace_bytes": (_sz, [_vp, _i, _i, _i]),
+    "aoc_gates_enqueue": (_i, [_vp, _i, _vp, _i, _i, _vp, _sz, _vp]),
     "aoc_local_window_match": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp]),
     "aoc_resize_bilinear_hwc": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _vp]),
     "aoc_resize_bilinear_hwc_ex": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _vp]),

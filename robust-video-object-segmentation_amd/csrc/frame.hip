@@ -207,4 +207,77 @@ int aoc_frame_enqueue(const aoc_frame_desc *d, aoc_seq_state *state, void *works
     return AOC_OK;
 }
 
+// ------------------------------------------------------------------------------------------
+// The modulation gates of CalibrationDecoding.forward (decoding_module.py:96-149, 162-210) as ONE call: the reference applies them inside a
+// single forward call; here a list of gate descriptors is walked and each gate issues exactly the launches of its module mirror
+// (attention.IA_gate / hotpath's extended-head gate / conditioning_layer.conditioning_block), so the outputs are bit-identical to the modules'.
+namespace {
+struct GateWs { float *pm, *hx, *gap, *code; char *cond; size_t cond_bytes, total; };
+inline GateWs gate_carve(void *base, const aoc_gate_desc *g, int n, int n_obj, int D) {
+    GateWs w;
+    int cmax = 1;
+    size_t cond = 0;
+    for (int i = 0; i < n; ++i) {
+        cmax = std::max(cmax, (int)g[i].channels);
+        if (g[i].kind == 2) cond = std::max(cond, aoc_cond_gate_pool_workspace_bytes(n_obj, g[i].channels, g[i].hw));
+    }
+    char *p = static_cast<char *>(base);
+    size_t off = 0;
+    auto take = [&](size_t bytes) { char *r = p ? p + off : nullptr; off += aoc_align_up(bytes, 256); return r; };
+    w.pm = reinterpret_cast<float *>(take((size_t)n_obj * cmax * sizeof(float)));
+    w.gap = reinterpret_cast<float *>(take((size_t)n_obj * cmax * sizeof(float)));
+    w.hx = reinterpret_cast<float *>(take((size_t)n_obj * (D + cmax) * sizeof(float)));
+    w.code = reinterpret_cast<float *>(take((size_t)n_obj * (2 * cmax + D) * sizeof(float)));
+    w.cond_bytes = cond;
+    w.cond = take(cond > 0 ? cond : 16);
+    w.total = off;
+    return w;
+}
+}  // namespace
+
+size_t aoc_gates_workspace_bytes(const aoc_gate_desc *gates, int n_gates, int n_obj, int head_dim) {
+    if (!gates || n_gates < 1 || n_obj < 1 || head_dim < 1) return 0;
+    return gate_carve(nullptr, gates, n_gates, n_obj, head_dim).total;
+}
+
+int aoc_gates_enqueue(const aoc_gate_desc *gates, int n_gates, const float *head, int n_obj, int head_dim, void *workspace, size_t workspace_bytes,
+                      aoc_stream_t stream) {
+    if (!gates || !head || !workspace || n_gates < 1 || n_obj < 1 || head_dim < 1) return AOC_ERR_INVALID_ARG;
+    if (workspace_bytes < aoc_gates_workspace_bytes(gates, n_gates, n_obj, head_dim)) return AOC_ERR_WORKSPACE;
+    const GateWs w = gate_carve(workspace, gates, n_gates, n_obj, head_dim);
+    const int D = head_dim;
+    hipStream_t st = aoc_hip_stream(stream);
+    int rc;
+    for (int i = 0; i < n_gates; ++i) {
+        const aoc_gate_desc &g = gates[i];
+        auto mark = [&](int k) { if (g.probe[k]) (void)hipEventRecord(static_cast<hipEvent_t>(g.probe[k]), st); };
+        if (!g.x || !g.y || !g.w || g.channels < 1 || g.hw < 1) return AOC_ERR_INVALID_ARG;
+        const int c = g.channels;
+        if (g.kind == 0) {                          // IA_gate, ATT:7-17
+            mark(0);
+            rc = aoc_film_scale(g.x, head, g.w, g.b, n_obj, D, c, g.hw, g.y, stream);
+            mark(1);
+        } else if (g.kind == 1) {                   // IA gate whose head carries the inter-object code of its input (decoding_module.py:126-130)
+            rc = aoc_plane_mean(g.x, (int64_t)n_obj * c, g.hw, w.pm, stream);
+            if (rc == AOC_OK) rc = aoc_head_delta(head, D, w.pm, n_obj, c, w.hx, stream);
+            mark(0);
+            if (rc == AOC_OK) rc = aoc_film_scale(g.x, w.hx, g.w, g.b, n_obj, D + c, c, g.hw, g.y, stream);
+            mark(1);
+        } else if (g.kind == 2) {                   // conditioning_block, CLB:50-86
+            if (!g.phi_w || !g.phi_b || !g.w1 || !g.b1 || !g.w2 || !g.b2 || !g.w3 || !g.b3) return AOC_ERR_INVALID_ARG;
+            mark(2);
+            rc = aoc_cond_gate_pool_ex(g.x, n_obj, c, g.hw, g.phi_w, g.phi_b, g.k_rank, w.gap, w.pm, nullptr, nullptr, w.cond, w.cond_bytes, stream);
+            mark(3);
+            if (rc == AOC_OK) rc = aoc_cond_codes(w.gap, w.pm, head, g.w1, g.b1, g.w2, g.b2, g.w3, g.b3, n_obj, c, D, w.code, stream);
+            mark(0);
+            if (rc == AOC_OK) rc = aoc_film_scale(g.x, w.code, g.w, g.b, n_obj, 2 * c + D, c, g.hw, g.y, stream);
+            mark(1);
+        } else {
+            return AOC_ERR_INVALID_ARG;
+        }
+        if (rc != AOC_OK) return rc;
+    }
+    return AOC_OK;
+}
+
 }  // extern "C"

@@ -543,6 +543,32 @@ class CalibrationGates(nn.Module):
                 ("IA10", e + r, h, w, e + r), ("IA11", int(e / 2), h, w, int(e / 2))]
 
     @torch.no_grad()
+    def forward_batched(self, activations, attention_head, slot=None, probes=None):
+        """forward() as ONE C call (aoc_gates_enqueue): the same launches in the same order, bit-identical outputs.  The outputs are persistent
+        buffers owned by this module (one set per list of activations: what a decoder that hands every gate's output straight to the next
+        convolution needs); the descriptor list is rebuilt when the activation buffers change."""
+        key = tuple(x.data_ptr() for x in activations) + (attention_head.shape[1],)
+        if not hasattr(self, "_batches"):
+            self._batches = {}
+        cached = self._batches.get(slot)                 # one set of output buffers per caller slot (e.g. per sequence in flight)
+        if cached is None or cached[0] != key:
+            entries = []
+            for (name, c, hh, ww, extra), x in zip(self.plan(0, 0), activations):
+                mod = getattr(self, name)
+                if isinstance(mod, conditioning_block):
+                    k_rank = int(mod.CL_1.beta_percentage * x.size()[-1] * x.size()[-2])
+                    if k_rank < 1:
+                        raise IndexError("conditioning_layer: beta_rank == 0 (the reference fails at beta_val[..., -1])")
+                    entries.append((2, x, (mod.mlp_layer.weight, mod.mlp_layer.bias, mod.CL_1.phi_layer.weight.reshape(-1), mod.CL_1.phi_layer.bias,
+                                           mod.CL_1.mlp_layer.weight, mod.CL_1.mlp_layer.bias, mod.CL_2.mlp_layer.weight, mod.CL_2.mlp_layer.bias,
+                                           mod.CL_3.mlp_layer.weight, mod.CL_3.mlp_layer.bias, k_rank)))
+                else:
+                    entries.append((1 if extra else 0, x, (mod.IA.weight, mod.IA.bias)))
+            cached = (key, ops.GateBatch(entries, activations[0].shape[0], attention_head.shape[1]))
+            self._batches[slot] = cached
+        return cached[1](attention_head, probes)
+
+    @torch.no_grad()
     def forward(self, activations, attention_head):
         """Applies every gate to its activation (list ordered as ``plan``); returns the modulated list.
         Gates whose head is extended with the inter-object code (IA9/IA10/IA11, decoding_module.py:126-130)

@@ -557,6 +557,51 @@ class _FrameDesc(ctypes.Structure):
                 ("feat", ctypes.c_void_p), ("head", ctypes.c_void_p), ("probe", ctypes.c_void_p * 6)]
 
 
+class _GateDesc(ctypes.Structure):
+    """aoc_gate_desc of include/aoc_hip.h."""
+    _fields_ = [("kind", ctypes.c_int32), ("channels", ctypes.c_int32), ("k_rank", ctypes.c_int32), ("reserved", ctypes.c_int32), ("hw", ctypes.c_int64),
+                ("x", ctypes.c_void_p), ("y", ctypes.c_void_p), ("w", ctypes.c_void_p), ("b", ctypes.c_void_p),
+                ("phi_w", ctypes.c_void_p), ("phi_b", ctypes.c_void_p), ("w1", ctypes.c_void_p), ("b1", ctypes.c_void_p), ("w2", ctypes.c_void_p),
+                ("b2", ctypes.c_void_p), ("w3", ctypes.c_void_p), ("b3", ctypes.c_void_p), ("probe", ctypes.c_void_p * 4)]
+
+
+class GateBatch:
+    """aoc_gates_enqueue: a fixed list of gates (modules + the activations they modulate + persistent outputs) applied by ONE C call per frame.
+    entries: (kind, x, params) with params = (w, b) for kinds 0 / 1 and (w, b, phi_w, phi_b, w1, b1, w2, b2, w3, b3, k_rank) for kind 2."""
+
+    def __init__(self, entries, n_obj, head_dim):
+        self.n, self.n_obj, self.D = len(entries), int(n_obj), int(head_dim)
+        self.arr = (_GateDesc * self.n)()
+        self.keep, self.outs = [], []
+        for i, (kind, x, prm) in enumerate(entries):
+            assert x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.shape[0] == n_obj
+            y = torch.empty_like(x)
+            ts = [_f32c(t.detach()) for t in prm[:10]]
+            self.keep.append((x, ts))
+            self.outs.append(y)
+            d = self.arr[i]
+            d.kind, d.channels, d.hw = int(kind), int(x.shape[1]), int(x.numel() // (x.shape[0] * x.shape[1]))
+            d.x, d.y, d.w, d.b = x.data_ptr(), y.data_ptr(), ts[0].data_ptr(), ts[1].data_ptr()
+            if kind == 2:
+                d.phi_w, d.phi_b, d.w1, d.b1, d.w2, d.b2, d.w3, d.b3 = [t.data_ptr() for t in ts[2:10]]
+                d.k_rank = int(prm[10])
+        L = _lib.lib()
+        self.ws = torch.empty(max(16, int(L.aoc_gates_workspace_bytes(ctypes.cast(self.arr, ctypes.c_void_p), self.n, self.n_obj, self.D))),
+                              dtype=torch.uint8, device=entries[0][1].device)
+
+    def __call__(self, head, probes=None):
+        """probes (measurement only): per gate a list of four raw hipEvent_t handles or None (aoc_gate_desc.probe)."""
+        head = _f32c(head)
+        _need_gpu(head)
+        assert tuple(head.shape) == (self.n_obj, self.D)
+        for i in range(self.n):
+            for k in range(4):
+                self.arr[i].probe[k] = probes[i][k] if probes is not None else None
+        _lib.check(_lib.lib().aoc_gates_enqueue(ctypes.cast(self.arr, ctypes.c_void_p), self.n, _p(head), self.n_obj, self.D, _p(self.ws), self.ws.numel(),
+                                                _stream()), "aoc_gates_enqueue")
+        return self.outs
+
+
 class _SeqState(ctypes.Structure):
     """aoc_seq_state of include/aoc_hip.h."""
     _fields_ = [("initialised", ctypes.c_int64), ("records_frames", ctypes.c_int64), ("ref_pool_key", ctypes.c_int64), ("plan_key", ctypes.c_int64),

@@ -95,3 +95,27 @@ def test_frame_call_vs_reference_golden(aoc, golden):
         feat, head = runner(ref_emb, ref_lab, dev(g["in_prev"]), prev_lab, dev(g["in_cur"]), b.cuda(), ahead)
         np.testing.assert_allclose(feat.cpu().numpy(), g["pre_to_cat"], rtol=0, atol=5e-6)
         np.testing.assert_allclose(head.cpu().numpy(), g["attention_head"], rtol=1e-5, atol=1e-6)
+
+
+def test_gates_one_call_equals_the_modules(aoc):
+    """aoc_gates_enqueue (CalibrationGates.forward_batched: the 10 IA gates and 4 conditioning blocks of CalibrationDecoding as ONE C call) against
+    the module-by-module path (attention.IA_gate / conditioning_block mirrors): the same launches in the same order -> torch.equal."""
+    hot = aoc.hotpath
+    torch.manual_seed(5)
+    mc = hot.MatchingConfig()
+    gates = hot.CalibrationGates(mc).cuda()
+    O, h, w = 3, 33, 45
+    g = torch.Generator().manual_seed(9)
+    acts = [torch.randn(O, c, hh, ww, generator=g).cuda() for (_, c, hh, ww, _) in gates.plan(h, w)]
+    head = torch.randn(O, 400, generator=g).cuda()
+    want = gates(acts, head)
+    got = gates.forward_batched(acts, head)
+    torch.cuda.synchronize()
+    assert len(got) == len(want) == 14
+    for name, a, b in zip([p[0] for p in gates.plan(h, w)], got, want):
+        assert torch.equal(a, b), name
+    # a second call re-uses descriptors and output buffers; another head gives another result
+    got2 = [t.clone() for t in gates.forward_batched(acts, head * 0.5)]
+    want2 = gates(acts, head * 0.5)
+    for a, b in zip(got2, want2):
+        assert torch.equal(a, b)

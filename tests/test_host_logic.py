@@ -62,14 +62,14 @@ def test_frame_call_structs_match_the_header(tmp_path):
     """aoc_frame_desc / aoc_seq_state as ctypes lays them out (ops._FrameDesc, ops._SeqState) against the C compiler's view of include/aoc_hip.h."""
     import ctypes
     src = tmp_path / "sz.c"
-    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "%s"\nint main(void){printf("%%zu %%zu %%zu %%zu %%zu %%zu\\n", sizeof(aoc_frame_desc), '
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "%s"\nint main(void){printf("%%zu %%zu %%zu %%zu %%zu %%zu %%zu %%zu %%zu\\n", sizeof(aoc_frame_desc), '
                    'sizeof(aoc_seq_state), offsetof(aoc_frame_desc, pool_key), offsetof(aoc_frame_desc, ref_emb), offsetof(aoc_frame_desc, feat), '
-                   'offsetof(aoc_frame_desc, probe));return 0;}\n' % os.path.join(ROOT, "include", "aoc_hip.h"))
+                   'offsetof(aoc_frame_desc, probe), sizeof(aoc_gate_desc), offsetof(aoc_gate_desc, x), offsetof(aoc_gate_desc, probe));return 0;}\n' % os.path.join(ROOT, "include", "aoc_hip.h"))
     exe = tmp_path / "sz"
     subprocess.run(["gcc", "-o", str(exe), str(src)], check=True)
     got = [int(v) for v in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
-    D, S = aoc_amd.ops._FrameDesc, aoc_amd.ops._SeqState
-    assert got == [ctypes.sizeof(D), ctypes.sizeof(S), D.pool_key.offset, D.ref_emb.offset, D.feat.offset, D.probe.offset]
+    D, S, G = aoc_amd.ops._FrameDesc, aoc_amd.ops._SeqState, aoc_amd.ops._GateDesc
+    assert got == [ctypes.sizeof(D), ctypes.sizeof(S), D.pool_key.offset, D.ref_emb.offset, D.feat.offset, D.probe.offset, ctypes.sizeof(G), G.x.offset, G.probe.offset]
     L = aoc_amd._lib.lib()
     assert L.aoc_frame_channels(6, 1, 1) == 24 and L.aoc_frame_channels(6, 3, 1) == 28 and L.aoc_frame_channels(6, 1, 0) == 17      # aocnet.py:43-46
     assert L.aoc_frame_workspace_bytes(121, 213, 100, 4, 12, 6, 1) > 0 and L.aoc_frame_workspace_bytes(121, 213, 64, 4, 12, 6, 1) > 0
