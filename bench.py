@@ -1181,7 +1181,7 @@ def main():
         if world == 1 and not args.no_extras and args.config == "cfg2":
             try:
                 r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "backbone_e2e.py")],
-                                   capture_output=True, text=True, timeout=420)
+                                   capture_output=True, text=True, timeout=240)
                 e2e = json.loads(r.stdout.strip().splitlines()[-1])
             except Exception as e:
                 e2e = dict(error=repr(e)[:200])

@@ -2286,7 +2286,7 @@ __device__ __forceinline__ void os_ordered_sum_body(int j, int s, int grp, float
 #define AOC_OD_NPROD 3
 #endif
 #ifndef AOC_OD_DEPTH
-#define AOC_OD_DEPTH 2
+#define AOC_OD_DEPTH 1
 #endif
 constexpr int OD_NPROD = AOC_OD_NPROD;                         // producer waves
 constexpr int OD_HALF = 64;                                    // members per producer and step

@@ -547,7 +547,7 @@ class CalibrationGates(nn.Module):
         """forward() as ONE C call (aoc_gates_enqueue): the same launches in the same order, bit-identical outputs.  The outputs are persistent
         buffers owned by this module (one set per list of activations: what a decoder that hands every gate's output straight to the next
         convolution needs); the descriptor list is rebuilt when the activation buffers change."""
-        key = tuple(x.data_ptr() for x in activations) + (attention_head.shape[1],)
+        key = tuple((x.data_ptr(), tuple(x.shape)) for x in activations) + (attention_head.shape[1],)
         if not hasattr(self, "_batches"):
             self._batches = {}
         cached = self._batches.get(slot)                 # one set of output buffers per caller slot (e.g. per sequence in flight)
