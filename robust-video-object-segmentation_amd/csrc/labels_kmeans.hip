@@ -2603,6 +2603,22 @@ inline int ks_sum_mode() {
 template <int MODE>
 inline void ks_launch_sums(hipStream_t st, const float *pool, uint32_t pool_bytes, int C, const int32_t *seg_offsets, const int32_t *seg_k,
                            const int32_t *counts, const KsWorkspace &ws, int kmax, int n_seg, float *dst) {
+#ifndef AOC_DEV
+    // release build: literal heads by LDS-DMA + any-order chunk sums in one launch, then the fold (binade prediction inside it while no cluster
+    // can have more than KC_INLINE_PREDICT_CHUNKS chunks) -- the alternatives below only exist in the development build
+    const int start = KS_HEAD_CHUNKS;
+    hipLaunchKernelGGL((km_heads_chunk_sums_kernel<MODE, true>), dim3(kmax * n_seg * os_groups(C) + ws.nch_cap), dim3(256), 0, st, pool, pool_bytes, C,
+                       seg_offsets, seg_k, counts, ws.cbase, ws.moff, kmax, n_seg, dst, KS_HEAD_CHUNKS * KS_CHUNK, ws.head, ws.owner_cluster, ws.owner_local,
+                       ws.csum, start, 1);
+    {
+        const bool inline_predict = ws.seg_chunks_max <= KC_INLINE_PREDICT_CHUNKS;
+        if (!inline_predict)
+            hipLaunchKernelGGL(km_chunk_predict_kernel, dim3(kmax, n_seg), dim3(128), 0, st, seg_k, counts, ws.cchunk, ws.csum, kmax, C, ws.cexp, start, ws.head);
+        hipLaunchKernelGGL(km_chunk_fold_kernel, dim3((unsigned)ws.nch_cap * ((C + KC_FG - 1) / KC_FG)), dim3(256), 0, st, pool, C, seg_offsets, counts, ws.cbase, ws.moff,
+                           kmax, ws.owner_cluster, ws.owner_local, ws.cexp, ws.cinc0, ws.cinc1, start, inline_predict ? ws.csum : (const float *)nullptr,
+                           ws.cchunk, ws.head, ws.nch_cap, (C + KC_FG - 1) / KC_FG, 1);
+    }
+#else
     const int mode = ks_sum_mode();
     const int start = (mode == 2) ? KS_HEAD_CHUNKS : 0;
     static const bool fused = AOC_DEV_ENV_INT("AOC_KM_FUSED", 0) == 1;
@@ -2647,10 +2663,16 @@ inline void ks_launch_sums(hipStream_t st, const float *pool, uint32_t pool_byte
                            kmax, ws.owner_cluster, ws.owner_local, ws.cexp, ws.cinc0, ws.cinc1, start, inline_predict ? ws.csum : (const float *)nullptr,
                            ws.cchunk, ws.head, ws.nch_cap, (C + KC_FG - 1) / KC_FG, km_xcd_aware());
     }
+#endif
     static const int nf = AOC_DEV_ENV_INT("AOC_KS_NF", 1);       // features per stitch wave (developer switch)
 #define AOC_KSS(NF) hipLaunchKernelGGL((km_sum_scan_kernel<MODE, NF>), dim3((unsigned)(C / NF) * kmax * n_seg), dim3(64), 0, st, pool, pool_bytes, C, seg_offsets, seg_k, \
                                        counts, ws.cbase, ws.moff, kmax, dst, ws.cchunk, ws.cexp, ws.cinc0, ws.cinc1, start, ws.head, n_seg, km_xcd_aware())
+#ifdef AOC_DEV
     if (nf == 4) AOC_KSS(4); else if (nf == 2) AOC_KSS(2); else AOC_KSS(1);
+#else
+    (void)nf;
+    AOC_KSS(1);
+#endif
 #undef AOC_KSS
 }
 
