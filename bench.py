@@ -1086,12 +1086,12 @@ def main():
                            avg_launch_ms=km["avg_ms"], algorithmic_bytes_per_launch=km["avg_bytes"],
                            note="a dependent chain of ~105 launches whose ordered float32 sums are latency-bound by construction; the in-run "
                                 "figure spans the time the chain shares the GPU with the other streams",
-                           traffic_offline=dict(file="profiles/r04_pmc_kmeans_R6_F3.txt", commit="d729f67", source="constants copied from the committed file, not measured in this run",
+                           traffic_offline=dict(file="profiles/r04_pmc_kmeans_R6_F3.txt", commit="2af9134", source="constants copied from the committed file, not measured in this run",
                                                 workload="three frames per chain, R = 6 pool frames (61.9 MB of pool rows), per Lloyd iteration",
-                                                fetch_bytes_per_iteration=338.0e6, rows_bytes=61.9e6, reads_per_frame_and_iteration=round(338.0 / 3 / 61.9, 2),
+                                                fetch_bytes_per_iteration=336.0e6, rows_bytes=61.9e6, reads_per_frame_and_iteration=round(336.0 / 3 / 61.9, 2),
                                                 note="FETCH_SIZE x 2 (gfx950 counts 128-byte requests as 64) summed over the five kernels of an iteration: "
-                                                     "1.82 passes over the rows per frame and iteration (assignment 0.34: one pass for three replicas; "
-                                                     "heads + chunk sums 1.03; fold 0.36; stitch 0.06; scan + scatter 0.03); round 3: 1.98, round 2: 2.84"))
+                                                     "1.81 passes over the rows per frame and iteration (assignment 0.34: one pass for three replicas; "
+                                                     "heads + chunk sums 1.02; fold 0.36; stitch 0.06; scan + scatter 0.03); round 3: 1.98, round 2: 2.84"))
 
         def hbm_roof(name, kernel, note):
             kk = kernels.get(name)
