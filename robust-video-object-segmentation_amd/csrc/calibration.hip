@@ -324,6 +324,7 @@ __global__ __launch_bounds__(256) void channel_scale_kernel(const float *__restr
     }
 }
 
+#ifdef AOC_DEV
 // FiLM gate in one launch: every block first computes its plane's gain 1 + tanh(head[o,:].W[c,:] + b[c]) (a D-long
 // dot product, block-reduced), then streams its slice of the plane.  Saves the separate gain launch + round trip.
 __global__ __launch_bounds__(256) void film_scale_kernel(const float *__restrict__ x, const float *__restrict__ head, const float *__restrict__ weight,
@@ -388,6 +389,72 @@ __global__ __launch_bounds__(256) void film_scale_kernel(const float *__restrict
         if (tid < hw - tail0) yp[tail0 + tid] = g * xp[tail0 + tid];
     } else {
         for (int64_t i = tid; i < hw; i += nthreads) yp[i] = g * xp[i];
+    }
+}
+#endif  // AOC_DEV
+
+// FiLM gate in one launch: y[o,c,:] = (1 + tanh(head[o,:].W[c,:] + b[c])) x[o,c,:]  (ATT:12-17, CLB:81-84), the gain computed by every workgroup
+// of the plane (a D-long dot product, block-reduced) -- no separate gain launch.  The workgroup's whole slice of the plane is requested BEFORE
+// the dot product: a workgroup lives for one memory round
+// trip (its U float4 per thread, the weight row and the head row are all in flight together) instead of two dependent ones, and U x 256 float4
+// per workgroup keeps the half-resolution planes (1 631 float4) at one or two workgroups per plane instead of seven that move one float4 per
+// thread behind a 400-long dot product each.
+template <int U>
+__global__ __launch_bounds__(256) void film_scale_ahead_kernel(const float *__restrict__ x, const float *__restrict__ head, const float *__restrict__ weight,
+                                                                const float *__restrict__ bias, int D, int channels, int64_t hw, int chunk, float *__restrict__ y) {
+    typedef float f32x4_t __attribute__((ext_vector_type(4)));
+    __shared__ float wsum[4];
+    const int64_t plane = blockIdx.y;
+    const int o = (int)(plane / channels), c = (int)(plane - (int64_t)o * channels);
+    const float *xp = x + plane * hw;
+    float *yp = y + plane * hw;
+    const uintptr_t addr = reinterpret_cast<uintptr_t>(xp);
+    int64_t headn = ((16 - (addr & 15)) & 15) / 4;
+    if (headn > hw) headn = hw;
+    const int64_t body4 = (hw - headn) / 4;
+    const bool vec = ((reinterpret_cast<uintptr_t>(yp) & 15) == (addr & 15)) && body4 > 0;
+    const f32x4_t *x4 = reinterpret_cast<const f32x4_t *>(xp + headn);
+    // the plane's float4 split evenly over the workgroups of the row (the last one is not a mostly empty straggler)
+    const int64_t i0 = (int64_t)blockIdx.x * chunk, i1 = min(body4, i0 + chunk);          // chunk = ceil((hw / 4) / gridDim.x) <= 256 U
+    f32x4_t v[U];
+    if (vec) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t i = i0 + threadIdx.x + u * 256;
+            if (i < i1) v[u] = __builtin_nontemporal_load(x4 + i);
+        }
+    }
+    const float *h = head + (size_t)o * D, *w = weight + (size_t)c * D;
+    float acc = 0.0f;
+    for (int d0 = threadIdx.x; d0 < D; d0 += 4 * 256) {
+        float wv[4], hv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int d = min(d0 + u * 256, D - 1);
+            wv[u] = w[d];
+            hv[u] = h[d];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc += (d0 + u * 256 < D) ? wv[u] * hv[u] : 0.0f;
+    }
+    acc = aoc_wave_sum(acc);
+    if (aoc_lane() == 0) wsum[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    const float g = 1.0f + tanhf((wsum[0] + wsum[1] + wsum[2] + wsum[3]) + (bias ? bias[c] : 0.0f));
+    if (vec) {
+        f32x4_t *y4 = reinterpret_cast<f32x4_t *>(yp + headn);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t i = i0 + threadIdx.x + u * 256;
+            if (i < i1) __builtin_nontemporal_store(v[u] * g, y4 + i);
+        }
+        if (blockIdx.x == 0) {
+            const int64_t tail0 = headn + body4 * 4;
+            if (threadIdx.x < headn) yp[threadIdx.x] = g * xp[threadIdx.x];
+            if (threadIdx.x < hw - tail0) yp[tail0 + threadIdx.x] = g * xp[tail0 + threadIdx.x];
+        }
+    } else {
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < hw; i += (int64_t)gridDim.x * 256) yp[i] = g * xp[i];
     }
 }
 
@@ -797,19 +864,29 @@ __global__ __launch_bounds__(64) void linear_kernel(const float *__restrict__ x,
     if (threadIdx.x == 0) y[(size_t)n * out_dim + o] = acc + (bias ? bias[o] : 0.0f);
 }
 
-__global__ __launch_bounds__(256) void plane_mean_kernel(const float *__restrict__ x, int64_t hw, float *__restrict__ out) {
+// float4 loads, eight per thread in flight (32 KB per workgroup: one workgroup per plane, 4-8 workgroups per CU, needs that much outstanding to
+// reach the HBM rate); the 16-byte aligned body + scalar head / tail of the streaming kernels (hw is odd for the 16k + 1 input sizes)
+__global__ __launch_bounds__(256) void plane_mean4_kernel(const float *__restrict__ x, int64_t hw, float *__restrict__ out) {
+    typedef float f32x4_t __attribute__((ext_vector_type(4)));
     __shared__ float wsum[4];
     const float *xp = x + (size_t)blockIdx.x * hw;
+    int64_t headn = ((16 - (reinterpret_cast<uintptr_t>(xp) & 15)) & 15) / 4;
+    if (headn > hw) headn = hw;
+    const int64_t body4 = (hw - headn) / 4, tail0 = headn + body4 * 4;
+    const f32x4_t *x4 = reinterpret_cast<const f32x4_t *>(xp + headn);
     float acc = 0.0f;
-    int64_t p = threadIdx.x;
-    for (; p + 7 * (int64_t)blockDim.x < hw; p += 8 * (int64_t)blockDim.x) {
-        float v[8];
+    if (threadIdx.x < headn) acc += xp[threadIdx.x];
+    if (threadIdx.x < hw - tail0) acc += xp[tail0 + threadIdx.x];
+    for (int64_t i0 = threadIdx.x; i0 < body4; i0 += 8 * 256) {
+        f32x4_t v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = xp[p + u * blockDim.x];
+        for (int u = 0; u < 8; ++u) {
+            const int64_t i = i0 + u * 256;
+            v[u] = __builtin_nontemporal_load(x4 + (i < body4 ? i : body4 - 1));
+        }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) acc += v[u];
+        for (int u = 0; u < 8; ++u) acc += (i0 + u * 256 < body4) ? (v[u].x + v[u].y) + (v[u].z + v[u].w) : 0.0f;
     }
-    for (; p < hw; p += blockDim.x) acc += xp[p];
     acc = aoc_wave_sum(acc);
     if (aoc_lane() == 0) wsum[threadIdx.x >> 6] = acc;
     __syncthreads();
@@ -1140,14 +1217,28 @@ int aoc_film_scale(const float *x, const float *head, const float *weight, const
     if (!x || !head || !weight || !y || n_obj < 1 || head_dim < 1 || channels < 1 || hw < 1) return AOC_ERR_INVALID_ARG;
     const int64_t planes = (int64_t)n_obj * channels;
     if (planes > 65535) return AOC_ERR_UNSUPPORTED;
-    int bx = (int)((hw / 4 + 255) / 256);
-    if (bx < 1) bx = 1;
-    if (bx > 8) bx = 8;
-    // nontemporal stores: the gated activation is a pure stream-out, and every dirty line it would leave in the XCDs' L2s is written back at
-    // the next kernel boundary of ANY stream -- the k-means chain on the side stream has 125 of them per frame (bench: +2 % frames/s;
-    // AOC_FILM_NT=0 switches back)
-    static const int nt = AOC_DEV_ENV_INT("AOC_FILM_NT", 1);
-    hipLaunchKernelGGL(film_scale_kernel, dim3(bx, (unsigned)planes), dim3(256), 0, aoc_hip_stream(stream), x, head, weight, bias, head_dim, channels, hw, y, nt);
+    // U = 8 float4 per thread where that makes one workgroup per plane (the half-resolution maps), otherwise 4: measured equal within 2 % on
+    // the full-resolution maps (tools/bench_gates.py).  Loads and stores are nontemporal: the activation is read once and the gated copy is a
+    // pure stream-out -- every dirty line it would leave in the XCDs' L2s is written back at the next kernel boundary of ANY stream, and the
+    // k-means chain on the side stream has ~100 of them per frame (bench: +2 % frames/s when the stores went nontemporal in round 3).
+    static const int ahead = AOC_DEV_ENV_INT("AOC_FILM_AHEAD", -1);
+    const int U = ahead == 4 || ahead == 8 ? ahead : (hw / 4 <= 2048 ? 8 : 4);
+#ifdef AOC_DEV
+    if (ahead == 0) {                                           // the kernel of rounds 2-4 (dot product first, then the stream)
+        static const int nt = AOC_DEV_ENV_INT("AOC_FILM_NT", 1);
+        const int bx = (int)std::min<int64_t>(8, std::max<int64_t>(1, (hw / 4 + 255) / 256));
+        hipLaunchKernelGGL(film_scale_kernel, dim3(bx, (unsigned)planes), dim3(256), 0, aoc_hip_stream(stream), x, head, weight, bias, head_dim, channels, hw, y, nt);
+        AOC_RETURN_IF_LAUNCH_FAILED();
+        return AOC_OK;
+    }
+#endif
+    const int64_t per_wg = 256 * (int64_t)U;
+    const unsigned gx = (unsigned)std::max<int64_t>(1, (hw / 4 + per_wg - 1) / per_wg);
+    const int chunk = (int)std::max<int64_t>(1, (hw / 4 + gx - 1) / gx);
+    if (U == 4)
+        hipLaunchKernelGGL(film_scale_ahead_kernel<4>, dim3(gx, (unsigned)planes), dim3(256), 0, aoc_hip_stream(stream), x, head, weight, bias, head_dim, channels, hw, chunk, y);
+    else
+        hipLaunchKernelGGL(film_scale_ahead_kernel<8>, dim3(gx, (unsigned)planes), dim3(256), 0, aoc_hip_stream(stream), x, head, weight, bias, head_dim, channels, hw, chunk, y);
     AOC_RETURN_IF_LAUNCH_FAILED();
     return AOC_OK;
 }
@@ -1244,7 +1335,7 @@ int aoc_label_mix(const float *labels, const float *rows, int64_t n, int n_obj, 
 
 int aoc_plane_mean(const float *x, int64_t planes, int64_t hw, float *out, aoc_stream_t stream) {
     if (!x || !out || planes < 1 || hw < 1) return AOC_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(plane_mean_kernel, dim3((unsigned)planes), dim3(256), 0, aoc_hip_stream(stream), x, hw, out);
+    hipLaunchKernelGGL(plane_mean4_kernel, dim3((unsigned)planes), dim3(256), 0, aoc_hip_stream(stream), x, hw, out);
     AOC_RETURN_IF_LAUNCH_FAILED();
     return AOC_OK;
 }
