@@ -100,6 +100,23 @@ class OpTimer:
         self.hip.hipStreamWaitEvent.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint]
         self._pool = []
         self.streams = {}
+        self.want_segments = False
+        self.segments = {}                                   # --segments: per stream, the event tuples of its frames in order
+
+    def segment_summary(self):
+        """Mean milliseconds of the consecutive pieces of a frame ON ITS STREAM (developer output, --segments): what comes before the dense
+        op, the dense op, ..., the wait for the frame's proxies + the correlation launch, the gates, and the idle time to the next frame."""
+        names = ["pre_dense (pools, local prep, split rows)", "dense_op", "dense_end_to_local", "local_pair", "planes + wait for the proxies", "correlation",
+                 "proto_finish", "gates", "to_next_frame_on_this_stream"]
+        acc = [[] for _ in names]
+        for frames in self.segments.values():
+            for i, ev in enumerate(frames):
+                pts = list(ev) + ([frames[i + 1][0]] if i + 1 < len(frames) else [])
+                for j in range(len(pts) - 1):
+                    v = ctypes.c_float()
+                    if self.hip.hipEventElapsedTime(ctypes.byref(v), pts[j], pts[j + 1]) == 0:
+                        acc[j].append(v.value)
+        return {n: round(float(np.mean(a)), 4) for n, a in zip(names, acc) if a}
 
     def timeline(self):
         """[(op, stream, start_ms, end_ms)] of every timed call, relative to the first recorded event (developer output: --dump-timeline)."""
@@ -408,6 +425,15 @@ def _launch_batch(wl, frames):
             wl.ahead[f] = a
 
 
+HOST_S = dict(chain_launch=0.0, frame_call=0.0, gates_call=0.0, frames=0)      # --segments: host seconds spent inside the three enqueue calls
+
+
+def _launch_batch_timed(wl, todo):
+    t0 = time.perf_counter()
+    _launch_batch(wl, todo)
+    HOST_S["chain_launch"] += time.perf_counter() - t0
+
+
 def launch_chains(wl, done=None):
     """Enqueue the k-means chain of the current frame and of the following frames of its group (they all see the pool as it is now)
     on the side stream.  With a plan (--chain-plan, e.g. 1,2,2): the group's frames are cut into batches of those sizes, one chain per
@@ -427,18 +453,19 @@ def launch_chains(wl, done=None):
         for c in cuts[k:k + 1 + max(wl.chain_lead, len(wl.sides))]:
             todo = [f for f in c if f >= t and f != done and f not in wl.ahead]
             if todo:
-                _launch_batch(wl, todo)
+                _launch_batch_timed(wl, todo)
         return
     rest = wl.next_in_group()[:max(0, wl.chains - 1)]
-    _launch_batch(wl, [t])
+    _launch_batch_timed(wl, [t])
     if rest:
-        _launch_batch(wl, rest)
+        _launch_batch_timed(wl, rest)
 
 
 def frame_step(wl, gates, acts, dense_precision="split", pipeline=True, defer_corr=False):
     """One frame of one sequence; returns (feat, gate outputs, pending correlation or None)."""
     ref_emb, ref_lab = wl.refs()
     t = wl.t
+    seg = None
     if wl.bank is not None:
         feat, head, aux = hotpath.proto_mask_features(wl.mc, ref_emb, ref_lab, wl.emb[t - 1], wl.lab[t - 1], wl.emb[t], wl.bias,
                                                       cluster_ahead=wl.bank.handle(ref_lab), dense_state=wl.dense_state, dense_precision=dense_precision,
@@ -464,9 +491,15 @@ def frame_step(wl, gates, acts, dense_precision="split", pipeline=True, defer_co
             # ONE C call for the frame (aoc_frame_enqueue); the op timings the line reports come from events the call records itself
             tm = wl.timer
             probes = tm.frame_probes() if (tm is not None and tm.enabled) else None
+            seg_begin = tm._record() if (probes is not None and tm.want_segments) else None
+            h0 = time.perf_counter()
             feat, head = wl.runner(ref_emb, ref_lab, wl.emb[t - 1], wl.lab[t - 1], wl.emb[t], wl.bias, ahead, pool_key=wl.pool_gen, probes=probes)
+            HOST_S["frame_call"] += time.perf_counter() - h0
+            HOST_S["frames"] += 1
             if probes is not None:
                 tm.frame_done(probes, ref_emb.shape[0] * ref_emb.shape[1] * ref_emb.shape[2], wl.emb[t].shape[0] * wl.emb[t].shape[1], ahead.table.shape[0])
+                if seg_begin is not None:
+                    seg = [seg_begin, probes[0], probes[1], probes[4], probes[5], probes[2], probes[3], tm._record()]
             aux = dict(pending_correlation=None)
         else:
             feat, head, aux = hotpath.proto_mask_features(wl.mc, ref_emb, ref_lab, wl.emb[t - 1], wl.lab[t - 1], wl.emb[t], wl.bias,
@@ -479,9 +512,13 @@ def frame_step(wl, gates, acts, dense_precision="split", pipeline=True, defer_co
     if wl.batch_gates:
         tm = wl.timer
         gp = tm.gate_probes(gates, acts) if (tm is not None and tm.enabled) else None
+        h0 = time.perf_counter()
         outs = gates.forward_batched(acts, head, slot=id(wl), probes=gp)
+        HOST_S["gates_call"] += time.perf_counter() - h0
         if gp is not None:
             tm.gates_done(gp, gates, acts)
+            if seg is not None:
+                tm.segments.setdefault(ops._stream().value, []).append(seg + [tm._record()])
     else:
         outs = gates(acts, head)
     wl.advance()                                           # the walk moves on (a new group = a new pool state starts here)
@@ -693,6 +730,7 @@ def main():
                     help="batch sizes of the k-means chains of a group of MEM_EVERY frames, e.g. 1,2,2 (overrides --chains).  Default: 2,3 for cfg2 "
                          "(340-342 frames/s against 332-334 with --chains 3, three runs each; cfg3 / cfg4 are 2 %% slower with it), none otherwise; "
                          "'none' = the --chains schedule")
+    ap.add_argument("--segments", action="store_true", help="developer output: mean time of the consecutive pieces of a frame on its stream (key frame_segments_ms)")
     ap.add_argument("--dump-timeline", default="", help="developer output: write the timed ops' (name, stream, start, end) to this JSON file")
     ap.add_argument("--chain-streams", type=int, default=1, help="side streams per sequence for its k-means chains (with --chain-plan: the batches of a group run side by side)")
     ap.add_argument("--chain-lead", type=int, default=1, help="with --chain-plan: batches enqueued ahead of the one in use")
@@ -935,6 +973,7 @@ def main():
         ops.dense_prune_stats(reset=True)     # counters of the coarse-then-rescore dense kernel over the timed region (reads synchronise: outside it)
         for wl in workloads:
             wl.count_r = True
+        timer.want_segments = args.segments
         timer.enabled = True                 # HIP events around every op, on the stream the op is launched on
         # EXACTLY --steps steps per region, bracketed by barrier + synchronize; regions are repeated (the group walk simply continues) until
         # --min-region-s seconds are covered, and the line reports the median region
@@ -970,6 +1009,10 @@ def main():
             r_hist[r] = r_hist.get(r, 0) + c
 
     probe_ms = timer.kernel_probe.elapsed_ms()
+    segments = timer.segment_summary() if args.segments else None
+    if segments and HOST_S["frames"]:
+        segments["host_ms_per_frame (chain launch, frame call, gates call; warm-up included)"] = [round(HOST_S[k] / HOST_S["frames"] * 1e3, 4)
+                                                                                               for k in ("chain_launch", "frame_call", "gates_call")]
     prune = ops.dense_prune_stats(reset=True)
     if args.dump_timeline and rank == 0:
         with open(args.dump_timeline, "w") as f:
@@ -1240,6 +1283,7 @@ def main():
                        "dense_precision": ("fp16-split products (hi*hi + hi*lo + lo*hi), fp32 accumulate: fp32-equivalent; exact-fp32 take-over "
                                            "on overflow / soft labels" if args.dense == "split" else "exact fp32 MFMA")},
             "host_enqueue_ms_per_step": round(host_enqueue_s / args.steps * 1e3, 3),
+            **({"frame_segments_ms": segments} if segments else {}),
             "exact_fp32_dense_run": exact,
             "roofline": top_roof if top_roof is not None else roofline, "roofline_dense": roofline, "roofline_correlation_kernel": corr_roof,
             "roofline_kmeans_chain": km_roof, "roofline_film_scale": film_roof,

@@ -637,9 +637,14 @@ __device__ __forceinline__ void select_bin(const uint32_t *__restrict__ hist, ui
 // part_scores [n_chunks][N][hw]; plane_partial [n_tiles][N][C]
 constexpr int CS_PPT = 8, CS_TILE = 256 * CS_PPT, CS_CH = 32;
 __global__ __launch_bounds__(256) void cond_scores_part_kernel(const float *__restrict__ z, int C, int64_t hw, const float *__restrict__ phi_w,
-                                                                float *__restrict__ part_scores, float *__restrict__ plane_partial) {
+                                                                float *__restrict__ part_scores, float *__restrict__ plane_partial,
+                                                                uint32_t *__restrict__ hist) {
     __shared__ float lps[4][CS_CH];
     const int n = blockIdx.z, chunk = blockIdx.y, N = gridDim.z;
+    // the radix histograms of this call start at zero: the launches that add to them come after this one on the stream, the last reader
+    // of the previous call's came before it (no memset node per call)
+    if (blockIdx.x == 0 && blockIdx.y == 0)
+        for (int i = threadIdx.x; i < 4 * 256; i += 256) hist[(size_t)n * 4 * 256 + i] = 0u;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t p0 = (int64_t)blockIdx.x * CS_TILE + threadIdx.x;
     const int c0 = chunk * CS_CH, c1 = min(C, c0 + CS_CH);
@@ -740,6 +745,48 @@ __global__ __launch_bounds__(256) void cond_select_pass_kernel(const float *__re
     }
     __syncthreads();
     if (lh[threadIdx.x]) atomicAdd(&hist[((size_t)n * 4 + pass) * 256 + threadIdx.x], lh[threadIdx.x]);
+}
+
+// Radix digits 1..3 of the selection in ONE launch, one 1024-thread workgroup per sample: the keys of the sample stay in registers (KPT per
+// thread), digit 0 comes from the complete histogram the score reduction left in global memory, every later digit from the LDS histogram of
+// the pass before.  Below the top byte the keys of a map are spread over the bins, so plain LDS atomics do (the ballot pre-count of hist_add
+// is for the top byte, which the keys of one map share).  Leaves what cond_masked_gap_fused_kernel reads: hist[n][3] (plain stores) and
+// sel[n][2].  Replaces three dependent launches of ~4.6 us each.
+template <int KPT>
+__global__ __launch_bounds__(1024) void cond_select_tail_kernel(const float *__restrict__ scores, int64_t hw, int k_rank, uint32_t *__restrict__ hist,
+                                                                 CondSel *__restrict__ sel) {
+    __shared__ uint32_t lh[2][256];
+    __shared__ CondSel cur;
+    const int n = blockIdx.x;
+    const float *s = scores + (size_t)n * hw;
+    uint32_t key[KPT];
+#pragma unroll
+    for (int u = 0; u < KPT; ++u) {
+        const int64_t i = (int64_t)threadIdx.x + u * 1024;
+        key[u] = float_order_key(s[i < hw ? i : hw - 1]);
+    }
+    const int nv = (int)((hw - threadIdx.x + 1023) / 1024);           // valid keys of this thread
+    if (threadIdx.x < 512) lh[threadIdx.x >> 8][threadIdx.x & 255] = 0u;
+    CondSel prev = CondSel{0u, (uint32_t)k_rank};
+#pragma unroll
+    for (int pass = 1; pass <= 3; ++pass) {
+        if (threadIdx.x < 64) {
+            uint32_t bin, left;
+            select_bin(pass == 1 ? hist + (size_t)n * 4 * 256 : lh[pass & 1], prev.k, bin, left);
+            if (threadIdx.x == 0) cur = CondSel{prev.prefix | (bin << (8 * (4 - pass))), left};
+        }
+        __syncthreads();
+        prev = cur;
+        uint32_t *H = lh[(pass + 1) & 1];
+        const uint32_t mask = 0xffffffffu << (8 * (4 - pass)), shift = 8 * (3 - pass);
+#pragma unroll
+        for (int u = 0; u < KPT; ++u)
+            if (u < nv && (key[u] & mask) == prev.prefix) atomicAdd(&H[(key[u] >> shift) & 255u], 1u);
+        __syncthreads();
+        if (pass < 3 && threadIdx.x < 256) lh[pass & 1][threadIdx.x] = 0u;     // consumed by this pass's select_bin; the pass after next adds to it
+    }
+    if (threadIdx.x < 256) hist[((size_t)n * 4 + 3) * 256 + threadIdx.x] = lh[0][threadIdx.x];
+    if (threadIdx.x == 0) sel[(size_t)n * 4 + 2] = prev;
 }
 
 // gap[n,c] = (1/HW) * sum_p z[n,c,p] * (scores[n,p] > threshold[n])    (CL:36-43), threshold = the k-th largest score (last radix digit
@@ -1248,7 +1295,7 @@ struct CondWs {
     uint32_t *hist;
     CondSel *sel;
     int n_part, n_chunks;
-    size_t zero_bytes, total;
+    size_t total;
 };
 static inline CondWs cond_carve(void *base, int N, int C, int64_t hw) {
     CondWs w;
@@ -1257,8 +1304,7 @@ static inline CondWs cond_carve(void *base, int N, int C, int64_t hw) {
     auto take = [&](size_t bytes) { char *r = p ? p + off : nullptr; off += aoc_align_up(bytes, 256); return r; };
     w.n_part = (int)((hw + CS_TILE - 1) / CS_TILE);
     w.n_chunks = (C + CS_CH - 1) / CS_CH;
-    w.hist = reinterpret_cast<uint32_t *>(take((size_t)N * 4 * 256 * sizeof(uint32_t)));       // zeroed per call
-    w.zero_bytes = off;
+    w.hist = reinterpret_cast<uint32_t *>(take((size_t)N * 4 * 256 * sizeof(uint32_t)));       // zeroed by the first launch of a call
     w.sel = reinterpret_cast<CondSel *>(take((size_t)N * 4 * sizeof(CondSel)));
     w.scores = reinterpret_cast<float *>(take((size_t)N * hw * sizeof(float)));
     w.threshold = reinterpret_cast<float *>(take((size_t)N * sizeof(float)));
@@ -1288,12 +1334,20 @@ int aoc_cond_gate_pool_ex(const float *z, int N, int C, int64_t hw, const float 
     hipStream_t st = aoc_hip_stream(stream);
     const CondWs w = cond_carve(workspace, N, C, hw);
     float *sc = scores ? scores : w.scores;
-    if (hipMemsetAsync(w.hist, 0, w.zero_bytes, st) != hipSuccess) return AOC_ERR_LAUNCH;
     const dim3 pgrid((unsigned)((hw + CS_PIX - 1) / CS_PIX), N);
-    hipLaunchKernelGGL(cond_scores_part_kernel, dim3((unsigned)w.n_part, (unsigned)w.n_chunks, N), dim3(256), 0, st, z, C, hw, phi_w, w.part_scores, w.partial);
+    hipLaunchKernelGGL(cond_scores_part_kernel, dim3((unsigned)w.n_part, (unsigned)w.n_chunks, N), dim3(256), 0, st, z, C, hw, phi_w, w.part_scores, w.partial,
+                       w.hist);
     hipLaunchKernelGGL(cond_scores_reduce_kernel, pgrid, dim3(CS_PIX), 0, st, w.part_scores, w.n_chunks, hw, phi_b, sc, w.hist);
-    for (int pass = 1; pass <= 3; ++pass)
-        hipLaunchKernelGGL(cond_select_pass_kernel, pgrid, dim3(256), 0, st, sc, hw, k_rank, pass, w.hist, w.sel);
+    static const int tail = AOC_DEV_ENV_INT("AOC_COND_TAIL", 1);
+    if (tail && hw <= 8 * 1024)
+        hipLaunchKernelGGL(cond_select_tail_kernel<8>, dim3(N), dim3(1024), 0, st, sc, hw, k_rank, w.hist, w.sel);
+    else if (tail && hw <= 32 * 1024)
+        hipLaunchKernelGGL(cond_select_tail_kernel<32>, dim3(N), dim3(1024), 0, st, sc, hw, k_rank, w.hist, w.sel);
+    else if (tail && hw <= 64 * 1024)
+        hipLaunchKernelGGL(cond_select_tail_kernel<64>, dim3(N), dim3(1024), 0, st, sc, hw, k_rank, w.hist, w.sel);
+    else
+        for (int pass = 1; pass <= 3; ++pass)                     // larger maps: one launch per digit, spread over the GPU
+            hipLaunchKernelGGL(cond_select_pass_kernel, pgrid, dim3(256), 0, st, sc, hw, k_rank, pass, w.hist, w.sel);
     hipLaunchKernelGGL(cond_masked_gap_fused_kernel, dim3(C, N), dim3(256), 0, st, z, C, hw, sc, w.hist, w.sel, w.partial, w.n_part, threshold, gap,
                        plane_mean);
     AOC_RETURN_IF_LAUNCH_FAILED();
