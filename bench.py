@@ -1129,7 +1129,7 @@ def main():
                            avg_launch_ms=km["avg_ms"], algorithmic_bytes_per_launch=km["avg_bytes"],
                            note="a dependent chain of ~105 launches whose ordered float32 sums are latency-bound by construction; the in-run "
                                 "figure spans the time the chain shares the GPU with the other streams",
-                           traffic_offline=dict(file="profiles/r04_pmc_kmeans_R6_F3.txt", commit="2af9134", source="constants copied from the committed file, not measured in this run",
+                           traffic_offline=dict(file="profiles/r04_pmc_kmeans_R6_F3.txt", commit="e1871d4", source="constants copied from the committed file, not measured in this run",
                                                 workload="three frames per chain, R = 6 pool frames (61.9 MB of pool rows), per Lloyd iteration",
                                                 fetch_bytes_per_iteration=336.0e6, rows_bytes=61.9e6, reads_per_frame_and_iteration=round(336.0 / 3 / 61.9, 2),
                                                 note="FETCH_SIZE x 2 (gfx950 counts 128-byte requests as 64) summed over the five kernels of an iteration: "
@@ -1143,20 +1143,29 @@ def main():
             return dict(kernel=kernel, bound="hbm", achieved=kk["gbs"], peak=PEAK_HBM_GBS, unit="GB/s", frac=round(kk["gbs"] / PEAK_HBM_GBS, 4),
                         avg_launch_ms=kk["avg_ms"], algorithmic_bytes_per_launch=kk["avg_bytes"], calls=kk["calls"], note=note)
 
-        film_roof = hbm_roof("film_scale", "film_scale_kernel (aoc_film_scale: IA gates and the FiLM of the conditioning blocks)",
+        film_roof = hbm_roof("film_scale", "film_scale_ahead_kernel (aoc_film_scale: IA gates and the FiLM of the conditioning blocks)",
                              "in-run average over the 14 activation shapes of decoding_module.py:22-84; algorithmic bytes 2 O c h w 4 (SURVEY 8d)")
-        cond_roof = hbm_roof("cond_gate_pool", "cond_scores / cond_kth_largest / cond_masked_gap (aoc_cond_gate_pool)",
+        cond_roof = hbm_roof("cond_gate_pool", "cond_scores_part / cond_scores_reduce / cond_select_tail / cond_masked_gap_fused (aoc_cond_gate_pool_ex)",
                              "in-run average over the 4 conditioning blocks; algorithmic bytes O C H W 4 = ONE read of z (SURVEY 8d); the op reads z twice "
                              "(scores, masked pooling) around the exact k-th-largest selection")
-        calib_pmc = dict(file="profiles/r03_pmc_calibration_cfg2.txt", commit="3c2da86", source="constants copied from the committed file, not measured in this run")
+        calib_pmc = dict(file="profiles/r04_pmc_gates_cfg2.txt", commit="e1871d4", source="constants copied from the committed file, not measured in this run")
+        gates_alone = dict(file="profiles/r04_gates_standalone.txt", commit="e1871d4", source="constants copied from the committed file (tools/bench_gates.py on an idle GPU), "
+                                                                                                "not measured in this run")
         if film_roof is not None:
-            film_roof["traffic_offline"] = dict(calib_pmc, shape=[4, 256, 121, 213], algorithmic_bytes=211.1e6, fetch_bytes=121.8e6, write_bytes=105.8e6, ratio=1.08,
-                                                note="the kernel alone (tools/pmc_calib.sh): FETCH_SIZE x 2 + WRITE_SIZE against one read + one write of the planes")
+            film_roof["traffic_offline"] = dict(calib_pmc, shape=[4, 256, 121, 213], algorithmic_bytes=211.1e6, fetch_bytes=111.8e6, write_bytes=105.2e6, ratio=1.03,
+                                                note="the kernel alone: FETCH_SIZE x 2 + WRITE_SIZE against one read + one write of the planes")
+            film_roof["alone_offline"] = dict(gates_alone, shape=[4, 256, 121, 213], avg_launch_ms=0.0402, achieved=5252.0, frac=0.656,
+                                              all_14_gates_ms=0.3708, all_14_gates_frac=0.597,
+                                              note="film_scale_ahead_kernel: the plane slice is requested before the gain's dot product; round 3's kernel: 0.048 ms = 0.55 "
+                                                   "at this shape, 0.485 ms over the 14 gates")
         if cond_roof is not None:
-            cond_roof["traffic_offline"] = dict(calib_pmc, shape=[4, 256, 121, 213], algorithmic_bytes=105.6e6, fetch_bytes=104.8e6 + 107.4e6 + 5.0e6,
-                                                write_bytes=4.1e6, ratio=2.1,
-                                                note="the op alone: the scores pass and the masked pooling read z once each (104.8 + 107.4 MB), the score "
-                                                     "reduction, three radix-select passes and the codes move < 2 MB each; nothing is re-read")
+            cond_roof["traffic_offline"] = dict(calib_pmc, shape=[4, 256, 121, 213], algorithmic_bytes=105.6e6, fetch_bytes=104.8e6 + 107.3e6 + 4.2e6,
+                                                write_bytes=3.9e6, ratio=2.1,
+                                                note="the op alone: the scores pass and the masked pooling read z once each (104.8 + 107.3 MB), the score "
+                                                     "reduction, the one-launch selection tail and the codes move < 2 MB each; nothing is re-read")
+            cond_roof["alone_offline"] = dict(gates_alone, shape=[4, 256, 121, 213], avg_launch_ms=0.060, achieved=1760.0, frac=0.22, moved_frac=0.44,
+                                              note="five launches (round 3: seven + a memset, 0.066 ms); frac prices ONE read of z, moved_frac the two reads the "
+                                                   "exact k-th-largest selection forces")
         corr_name = next((k for k in ("proxy_corr_min_records", "proxy_corr_min_batched") if k in kernels), "proxy_corr_min")
         corr = kernels.get(corr_name)
         corr_roof = None
