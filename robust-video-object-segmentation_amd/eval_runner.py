@@ -174,13 +174,13 @@ class HotPathBackend:
             if i >= n:
                 break
             part = inits[i:i + b]
-            out += ([self.hot.launch_cluster_proxies(mc, ref_emb, ref_lab, part[0], self.side)] if len(part) == 1
-                    else self.hot.launch_cluster_proxies_batch(mc, ref_emb, ref_lab, part, self.side))
+            out += ([self.hot.launch_cluster_proxies(mc, ref_emb, ref_lab, part[0], self.side, prep=prep)] if len(part) == 1
+                    else self.hot.launch_cluster_proxies_batch(mc, ref_emb, ref_lab, part, self.side, prep=prep))
             i += len(part)
         if i < n:
             rest = inits[i:]
-            out += ([self.hot.launch_cluster_proxies(mc, ref_emb, ref_lab, rest[0], self.side)] if len(rest) == 1
-                    else self.hot.launch_cluster_proxies_batch(mc, ref_emb, ref_lab, rest, self.side))
+            out += ([self.hot.launch_cluster_proxies(mc, ref_emb, ref_lab, rest[0], self.side, prep=prep)] if len(rest) == 1
+                    else self.hot.launch_cluster_proxies_batch(mc, ref_emb, ref_lab, rest, self.side, prep=prep))
         self._ahead = out
 
     @torch.no_grad()

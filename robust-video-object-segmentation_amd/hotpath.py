@@ -73,7 +73,7 @@ def proxy_table_rows(cfg, n_obj):
     return len(levels) * n_obj * 2 * max(levels) + n_obj
 
 
-def launch_cluster_proxies_batch(cfg, ref_emb, ref_labels, init_rows_list, side_stream=None, wait_event=None):
+def launch_cluster_proxies_batch(cfg, ref_emb, ref_labels, init_rows_list, side_stream=None, wait_event=None, prep=None):
     """Label prep + sticky K + 20 Lloyd iterations + proxy construction (AEM:252-286) of the pool for len(init_rows_list) frames
     that see the same pool, times len(cfg.cluster_levels) levels, enqueued on ``side_stream`` (None = the current stream) without
     any host synchronisation.  All frames x levels x objects advance as segments of ONE k-means chain (same rows, different initial
@@ -83,6 +83,8 @@ def launch_cluster_proxies_batch(cfg, ref_emb, ref_labels, init_rows_list, side_
                     scipy's minit='points': permutation(n_i)[:K_i])
     wait_event      the side stream first waits for it (e.g. the pool append of the previous frame); None = it waits for everything
                     enqueued so far on the caller's current stream (which produced the pool)
+    prep            the ops.LabelPrep of ref_labels when the caller has already computed it on its own stream (the evaluation runner
+                    reads the row counts back from it): it is reused instead of being computed a second time on the side stream
     Returns one ClusterProxiesAhead per frame, to pass to proto_mask_features(cluster_ahead=...)."""
     F = len(init_rows_list)
     R, h, w, C = ref_emb.shape
@@ -110,7 +112,11 @@ def launch_cluster_proxies_batch(cfg, ref_emb, ref_labels, init_rows_list, side_
         tables = [torch.empty(n_ad + O, C, dtype=torch.float32, device=dev) for _ in range(F)]
         sqns = [torch.empty(n_ad + O, dtype=torch.float32, device=dev) for _ in range(F)]
         pool = ref_emb.reshape(R * hw, C)
-        prep = ops.label_prep(ref_labels.reshape(R * hw, O))
+        if prep is None:
+            prep = ops.label_prep(ref_labels.reshape(R * hw, O))
+        elif side is not main:
+            for t in (prep.right_bits, prep.wrong_bits, prep.fg_rows, prep.obj_rows, prep.counts, prep.obj_offsets):
+                t.record_stream(side)
         prep_event = torch.cuda.Event()
         prep_event.record(side)
         cap = prep.obj_rows.numel()
@@ -137,9 +143,9 @@ def launch_cluster_proxies_batch(cfg, ref_emb, ref_labels, init_rows_list, side_
     return outs
 
 
-def launch_cluster_proxies(cfg, ref_emb, ref_labels, init_rows_dev, side_stream=None, wait_event=None):
+def launch_cluster_proxies(cfg, ref_emb, ref_labels, init_rows_dev, side_stream=None, wait_event=None, prep=None):
     """launch_cluster_proxies_batch for one frame."""
-    return launch_cluster_proxies_batch(cfg, ref_emb, ref_labels, [init_rows_dev], side_stream, wait_event)[0]
+    return launch_cluster_proxies_batch(cfg, ref_emb, ref_labels, [init_rows_dev], side_stream, wait_event, prep)[0]
 
 
 class IncrementalProxyBank:
