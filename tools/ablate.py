@@ -1,6 +1,7 @@
 """Developer tool (GPU box): where does a bench step go?  Runs bench.py's timed region with parts of the hot path replaced by no-ops
 (the results are then WRONG: this only measures sensitivities).  AOC_ABLATE = comma list of {dense, gates, local, kmeans, corr}.
-Usage: AOC_ABLATE=dense python tools/ablate.py --steps 30 --no-cpu-baseline --exact-steps 0"""
+Usage: AOC_ABLATE=dense python tools/ablate.py --python-frames --no-extras --steps 30 --no-cpu-baseline --exact-steps 0
+(--python-frames: the ops are patched at the Python level, which the one-call-per-frame path of round 4 does not go through)"""
 import importlib
 import os
 import sys
