@@ -77,6 +77,15 @@ int aoc_label_bits(const float *labels, int64_t n, int n_obj, uint32_t *right_bi
 int aoc_kmeans_plan(const int32_t *counts, int n_seg, int cluster_num, int32_t *seg_k,
                     aoc_stream_t stream);
 
+/* HOST function (no device work, no stream): the initial rows of the k-means calls of n_frames frames x n_levels levels x n_obj objects that see
+ * one pool state, exactly as the reference draws them -- scipy kmeans2(minit='points') -> numpy.random.RandomState.choice(n, k, replace=False)
+ * = permutation(n)[:k] on the global legacy MT19937 stream, in the order frame, level, object, with the sticky cluster count of AEM:268 and no
+ * draw where it is zero (AEM:263-276).  mt_key [624] / *mt_pos: the generator's state (numpy get_state()[1:3]), advanced in place.
+ * counts [n_obj] (host), levels [n_levels] (host, each <= kmax); rows_out [n_frames][n_levels * n_obj][kmax] int32 (host), unused entries 0;
+ * states_out (may be NULL) [n_frames][625]: key + pos as each frame's first draw finds them (to hand unused frames' draws back). */
+int aoc_kmeans_init_rows_draw(uint32_t *mt_key, int32_t *mt_pos, const int32_t *counts, int n_obj, const int32_t *levels, int n_levels,
+                              int n_frames, int kmax, int32_t *rows_out, uint32_t *states_out);
+
 /* Segment lists replicated n_rep times: the k-means of several frames that see the SAME pool (the reference re-clusters
  * the whole pool every frame with fresh initial rows, AEM:268-276; the pool only changes every MEM_EVERY frames,
  * eval_manager_mm.py:356-361) can then advance together in one aoc_kmeans_segmented_ex call with n_rep * n_seg segments.

@@ -29,6 +29,7 @@ SIGNATURES = {
     "aoc_label_prep": (_i, [_vp, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "aoc_label_bits": (_i, [_vp, _i64, _i, _vp, _vp, _vp]),
     "aoc_kmeans_plan": (_i, [_vp, _i, _i, _vp, _vp]),
+    "aoc_kmeans_init_rows_draw": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp, _vp]),
     "aoc_kmeans_workspace_bytes": (_sz, [_i64, _i, _i, _i]),
     "aoc_kmeans_segmented": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
     "aoc_kmeans_segmented_ex": (_i, [_vp, _i64, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),

@@ -159,28 +159,23 @@ class HotPathBackend:
             return                                           # nothing labelled: the per-frame path handles it (AEM:588-589)
         levels = mc.cluster_levels
         kmax = max(levels)
-        inits = []
-        for _ in range(n):
-            self._ahead_rng.append(self.rng.get_state())
-            rows = np.zeros((len(levels) * O, kmax), np.int32)
-            for li, k in enumerate(levels):
-                for i in range(O):
-                    k = min(k, int(counts[i]))               # AEM:268 (sticky, per level)
-                    if k > 0:
-                        rows[li * O + i, :k] = self.rng.permutation(int(counts[i]))[:k]
-            inits.append(torch.from_numpy(rows).to(self.device, non_blocking=True))
-        out, i = [], 0
+        # the draws of a batch are made right before its chain is launched (numpy.random.RandomState.permutation(n)[:k] per frame, level and
+        # object, reproduced by aoc_kmeans_init_rows_draw): the GPU starts on the first frame's chain while the host draws for the others
+        sizes, left = [], n
         for b in self.chain_plan:                            # batch sizes of the chains of one pool state (default: the first frame's alone)
-            if i >= n:
+            if left <= 0:
                 break
-            part = inits[i:i + b]
-            out += ([self.hot.launch_cluster_proxies(mc, ref_emb, ref_lab, part[0], self.side, prep=prep)] if len(part) == 1
+            sizes.append(min(b, left))
+            left -= sizes[-1]
+        if left > 0:
+            sizes.append(left)
+        out = []
+        for b in sizes:
+            rows, states = ops.kmeans_init_rows_draw(self.rng, counts[:O], levels, b, kmax)
+            self._ahead_rng += states
+            part = [torch.from_numpy(rows[f]).to(self.device, non_blocking=True) for f in range(b)]
+            out += ([self.hot.launch_cluster_proxies(mc, ref_emb, ref_lab, part[0], self.side, prep=prep)] if b == 1
                     else self.hot.launch_cluster_proxies_batch(mc, ref_emb, ref_lab, part, self.side, prep=prep))
-            i += len(part)
-        if i < n:
-            rest = inits[i:]
-            out += ([self.hot.launch_cluster_proxies(mc, ref_emb, ref_lab, rest[0], self.side, prep=prep)] if len(rest) == 1
-                    else self.hot.launch_cluster_proxies_batch(mc, ref_emb, ref_lab, rest, self.side, prep=prep))
         self._ahead = out
 
     @torch.no_grad()

@@ -106,6 +106,28 @@ def kmeans_plan(counts, n_seg, cluster_num):
 
 
 # ------------------------------------------------------------------------------------------ k-means
+def kmeans_init_rows_draw(rng, counts, levels, n_frames, kmax=None):
+    """Initial rows of the k-means calls of `n_frames` frames that see one pool state, drawn from `rng` (a numpy.random.RandomState, advanced
+    in place) exactly as the reference's per-frame kmeans2(minit='points') calls would draw them (aoc_kmeans_init_rows_draw; HOST function).
+    counts: rows per object.  Returns (rows int32 [n_frames, len(levels) * n_obj, kmax], states): states[f] = the generator state in front of
+    frame f's draws (for rng.set_state when the frames from f on are not used after all)."""
+    import numpy as np
+    counts = np.ascontiguousarray(np.asarray(counts, dtype=np.int32).reshape(-1))
+    lv = np.ascontiguousarray(np.asarray(list(levels), dtype=np.int32))
+    kmax = int(max(levels) if kmax is None else kmax)
+    st = rng.get_state()
+    assert st[0] == "MT19937"
+    key = np.ascontiguousarray(st[1], dtype=np.uint32).copy()
+    pos = ctypes.c_int32(int(st[2]))
+    rows = np.empty((int(n_frames), len(lv) * len(counts), kmax), dtype=np.int32)
+    snaps = np.empty((int(n_frames), 625), dtype=np.uint32)
+    _lib.check(_lib.lib().aoc_kmeans_init_rows_draw(key.ctypes.data, ctypes.byref(pos), counts.ctypes.data, len(counts), lv.ctypes.data, len(lv),
+                                                    int(n_frames), kmax, rows.ctypes.data, snaps.ctypes.data), "aoc_kmeans_init_rows_draw")
+    rng.set_state((st[0], key, int(pos.value), st[3], st[4]))
+    states = [(st[0], snaps[f, :624].copy(), int(snaps[f, 624]), st[3], st[4]) for f in range(int(n_frames))]
+    return rows, states
+
+
 def kmeans_segmented(pool, rows, seg_offsets, seg_k, init_rows, kmax, iters=20, rows_capacity=None, n_rep=1):
     """Segmented k-means, bit-identical to scipy kmeans2 (see include/aoc_hip.h).
     n_rep > 1: the segment lists are n_rep replicas of n_seg / n_rep base segments (kmeans_replicate[_levels]).

@@ -326,3 +326,51 @@ def test_oracle_davis_metrics_known_answers():
     assert om.db_eval_boundary(a, np.zeros_like(a)) == 0.0
     bm = om.seg2bmap(a)
     assert bm[4, 10] and bm[14, 10] and not bm[8, 10] and bm[8, 4] and bm[8, 19]
+
+
+def _numpy_init_rows(rng, counts, levels, n_frames, kmax):
+    """What eval_runner drew before aoc_kmeans_init_rows_draw existed: scipy kmeans2(minit='points') = RandomState.permutation(n)[:k]
+    per frame, level and object, with the sticky cluster count of AEM:268."""
+    rows = np.zeros((n_frames, len(levels) * len(counts), kmax), np.int32)
+    states = []
+    for f in range(n_frames):
+        states.append(rng.get_state())
+        for li, k in enumerate(levels):
+            for i in range(len(counts)):
+                k = min(k, int(counts[i]))
+                if k > 0:
+                    rows[f, li * len(counts) + i, :k] = rng.permutation(int(counts[i]))[:k]
+    return rows, states
+
+
+def test_init_rows_draw_is_numpys_legacy_stream():
+    """aoc_kmeans_init_rows_draw (host function of the library) against numpy itself: same rows, same generator state afterwards (key,
+    position, cached gaussian untouched), same per-frame snapshots -- over object sizes 0 / 1 / 2 / powers of two +- 1, generator positions
+    in the middle and at the end of a 624-word block, one to three levels."""
+    r = np.random.RandomState(11)
+    sizes = [0, 1, 2, 3, 4, 5, 17, 31, 32, 33, 255, 256, 257, 1000, 4097, 30000]
+    for trial in range(120):
+        counts = [int(x) for x in r.choice(sizes, r.randint(1, 7))]
+        levels = [[16], [8, 16, 32], [4], [64, 2]][r.randint(4)]
+        n = int(r.randint(1, 6))
+        seed = int(r.randint(1 << 30))
+        a, b = np.random.RandomState(seed), np.random.RandomState(seed)
+        skip = int(r.choice([0, 1, 623, 624, 625, 1247, 1500]))
+        a.randint(0, 10, skip)
+        b.randint(0, 10, skip)
+        if r.rand() < 0.3:
+            a.randn(1), b.randn(1)                          # a cached gaussian in the state: must survive
+        want, want_states = _numpy_init_rows(a, counts, levels, n, max(levels))
+        got, got_states = aoc_amd.ops.kmeans_init_rows_draw(b, counts, levels, n)
+        assert np.array_equal(want, got), (trial, counts, levels, n)
+        sa, sb = a.get_state(), b.get_state()
+        assert np.array_equal(sa[1], sb[1]) and sa[2:] == sb[2:]
+        for x, y in zip(want_states, got_states):
+            assert np.array_equal(x[1], y[1]) and x[2:] == y[2:]
+        assert a.randint(0, 1 << 30) == b.randint(0, 1 << 30)
+    # a handed-back frame: restoring a snapshot replays the same draws
+    a = np.random.RandomState(3)
+    rows, states = aoc_amd.ops.kmeans_init_rows_draw(a, [500, 20, 0, 7], [8, 16], 4)
+    a.set_state(states[2])
+    again, _ = aoc_amd.ops.kmeans_init_rows_draw(a, [500, 20, 0, 7], [8, 16], 2)
+    assert np.array_equal(again, rows[2:])
