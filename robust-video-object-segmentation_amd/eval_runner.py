@@ -81,6 +81,7 @@ class HotPathBackend:
         import os
         self.chain_plan = [int(x) for x in os.environ.get("AOC_EVAL_CHAIN_PLAN", "1").split(",") if x.strip()] or [1]   # developer switch
         self.side = None
+        self._worker, self._pending = None, None
 
     def _head(self, n_ch):
         if n_ch not in self._heads:
@@ -108,6 +109,7 @@ class HotPathBackend:
         self._pool_emb = torch.empty(cap, spec.h, spec.w, 100, dtype=torch.float32, device=self.device)
         self._pool_lab = torch.empty(cap, spec.h, spec.w, spec.n_obj, dtype=torch.float32, device=self.device)
         self._pool_R = 0
+        self._drop_pending()
         self._ahead, self._ahead_rng = [], []
         # ONE C call per frame (aoc_frame_enqueue) where the configuration allows: its workspace is kept per map size / object count
         self.runner = None
@@ -148,9 +150,10 @@ class HotPathBackend:
         n = (-(-t // m) * m - t + 1) if m > 0 else 5
         n = max(1, min(n, spec.frames - t))
         O = spec.n_obj
+        self._join_pending(launch=False)                     # a worker may still be drawing for the pool state that just ended
         prep = ops.label_prep(ref_lab.reshape(-1, O))
         counts = prep.counts.cpu().numpy()
-        if self._ahead and self._ahead_rng:
+        if self._ahead_rng:
             # chains enqueued for a pool that changed earlier than predicted (a later frame carried ground truth) are dropped: their initial
             # rows go back into the stream, so that the draws stay those of the per-frame path (and of the reference: one kmeans2 per frame)
             self.rng.set_state(self._ahead_rng[0])
@@ -169,20 +172,52 @@ class HotPathBackend:
             left -= sizes[-1]
         if left > 0:
             sizes.append(left)
-        out = []
-        for b in sizes:
-            rows, states = ops.kmeans_init_rows_draw(self.rng, counts[:O], levels, b, kmax)
-            self._ahead_rng += states
-            part = [torch.from_numpy(rows[f]).to(self.device, non_blocking=True) for f in range(b)]
-            out += ([self.hot.launch_cluster_proxies(mc, ref_emb, ref_lab, part[0], self.side, prep=prep)] if b == 1
-                    else self.hot.launch_cluster_proxies_batch(mc, ref_emb, ref_lab, part, self.side, prep=prep))
-        self._ahead = out
+        # the first batch is drawn and launched now; the draws of the others (a host computation of milliseconds that releases the GIL) run on a
+        # worker thread while this thread enqueues the other lanes' frames, and their chains are launched when this lane comes round again
+        ready = torch.cuda.Event()                           # the pool and its label prep are final here: all a chain has to wait for
+        ready.record()
+        self._launch_batch(ops.kmeans_init_rows_draw(self.rng, counts[:O], levels, sizes[0], kmax), ref_emb, ref_lab, prep, ready)
+        if len(sizes) > 1:
+            if self._worker is None:
+                from concurrent.futures import ThreadPoolExecutor
+                self._worker = ThreadPoolExecutor(max_workers=1)
+            rng, c = self.rng, counts[:O].copy()
+            fut = self._worker.submit(lambda: [ops.kmeans_init_rows_draw(rng, c, levels, b, kmax) for b in sizes[1:]])
+            self._pending = (fut, ref_emb, ref_lab, prep, ready)
+
+    def _launch_batch(self, drawn, ref_emb, ref_lab, prep, ready):
+        rows, states = drawn
+        self._ahead_rng += states
+        with torch.cuda.stream(self.side):                   # the rows are uploaded on the chain's own stream: nothing of the frame in front of them
+            part = [torch.from_numpy(rows[f]).to(self.device, non_blocking=True) for f in range(rows.shape[0])]
+        self._ahead += ([self.hot.launch_cluster_proxies(self.mc, ref_emb, ref_lab, part[0], self.side, wait_event=ready, prep=prep)] if len(part) == 1
+                        else self.hot.launch_cluster_proxies_batch(self.mc, ref_emb, ref_lab, part, self.side, wait_event=ready, prep=prep))
+
+    def _join_pending(self, launch=True):
+        """The draws a worker thread made for the later batches of the current pool state: their generator states join the hand-back list,
+        their chains are launched (unless the pool state is over)."""
+        if self._pending is None:
+            return
+        fut, ref_emb, ref_lab, prep, ready = self._pending
+        self._pending = None
+        for drawn in fut.result():
+            if launch:
+                self._launch_batch(drawn, ref_emb, ref_lab, prep, ready)
+            else:
+                self._ahead_rng += drawn[1]
+
+    def _drop_pending(self):
+        if getattr(self, "_pending", None) is not None:
+            self._pending[0].result()
+        self._pending = None
 
     @torch.no_grad()
     def frame(self, emb):
         """emb [h, w, C] -> predicted label map [H, W] int32 (H = 4 h: the reference's masks live at image resolution)."""
         spec, h, w = self.spec, self.spec.h, self.spec.w
         ref_emb, ref_lab, prev_emb, prev_lab, changed = self._reference_pool()
+        if not changed:
+            self._join_pending()
         if self.ahead and (changed or not self._ahead):
             self._launch_ahead(ref_emb, ref_lab)
         ahead = self._ahead.pop(0) if self._ahead else None
