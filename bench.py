@@ -1220,7 +1220,10 @@ def main():
             other = {}
             for name in ("cfg3", "cfg4"):
                 try:
-                    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--config", name, "--steps", "10", "--warmup", "3", "--min-region-s", "0.3",
+                    # a region = whole walks over the config's clip (frames - 1 steps each), like the cfg2 default: every pool size in proportion
+                    walk = syn.CONFIGS[name].frames - 1
+                    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--config", name, "--steps", str(walk * (2 if walk < 10 else 1)), "--warmup", "3",
+                                        "--min-region-s", "0.3",
                                         "--no-cpu-baseline", "--exact-steps", "0", "--no-extras"], capture_output=True, text=True, timeout=420)
                     j = json.loads(r.stdout.strip().splitlines()[-1])
                     other[name] = dict(value=j["value"], unit=j["unit"], ms_per_step=j["ms_per_step"], steps=j["steps"], timed_regions=j["timed_regions"],

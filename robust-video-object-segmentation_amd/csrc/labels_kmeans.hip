@@ -1050,8 +1050,12 @@ __global__ __launch_bounds__(256, 2) void km_assign_mfma_rep_kernel(const float 
             for (int r = 0; r < ng; ++r) {
                 float low = INFINITY;
                 int arg = 0;
+                // cluster tiles this replica really has (levels 8 / 16 next to 32 in one chain: kmax = 32 pads every code book to two tiles);
+                // the padding rows carry the norm +inf and can never be the minimum, so leaving their MFMAs out changes nothing
+                const int ktr = (lk[r] + 15) >> 4;
 #pragma unroll
                 for (int kt = 0; kt < KT; ++kt) {
+                    if (kt >= ktr) continue;
                     // A operands of replica r: lane (i = j, kq = g) holds c[16 kt + i][4t + kq]
                     const float *st = cimg + (size_t)r * CB + (size_t)(kt * 16 + j) * RS + g * TP;
                     float4 ca[NB4];
