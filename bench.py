@@ -1115,6 +1115,10 @@ def main():
                                      "GPU -- including, unless --dense-order is given, the other sequence's dense kernel (0.22 overlapping, 0.24 one "
                                      "after the other, 0.31 alone); traffic (PMC FETCH/WRITE) is not measurable inside the run: the separate --pmc passes are under profiles/",
                                 op_avg_ms=k.get("op_avg_ms"))
+                roofline["alone_offline"] = dict(file="profiles/r04_pmc_dense_R6.txt", commit="05709ec", source="constants copied from the committed file (tools/bench_dense.py 6 "
+                                                 "on an idle GPU, all 256 CUs), not measured in this run", pool_frames=6, avg_launch_ms=1.082, achieved=736.7, frac=0.295,
+                                                 fetch_bytes=366.0e6, record_bytes=80.8e6, mfma_busy_share_of_simd_cycles=0.49,
+                                                 note="FETCH_SIZE x 2 per launch = 4.5 x the split records at 0.34 TB/s: the kernel does not wait for that traffic")
                 if args.cu_reserve > 0:
                     # the kernel is launched on a stream whose CU mask leaves cu_reserve CUs to the k-means chains
                     cus = n_cu - args.cu_reserve
