@@ -101,6 +101,7 @@ class OpTimer:
         self._pool = []
         self.streams = {}
         self.want_segments = False
+        self.probe_every = 1
         self.segments = {}                                   # --segments: per stream, the event tuples of its frames in order
 
     def segment_summary(self):
@@ -465,7 +466,7 @@ def frame_step(wl, gates, acts, dense_precision="split", pipeline=True, defer_co
     """One frame of one sequence; returns (feat, gate outputs, pending correlation or None)."""
     ref_emb, ref_lab = wl.refs()
     t = wl.t
-    seg = None
+    seg = probes = None
     if wl.bank is not None:
         feat, head, aux = hotpath.proto_mask_features(wl.mc, ref_emb, ref_lab, wl.emb[t - 1], wl.lab[t - 1], wl.emb[t], wl.bias,
                                                       cluster_ahead=wl.bank.handle(ref_lab), dense_state=wl.dense_state, dense_precision=dense_precision,
@@ -490,7 +491,11 @@ def frame_step(wl, gates, acts, dense_precision="split", pipeline=True, defer_co
         if wl.runner is not None and dense_precision == "split" and wl.dense_stream is None and not defer_corr:
             # ONE C call for the frame (aoc_frame_enqueue); the op timings the line reports come from events the call records itself
             tm = wl.timer
-            probes = tm.frame_probes() if (tm is not None and tm.enabled) else None
+            # the event brackets are placed on every --probe-every-th frame of a sequence (on every frame they cost 2.6 % of the throughput:
+            # ~40 event records per frame on the stream); the two sequences are probed on different steps
+            wl.n_probe_tick = getattr(wl, "n_probe_tick", getattr(wl, "probe_phase", 0)) + 1
+            sample = tm is not None and tm.enabled and wl.n_probe_tick % max(tm.probe_every, 1) == 0
+            probes = tm.frame_probes() if sample else None
             seg_begin = tm._record() if (probes is not None and tm.want_segments) else None
             h0 = time.perf_counter()
             feat, head = wl.runner(ref_emb, ref_lab, wl.emb[t - 1], wl.lab[t - 1], wl.emb[t], wl.bias, ahead, pool_key=wl.pool_gen, probes=probes)
@@ -511,7 +516,7 @@ def frame_step(wl, gates, acts, dense_precision="split", pipeline=True, defer_co
                                                       dense_state=wl.dense_state, dense_precision=dense_precision, defer_correlation=defer_corr)
     if wl.batch_gates:
         tm = wl.timer
-        gp = tm.gate_probes(gates, acts) if (tm is not None and tm.enabled) else None
+        gp = tm.gate_probes(gates, acts) if (tm is not None and tm.enabled and (probes is not None or wl.runner is None)) else None
         h0 = time.perf_counter()
         outs = gates.forward_batched(acts, head, slot=id(wl), probes=gp)
         HOST_S["gates_call"] += time.perf_counter() - h0
@@ -730,6 +735,8 @@ def main():
                     help="batch sizes of the k-means chains of a group of MEM_EVERY frames, e.g. 1,2,2 (overrides --chains).  Default: 2,3 for cfg2 "
                          "(340-342 frames/s against 332-334 with --chains 3, three runs each; cfg3 / cfg4 are 2 %% slower with it), none otherwise; "
                          "'none' = the --chains schedule")
+    ap.add_argument("--probe-every", type=int, default=4,
+                    help="HIP-event brackets (in-run op timings of the roofline objects) on every N-th frame of a sequence; 1 = every frame (costs 2.6 %% frames/s)")
     ap.add_argument("--segments", action="store_true", help="developer output: mean time of the consecutive pieces of a frame on its stream (key frame_segments_ms)")
     ap.add_argument("--dump-timeline", default="", help="developer output: write the timed ops' (name, stream, start, end) to this JSON file")
     ap.add_argument("--chain-streams", type=int, default=1, help="side streams per sequence for its k-means chains (with --chain-plan: the batches of a group run side by side)")
@@ -974,6 +981,9 @@ def main():
         for wl in workloads:
             wl.count_r = True
         timer.want_segments = args.segments
+        timer.probe_every = args.probe_every
+        for i, wl in enumerate(workloads):
+            wl.probe_phase = i * max(1, args.probe_every // 2)
         timer.enabled = True                 # HIP events around every op, on the stream the op is launched on
         # EXACTLY --steps steps per region, bracketed by barrier + synchronize; regions are repeated (the group walk simply continues) until
         # --min-region-s seconds are covered, and the line reports the median region
@@ -1299,6 +1309,8 @@ def main():
                        "dense_precision": ("fp16-split products (hi*hi + hi*lo + lo*hi), fp32 accumulate: fp32-equivalent; exact-fp32 take-over "
                                            "on overflow / soft labels" if args.dense == "split" else "exact fp32 MFMA")},
             "host_enqueue_ms_per_step": round(host_enqueue_s / args.steps * 1e3, 3),
+            "probe_sampling": (f"the HIP-event brackets behind `kernels` / the roofline objects are placed on every {args.probe_every}-th frame of each sequence "
+                               "inside the timed region (on every frame -- --probe-every 1 -- their ~40 event records per frame cost 2.6 % frames/s)"),
             **({"frame_segments_ms": segments} if segments else {}),
             "exact_fp32_dense_run": exact,
             "roofline": top_roof if top_roof is not None else roofline, "roofline_dense": roofline, "roofline_correlation_kernel": corr_roof,
