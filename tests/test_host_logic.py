@@ -228,6 +228,22 @@ def test_c_abi_rejects_bad_arguments_without_a_gpu():
     fr[0].query_rec = None
     assert L.aoc_proxy_corr_min_records(fp, 1, 64, 100, 4, 1, ip, ip, lp, 1, wp, 256, None) == INVALID         # a frame without records
 
+    # the host-side draw of the k-means initial rows: generator position outside 0..624, a level above kmax, a negative count
+    key = (ctypes.c_uint32 * 624)()
+    pos = ctypes.c_int32(700)
+    counts = (ctypes.c_int32 * 2)(5, 3)
+    lv = (ctypes.c_int32 * 1)(4)
+    rows = (ctypes.c_int32 * 8)()
+    kp, cp, lvp, rp = (ctypes.cast(x, vp) for x in (key, counts, lv, rows))
+    assert L.aoc_kmeans_init_rows_draw(kp, ctypes.byref(pos), cp, 2, lvp, 1, 1, 4, rp, None) == INVALID
+    pos.value = 624
+    lv[0] = 5
+    assert L.aoc_kmeans_init_rows_draw(kp, ctypes.byref(pos), cp, 2, lvp, 1, 1, 4, rp, None) == INVALID
+    lv[0], counts[1] = 4, -1
+    assert L.aoc_kmeans_init_rows_draw(kp, ctypes.byref(pos), cp, 2, lvp, 1, 1, 4, rp, None) == INVALID
+    counts[1] = 3
+    assert L.aoc_kmeans_init_rows_draw(kp, ctypes.byref(pos), cp, 2, lvp, 1, 1, 4, rp, None) == 0 and pos.value != 624
+
 
 def test_mirrors_refuse_to_run_under_autograd():
     """the drop-in names include the reference's training-time ones; they build no autograd graph, so they must raise
