@@ -41,8 +41,12 @@ class conditioning_layer(nn.Module):
 class conditioning_block(nn.Module):
     """Paper Eq. 5, CLB:50-86."""
 
-    def __init__(self, in_dim=256, proxy_dim=400, beta_percentage=0.3):
+    def __init__(self, in_dim=256, proxy_dim=400, beta_percentage=0.3, attention_dim=None):
         super(conditioning_block, self).__init__()
+        # decoding_module.py:27-50 constructs the blocks with ``attention_dim=`` (a keyword the reference's own class rejects, CLB:54):
+        # accepted here as the width of the IA head, i.e. as ``proxy_dim``
+        if attention_dim is not None:
+            proxy_dim = attention_dim
         self.CL_1 = conditioning_layer(in_dim, beta_percentage)
         self.CL_2 = conditioning_layer(in_dim, beta_percentage)
         self.CL_3 = conditioning_layer(proxy_dim, 1)

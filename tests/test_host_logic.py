@@ -390,3 +390,65 @@ def test_init_rows_draw_is_numpys_legacy_stream():
     a.set_state(states[2])
     again, _ = aoc_amd.ops.kmeans_init_rows_draw(a, [500, 20, 0, 7], [8, 16], 2)
     assert np.array_equal(again, rows[2:])
+
+
+_INTEGRATION = r'''
+import importlib, sys
+sys.dont_write_bytecode = True                           # never write into /root/reference
+ref_root, repo = sys.argv[1], sys.argv[2]
+sys.path.insert(0, ref_root); sys.path.insert(0, repo)
+import aoc_amd
+# INTEGRATION.md section 1, verbatim
+sys.modules["networks.layers.matching"] = aoc_amd.matching
+sys.modules["networks.layers.attention"] = aoc_amd.attention
+sys.modules["networks.aoc.conditioning_layer"] = aoc_amd.conditioning_layer
+sys.modules["networks.p2t.conditioning_layer"] = aoc_amd.conditioning_layer
+sys.modules["networks.layers.gct"] = aoc_amd.gct          # the reference's gct.py imports networks.p2t.center_module, which it does not ship
+dm = importlib.import_module("networks.aoc.decoding_module")
+sys.modules["networks.p2t.decoding_module"] = dm          # aocnet.py:8 names a path the reference does not ship: its own decoder module
+an = importlib.import_module("networks.aoc.aocnet")
+# every name the two files import from the aliased modules is the mirror's object
+for name in ("global_matching", "global_matching_for_eval", "local_matching", "foreground2background", "global_matching_proxy", "local_matching_proxy",
+             "global_matching_cluster2", "global_matching_cluster", "global_matching_for_eval_cluster", "global_matching_for_eval_proxy"):
+    assert getattr(an, name) is getattr(aoc_amd.matching, name), name
+for name in ("calculate_attention_head", "calculate_attention_head_for_eval", "calculate_attention_head_p_m", "calculate_attention_head_for_eval_p_m"):
+    assert getattr(an, name) is getattr(aoc_amd.attention, name), name
+assert dm.IA_gate is aoc_amd.attention.IA_gate and dm.Bottleneck is aoc_amd.gct.Bottleneck and dm.GCT is aoc_amd.gct.GCT
+assert dm.conditioning_block is aoc_amd.conditioning_layer.conditioning_block and dm.conditioning_layer is aoc_amd.conditioning_layer.conditioning_layer
+assert an.CalibrationDecoding is dm.CalibrationDecoding and an.DynamicPreHead is dm.DynamicPreHead
+# the reference's decoder constructor with the arguments aocnet.py:37-42 passes (configs/resnet101_aocnet.py: 100 + 64, 400, 256, 64, 256).  Two names the
+# constructor reads are undefined in the reference (decoding_module.py:21 `unc_topk_ratio`, :30 `self.beta_percentage`): injected, nothing else is touched
+dm.unc_topk_ratio = 0.3
+dm.CalibrationDecoding.beta_percentage = 0.3
+dec = dm.CalibrationDecoding(in_dim=164, attention_dim=400, embed_dim=256, refine_dim=64, low_level_dim=256)
+A = aoc_amd
+assert isinstance(dec.IA1, A.attention.IA_gate) and dec.IA1.IA.weight.shape == (164, 400)
+assert isinstance(dec.CLB2, A.conditioning_layer.conditioning_block) and dec.CLB2.CL_3.mlp_layer.weight.shape == (400, 400)
+assert dec.CLB4.mlp_layer.weight.shape == (512, 2 * 512 + 400) and dec.CLB2.CL_1.beta_percentage == 0.3
+assert isinstance(dec.layer2, A.gct.Bottleneck) and isinstance(dec.GCT_sc, A.gct.GCT) and dec.GCT_sc.alpha.shape == (1, 512, 1, 1)
+assert dec.IA9.IA.weight.shape == (512, 400 + 512) and dec.IA10.IA.weight.shape == (320, 400 + 320) and dec.IA11.IA.weight.shape == (128, 400 + 128)
+# the gates of the decoder are the ones hotpath.CalibrationGates holds, name by name and shape by shape (a reference state_dict loads into either)
+gates = A.hotpath.CalibrationGates(A.hotpath.MatchingConfig())
+sd = dec.state_dict()
+for k, v in gates.state_dict().items():
+    assert k in sd and sd[k].shape == v.shape, k
+pre = dm.DynamicPreHead(in_dim=24, embed_dim=64)
+mine = A.hotpath.DynamicPreHead(in_dim=24, embed_dim=64)
+assert {k: tuple(v.shape) for k, v in pre.state_dict().items()} == {k: tuple(v.shape) for k, v in mine.state_dict().items()}
+print("INTEGRATION_OK", len(sd))
+'''
+
+_REF_ROOT = "/root/reference/AOC-Net/complete_project/AOCNet"
+
+
+@pytest.mark.skipif(not os.path.isdir(_REF_ROOT), reason="the reference only exists in the build container (nothing of it travels to the GPU box)")
+def test_reference_model_files_import_against_the_mirrors(tmp_path):
+    """INTEGRATION.md section 1 applied for real: with the sys.modules aliases in place the reference's OWN networks/aoc/aocnet.py and
+    networks/aoc/decoding_module.py import, every name they import resolves to a mirror, and the reference's decoder constructor
+    (decoding_module.py:10-93, arguments of aocnet.py:37-42) builds on the mirrors' constructors -- incl. the ``attention_dim=`` keyword it
+    passes to conditioning_block.  CPU only: constructors, no forward."""
+    script = tmp_path / "integration.py"
+    script.write_text(_INTEGRATION)
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-B", str(script), _REF_ROOT, repo], capture_output=True, text=True, timeout=300, cwd=str(tmp_path))
+    assert r.returncode == 0 and "INTEGRATION_OK" in r.stdout, r.stdout + r.stderr
