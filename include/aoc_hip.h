@@ -342,6 +342,10 @@ int aoc_dense_match_min_split_cached(const float *query, const void *query_rec, 
  * since the last reset (synchronises the device): out4[0] (reference tile, query tile) pairs tested with one fp16 product,
  * out4[1] pairs rescored with all three products, out4[2] reference tiles with at least one rescoring, out4[3] reference tiles. */
 int aoc_dense_prune_stats(uint64_t *out4, int reset);
+/* The same counters plus out8[4] = pairs that stopped at the kernel's checkpoint (after 3 of the 7 k-steps an upper bound of the pair's final
+ * value -- the partial product plus the Cauchy-Schwarz bound of the rest, both rest norms carried by the records -- was already below what is
+ * known for its pixels); out8[5..7] reserved (0). */
+int aoc_dense_prune_stats_ex(uint64_t *out8, int reset);
 
 /* How many CUs the streams that launch the matrix kernels (dense matching, batched correlation) may use -- a caller that runs them under a
  * HIP CU mask says so here and the kernels size their grids in whole rounds of that many CUs; 0 (default) = every CU of the device.

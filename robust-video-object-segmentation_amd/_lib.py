@@ -64,6 +64,7 @@ SIGNATURES = {
     "aoc_split_rows_tiled": (_i, [_vp, _i64, _i, _vp, _vp, _vp, _vp]),
     "aoc_dense_match_split_workspace_bytes": (_sz, [_i64, _i64, _i]),
     "aoc_dense_prune_stats": (_i, [_vp, _i]),
+    "aoc_dense_prune_stats_ex": (_i, [_vp, _i]),
     "aoc_dense_match_min_split": (_i, [_vp, _vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i64, _i64, _i,
                                        _vp, _sz, _vp]),
     "aoc_dense_match_min_split_cached": (_i, [_vp, _vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i64, _i64, _i,

@@ -14,6 +14,7 @@
 // exactly one object; both facts are device flags, and the exact-fp32 kernels of correlation.hip take over on
 // the same stream otherwise (each side checks the flag itself: no host round trip).
 #include <atomic>
+#include <type_traits>
 
 #include "aoc_common.h"
 
@@ -27,6 +28,8 @@ constexpr int SP_K = SP_KS * 16;
 constexpr int SP_HALF = SP_KS * 2;             // 16-byte chunks per plane: per k-step [k0-7][k8-15]
 constexpr int SP_REC = 2 * SP_HALF;            // 16-byte chunks per record: the hi plane (14 chunks), then the lo plane
 constexpr int SP_NORM_SLOT = 100;              // slots 100..102 of the hi plane: the three fp16 pieces of -16 |r|^2
+constexpr int SP_REST_SLOT = 104;              // slots 104, 105 of the hi plane: upper bounds of the Euclidean norm of the row's hi plane over the k-steps
+                                               // 2..5 / 3..5 (channels 32..95 / 48..95): the checkpoint bound of dense_prune_kernel<NW, 3 / 4>
 constexpr float SP_SCALE = 1024.0f;            // 2^10
 constexpr float SP_QCONST = 32768.0f;          // query-side value of the norm slots: 2^15 * (-16 |r|^2) = -2^19 |r|^2
 constexpr float SP_UNSCALE = -1.0f / 524288.0f;   // d - |q|^2 = -2^-19 * acc
@@ -36,6 +39,7 @@ constexpr int SP_NW = 8;                       // waves per block
 constexpr int SP_NQ = 2;                       // 32-pixel query tiles per wave (stationary B operands in registers)
 
 static_assert(SP_NORM_SLOT + 4 <= SP_K && SP_NORM_SLOT / 16 == SP_KS - 1 && (SP_NORM_SLOT % 16) + 4 <= 8, "norm slots live in the low half of the last k-step");
+static_assert(SP_REST_SLOT / 16 == SP_KS - 1 && SP_REST_SLOT % 16 == 8, "the rest-norm slots are the first two halves of the last k-step's high chunk");
 
 // ------------------------------------------------------------------------------------------
 // fp32 rows -> split records (+ |x|^2).  One thread per (row, k-step).  Record = hi plane (14 x 16 B: per k-step [k0-7][k8-15]), then the
@@ -85,7 +89,7 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float *__restrict
         }
     }
     if (ks == SP_KS - 1) {
-        float s = 0.0f, sl = 0.0f;
+        float s = 0.0f, sl = 0.0f, hr3 = 0.0f, hr4 = 0.0f;
         // the whole row as 25 float4 loads issued together (a scalar loop is one dependent round trip per channel); the additions keep
         // the sequential order t = 0 .. C-1
         float4 rv[SP_NORM_SLOT / 4];
@@ -100,8 +104,11 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float *__restrict
                 for (int u = 0; u < 4; ++u) {
                     s += e[u] * e[u];
                     const float v = e[u] * SP_SCALE;
-                    const float l = (float)(_Float16)(v - (float)(_Float16)v);      // the lo value of the channel, as its own thread stores it
+                    const float hv = (float)(_Float16)v;                            // the hi value of the channel, as its own thread stores it
+                    const float l = (float)(_Float16)(v - hv);                      // ... and the lo value
                     sl += l * l;
+                    if (t4 >= 8 && t4 < 24) hr3 += hv * hv;                         // k-steps 2..5
+                    if (t4 >= 12 && t4 < 24) hr4 += hv * hv;                        // k-steps 3..5
                 }
             }
         }
@@ -117,6 +124,12 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float *__restrict
         // slot 103: an upper bound of the Euclidean norm of the row's lo plane (the rescoring margin of the dense kernel); the
         // query side multiplies it by zero
         hi[SP_NORM_SLOT % 16 + 3] = (_Float16)(sqrtf(sl) * 1.002f + 1e-6f);
+        // slots 104, 105: upper bounds of |hi plane| over the channels the dense kernel has NOT yet accumulated at its checkpoint (after the
+        // k-steps 6, 0, 1 / 6, 0, 1, 2): Cauchy-Schwarz turns the two sides' values into an upper bound of the rest of the hi x hi product.
+        // Every consumer multiplies them by zero on one side except that kernel (the query side's other slot is masked there; the proxy image of
+        // the correlation kernel has zeros in slots 103..111)
+        hi[SP_REST_SLOT % 16] = (_Float16)(sqrtf(hr3) * 1.002f + 1e-6f);
+        hi[SP_REST_SLOT % 16 + 1] = (_Float16)(sqrtf(hr4) * 1.002f + 1e-6f);
     }
     if (bad && live) atomicOr(overflow, 1);
     union { _Float16 h[32]; uint4 q[4]; } u;
@@ -225,7 +238,7 @@ __device__ __forceinline__ uint32_t load_relaxed(const uint32_t *p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-__device__ unsigned long long g_prune_stats[4];    // (tile, query tile) pairs tested / rescored, tiles with any rescoring, tiles
+__device__ unsigned long long g_prune_stats[8];    // (tile, query tile) pairs tested / rescored, tiles with any rescoring, tiles, pairs stopped at the checkpoint
 
 // LDS-DMA: 64 lanes x 16 bytes (or 4 bytes) from per-lane global addresses to the LDS bytes [lds_dst + 16 lane, +16).  Written in asm so
 // that hipcc neither counts nor drains it: completion is the kernel's own vmcnt arithmetic (see the step loop).
@@ -266,7 +279,17 @@ constexpr int SP_TILE_SLACK = 2;                                  // the plan al
 // way.  LDS rows are unpadded (448 B); chunk c of row r sits at position c ^ ((r >> 3) & 3), which makes every ds_read_b128 of an A
 // fragment conflict-free -- the swizzle is applied on the SOURCE address of the DMA, whose destination is lane-linear.  The transfers
 // are asm statements that hipcc neither counts nor drains; one vmcnt(0) + barrier per step (4 tiles) publishes them.
-template <int NW>
+//
+// Checkpoint (CKPT = 3 or 4, development build only; 0 = off = the product: built and measured in round 5, correct and SLOWER, see split_ckpt()).  After CKPT of the 7 k-steps -- order 6, 0, 1, 2, ...: the norm slots first -- the
+// accumulator holds 2^20 (P - |r|^2 / 2) with P the hi x hi product over the channels seen so far.  What the remaining k-steps can add is at most
+// |qh_rest| |rh_rest| (Cauchy-Schwarz on the hi planes).  Both norms ride in the records (slot 104: rest = k-steps 2..5, slot 105: rest =
+// k-steps 3..5, rounded up), so the FIRST MFMA of the tile already adds their product: at the checkpoint the accumulator is an UPPER BOUND of the
+// final coarse value of every pair, and a (reference tile, query tile) pair whose largest bound plus eps is below what is already known for
+// its pixels stops there -- 4 (3) k-steps, its final test and any rescoring skipped.  A surviving pair takes the product out again with one more
+// MFMA whose A fragment is zero except for the negated norm slot, then continues as before.  The bound is rigorous (the products of the fp16
+// values are exact, the norms are rounded up, the accumulations' roundings are inside eps), so the set of discarded pairs can never contain
+// the maximum: same results as CKPT = 0, deterministic as before (a pair's value does not depend on what else was evaluated).
+template <int NW, int CKPT>
 __global__ __launch_bounds__(NW * 64, 1) void dense_prune_kernel(const uint4 *__restrict__ qrec, const float *__restrict__ q2, int64_t m,
                                                                      const uint4 *__restrict__ prec, const int32_t *__restrict__ tile_rows,
                                                                      const int32_t *__restrict__ tile_obj, const int32_t *__restrict__ n_tiles_ptr,
@@ -275,6 +298,7 @@ __global__ __launch_bounds__(NW * 64, 1) void dense_prune_kernel(const uint4 *__
     if (*gate) return;
     extern __shared__ __attribute__((aligned(16))) uint4 lds4[];
     static_assert(SP_NB == 4 && SP_NQ == 2 && (NW == 8 || NW == 4), "the step structure below is written for 4 tiles x 2 query tiles x 8 (or 4) waves");
+    static_assert(CKPT == 0 || CKPT == 3 || CKPT == 4, "checkpoint after 3 or 4 k-steps (rest norms in slots 104 / 105), or none");
     constexpr int SP_DMA_PER_WAVE = SP_CHUNK_BYTES / 1024 / NW;      // 7 (14) wave-wide 1 KiB transfers per wave and chunk
     constexpr int W_ID0 = NW / 2, W_ID1 = NW - 1, W_OBJ = 1;         // the waves that also fetch the row ids / the tiles' objects
     const uint32_t lds_base = (uint32_t)reinterpret_cast<uintptr_t>(lds4);
@@ -333,13 +357,19 @@ __global__ __launch_bounds__(NW * 64, 1) void dense_prune_kernel(const uint4 *__
             bh[iq][SP_KS - 1][SP_NORM_SLOT % 16] = (_Float16)SP_QCONST;
             bh[iq][SP_KS - 1][SP_NORM_SLOT % 16 + 1] = (_Float16)SP_QCONST;
             bh[iq][SP_KS - 1][SP_NORM_SLOT % 16 + 2] = (_Float16)SP_QCONST;
+        } else {
+            // slots 104 / 105: the query pixel's own rest norms.  The checkpoint's one stays (x the reference row's = the bound's rank-1 term),
+            // the other one -- both without a checkpoint -- is multiplied by zero
+            if (CKPT != 3) bh[iq][SP_KS - 1][0] = (_Float16)0.0f;
+            if (CKPT != 4) bh[iq][SP_KS - 1][1] = (_Float16)0.0f;
         }
         // |exact - coarse| = |qh.rl + ql.rh| <= |qh| |rl| + |ql| |rh| (Euclidean norms of the planes, Cauchy-Schwarz) with |qh| <= 2^10 |q|
         // (1 + 2^-11), the lo norms as the records carry them (rounded up) and the maxima over the kept reference pixels, plus the
         // roundings of 14 more accumulations
         const float qn = valid[iq] ? sqrtf(q2[row]) : 0.0f;
         const float ql = valid[iq] ? __shfl(ql_own, col) : 0.0f;
-        eps[iq] = (1026.0f * (qn * plmax + ql * pmax) + 8.0f * pmax * pmax + 8.0f) * ((dbg & 64) ? 0.4f : 1.0f);
+        // (with a checkpoint the partial sums also carry the bound's term, at most 2^20 |q| max|r|: 16 |q| max|r| covers the roundings at that size)
+        eps[iq] = (1026.0f * (qn * plmax + ql * pmax) + 8.0f * pmax * pmax + 16.0f * qn * pmax + 8.0f) * ((dbg & 64) ? 0.4f : 1.0f);
     }
 
     // ---- DMA plan of this wave: transfer k of a chunk fills the LDS slots [64 (7 wave + k), +64); slot j holds row j / 28, position j % 28.
@@ -383,7 +413,7 @@ __global__ __launch_bounds__(NW * 64, 1) void dense_prune_kernel(const uint4 *__
         shared[iq] = INFINITY;
     }
     int cur = -1;
-    unsigned n_rescored = 0, n_any = 0, n_seen = 0;
+    unsigned n_rescored = 0, n_any = 0, n_seen = 0, n_dead = 0;
     // what the other workgroups have published for the current object: one 4-byte transfer per query tile into this wave's own LDS
     // words, read back one step later (device-scope load: the values come from L2, not from this CU's vector cache)
     auto dma_bound = [&]() {
@@ -453,7 +483,8 @@ __global__ __launch_bounds__(NW * 64, 1) void dense_prune_kernel(const uint4 *__
             for (int iq = 0; iq < SP_NQ; ++iq)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[iq][r] = 0.0f;
-            {
+            bool live[SP_NQ] = {true, true};
+            if constexpr (CKPT == 0) {
                 f16x8 af[3];
                 af[0] = pre0;
                 af[1] = pre1;
@@ -468,13 +499,63 @@ __global__ __launch_bounds__(NW * 64, 1) void dense_prune_kernel(const uint4 *__
                     pre0 = frag(tile_base + SP_TILE * SP_REC * 16, 2 * ks_of(0));
                     pre1 = frag(tile_base + SP_TILE * SP_REC * 16, 2 * ks_of(1));
                 }
+            } else {
+                // phase 1: the first CKPT k-steps (k-step 6 carries the norm slots AND the bound's rank-1 term)
+                // (only the FIRST fragment of the next tile is requested ahead here: a second one would be live across phase 2 and the rescoring,
+                // where the register file is full)
+                f16x8 af[3];
+                af[0] = pre0;
+                af[1] = frag(tile_base, 2 * ks_of(1));
+                const uint32_t a6d0 = __builtin_bit_cast(uint4, pre0).x;        // lanes h == 1: the reference row's slots 104 | 105
+#pragma unroll
+                for (int kk = 0; kk < CKPT; ++kk) {
+                    if (kk + 2 < CKPT) af[(kk + 2) % 3] = frag(tile_base, 2 * ks_of(kk + 2));
+#pragma unroll
+                    for (int iq = 0; iq < SP_NQ; ++iq)
+                        acc[iq] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[kk % 3], bh[iq][ks_of(kk)], acc[iq], 0, 0, 0);
+                }
+                if (t + 1 < n_here) pre0 = frag(tile_base + SP_TILE * SP_REC * 16, 2 * ks_of(0));
+                // checkpoint: can any pair of this (reference tile, query tile) still reach what is known for its pixel?  (wave-uniform)
+#pragma unroll
+                for (int iq = 0; iq < SP_NQ; ++iq) {
+                    const float cm = max16(acc[iq]);
+                    live[iq] = (__builtin_amdgcn_ballot_w64(cm + eps[iq] >= __builtin_fmaxf(best[iq], shared[iq])) != 0ull) || (dbg & 128);
+                    if (!live[iq]) n_dead += 1;
+                }
+                if (live[0] || live[1]) {
+                    // phase 2: take the rank-1 term out again (A = the negated norm slot, zero elsewhere), then the remaining k-steps.  Three
+                    // straight-line variants (both query tiles / one of them): no branch between the MFMAs
+                    uint4 c4 = make_uint4(0u, 0u, 0u, 0u);
+                    if (h == 1) c4.x = (CKPT == 3) ? ((a6d0 & 0x0000ffffu) ^ 0x00008000u) : ((a6d0 & 0xffff0000u) ^ 0x80000000u);
+                    const f16x8 a6c = __builtin_bit_cast(f16x8, c4);
+                    auto phase2 = [&](auto q0, auto q1) {
+                        constexpr bool Q0 = decltype(q0)::value, Q1 = decltype(q1)::value;
+                        f16x8 ar[3];
+                        ar[0] = frag(tile_base, 2 * ks_of(CKPT));
+                        ar[1] = frag(tile_base, 2 * ks_of(CKPT + 1));
+                        if (Q0) acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a6c, bh[0][SP_KS - 1], acc[0], 0, 0, 0);
+                        if (Q1) acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a6c, bh[1][SP_KS - 1], acc[1], 0, 0, 0);
+#pragma unroll
+                        for (int kk = CKPT; kk < SP_KS; ++kk) {
+                            if (kk + 2 < SP_KS) ar[(kk + 2 - CKPT) % 3] = frag(tile_base, 2 * ks_of(kk + 2));
+                            if (Q0) acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ar[(kk - CKPT) % 3], bh[0][ks_of(kk)], acc[0], 0, 0, 0);
+                            if (Q1) acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ar[(kk - CKPT) % 3], bh[1][ks_of(kk)], acc[1], 0, 0, 0);
+                        }
+                    };
+                    if (live[0] && live[1]) phase2(std::true_type{}, std::true_type{});
+                    else if (live[0]) phase2(std::true_type{}, std::false_type{});
+                    else phase2(std::false_type{}, std::true_type{});
+                }
             }
             // which query tiles may hold a new maximum (wave-uniform)
             bool want[SP_NQ];
 #pragma unroll
             for (int iq = 0; iq < SP_NQ; ++iq) {
-                const float cm = max16(acc[iq]);
-                want[iq] = __builtin_amdgcn_ballot_w64(cm + eps[iq] >= __builtin_fmaxf(best[iq], shared[iq])) != 0ull;
+                want[iq] = false;
+                if (live[iq]) {
+                    const float cm = max16(acc[iq]);
+                    want[iq] = __builtin_amdgcn_ballot_w64(cm + eps[iq] >= __builtin_fmaxf(best[iq], shared[iq])) != 0ull;
+                }
             }
             n_seen += 1;
             if ((want[0] || want[1]) && !(dbg & 2)) {
@@ -530,6 +611,7 @@ __global__ __launch_bounds__(NW * 64, 1) void dense_prune_kernel(const uint4 *__
         atomicAdd(&g_prune_stats[1], (unsigned long long)n_rescored);
         atomicAdd(&g_prune_stats[2], (unsigned long long)n_any);
         atomicAdd(&g_prune_stats[3], (unsigned long long)n_seen);
+        atomicAdd(&g_prune_stats[4], (unsigned long long)n_dead);
     }
 }
 
@@ -603,6 +685,15 @@ inline int split_nsplit(int64_t m) {
         if (eff >= best_eff - 0.005) { best_eff = eff > best_eff ? eff : best_eff; best = (int)ns; }
     }
     return best;
+}
+
+inline int split_ckpt() {
+    // checkpoint of dense_prune_kernel after this many of the 7 k-steps; developer switch AOC_DENSE_CKPT = 3 / 4 (development build only).
+    // Default 0 = none: measured in round 5 (profiles/r05_dense_experiments.txt) the checkpoint stops 26 % (after 3 k-steps) / 40 % (after 4) of
+    // the pairs of the bench's R = 6 pools, same results -- and the kernel is 16 % / 13 % SLOWER: the wave has to wait for its own MFMA results
+    // in the middle of every tile, and with two waves per SIMD nothing hides that wait.
+    static const int c = AOC_DEV_ENV_INT("AOC_DENSE_CKPT", 0);
+    return (c == 3 || c == 4) ? c : 0;
 }
 
 struct SplitWs {
@@ -708,19 +799,30 @@ int aoc_dense_match_min_split_cached(const float *query, const void *query_rec, 
     const int64_t rpb = (int64_t)nw * SP_NQ * 32;
     const dim3 grid((unsigned)((m + rpb - 1) / rpb), ns);
     const size_t lds = SP_LDS_BYTES;
-    static const bool lds_ok =
-        hipFuncSetAttribute(reinterpret_cast<const void *>(dense_prune_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
-        hipFuncSetAttribute(reinterpret_cast<const void *>(dense_prune_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
-    if (!lds_ok) return AOC_ERR_LAUNCH;
     const AocDenseProbe probe = aoc_take_dense_probe();
     static const int dbg = AOC_DEV_ENV_INT("AOC_DENSE_DEBUG", 0);       // developer switch: timing experiments only
-    if (probe.start) (void)hipEventRecord(probe.start, st);
-    if (nw == 4)
-        hipLaunchKernelGGL(dense_prune_kernel<4>, grid, dim3(4 * 64), lds, st, static_cast<const uint4 *>(query_rec), query_sqnorm, m,
-                           static_cast<const uint4 *>(pool_rec), w.tile_rows, w.tile_obj, w.n_tiles, w.gate, w.pmax, n_obj, w.gbest, dbg, query_rec_tiled ? 1 : 0);
-    else
-        hipLaunchKernelGGL(dense_prune_kernel<8>, grid, dim3(8 * 64), lds, st, static_cast<const uint4 *>(query_rec), query_sqnorm, m,
-                           static_cast<const uint4 *>(pool_rec), w.tile_rows, w.tile_obj, w.n_tiles, w.gate, w.pmax, n_obj, w.gbest, dbg, query_rec_tiled ? 1 : 0);
+    const int ckpt = split_ckpt();
+    int launched = 0;
+#define AOC_DENSE_LAUNCH(NW_, CK_)                                                                                                                          \
+    if (!launched && nw == NW_ && ckpt == CK_) {                                                                                                            \
+        static const bool lds_ok = hipFuncSetAttribute(reinterpret_cast<const void *>(dense_prune_kernel<NW_, CK_>),                                       \
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;                                \
+        if (!lds_ok) return AOC_ERR_LAUNCH;                                                                                                                 \
+        if (probe.start) (void)hipEventRecord(probe.start, st);                                                                                             \
+        hipLaunchKernelGGL((dense_prune_kernel<NW_, CK_>), grid, dim3(NW_ * 64), lds, st, static_cast<const uint4 *>(query_rec), query_sqnorm, m,           \
+                           static_cast<const uint4 *>(pool_rec), w.tile_rows, w.tile_obj, w.n_tiles, w.gate, w.pmax, n_obj, w.gbest, dbg,                   \
+                           query_rec_tiled ? 1 : 0);                                                                                                        \
+        launched = 1;                                                                                                                                       \
+    }
+    AOC_DENSE_LAUNCH(8, 0)
+#ifdef AOC_DEV
+    AOC_DENSE_LAUNCH(8, 3)
+    AOC_DENSE_LAUNCH(8, 4)
+    AOC_DENSE_LAUNCH(4, 0)
+    AOC_DENSE_LAUNCH(4, 3)
+#endif
+#undef AOC_DENSE_LAUNCH
+    if (!launched) return AOC_ERR_UNSUPPORTED;
     if (probe.stop) (void)hipEventRecord(probe.stop, st);
     hipLaunchKernelGGL(dense_split_finalize_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, w.gbest, m, n_obj, counts, w.gate,
                        query_sqnorm, obj_bias, out, out_pixel_stride, out_obj_stride, transform);
@@ -741,11 +843,20 @@ int aoc_set_stream_cus(int n_cus) {
 // out[0] (reference tile, query tile) pairs tested, out[1] pairs rescored, out[2] reference tiles with a rescoring, out[3] reference tiles.
 int aoc_dense_prune_stats(uint64_t *out4, int reset) {
     if (!out4) return AOC_ERR_INVALID_ARG;
-    unsigned long long v[4] = {0, 0, 0, 0};
+    uint64_t v[8];
+    const int rc = aoc_dense_prune_stats_ex(v, reset);
+    for (int i = 0; i < 4 && rc == AOC_OK; ++i) out4[i] = v[i];
+    return rc;
+}
+
+// out8[0..3] as aoc_dense_prune_stats; out8[4] = (reference tile, query tile) pairs that stopped at the checkpoint; out8[5..7] = 0.
+int aoc_dense_prune_stats_ex(uint64_t *out8, int reset) {
+    if (!out8) return AOC_ERR_INVALID_ARG;
+    unsigned long long v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (hipMemcpyFromSymbol(v, HIP_SYMBOL(g_prune_stats), sizeof(v)) != hipSuccess) return AOC_ERR_LAUNCH;
-    for (int i = 0; i < 4; ++i) out4[i] = v[i];
+    for (int i = 0; i < 8; ++i) out8[i] = v[i];
     if (reset) {
-        const unsigned long long z[4] = {0, 0, 0, 0};
+        const unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         if (hipMemcpyToSymbol(HIP_SYMBOL(g_prune_stats), z, sizeof(z)) != hipSuccess) return AOC_ERR_LAUNCH;
     }
     return AOC_OK;

@@ -387,11 +387,12 @@ def split_rows(x_flat, out=None, row0=0, overflow=None, tiled=False):
 
 
 def dense_prune_stats(reset=True):
-    """Developer counters of the coarse-then-rescore dense kernel (aoc_dense_prune_stats): dict(tested, rescored, tiles_rescored, tiles)."""
+    """Developer counters of the coarse-then-rescore dense kernel (aoc_dense_prune_stats_ex): dict(tested, rescored, tiles_rescored, tiles,
+    stopped = pairs that ended at the kernel's checkpoint)."""
     import ctypes
-    v = (ctypes.c_uint64 * 4)()
-    _lib.check(_lib.lib().aoc_dense_prune_stats(v, 1 if reset else 0), "aoc_dense_prune_stats")
-    return dict(tested=int(v[0]), rescored=int(v[1]), tiles_rescored=int(v[2]), tiles=int(v[3]))
+    v = (ctypes.c_uint64 * 8)()
+    _lib.check(_lib.lib().aoc_dense_prune_stats_ex(v, 1 if reset else 0), "aoc_dense_prune_stats_ex")
+    return dict(tested=int(v[0]), rescored=int(v[1]), tiles_rescored=int(v[2]), tiles=int(v[3]), stopped=int(v[4]))
 
 
 def dense_match_min_split(query_flat, query_split, pool, pool_split, prep, obj_bias, out, out_pixel_stride, out_obj_stride, transform=True):

@@ -41,8 +41,8 @@ for mode in ("fp32", "split"):
     res = out.clone()
     if mode == "split":
         st = ops.dense_prune_stats()
-        print("  rescored %.3f of the (reference tile, query tile) pairs; %.3f of the reference tiles had a rescoring" %
-              (st["rescored"] / max(st["tested"], 1), st["tiles_rescored"] / max(st["tiles"], 1)), flush=True)
+        print("  rescored %.3f of the (reference tile, query tile) pairs; %.3f of the reference tiles had a rescoring; %.3f of the pairs stopped at the checkpoint" %
+              (st["rescored"] / max(st["tested"], 1), st["tiles_rescored"] / max(st["tiles"], 1), st["stopped"] / max(st["tested"], 1)), flush=True)
     if mode == "fp32":
         ref = res
 print("max |split - fp32| =", float((res - ref).abs().max()))
