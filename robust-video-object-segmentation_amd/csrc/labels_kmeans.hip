@@ -1439,6 +1439,30 @@ __device__ __forceinline__ int kc_predict_binade(float pre, float end) {
     }
     return e;
 }
+// Round 5: the binade of a tail chunk PREDICTED FROM THE PREVIOUS LLOYD ITERATION.  The stitch of iteration i walks every cluster's tail
+// with the exact running sum; it leaves, per (cluster, feature), the exponent in front of the tail (e0) and the local indices of the chunks
+// inside which the exponent changed, with the exponent behind them (at most KP_CROSS: a running sum of non-negative values doubles once per
+// doubling of the member count).  Between two iterations few rows change cluster, so chunk c of iteration i + 1 almost always sits in the
+// binade chunk c of iteration i sat in: the fold of iteration i + 1 takes that binade WITHOUT the any-order chunk sums (one pass over the
+// tail rows and one launch less per iteration).  As before the stitch verifies every summary against the exact running sum (same exponent,
+// n stays below 2^24) and folds a chunk from its rows when the check fails: a wrong prediction costs time, never exactness.  Clusters
+// without a tail get e0 from their literal head sum (a tail that appears in the next iteration starts near it).
+constexpr int KP_CROSS = 4;
+struct KsPred {
+    int8_t *e0;          // [n_seg * kmax * C]
+    uint16_t *cidx;      // [n_seg * kmax * C * KP_CROSS]  local chunk index of the j-th crossing, 0xFFFF = none
+    int8_t *ce;          // [n_seg * kmax * C * KP_CROSS]  exponent behind it (KC_UNSAFE: more crossings than slots -- nothing predicted from there on)
+};
+__device__ __forceinline__ int kp_predict(const KsPred &p, size_t idx, int c) {
+    int e = p.e0[idx];
+#pragma unroll
+    for (int i = 0; i < KP_CROSS; ++i) {
+        const int ci = p.cidx[idx * KP_CROSS + i];
+        if (e == KC_UNSAFE || ci == 0xFFFF || c < ci) break;
+        e = (c == ci) ? KC_UNSAFE : (int)p.ce[idx * KP_CROSS + i];      // the chunk that crossed last time is left to the stitch
+    }
+    return e;
+}
 __global__ __launch_bounds__(128) void km_chunk_predict_kernel(const int32_t *__restrict__ seg_k, const int32_t *__restrict__ counts,
                                                                 const int32_t *__restrict__ cchunk, const float *__restrict__ csum, int kmax,
                                                                 int C, int8_t *__restrict__ cexp, int start_chunk,
@@ -1519,22 +1543,26 @@ __device__ __forceinline__ void kc_fold_block2(float x, float inv_u, KcFold &k) 
 constexpr int KC_FW = 5;                 // features per wave
 constexpr int KC_FG = 4 * KC_FW;         // features per workgroup (20 = 5 float4)
 constexpr int KC_G_LD = KC_FG + 1;       // LDS row stride of the group tile
-__global__ __launch_bounds__(256) void km_chunk_fold_kernel(const float *__restrict__ pool, int C, const int32_t *__restrict__ seg_off,
-                                                             const int32_t *__restrict__ counts, const int32_t *__restrict__ cbase,
-                                                             const uint32_t *__restrict__ moff, int kmax,
-                                                             const int32_t *__restrict__ owner_cluster, const int32_t *__restrict__ owner_local,
-                                                             int8_t *__restrict__ cexp, int32_t *__restrict__ cinc0, int32_t *__restrict__ cinc1,
-                                                             int start_chunk, const float *__restrict__ csum, const int32_t *__restrict__ cchunk,
-                                                             const float *__restrict__ head_state, int n_chunks_grid, int n_groups, int xcd_aware) {
-    __shared__ float tile[2][64 * KC_G_LD];
-    __shared__ uint32_t loffs[KS_CHUNK];
-    __shared__ int lexp[KC_FG];
+constexpr int KC_FOLD_LDS_FLOATS = 2 * 64 * KC_G_LD + KS_CHUNK + KC_FG;      // tile[2][64 x KC_G_LD] | loffs[KS_CHUNK] | lexp[KC_FG]
+// b = workgroup index inside the fold role's 1-D grid; lds = KC_FOLD_LDS_FLOATS floats; 256 threads run it.
+// pred != nullptr: binades from the previous Lloyd iteration (KsPred) instead of csum / km_chunk_predict_kernel.
+__device__ __forceinline__ void kc_chunk_fold_body(int b, float *__restrict__ lds, const float *__restrict__ pool, int C, const int32_t *__restrict__ seg_off,
+                                                   const int32_t *__restrict__ counts, const int32_t *__restrict__ cbase,
+                                                   const uint32_t *__restrict__ moff, int kmax,
+                                                   const int32_t *__restrict__ owner_cluster, const int32_t *__restrict__ owner_local,
+                                                   int8_t *__restrict__ cexp, int32_t *__restrict__ cinc0, int32_t *__restrict__ cinc1,
+                                                   int start_chunk, const float *__restrict__ csum, const int32_t *__restrict__ cchunk,
+                                                   const float *__restrict__ head_state, int n_chunks_grid, int n_groups, int xcd_aware,
+                                                   const KsPred *__restrict__ pred) {
+    float (*tile)[64 * KC_G_LD] = reinterpret_cast<float (*)[64 * KC_G_LD]>(lds);
+    uint32_t *loffs = reinterpret_cast<uint32_t *>(lds + 2 * 64 * KC_G_LD);
+    int *lexp = reinterpret_cast<int *>(lds + 2 * 64 * KC_G_LD + KS_CHUNK);
     // 1-D grid, XCD-aware: the feature groups of ONE chunk read neighbouring 80-byte pieces of the same member rows; with ids that differ
     // by 8 they run on the same XCD at about the same time and share the 64-byte sectors in its L2 (workgroups are dealt round-robin to
     // the XCDs).  Blocks of 8 chunks x n_groups; the last block may hold fewer chunks.
     int chunk, grp;
     {
-        const int b = blockIdx.x, blk = b / (8 * n_groups), rem = b - blk * (8 * n_groups);
+        const int blk = b / (8 * n_groups), rem = b - blk * (8 * n_groups);
         const int pc = min(8, n_chunks_grid - blk * 8);
         grp = rem / pc;
         chunk = blk * 8 + rem - grp * pc;
@@ -1564,7 +1592,10 @@ __global__ __launch_bounds__(256) void km_chunk_fold_kernel(const float *__restr
         const int f = f0 + wave * KC_FW + i;
         int e = KC_UNSAFE;
         if (f < C) {
-            if (csum) {
+            if (pred) {
+                e = kp_predict(*pred, (size_t)oc * C + f, plocal);
+                if (lane == 0) cexp[(size_t)chunk * C + f] = (int8_t)e;
+            } else if (csum) {
                 float part = 0.0f;
                 for (int c = start_chunk + lane; c < plocal; c += 64) part += csum[(size_t)(pbase + c) * C + f];
                 part = aoc_wave_sum(part);
@@ -1587,7 +1618,7 @@ __global__ __launch_bounds__(256) void km_chunk_fold_kernel(const float *__restr
     for (int i = 0; i < KC_FG; ++i) block_live |= (lexp[i] != KC_UNSAFE);
     if (!block_live) return;
 
-    for (int i = threadIdx.x; i < KS_CHUNK; i += blockDim.x) loffs[i] = (i < members) ? list[first + i] : 0u;
+    for (int i = threadIdx.x; i < KS_CHUNK; i += 256) loffs[i] = (i < members) ? list[first + i] : 0u;
     __syncthreads();
     // staging: 64 rows x (KC_FG / 4) float4 = 320 pieces per block; thread t takes pieces t and t + 256
     const int npiece = KC_FG / 4;
@@ -1638,6 +1669,17 @@ __global__ __launch_bounds__(256) void km_chunk_fold_kernel(const float *__restr
             }
         }
     }
+}
+__global__ __launch_bounds__(256) void km_chunk_fold_kernel(const float *__restrict__ pool, int C, const int32_t *__restrict__ seg_off,
+                                                             const int32_t *__restrict__ counts, const int32_t *__restrict__ cbase,
+                                                             const uint32_t *__restrict__ moff, int kmax,
+                                                             const int32_t *__restrict__ owner_cluster, const int32_t *__restrict__ owner_local,
+                                                             int8_t *__restrict__ cexp, int32_t *__restrict__ cinc0, int32_t *__restrict__ cinc1,
+                                                             int start_chunk, const float *__restrict__ csum, const int32_t *__restrict__ cchunk,
+                                                             const float *__restrict__ head_state, int n_chunks_grid, int n_groups, int xcd_aware) {
+    __shared__ __attribute__((aligned(16))) float lds[KC_FOLD_LDS_FLOATS];
+    kc_chunk_fold_body(blockIdx.x, lds, pool, C, seg_off, counts, cbase, moff, kmax, owner_cluster, owner_local, cexp, cinc0, cinc1, start_chunk, csum, cchunk,
+                       head_state, n_chunks_grid, n_groups, xcd_aware, nullptr);
 }
 
 // P0 + P1 + P2 in one pass over the rows ("scan-fold").  Same grid and roles as km_chunk_fold_kernel, but the workgroup keeps all
@@ -1912,7 +1954,8 @@ __global__ __launch_bounds__(64) void km_sum_scan_kernel(const float *__restrict
                                                           const uint32_t *__restrict__ moff, int kmax, float *__restrict__ dst,
                                                           const int32_t *__restrict__ cchunk, const int8_t *__restrict__ cexp,
                                                           const int32_t *__restrict__ cinc0, const int32_t *__restrict__ cinc1,
-                                                          int start_chunk, const float *__restrict__ head_state, int n_seg_grid, int xcd_aware) {
+                                                          int start_chunk, const float *__restrict__ head_state, int n_seg_grid, int xcd_aware,
+                                                          KsPred pred) {
     // 1-D grid, XCD-aware: the C / NF waves of ONE cluster each read 4 NF bytes of the same member rows (the chunks whose summaries do
     // not apply); with ids that differ by 8 they run on one XCD and fetch every 64-byte sector once instead of once per XCD.  Blocks of 8
     // clusters x n_q waves; the last block may hold fewer clusters.
@@ -2049,6 +2092,23 @@ __global__ __launch_bounds__(64) void km_sum_scan_kernel(const float *__restrict
             to_int(f);
         }
     }
+    // what the next Lloyd iteration's fold predicts its binades from (KsPred): exponent in front of the tail, chunks that changed it
+    int pe0[NF], pn[NF], pci[NF][KP_CROSS], pce[NF][KP_CROSS];
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+        pe0[f] = se[f];
+        pn[f] = 0;
+#pragma unroll
+        for (int i = 0; i < KP_CROSS; ++i) { pci[f][i] = 0xFFFF; pce[f][i] = KC_UNSAFE; }
+    }
+    auto note_crossing = [&](int f, int c, int e_before) {
+        if (se[f] == e_before) return;
+#pragma unroll
+        for (int i = 0; i < KP_CROSS; ++i) {
+            if (i == pn[f]) { pci[f][i] = c; pce[f][i] = (i + 1 < KP_CROSS) ? se[f] : KC_UNSAFE; }      // the last slot only says "unknown from here on"
+        }
+        if (pn[f] < KP_CROSS) pn[f] += 1;
+    };
     // rows of the next chunk that will need them (pending) are in flight in nxt; the member offsets of the one after
     // that (pending2) are already in registers, so its rows cost one memory latency, not two, when their turn comes
     KsChunk cur, nxt;
@@ -2078,10 +2138,12 @@ __global__ __launch_bounds__(64) void km_sum_scan_kernel(const float *__restrict
         }
         bool skip[NF];
         bool all_skip = true;
+        int e_in[NF];
         const long long ks_ta = KS_CLK();
 #pragma unroll
         for (int f = 0; f < NF; ++f) {
             skip[f] = false;
+            e_in[f] = se[f];
             if (have_summ) {
                 const int l = c - batch0;
                 const int e = __builtin_amdgcn_readlane(sc.e[f], l);
@@ -2097,7 +2159,7 @@ __global__ __launch_bounds__(64) void km_sum_scan_kernel(const float *__restrict
             all_skip &= skip[f];
         }
         ks_tsum += KS_CLK() - ks_ta;
-        if (all_skip) continue;
+        if (all_skip) continue;                                        // (a verified summary never changes the exponent)
         const long long ks_tb = KS_CLK();
         // ---- this chunk needs its rows
         if (pending == c) {
@@ -2122,6 +2184,8 @@ __global__ __launch_bounds__(64) void km_sum_scan_kernel(const float *__restrict
         }
         ks_tex += KS_CLK() - ks_tb;
         if (ks_big) KS_STAT(2, 1);
+#pragma unroll
+        for (int f = 0; f < NF; ++f) note_crossing(f, c, e_in[f]);
     }
 #pragma unroll
     for (int f = 0; f < NF; ++f) st[f] = to_float(f);
@@ -2130,6 +2194,18 @@ __global__ __launch_bounds__(64) void km_sum_scan_kernel(const float *__restrict
         const float fc = (float)cnt;
 #pragma unroll
         for (int f = 0; f < NF; ++f) out[f] = st[f] / fc;
+        if (pred.e0) {
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+                const size_t idx = ((size_t)s * kmax + j) * C + NF * q + f;
+                pred.e0[idx] = (int8_t)pe0[f];
+#pragma unroll
+                for (int i = 0; i < KP_CROSS; ++i) {
+                    pred.cidx[idx * KP_CROSS + i] = (uint16_t)pci[f][i];
+                    pred.ce[idx * KP_CROSS + i] = (int8_t)pce[f][i];
+                }
+            }
+        }
     }
 }
 
@@ -2327,7 +2403,7 @@ __device__ __forceinline__ void os_head_dma_body(int j, int s, int grp, float *_
                                                  const int32_t *__restrict__ seg_off, const int32_t *__restrict__ seg_k,
                                                  const int32_t *__restrict__ counts, const int32_t *__restrict__ cbase,
                                                  const uint32_t *__restrict__ moff, int kmax, float *__restrict__ dst, int member_cap,
-                                                 float *__restrict__ head_state) {
+                                                 float *__restrict__ head_state, KsPred pred) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = aoc_lane();
     if (wave > OD_NPROD) return;                               // the launch is 256 wide for the chunk-sum role
     if (j >= seg_k[s]) return;
@@ -2393,6 +2469,13 @@ __device__ __forceinline__ void os_head_dma_body(int j, int s, int grp, float *_
         if (active) {
             if (head_only) head_state[(size_t)oc * C + f0 + lane] = sum;
             else out[lane] = sum / (float)cnt;
+            if (!head_only && pred.e0) {
+                // no tail this time: should the cluster grow one, its chunks start from the binade of this sum (KsPred)
+                const size_t idx = (size_t)oc * C + f0 + lane;
+                const KsBinade bb = ks_binade(sum);
+                pred.e0[idx] = (int8_t)(bb.ok ? (int)((__float_as_uint(sum) >> 23) & 0xff) - 127 : KC_UNSAFE);
+                pred.cidx[idx * KP_CROSS] = (uint16_t)0xFFFF;
+            }
         }
         return;
     }
@@ -2466,9 +2549,13 @@ __global__ __launch_bounds__(DMA ? 256 : (OS_NPROD + 1) * 64) void km_heads_chun
                                                                                    const uint32_t *__restrict__ moff, int kmax, int n_seg, float *__restrict__ dst,
                                                                                    int member_cap, float *__restrict__ head_state,
                                                                                    const int32_t *__restrict__ owner_cluster, const int32_t *__restrict__ owner_local,
-                                                                                   float *__restrict__ csum, int start_chunk, int xcd_aware) {
+                                                                                   float *__restrict__ csum, int start_chunk, int xcd_aware,
+                                                                                   KsPred pred, int spec_fold, int8_t *__restrict__ cexp,
+                                                                                   int32_t *__restrict__ cinc0, int32_t *__restrict__ cinc1,
+                                                                                   const int32_t *__restrict__ cchunk, int n_chunks_grid, int n_fold_groups) {
     __shared__ __attribute__((aligned(16))) float os_lds[DMA ? (OD_LDS_FLOATS > 2 * OS_BATCH * OS_LD ? OD_LDS_FLOATS : 2 * OS_BATCH * OS_LD) : 2 * OS_BATCH * OS_LD];
     static_assert(sizeof(float) * 2 * OS_BATCH * OS_LD >= sizeof(uint32_t) * KS_CHUNK + sizeof(float4) * 256, "the chunk role's buffers fit the head role's");
+    static_assert(2 * OS_BATCH * OS_LD >= KC_FOLD_LDS_FLOATS, "the fold role's buffers fit the head role's");
     const int n_head = kmax * n_seg * os_groups_dev(C);
     const int b = blockIdx.x;
     if (b < n_head) {
@@ -2483,11 +2570,18 @@ __global__ __launch_bounds__(DMA ? 256 : (OS_NPROD + 1) * 64) void km_heads_chun
         int grp = rem / pc, c = blk * 8 + rem - grp * pc;
         if (!xcd_aware) { c = b % n_cl; grp = b / n_cl; }       // developer switch AOC_KM_XCD=0: the group-major order of before
         const int j = c % kmax, s = c / kmax;
-        if (DMA) os_head_dma_body<MODE>(j, s, grp, os_lds, pool, C, seg_off, seg_k, counts, cbase, moff, kmax, dst, member_cap, head_state);
+        if (DMA) os_head_dma_body<MODE>(j, s, grp, os_lds, pool, C, seg_off, seg_k, counts, cbase, moff, kmax, dst, member_cap, head_state, pred);
         else os_ordered_sum_body<MODE>(j, s, grp, os_lds, pool, pool_bytes, C, seg_off, seg_k, counts, cbase, moff, kmax, dst, member_cap, head_state);
         return;
     }
     if (threadIdx.x >= 256) return;
+    if (DMA && spec_fold) {
+        // round 5: the tail chunks' integer folds in their PREDICTED binades (KsPred: the previous Lloyd iteration's) ride in this launch --
+        // no any-order chunk sums, no separate fold launch; the stitch verifies every summary as before
+        kc_chunk_fold_body(b - n_head, os_lds, pool, C, seg_off, counts, cbase, moff, kmax, owner_cluster, owner_local, cexp, cinc0, cinc1, start_chunk,
+                           nullptr, cchunk, head_state, n_chunks_grid, n_fold_groups, xcd_aware, &pred);
+        return;
+    }
     uint32_t *loffs = reinterpret_cast<uint32_t *>(os_lds);
     float4 *part = reinterpret_cast<float4 *>(os_lds + KS_CHUNK);
     kc_chunk_sum_body(b - n_head, loffs, part, pool, C, seg_off, counts, cbase, moff, kmax, owner_cluster, owner_local, csum, start_chunk);
@@ -2539,7 +2633,12 @@ struct KsWorkspace {
     int8_t *cexp;
     uint32_t *cflag;          // per (chunk, feature group): local sums published (km_chunk_scanfold_kernel)
     int seg_chunks_max;       // no segment (hence no cluster) has more chunks than this
+    KsPred pred;              // binades of the tail chunks as the last stitch left them (round 5)
 };
+inline size_t ks_pred_bytes(int n_seg, int kmax) {
+    const size_t n = (size_t)n_seg * kmax * (AOC_MAX_CHANNELS / 2);
+    return aoc_align_up(n, 256) + aoc_align_up(n * KP_CROSS * 2, 256) + aoc_align_up(n * KP_CROSS, 256);
+}
 inline int ks_chunk_capacity(int64_t cap, int n_seg, int kmax) { return (int)(cap / KS_CHUNK) + n_seg * (kmax + 1) + 2; }
 inline size_t ks_workspace_bytes(int64_t cap, int n_seg, int kmax) {
     const size_t nb = (size_t)(cap + 255) / 256 + 1;
@@ -2547,7 +2646,7 @@ inline size_t ks_workspace_bytes(int64_t cap, int n_seg, int kmax) {
     return aoc_align_up((size_t)cap * 4, 256) + aoc_align_up((size_t)cap * 2, 256) + aoc_align_up((size_t)n_seg * nb * kmax * 4, 256) +
            3 * aoc_align_up((size_t)n_seg * kmax * 4, 256) + aoc_align_up(((size_t)cap + 64) * 4, 256) + 2 * aoc_align_up(nch * 4, 256) +
            3 * aoc_align_up(nch * AOC_MAX_CHANNELS / 2 * 4, 256) + aoc_align_up(nch * AOC_MAX_CHANNELS / 2, 256) +
-           aoc_align_up((size_t)n_seg * kmax * (AOC_MAX_CHANNELS / 2) * 4, 256) + aoc_align_up(nch * 8 * 4, 256);
+           aoc_align_up((size_t)n_seg * kmax * (AOC_MAX_CHANNELS / 2) * 4, 256) + aoc_align_up(nch * 8 * 4, 256) + ks_pred_bytes(n_seg, kmax);
 }
 inline KsWorkspace ks_carve(void *workspace, int64_t cap, int n_seg, int kmax, int64_t seg_bound = 0) {
     KsWorkspace w;
@@ -2571,7 +2670,13 @@ inline KsWorkspace ks_carve(void *workspace, int64_t cap, int n_seg, int kmax, i
     w.cinc1 = reinterpret_cast<int32_t *>(p); p += aoc_align_up(nch * AOC_MAX_CHANNELS / 2 * 4, 256);
     w.cexp = reinterpret_cast<int8_t *>(p); p += aoc_align_up(nch * AOC_MAX_CHANNELS / 2, 256);
     w.head = reinterpret_cast<float *>(p); p += aoc_align_up((size_t)n_seg * kmax * (AOC_MAX_CHANNELS / 2) * 4, 256);
-    w.cflag = reinterpret_cast<uint32_t *>(p);
+    w.cflag = reinterpret_cast<uint32_t *>(p); p += aoc_align_up(nch * 8 * 4, 256);
+    {
+        const size_t n = (size_t)n_seg * kmax * (AOC_MAX_CHANNELS / 2);
+        w.pred.e0 = reinterpret_cast<int8_t *>(p); p += aoc_align_up(n, 256);
+        w.pred.cidx = reinterpret_cast<uint16_t *>(p); p += aoc_align_up(n * KP_CROSS * 2, 256);
+        w.pred.ce = reinterpret_cast<int8_t *>(p);
+    }
     return w;
 }
 
@@ -2604,16 +2709,37 @@ inline int ks_sum_mode() {
     }();
     return mode;
 }
+// spec: MODE 0, Lloyd iteration >= 1 -- the tail chunks are folded in the binades the previous iteration's stitch recorded (ws.pred), inside the
+// heads launch: FOUR launches per iteration (assignment, scan + scatter, heads + folds, stitch) and one pass over the tail rows instead of two.
+// Iteration 0 and the proxy sums (MODE 1: other rows, another workspace) have no previous stitch and take the any-order chunk sums + fold launch.
 template <int MODE>
 inline void ks_launch_sums(hipStream_t st, const float *pool, uint32_t pool_bytes, int C, const int32_t *seg_offsets, const int32_t *seg_k,
-                           const int32_t *counts, const KsWorkspace &ws, int kmax, int n_seg, float *dst) {
+                           const int32_t *counts, const KsWorkspace &ws, int kmax, int n_seg, float *dst, bool spec = false) {
+    const KsPred no_pred = {nullptr, nullptr, nullptr};
+    const KsPred pred = (MODE == 0) ? ws.pred : no_pred;             // MODE 0: every stitch (and every head without a tail) records for the next iteration
+    const int n_fold_groups = (C + KC_FG - 1) / KC_FG;
+#ifdef AOC_DEV
+    static const bool spec_on = AOC_DEV_ENV_INT("AOC_KM_SPEC", 1) != 0;      // developer switch: 0 = the five-launch iteration of round 4
+    spec = spec && spec_on && ks_sum_mode() == 2 && AOC_DEV_ENV_INT("AOC_KM_FUSED", 0) != 1 && AOC_DEV_ENV_INT("AOC_KM_HEADS_DMA", 1) != 0 &&
+           !(AOC_DEV_ENV("AOC_KM_HEADS") && strcmp(AOC_DEV_ENV("AOC_KM_HEADS"), "kernel") == 0);
+#endif
+    spec = spec && MODE == 0 && C <= KC_FG * 8;
+    if (spec) {
+        const int start = KS_HEAD_CHUNKS;
+        hipLaunchKernelGGL((km_heads_chunk_sums_kernel<MODE, true>), dim3(kmax * n_seg * os_groups(C) + (unsigned)ws.nch_cap * n_fold_groups), dim3(256), 0, st, pool,
+                           pool_bytes, C, seg_offsets, seg_k, counts, ws.cbase, ws.moff, kmax, n_seg, dst, KS_HEAD_CHUNKS * KS_CHUNK, ws.head, ws.owner_cluster,
+                           ws.owner_local, ws.csum, start, km_xcd_aware(), pred, 1, ws.cexp, ws.cinc0, ws.cinc1, ws.cchunk, ws.nch_cap, n_fold_groups);
+        hipLaunchKernelGGL((km_sum_scan_kernel<MODE, 1>), dim3((unsigned)C * kmax * n_seg), dim3(64), 0, st, pool, pool_bytes, C, seg_offsets, seg_k, counts, ws.cbase,
+                           ws.moff, kmax, dst, ws.cchunk, ws.cexp, ws.cinc0, ws.cinc1, start, ws.head, n_seg, km_xcd_aware(), pred);
+        return;
+    }
 #ifndef AOC_DEV
     // release build: literal heads by LDS-DMA + any-order chunk sums in one launch, then the fold (binade prediction inside it while no cluster
     // can have more than KC_INLINE_PREDICT_CHUNKS chunks) -- the alternatives below only exist in the development build
     const int start = KS_HEAD_CHUNKS;
     hipLaunchKernelGGL((km_heads_chunk_sums_kernel<MODE, true>), dim3(kmax * n_seg * os_groups(C) + ws.nch_cap), dim3(256), 0, st, pool, pool_bytes, C,
                        seg_offsets, seg_k, counts, ws.cbase, ws.moff, kmax, n_seg, dst, KS_HEAD_CHUNKS * KS_CHUNK, ws.head, ws.owner_cluster, ws.owner_local,
-                       ws.csum, start, 1);
+                       ws.csum, start, 1, pred, 0, ws.cexp, ws.cinc0, ws.cinc1, ws.cchunk, ws.nch_cap, n_fold_groups);
     {
         const bool inline_predict = ws.seg_chunks_max <= KC_INLINE_PREDICT_CHUNKS;
         if (!inline_predict)
@@ -2635,11 +2761,11 @@ inline void ks_launch_sums(hipStream_t st, const float *pool, uint32_t pool_byte
         if (dma)
             hipLaunchKernelGGL((km_heads_chunk_sums_kernel<MODE, true>), dim3(kmax * n_seg * os_groups(C) + ws.nch_cap), dim3(256), 0, st, pool, pool_bytes, C,
                                seg_offsets, seg_k, counts, ws.cbase, ws.moff, kmax, n_seg, dst, KS_HEAD_CHUNKS * KS_CHUNK, ws.head, ws.owner_cluster, ws.owner_local,
-                               ws.csum, start, km_xcd_aware());
+                               ws.csum, start, km_xcd_aware(), pred, 0, ws.cexp, ws.cinc0, ws.cinc1, ws.cchunk, ws.nch_cap, n_fold_groups);
         else
             hipLaunchKernelGGL((km_heads_chunk_sums_kernel<MODE, false>), dim3(kmax * n_seg * os_groups(C) + ws.nch_cap), dim3((OS_NPROD + 1) * 64), 0, st, pool, pool_bytes, C,
                                seg_offsets, seg_k, counts, ws.cbase, ws.moff, kmax, n_seg, dst, KS_HEAD_CHUNKS * KS_CHUNK, ws.head, ws.owner_cluster, ws.owner_local,
-                               ws.csum, start, km_xcd_aware());
+                               ws.csum, start, km_xcd_aware(), pred, 0, ws.cexp, ws.cinc0, ws.cinc1, ws.cchunk, ws.nch_cap, n_fold_groups);
     } else if (mode != 0) {
         const int cap = (mode == 2) ? KS_HEAD_CHUNKS * KS_CHUNK : 0;
         hipLaunchKernelGGL(km_ordered_sum_kernel<MODE>, dim3(kmax, n_seg, os_groups(C)), dim3((OS_NPROD + 1) * 64), 0, st, pool, pool_bytes, C, seg_offsets,
@@ -2670,7 +2796,7 @@ inline void ks_launch_sums(hipStream_t st, const float *pool, uint32_t pool_byte
 #endif
     static const int nf = AOC_DEV_ENV_INT("AOC_KS_NF", 1);       // features per stitch wave (developer switch)
 #define AOC_KSS(NF) hipLaunchKernelGGL((km_sum_scan_kernel<MODE, NF>), dim3((unsigned)(C / NF) * kmax * n_seg), dim3(64), 0, st, pool, pool_bytes, C, seg_offsets, seg_k, \
-                                       counts, ws.cbase, ws.moff, kmax, dst, ws.cchunk, ws.cexp, ws.cinc0, ws.cinc1, start, ws.head, n_seg, km_xcd_aware())
+                                       counts, ws.cbase, ws.moff, kmax, dst, ws.cchunk, ws.cexp, ws.cinc0, ws.cinc1, start, ws.head, n_seg, km_xcd_aware(), pred)
 #ifdef AOC_DEV
     if (nf == 4) AOC_KSS(4); else if (nf == 2) AOC_KSS(2); else AOC_KSS(1);
 #else
@@ -2846,7 +2972,7 @@ int aoc_kmeans_segmented_rep(const float *pool, int64_t pool_rows, int C, const 
             hipLaunchKernelGGL(km_scan_scatter_kernel, sgrid, dim3(256), 0, st, rows, (const int32_t *)nullptr, seg_offsets, seg_k, n_seg, labels, ws.rank16,
                                ws.hist, ws.nb_max, kmax, (uint32_t)C * 4u, ws.moff, cluster_counts, ws.cbase, ws.cchunk, ws.owner_cluster, ws.owner_local,
                                ws.nch_cap, ws.cflag);
-            ks_launch_sums<0>(st, pool, pool_bytes, C, seg_offsets, seg_k, cluster_counts, ws, kmax, n_seg, centroids);
+            ks_launch_sums<0>(st, pool, pool_bytes, C, seg_offsets, seg_k, cluster_counts, ws, kmax, n_seg, centroids, it > 0);
             continue;
         }
         if ((C % 4) == 0 && C <= 100)
