@@ -1670,16 +1670,116 @@ __device__ __forceinline__ void kc_chunk_fold_body(int b, float *__restrict__ ld
         }
     }
 }
+// The fold of ONE chunk x feature group in the predicted binades (KsPred), for the heads launch: that launch's workgroups own 43 KB of LDS each
+// (the heads' ring), so only three of them fit a CU and the block-by-block pipeline of kc_chunk_fold_body -- one memory round trip per
+// 64-member block, hidden by eight resident workgroups in its own launch -- would be exposed.  Here the workgroup requests ALL its rows at once
+// (512 members x 80 bytes: ten 16-byte loads per thread, offsets first), parks them in the LDS it owns anyway and folds the eight blocks
+// back to back: two round trips per chunk instead of eight.  Same arithmetic, same summaries.
+constexpr int KC_WIDE_LDS_FLOATS = KS_CHUNK * KC_G_LD + KC_FG;
+__device__ __forceinline__ void kc_chunk_fold_wide_body(int b, float *__restrict__ lds, const float *__restrict__ pool, int C, const int32_t *__restrict__ seg_off,
+                                                        const int32_t *__restrict__ counts, const int32_t *__restrict__ cbase,
+                                                        const uint32_t *__restrict__ moff, int kmax,
+                                                        const int32_t *__restrict__ owner_cluster, const int32_t *__restrict__ owner_local,
+                                                        int8_t *__restrict__ cexp, int32_t *__restrict__ cinc0, int32_t *__restrict__ cinc1,
+                                                        int start_chunk, int n_chunks_grid, int n_groups, int xcd_aware, const KsPred &pred) {
+    float *tile = lds;                                                  // [KS_CHUNK][KC_G_LD]
+    int *lexp = reinterpret_cast<int *>(lds + KS_CHUNK * KC_G_LD);
+    int chunk, grp;
+    {
+        const int blk = b / (8 * n_groups), rem = b - blk * (8 * n_groups);
+        const int pc = min(8, n_chunks_grid - blk * 8);
+        grp = rem / pc;
+        chunk = blk * 8 + rem - grp * pc;
+        if (!xcd_aware) { chunk = b % n_chunks_grid; grp = b / n_chunks_grid; }
+    }
+    const int oc = owner_cluster[chunk];
+    if (oc < 0) return;
+    const int plocal = owner_local[chunk];
+    if (plocal < start_chunk) return;
+    const int f0 = grp * KC_FG;
+    const int s = oc / kmax;
+    const int cnt = counts[oc];
+    const uint32_t *list = moff + seg_off[s] + cbase[oc];
+    const int first = plocal * KS_CHUNK;
+    const int lane = aoc_lane(), wave = threadIdx.x >> 6;
+    const int members = min(KS_CHUNK, cnt - first);
+    const int nblk = (members + 63) / 64;
+    // the member offsets this thread needs (its ten pieces belong to members idx / 5): requested before anything else
+    constexpr int NP = KC_FG / 4;                                       // 5 float4 pieces per member
+    constexpr int NIT = KS_CHUNK * NP / 256;                            // 10 pieces per thread
+    uint32_t off[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) off[it] = list[first + min((it * 256 + (int)threadIdx.x) / NP, members - 1)];
+
+    KcFold k[KC_FW];
+    float inv_u[KC_FW];
+    bool live[KC_FW];
+    bool any_live = false;
+#pragma unroll
+    for (int i = 0; i < KC_FW; ++i) {
+        const int f = f0 + wave * KC_FW + i;
+        int e = KC_UNSAFE;
+        if (f < C) {
+            e = kp_predict(pred, (size_t)oc * C + f, plocal);
+            if (lane == 0) cexp[(size_t)chunk * C + f] = (int8_t)e;
+        }
+        if (lane == 0) lexp[wave * KC_FW + i] = e;
+        live[i] = e != KC_UNSAFE;
+        inv_u[i] = __uint_as_float((uint32_t)(23 - (live[i] ? e : 0) + 127) << 23);
+        k[i].acc = 0; k[i].par0 = 0; k[i].par1 = 1; k[i].bump0 = 0; k[i].bump1 = 0; k[i].bad = 0;
+        any_live |= live[i];
+    }
+    __syncthreads();
+    bool block_live = false;
+    for (int i = 0; i < KC_FG; ++i) block_live |= (lexp[i] != KC_UNSAFE);
+    if (!block_live) return;                                            // (uniform per workgroup)
+    float4 v[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int idx = it * 256 + threadIdx.x;
+        const int mloc = idx / NP, piece = idx - mloc * NP;
+        const bool in = f0 + piece * 4 < C;
+        v[it] = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(pool) + off[it] + (in ? (f0 + piece * 4) * 4 : 0));
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int idx = it * 256 + threadIdx.x;
+        const int mloc = idx / NP, piece = idx - mloc * NP;
+        const bool in = mloc < members && f0 + piece * 4 < C;
+        float *d = tile + mloc * KC_G_LD + piece * 4;
+        d[0] = in ? v[it].x : 0.0f; d[1] = in ? v[it].y : 0.0f; d[2] = in ? v[it].z : 0.0f; d[3] = in ? v[it].w : 0.0f;
+    }
+    __syncthreads();
+    if (!any_live) return;
+    for (int bb = 0; bb < nblk; ++bb) {
+#pragma unroll
+        for (int i = 0; i < KC_FW; ++i)
+            if (live[i]) kc_fold_block2(tile[(bb * 64 + lane) * KC_G_LD + wave * KC_FW + i], inv_u[i], k[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < KC_FW; ++i) {
+        if (live[i]) {
+            const int f = f0 + wave * KC_FW + i;
+            const int t = ks_wave_sum(k[i].acc);
+            if (lane == 0) {
+                if (k[i].bad) cexp[(size_t)chunk * C + f] = (int8_t)KC_UNSAFE;
+                cinc0[(size_t)chunk * C + f] = t + k[i].bump0;
+                cinc1[(size_t)chunk * C + f] = t + k[i].bump1;
+            }
+        }
+    }
+}
 __global__ __launch_bounds__(256) void km_chunk_fold_kernel(const float *__restrict__ pool, int C, const int32_t *__restrict__ seg_off,
                                                              const int32_t *__restrict__ counts, const int32_t *__restrict__ cbase,
                                                              const uint32_t *__restrict__ moff, int kmax,
                                                              const int32_t *__restrict__ owner_cluster, const int32_t *__restrict__ owner_local,
                                                              int8_t *__restrict__ cexp, int32_t *__restrict__ cinc0, int32_t *__restrict__ cinc1,
                                                              int start_chunk, const float *__restrict__ csum, const int32_t *__restrict__ cchunk,
-                                                             const float *__restrict__ head_state, int n_chunks_grid, int n_groups, int xcd_aware) {
+                                                             const float *__restrict__ head_state, int n_chunks_grid, int n_groups, int xcd_aware,
+                                                             KsPred pred) {
     __shared__ __attribute__((aligned(16))) float lds[KC_FOLD_LDS_FLOATS];
     kc_chunk_fold_body(blockIdx.x, lds, pool, C, seg_off, counts, cbase, moff, kmax, owner_cluster, owner_local, cexp, cinc0, cinc1, start_chunk, csum, cchunk,
-                       head_state, n_chunks_grid, n_groups, xcd_aware, nullptr);
+                       head_state, n_chunks_grid, n_groups, xcd_aware, pred.e0 ? &pred : nullptr);
 }
 
 // P0 + P1 + P2 in one pass over the rows ("scan-fold").  Same grid and roles as km_chunk_fold_kernel, but the workgroup keeps all
@@ -1881,7 +1981,6 @@ struct KsChunkT {
 template <int F, int NF>
 __device__ __forceinline__ float ks_chunk_exact(float s, const KsChunkT<NF> &ch, int nblk, int lane, bool dbg = false) {
     int from = 0;
-    if (dbg) KS_STAT(5, 1);                               // calls
 #pragma unroll 1
     for (int round = 0; round < 3 && from < nblk; ++round) {
         const KsBinade bb = ks_binade(s);
@@ -1939,11 +2038,10 @@ __device__ __forceinline__ float ks_chunk_exact(float s, const KsChunkT<NF> &ch,
             if (b == bcross) xc = __uint_as_float(ch.x[b][F]);
         s = ks_block_exact(s, xc, lane);
         from = bcross + 1;
-        if (dbg) KS_STAT(6, 1);                           // crossings resolved
     }
 #pragma unroll
     for (int b = 0; b < KS_T; ++b)
-        if (b >= from && b < nblk) { s = ks_block_exact(s, __uint_as_float(ch.x[b][F]), lane); if (dbg) KS_STAT(7, 1); }
+        if (b >= from && b < nblk) s = ks_block_exact(s, __uint_as_float(ch.x[b][F]), lane);
     return s;
 }
 
@@ -2159,6 +2257,13 @@ __global__ __launch_bounds__(64) void km_sum_scan_kernel(const float *__restrict
             all_skip &= skip[f];
         }
         ks_tsum += KS_CLK() - ks_ta;
+#ifdef AOC_KS_STATS
+        if (lane == 0) {                                               // all waves: tail chunks visited / verified / refolded without a prefetch
+            atomicAdd(&aoc_ks_stats[5], 1ull);
+            if (all_skip) atomicAdd(&aoc_ks_stats[6], 1ull);
+            else if (pending != c) atomicAdd(&aoc_ks_stats[7], 1ull);
+        }
+#endif
         if (all_skip) continue;                                        // (a verified summary never changes the exponent)
         const long long ks_tb = KS_CLK();
         // ---- this chunk needs its rows
@@ -2578,8 +2683,9 @@ __global__ __launch_bounds__(DMA ? 256 : (OS_NPROD + 1) * 64) void km_heads_chun
     if (DMA && spec_fold) {
         // round 5: the tail chunks' integer folds in their PREDICTED binades (KsPred: the previous Lloyd iteration's) ride in this launch --
         // no any-order chunk sums, no separate fold launch; the stitch verifies every summary as before
-        kc_chunk_fold_body(b - n_head, os_lds, pool, C, seg_off, counts, cbase, moff, kmax, owner_cluster, owner_local, cexp, cinc0, cinc1, start_chunk,
-                           nullptr, cchunk, head_state, n_chunks_grid, n_fold_groups, xcd_aware, &pred);
+        static_assert(!DMA || OD_LDS_FLOATS >= KC_WIDE_LDS_FLOATS, "the wide fold's tile fits the heads' ring");
+        kc_chunk_fold_wide_body(b - n_head, os_lds, pool, C, seg_off, counts, cbase, moff, kmax, owner_cluster, owner_local, cexp, cinc0, cinc1, start_chunk,
+                                n_chunks_grid, n_fold_groups, xcd_aware, pred);
         return;
     }
     uint32_t *loffs = reinterpret_cast<uint32_t *>(os_lds);
@@ -2718,17 +2824,31 @@ inline void ks_launch_sums(hipStream_t st, const float *pool, uint32_t pool_byte
     const KsPred no_pred = {nullptr, nullptr, nullptr};
     const KsPred pred = (MODE == 0) ? ws.pred : no_pred;             // MODE 0: every stitch (and every head without a tail) records for the next iteration
     const int n_fold_groups = (C + KC_FG - 1) / KC_FG;
+    // Where the folds run: INSIDE the heads launch (4 launches per iteration; smode 1).  A heads workgroup owns 43 KB of LDS, so three fit a CU, a
+    // cluster that fills its literal head keeps four of them for ~60 us, and the folds of the launch compete for the same slots; with the
+    // whole-chunk staging of kc_chunk_fold_wide_body that still beats heads + folds as two launches (smode 2, development switch) and the
+    // five-launch iteration of round 4 (smode 0) alone at every size measured (profiles/r05_kmeans_spec_fold_ab.txt: cfg2 R = 6, three frames per
+    // chain 3.7-3.8 -> 3.1 ms; cfg3 R = 2 4.9 -> 4.1; cfg4 R = 3 7.4 -> 6.7) except cfg3 at R = 6 on one of two boxes (10.7 -> 11.1 ms there, 12.3 -> 11.2
+    // on the other: the K = 8 level has ~200 clusters that fill their head, more head workgroups than slots).
+    int smode = spec ? 1 : 0;
 #ifdef AOC_DEV
-    static const bool spec_on = AOC_DEV_ENV_INT("AOC_KM_SPEC", 1) != 0;      // developer switch: 0 = the five-launch iteration of round 4
-    spec = spec && spec_on && ks_sum_mode() == 2 && AOC_DEV_ENV_INT("AOC_KM_FUSED", 0) != 1 && AOC_DEV_ENV_INT("AOC_KM_HEADS_DMA", 1) != 0 &&
-           !(AOC_DEV_ENV("AOC_KM_HEADS") && strcmp(AOC_DEV_ENV("AOC_KM_HEADS"), "kernel") == 0);
+    static const int spec_env = AOC_DEV_ENV_INT("AOC_KM_SPEC", -1);      // developer switch: 0 = the five-launch iteration of round 4, 1 = folds in the heads launch, 2 = folds apart
+    if (spec && spec_env >= 0) smode = spec_env;
+    if (!(ks_sum_mode() == 2 && AOC_DEV_ENV_INT("AOC_KM_FUSED", 0) != 1 && AOC_DEV_ENV_INT("AOC_KM_HEADS_DMA", 1) != 0 &&
+          !(AOC_DEV_ENV("AOC_KM_HEADS") && strcmp(AOC_DEV_ENV("AOC_KM_HEADS"), "kernel") == 0)))
+        smode = 0;
 #endif
-    spec = spec && MODE == 0 && C <= KC_FG * 8;
-    if (spec) {
+    if (!(MODE == 0 && C <= KC_FG * 8)) smode = 0;
+    if (smode != 0) {
         const int start = KS_HEAD_CHUNKS;
-        hipLaunchKernelGGL((km_heads_chunk_sums_kernel<MODE, true>), dim3(kmax * n_seg * os_groups(C) + (unsigned)ws.nch_cap * n_fold_groups), dim3(256), 0, st, pool,
+        const unsigned n_head_wg = (unsigned)(kmax * n_seg * os_groups(C));
+        hipLaunchKernelGGL((km_heads_chunk_sums_kernel<MODE, true>), dim3(n_head_wg + (smode == 1 ? (unsigned)ws.nch_cap * n_fold_groups : 0u)), dim3(256), 0, st, pool,
                            pool_bytes, C, seg_offsets, seg_k, counts, ws.cbase, ws.moff, kmax, n_seg, dst, KS_HEAD_CHUNKS * KS_CHUNK, ws.head, ws.owner_cluster,
                            ws.owner_local, ws.csum, start, km_xcd_aware(), pred, 1, ws.cexp, ws.cinc0, ws.cinc1, ws.cchunk, ws.nch_cap, n_fold_groups);
+        if (smode == 2)
+            hipLaunchKernelGGL(km_chunk_fold_kernel, dim3((unsigned)ws.nch_cap * n_fold_groups), dim3(256), 0, st, pool, C, seg_offsets, counts, ws.cbase, ws.moff,
+                               kmax, ws.owner_cluster, ws.owner_local, ws.cexp, ws.cinc0, ws.cinc1, start, (const float *)nullptr, ws.cchunk, ws.head, ws.nch_cap,
+                               n_fold_groups, km_xcd_aware(), pred);
         hipLaunchKernelGGL((km_sum_scan_kernel<MODE, 1>), dim3((unsigned)C * kmax * n_seg), dim3(64), 0, st, pool, pool_bytes, C, seg_offsets, seg_k, counts, ws.cbase,
                            ws.moff, kmax, dst, ws.cchunk, ws.cexp, ws.cinc0, ws.cinc1, start, ws.head, n_seg, km_xcd_aware(), pred);
         return;
@@ -2746,7 +2866,7 @@ inline void ks_launch_sums(hipStream_t st, const float *pool, uint32_t pool_byte
             hipLaunchKernelGGL(km_chunk_predict_kernel, dim3(kmax, n_seg), dim3(128), 0, st, seg_k, counts, ws.cchunk, ws.csum, kmax, C, ws.cexp, start, ws.head);
         hipLaunchKernelGGL(km_chunk_fold_kernel, dim3((unsigned)ws.nch_cap * ((C + KC_FG - 1) / KC_FG)), dim3(256), 0, st, pool, C, seg_offsets, counts, ws.cbase, ws.moff,
                            kmax, ws.owner_cluster, ws.owner_local, ws.cexp, ws.cinc0, ws.cinc1, start, inline_predict ? ws.csum : (const float *)nullptr,
-                           ws.cchunk, ws.head, ws.nch_cap, (C + KC_FG - 1) / KC_FG, 1);
+                           ws.cchunk, ws.head, ws.nch_cap, (C + KC_FG - 1) / KC_FG, 1, no_pred);
     }
 #else
     const int mode = ks_sum_mode();
@@ -2791,7 +2911,7 @@ inline void ks_launch_sums(hipStream_t st, const float *pool, uint32_t pool_byte
             hipLaunchKernelGGL(km_chunk_predict_kernel, dim3(kmax, n_seg), dim3(128), 0, st, seg_k, counts, ws.cchunk, ws.csum, kmax, C, ws.cexp, start, ws.head);
         hipLaunchKernelGGL(km_chunk_fold_kernel, dim3((unsigned)ws.nch_cap * ((C + KC_FG - 1) / KC_FG)), dim3(256), 0, st, pool, C, seg_offsets, counts, ws.cbase, ws.moff,
                            kmax, ws.owner_cluster, ws.owner_local, ws.cexp, ws.cinc0, ws.cinc1, start, inline_predict ? ws.csum : (const float *)nullptr,
-                           ws.cchunk, ws.head, ws.nch_cap, (C + KC_FG - 1) / KC_FG, km_xcd_aware());
+                           ws.cchunk, ws.head, ws.nch_cap, (C + KC_FG - 1) / KC_FG, km_xcd_aware(), no_pred);
     }
 #endif
     static const int nf = AOC_DEV_ENV_INT("AOC_KS_NF", 1);       // features per stitch wave (developer switch)

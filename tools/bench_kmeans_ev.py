@@ -84,3 +84,16 @@ all_chain.sort()
 all_prox.sort()
 print(f"k-means chain {CFG} R={R} F={F}: median {all_chain[len(all_chain) // 2]:.3f} ms (min {all_chain[0]:.3f}, max {all_chain[-1]:.3f}) per chain, "
       f"proxy construction median {all_prox[len(all_prox) // 2]:.3f} ms", flush=True)
+# a library built with -DAOC_KS_STATS (tools/build_variant.sh kstat labels_kmeans.hip "-DAOC_KS_STATS -DAOC_DEV"; AOC_LIB_FILE=libaoc_hip_kstat.so) counts what
+# the stitch did with the tail chunks' summaries over everything above
+try:
+    import ctypes
+    fn = aoc_amd._lib.lib().aoc_debug_ks_stats
+    fn.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    buf = (ctypes.c_ulonglong * 8)()
+    fn(buf, 1)
+    v, ok, cold = int(buf[5]), int(buf[6]), int(buf[7])
+    print(f"  stitch: {v} (tail chunk, feature) visits, {ok / max(v, 1):.4f} verified summaries, {(v - ok - cold) / max(v, 1):.4f} refolded with prefetched rows, "
+          f"{cold / max(v, 1):.4f} refolded without a prefetch (mispredicted)", flush=True)
+except AttributeError:
+    pass
