@@ -1002,6 +1002,18 @@ def main():
         timer.enabled = False
         for wl in workloads:
             wl.count_r = False
+        # What the enqueue calls of a step cost the host when nothing blocks: a few extra steps (outside the timed regions, the group walk simply
+        # continues) with the queues drained in front of each -- the wall time of run_steps(1) is then the CPU time of the step's enqueue calls,
+        # while `enqueue` above also contains the time the host sits in the runtime waiting for room in full queues (it runs ~3 ms ahead)
+        cpu_enqueue = []
+        for _ in range(8):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            run_steps(1)
+            cpu_enqueue.append(time.perf_counter() - t0)
+        torch.cuda.synchronize()
+        cpu_enqueue.sort()
+        host_cpu_enqueue_s = cpu_enqueue[len(cpu_enqueue) // 2]
     n_regions = len(regions)
 
     el = torch.tensor(regions, dtype=torch.float64, device=red_dev)
@@ -1125,7 +1137,8 @@ def main():
                                      "GPU -- including, unless --dense-order is given, the other sequence's dense kernel (0.22 overlapping, 0.24 one "
                                      "after the other, 0.31 alone); traffic (PMC FETCH/WRITE) is not measurable inside the run: the separate --pmc passes are under profiles/",
                                 op_avg_ms=k.get("op_avg_ms"))
-                roofline["alone_offline"] = dict(file="profiles/r04_pmc_dense_R6.txt", commit="05709ec", source="constants copied from the committed file (tools/bench_dense.py 6 "
+                if args.config == "cfg2":
+                  roofline["alone_offline"] = dict(file="profiles/r04_pmc_dense_R6.txt", commit="05709ec", source="constants copied from the committed file (tools/bench_dense.py 6 "
                                                  "on an idle GPU, all 256 CUs), not measured in this run", pool_frames=6, avg_launch_ms=1.082, achieved=736.7, frac=0.295,
                                                  fetch_bytes=366.0e6, record_bytes=80.8e6, mfma_busy_share_of_simd_cycles=0.49,
                                                  note="FETCH_SIZE x 2 per launch = 4.5 x the split records at 0.34 TB/s: the kernel does not wait for that traffic")
@@ -1241,7 +1254,14 @@ def main():
                                         "--no-cpu-baseline", "--exact-steps", "0", "--no-extras"], capture_output=True, text=True, timeout=420)
                     j = json.loads(r.stdout.strip().splitlines()[-1])
                     other[name] = dict(value=j["value"], unit=j["unit"], ms_per_step=j["ms_per_step"], steps=j["steps"], timed_regions=j["timed_regions"],
-                                       workload=j["config"]["workload"], host_enqueue_ms_per_step=j["host_enqueue_ms_per_step"])
+                                       workload=j["config"]["workload"], host_enqueue_ms_per_step=j["host_enqueue_ms_per_step"],
+                                       host_enqueue_wall_ms_per_step=j.get("host_enqueue_wall_ms_per_step"), R_timed=j["config"].get("R_timed"))
+                    # the same per-kernel roofline objects the cfg2 line carries, measured in the child's own timed region (in-run event brackets)
+                    for key in ("roofline_dense", "roofline_correlation_kernel", "roofline_kmeans_chain", "roofline_film_scale", "roofline_cond_gate_pool"):
+                        rf = j.get(key)
+                        if isinstance(rf, dict):
+                            rf = {k: v for k, v in rf.items() if k not in ("note", "isolated")}
+                        other[name][key] = rf
                 except Exception as e:                      # the headline must not depend on the extras
                     other[name] = dict(error=repr(e)[:200])
         # SURVEY 8(d) "reported separately": plain-PyTorch random-weight ResNet101-DeepLabv3+ in front of the hot path (tools/backbone_e2e.py; the
@@ -1308,7 +1328,10 @@ def main():
                                       if workloads[0].runner is not None else "hotpath.proto_mask_features: the individual C entry points, ~45 ctypes calls per frame"),
                        "dense_precision": ("fp16-split products (hi*hi + hi*lo + lo*hi), fp32 accumulate: fp32-equivalent; exact-fp32 take-over "
                                            "on overflow / soft labels" if args.dense == "split" else "exact fp32 MFMA")},
-            "host_enqueue_ms_per_step": round(host_enqueue_s / args.steps * 1e3, 3),
+            # CPU time of one step's enqueue calls (queues drained in front of the step: median of 8); `host_enqueue_wall_ms_per_step` = the wall time
+            # of the timed region's enqueue loop per step, which also counts the time the host waits for room in full queues (rounds 1-4 reported that)
+            "host_enqueue_ms_per_step": round(host_cpu_enqueue_s * 1e3, 3),
+            "host_enqueue_wall_ms_per_step": round(host_enqueue_s / args.steps * 1e3, 3),
             "probe_sampling": (f"the HIP-event brackets behind `kernels` / the roofline objects are placed on every {args.probe_every}-th frame of each sequence "
                                "inside the timed region (on every frame -- --probe-every 1 -- their ~40 event records per frame cost 2.6 % frames/s)"),
             **({"frame_segments_ms": segments} if segments else {}),
