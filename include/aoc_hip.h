@@ -602,7 +602,13 @@ typedef struct aoc_frame_desc {
     int32_t matching_background;     /* MODEL_MATCHING_BACKGROUND */
     int32_t n_adaptive;              /* = n_levels * n_obj * 2 * kmax rows of the proxy table in front of the n_obj k = 1 rows */
     float epsilon;                   /* MODEL_EPSILON */
-    int64_t pool_key;                /* != 0; changes whenever the pool's content changes (append-only pool: R) */
+    int32_t pool_prefix_frames;      /* how many leading pool frames are UNCHANGED since the previous call on this state: their split records are
+                                        kept, the frames behind them are converted again.  Append-only pool: R (or anything >= the previous R);
+                                        a pool whose frames were replaced: the first replaced frame's index; 0 converts everything */
+    int32_t stream_cus;              /* CUs `stream` may use when the caller created it with a HIP CU mask: the matrix kernels of THIS call size their
+                                        grids in whole rounds of that many CUs; 0 = the process-wide aoc_set_stream_cus value */
+    int64_t pool_key;                /* != 0; changes whenever the pool's content changes (append-only pool: R).  Keys the pooled reference
+                                        heads and the dense kernel's plan */
     const float *ref_emb;            /* [R * h * w, C]   reference pool, resident, append-only */
     const float *ref_labels;         /* [R * h * w, n_obj] float 0 / 1 */
     const float *prev_emb, *prev_labels, *cur_emb;     /* [h * w, C], [h * w, n_obj], [h * w, C] */

@@ -85,3 +85,5 @@ AocDenseProbe aoc_take_dense_probe();
 
 // CUs the launching stream may use (aoc_set_stream_cus; 0 = all CUs of the device).  Defined in dense_split.hip.
 int aoc_stream_cus();
+// CU budget of the call in progress on THIS thread (0 = the process-wide aoc_set_stream_cus value); returns the previous one
+int aoc_stream_cus_scope(int n_cus);

@@ -864,4 +864,11 @@ int aoc_dense_prune_stats_ex(uint64_t *out8, int reset) {
 
 }  // extern "C"
 
-int aoc_stream_cus() { return g_stream_cus.load(std::memory_order_relaxed); }
+// the budget of the call in progress on this thread (aoc_frame_enqueue: aoc_frame_desc.stream_cus), else the process-wide setting
+static thread_local int t_stream_cus = 0;
+int aoc_stream_cus() { return t_stream_cus > 0 ? t_stream_cus : g_stream_cus.load(std::memory_order_relaxed); }
+int aoc_stream_cus_scope(int n_cus) {
+    const int before = t_stream_cus;
+    t_stream_cus = n_cus > 0 ? n_cus : 0;
+    return before;
+}

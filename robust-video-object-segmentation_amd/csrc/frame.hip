@@ -107,6 +107,15 @@ int aoc_frame_enqueue(const aoc_frame_desc *d, aoc_seq_state *state, void *works
     const int n_set = frame_sets(d);
     const int n_ad = L * O * 2 * kmax;
     if (d->n_adaptive != n_ad) return AOC_ERR_INVALID_ARG;
+    // everything a later stage would reject is rejected HERE, before the first launch and before the state record is touched: the cluster
+    // levels (set sizes of the correlation launch), the window radii (aoc_local_window_match_pair: ascending, window inside the kernel's reach)
+    if (d->pool_prefix_frames < 0 || d->stream_cus < 0) return AOC_ERR_INVALID_ARG;
+    for (int l = 0; l < L; ++l)
+        if (d->levels[l] < 1 || d->levels[l] > kmax) return AOC_ERR_INVALID_ARG;
+    for (int i = 0; i < nl; ++i)
+        if (d->radii[i] < 0 || (i > 0 && d->radii[i] <= d->radii[i - 1])) return AOC_ERR_INVALID_ARG;
+    if (d->radii[nl - 1] > 31) return AOC_ERR_UNSUPPORTED;
+    if (kmax > AOC_MAX_CLUSTERS) return AOC_ERR_UNSUPPORTED;
     if (workspace_bytes < aoc_frame_workspace_bytes(h, w, C, O, d->R_capacity, nl, L)) return AOC_ERR_WORKSPACE;
     const FrameWs f = frame_carve(workspace, h, w, C, O, d->R_capacity, nl, n_set);
     hipStream_t st = aoc_hip_stream(stream);
@@ -120,6 +129,12 @@ int aoc_frame_enqueue(const aoc_frame_desc *d, aoc_seq_state *state, void *works
     int rc;
 #define AOC_TRY(call) do { rc = (call); if (rc != AOC_OK) return rc; } while (0)
     auto mark = [&](int i) { if (d->probe[i]) (void)hipEventRecord(static_cast<hipEvent_t>(d->probe[i]), st); };
+    // the CU budget of this call's stream (a caller that runs it under a HIP CU mask), for the duration of the call on this thread
+    struct CuScope {
+        int before;
+        explicit CuScope(int n) : before(aoc_stream_cus_scope(n)) {}
+        ~CuScope() { aoc_stream_cus_scope(before); }
+    } cu_scope(d->stream_cus > 0 ? d->stream_cus : 0);
 
     if (!state->initialised) {
         if (hipMemsetAsync(workspace, 0, f.init_bytes, st) != hipSuccess) return AOC_ERR_LAUNCH;
@@ -143,6 +158,8 @@ int aoc_frame_enqueue(const aoc_frame_desc *d, aoc_seq_state *state, void *works
 
     // ---- split records: pool frames that joined since the last call, and the query (tile-major)
     if (state->records_frames > R) state->records_frames = 0;             // the pool restarted: the caller should have reset the state
+    // records behind the unchanged prefix belong to frames whose content was replaced (a pool that is not append-only): converted again
+    if (state->records_frames > d->pool_prefix_frames) state->records_frames = d->pool_prefix_frames;
     if (state->records_frames < R) {
         const int64_t r0 = state->records_frames * hw;
         AOC_TRY(aoc_split_rows(d->ref_emb + (size_t)r0 * C, n - r0, C, f.pool_rec + (size_t)r0 * aoc_split_record_bytes(C), f.pool_sq + r0, f.overflow, stream));

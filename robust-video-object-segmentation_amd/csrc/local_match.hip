@@ -7,6 +7,8 @@
 // them (v_mfma_f32_16x16x4_f32) and folds the masked distances into per-(pixel, ring, object)
 // minima in LDS with ds_min_f32.  "ring" = max(|dy|,|dx|) bucketed by the nested window radii, so
 // the nested-window minima of AEM:1036-1046 are a prefix-min over rings at the end.
+#include <algorithm>
+
 #include "aoc_common.h"
 #include <stdlib.h>
 #include <string.h>
@@ -831,7 +833,10 @@ int aoc_local_prep(const float *cur_emb, const float *prev_emb, const float *pre
     if (!cur_emb || !prev_emb || !prev_labels || !prev_pos || !q2 || !p2 || !pm2 || !bits2) return AOC_ERR_INVALID_ARG;
     if (h < 1 || w < 1 || C < 1 || n_obj < 1 || H2 < 1 || W2 < 1 || n_pair_sets < 0 || n_copy_a < 0 || n_copy_b < 0) return AOC_ERR_INVALID_ARG;
     if (n_obj > AOC_MAX_OBJECTS) return AOC_ERR_UNSUPPORTED;
-    const int64_t total = (int64_t)H2 * W2 * C;
+    // one thread per element of the half-resolution maps; the same threads also write the per-set bias table and the two piggy-backed copies
+    // (idx < n): the launch has to be at least as wide as the longest of those tables (tiny maps with many objects)
+    int64_t total = (int64_t)H2 * W2 * C;
+    total = std::max<int64_t>(total, std::max<int64_t>(std::max(n_copy_a, n_copy_b), (int64_t)n_pair_sets + n_obj));
     hipLaunchKernelGGL(local_prep_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, aoc_hip_stream(stream), cur_emb, prev_emb, prev_labels,
                        prev_pos, h, w, C, n_obj, q2, p2, pm2, bits2, H2, W2, align_corners_scale(h, H2), align_corners_scale(w, W2),
                        (float)h / (float)H2, (float)w / (float)W2, obj_bias, n_pair_sets, set_bias_out, copy_src_a, copy_dst_a, n_copy_a, copy_src_b,

@@ -77,6 +77,7 @@ class HotPathBackend:
         self.dense_precision = dense_precision
         self._heads = {}
         self._runners = {}
+        self.max_runners = 4                   # frame-call workspaces kept per lane (LRU)
         self.ahead = bool(ahead)               # False: the per-frame reference-API path (label prep + count read-back + chain on the frame's stream)
         import os
         self.chain_plan = [int(x) for x in os.environ.get("AOC_EVAL_CHAIN_PLAN", "1").split(",") if x.strip()] or [1]   # developer switch
@@ -117,8 +118,13 @@ class HotPathBackend:
             wcap = (cap + 3) // 4 * 4                      # few distinct workspace sizes per lane
             key = (spec.h, spec.w, spec.n_obj, tuple(spec.levels), wcap)
             if key not in self._runners:
+                # a workspace is hundreds of MB (pool records + dense workspace): keep the few most recently used configurations, not one
+                # per (map size, object count, capacity) ever seen
+                while len(self._runners) >= self.max_runners:
+                    self._runners.pop(next(iter(self._runners)))
                 self._runners[key] = self.hot.FrameRunner(self.mc, spec.h, spec.w, 100, spec.n_obj, wcap, self.device)
-            self.runner = self._runners[key]
+            self.runner = self._runners.pop(key)
+            self._runners[key] = self.runner                 # most recently used last
             self.runner.reset()
         if self.ahead and self.side is None:
             self.side = torch.cuda.Stream(self.device, priority=-1)

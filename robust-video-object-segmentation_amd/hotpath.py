@@ -479,7 +479,9 @@ class FrameRunner:
         st = self.call.state
         st.records_frames = min(int(st.records_frames), int(valid_frames))
 
-    def __call__(self, ref_emb, ref_labels, prev_emb, prev_labels, cur_emb, dis_bias, cluster_ahead, pool_key=None, probes=None):
+    def __call__(self, ref_emb, ref_labels, prev_emb, prev_labels, cur_emb, dis_bias, cluster_ahead, pool_key, probes=None, pool_prefix_frames=None):
+        """pool_key (required): a non-zero value that changes whenever the pool's content changes (an append-only pool may pass its frame count);
+        pool_prefix_frames: see ops.FrameCall.__call__ (None = append-only pool)."""
         a = cluster_ahead
         assert a is not None and a.cluster_sets is None and a.R == ref_emb.shape[0], "FrameRunner takes the ClusterProxiesAhead of this frame's pool"
         O = ref_labels.shape[-1]
@@ -487,7 +489,7 @@ class FrameRunner:
         main = torch.cuda.current_stream()
         for t in (a.table, a.sqn, a.prep.right_bits, a.prep.wrong_bits, a.prep.fg_rows, a.prep.obj_rows, a.prep.counts, a.prep.obj_offsets):
             t.record_stream(main)
-        return self.call(ref_emb, ref_labels, prev_emb, prev_labels, cur_emb, bias, a.prep, a.table, a.sqn, a.prep_event, a.done_event, pool_key, probes)
+        return self.call(ref_emb, ref_labels, prev_emb, prev_labels, cur_emb, bias, a.prep, a.table, a.sqn, a.prep_event, a.done_event, pool_key, probes, pool_prefix_frames)
 
 
 class DynamicPreHead(nn.Module):
@@ -550,10 +552,14 @@ class CalibrationGates(nn.Module):
 
     @torch.no_grad()
     def forward_batched(self, activations, attention_head, slot=None, probes=None):
-        """forward() as ONE C call (aoc_gates_enqueue): the same launches in the same order, bit-identical outputs.  The outputs are persistent
-        buffers owned by this module (one set per list of activations: what a decoder that hands every gate's output straight to the next
-        convolution needs); the descriptor list is rebuilt when the activation buffers change."""
-        key = tuple((x.data_ptr(), tuple(x.shape)) for x in activations) + (attention_head.shape[1],)
+        """forward() as ONE C call (aoc_gates_enqueue): the same launches in the same order, bit-identical outputs.  The outputs are PERSISTENT
+        buffers owned by this module (one set per `slot`: what a decoder that hands every gate's output straight to the next convolution needs) --
+        the next call with the same slot OVERWRITES them, so a caller that keeps a result across calls clones it.  The descriptor list is rebuilt
+        when the activation buffers or the weights' storage change."""
+        # the descriptors hold raw pointers: of the activations AND of the module weights -- both are part of the key (module.to(), .float(),
+        # load_state_dict(assign=True) or a re-assigned parameter give the weights new storage; an in-place update keeps it and needs no rebuild)
+        key = (tuple((x.data_ptr(), tuple(x.shape)) for x in activations) + (attention_head.shape[1],) +
+               tuple((p.data_ptr(), p.dtype) for p in self.parameters()))
         if not hasattr(self, "_batches"):
             self._batches = {}
         cached = self._batches.get(slot)                 # one set of output buffers per caller slot (e.g. per sequence in flight)

@@ -571,6 +571,7 @@ class _FrameDesc(ctypes.Structure):
                 ("n_radii", ctypes.c_int32), ("radii", ctypes.c_int32 * 8),
                 ("n_levels", ctypes.c_int32), ("levels", ctypes.c_int32 * 8),
                 ("kmax", ctypes.c_int32), ("matching_background", ctypes.c_int32), ("n_adaptive", ctypes.c_int32), ("epsilon", ctypes.c_float),
+                ("pool_prefix_frames", ctypes.c_int32), ("stream_cus", ctypes.c_int32),
                 ("pool_key", ctypes.c_int64),
                 ("ref_emb", ctypes.c_void_p), ("ref_labels", ctypes.c_void_p), ("prev_emb", ctypes.c_void_p), ("prev_labels", ctypes.c_void_p),
                 ("cur_emb", ctypes.c_void_p), ("dis_bias", ctypes.c_void_p),
@@ -665,9 +666,14 @@ class FrameCall:
         ctypes.memset(ctypes.byref(self.state), 0, ctypes.sizeof(self.state))
 
     def __call__(self, ref_emb, ref_labels, prev_emb, prev_labels, cur_emb, dis_bias, prep, table, sqn, prep_event=None, done_event=None, pool_key=None,
-                 probes=None):
+                 probes=None, pool_prefix_frames=None, stream_cus=0):
         """ref_emb [R, h, w, C] / ref_labels [R, h, w, O] contiguous fp32 views of the resident pool; prep = LabelPrep of ref_labels; table / sqn = this
-        frame's proxy table (adaptive rows written by the k-means chain).  Returns (feat [O, n_ch, h, w], head [O, 4C])."""
+        frame's proxy table (adaptive rows written by the k-means chain).  Returns (feat [O, n_ch, h, w], head [O, 4C]).
+        pool_key (REQUIRED, != 0): identifies the pool's content -- it keys the pooled reference heads and the dense kernel's plan; an append-only pool
+        may pass its frame count.  pool_prefix_frames: leading pool frames unchanged since the previous call (their split records are kept); None =
+        the pool is append-only (everything converted so far stays valid); a caller that REPLACES pool frames passes the first replaced index."""
+        if pool_key is None or int(pool_key) == 0:
+            raise _lib.AocHipError("FrameCall: pool_key is required (a non-zero value that changes whenever the pool's content changes)")
         _need_gpu(ref_emb, ref_labels, prev_emb, prev_labels, cur_emb, dis_bias, table, sqn)
         for t in (ref_emb, ref_labels, prev_emb, prev_labels, cur_emb, dis_bias, table, sqn):
             assert t.dtype == torch.float32 and t.is_contiguous(), "aoc_frame_enqueue takes contiguous float32 tensors"
@@ -678,7 +684,9 @@ class FrameCall:
         feat = torch.empty(self.n_obj, self.n_ch, self.h, self.w, dtype=torch.float32, device=self.device)
         head = torch.empty(self.n_obj, 4 * self.C, dtype=torch.float32, device=self.device)
         d.R = R
-        d.pool_key = int(R if pool_key is None else pool_key)
+        d.pool_key = int(pool_key)
+        d.pool_prefix_frames = int(R if pool_prefix_frames is None else pool_prefix_frames)
+        d.stream_cus = int(stream_cus)              # > 0: this call's stream runs under a CU mask of that many CUs (else: aoc_set_stream_cus)
         d.ref_emb, d.ref_labels, d.prev_emb, d.prev_labels, d.cur_emb = ref_emb.data_ptr(), ref_labels.data_ptr(), prev_emb.data_ptr(), prev_labels.data_ptr(), cur_emb.data_ptr()
         d.dis_bias = dis_bias.data_ptr()
         d.right_bits, d.wrong_bits, d.fg_rows, d.obj_rows = prep.right_bits.data_ptr(), prep.wrong_bits.data_ptr(), prep.fg_rows.data_ptr(), prep.obj_rows.data_ptr()

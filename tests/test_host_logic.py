@@ -245,6 +245,55 @@ def test_c_abi_rejects_bad_arguments_without_a_gpu():
     assert L.aoc_kmeans_init_rows_draw(kp, ctypes.byref(pos), cp, 2, lvp, 1, 1, 4, rp, None) == 0 and pos.value != 624
 
 
+def test_frame_call_validates_everything_before_it_touches_the_state():
+    """aoc_frame_enqueue rejects a bad cluster level / window radius / prefix count up front -- nothing is launched (this runs without a
+    GPU) and the caller's aoc_seq_state is untouched -- instead of failing in the correlation or local-matching stage of a half-enqueued frame."""
+    import ctypes
+    L = aoc_amd._lib.lib()
+    D, S = aoc_amd.ops._FrameDesc, aoc_amd.ops._SeqState
+    buf = (ctypes.c_float * 64)()
+    ptr = ctypes.addressof(buf)
+
+    def desc():
+        d = D()
+        d.h, d.w, d.C, d.n_obj, d.R, d.R_capacity = 24, 40, 100, 3, 1, 2
+        d.n_radii, d.n_levels, d.kmax, d.matching_background, d.epsilon = 2, 2, 16, 1, 1e-5
+        d.radii[0], d.radii[1] = 4, 8
+        d.levels[0], d.levels[1] = 8, 16
+        d.n_adaptive = 2 * 3 * 2 * 16
+        d.pool_key, d.pool_prefix_frames = 1, 1
+        for name in ("ref_emb", "ref_labels", "prev_emb", "prev_labels", "cur_emb", "dis_bias", "right_bits", "wrong_bits", "fg_rows", "obj_rows", "counts",
+                     "obj_offsets", "proxy_table", "proxy_sqnorm", "feat", "head"):
+            setattr(d, name, ptr)
+        return d
+    need = L.aoc_frame_workspace_bytes(24, 40, 100, 3, 2, 2, 2)
+    assert need > 0
+    INVALID, WORKSPACE, UNSUPPORTED = -1, -2, -4
+
+    def call(d, nbytes=need):
+        st = S()
+        rc = L.aoc_frame_enqueue(ctypes.byref(d), ctypes.byref(st), ctypes.c_void_p(ptr), nbytes, None)
+        assert (st.initialised, st.records_frames, st.ref_pool_key, st.plan_key, st.plan_rows) == (0, 0, 0, 0, 0), "the state record was touched"
+        return rc
+    d = desc(); d.levels[1] = 17                      # a level above kmax
+    assert call(d) == INVALID
+    d = desc(); d.levels[0] = 0
+    assert call(d) == INVALID
+    d = desc(); d.radii[1] = 4                        # radii not ascending
+    assert call(d) == INVALID
+    d = desc(); d.radii[1] = 40                       # window beyond the kernel's reach
+    assert call(d) == UNSUPPORTED
+    d = desc(); d.pool_prefix_frames = -1
+    assert call(d) == INVALID
+    d = desc(); d.stream_cus = -3
+    assert call(d) == INVALID
+    d = desc(); d.pool_key = 0                        # a key is required
+    assert call(d) == INVALID
+    d = desc(); d.n_adaptive = 5
+    assert call(d) == INVALID
+    assert call(desc(), nbytes=1024) == WORKSPACE     # a complete descriptor: the next check is the workspace size
+
+
 def test_mirrors_refuse_to_run_under_autograd():
     """the drop-in names include the reference's training-time ones; they build no autograd graph, so they must raise
     (instead of silently training nothing) when a gradient is wanted."""
