@@ -398,6 +398,10 @@ int aoc_resize_bilinear_hwc_ex(const float *in, int h, int w, int C, float *out,
 int aoc_resize_bilinear_planes(const float *in, int P, int h, int w, float *out, int H, int W,
                                int inner_count, int64_t out_outer_stride, int64_t out_plane_stride,
                                int64_t out_pixel_stride, aoc_stream_t stream);
+/* Atrous sub-sampling of a channel-last map (AEM:533-579, the atrous_obj_pixel_num == 0 branch: pad to a multiple of the rate, view as
+ * [h', rate, w', rate, X], keep [:, 0, :, 0]): out [h', w', X] = in[rate * y', rate * x', :] with h' = ceil(h / rate), w' = ceil(w / rate) -- the
+ * padding is never selected.  For the embeddings AND the label maps of a pool frame (a device-side gather: no host-side pad / view arithmetic). */
+int aoc_atrous_subsample(const float *in, int h, int w, int X, int rate, float *out, aoc_stream_t stream);
 /* torch 'nearest' resize of per-pixel label bits [h,w] -> [H,W]  (AEM:1017-1018). */
 int aoc_resize_nearest_bits(const uint32_t *in, int h, int w, uint32_t *out, int H, int W,
                             aoc_stream_t stream);
@@ -583,8 +587,11 @@ int aoc_mask_jf_accumulate(const int32_t *pred, const int32_t *gt, int H, int W,
  * what only depends on the reference pool: its fp16 split records (append-only pool: only new frames are converted), the pooled reference
  * heads (ATT:155-170) and the dense kernel's plan -- keyed by pool_key.
  *
- * Covered configuration: C = 100, <= 16 objects, fp32 matching (MODEL_FLOAT16_MATCHING = False), MODEL_LOCAL_DOWNSAMPLE = True, atrous rates 1
- * (configs/resnet101_aocnet.py); anything else returns AOC_ERR_UNSUPPORTED (use the individual entry points).
+ * Covered configuration: C = 100, <= 30 objects (AOC_MAX_OBJECTS; beyond 16 the dense matching takes the exact-fp32 kernel in slices of 16 and
+ * the correlation the non-record entry point, as hotpath.proto_mask_features does), and every switch the reference's evaluation CLI / config
+ * exposes: MODEL_FLOAT16_MATCHING, MODEL_LOCAL_DOWNSAMPLE on / off, TEST_LOCAL_ATROUS_RATE, TEST_GLOBAL_ATROUS_RATE (round 5; the default
+ * configuration -- fp32, down-sampled local matching, atrous rates 1, <= 16 objects -- keeps the fused launches of round 4, the others go
+ * through the individual entry points the drop-in mirrors use, in the same order: results equal theirs).  Other widths return AOC_ERR_UNSUPPORTED.
  *
  * The adaptive proxies (k-means chain, AEM:252-286: aoc_label_prep, aoc_kmeans_replicate_levels, aoc_kmeans_segmented_rep,
  * aoc_build_proxies) only depend on the pool and are produced by the caller on ANOTHER stream, ahead of the frame; this call gets the label
@@ -607,10 +614,20 @@ typedef struct aoc_frame_desc {
                                         a pool whose frames were replaced: the first replaced frame's index; 0 converts everything */
     int32_t stream_cus;              /* CUs `stream` may use when the caller created it with a HIP CU mask: the matrix kernels of THIS call size their
                                         grids in whole rounds of that many CUs; 0 = the process-wide aoc_set_stream_cus value */
+    /* the switches the reference's evaluation CLI / config exposes (tools/eval_net_mm_rpa.py:9-35, configs/resnet101_aocnet.py:71,78,125,126) */
+    int32_t float16_matching;        /* MODEL_FLOAT16_MATCHING (--float16): the reference's `.half()` arithmetic for the dense, k = 1 proxy and local
+                                        matchings; the cluster channels are the constant 1 the reference degrades to */
+    int32_t local_downsample;        /* MODEL_LOCAL_DOWNSAMPLE: local matching at (h / 2 + 1, w / 2 + 1) (1) or at full resolution (0) */
+    int32_t local_atrous_rate;       /* TEST_LOCAL_ATROUS_RATE (>= 1) */
+    int32_t match_hw;                /* TEST_GLOBAL_ATROUS_RATE > 1 (--global_atrous_rate): rows per pool frame of match_emb (the pool sub-sampled on the
+                                        atrous grid, AEM:533-579: every rate-th row and column); 0 = the matching pool is ref_emb itself */
     int64_t pool_key;                /* != 0; changes whenever the pool's content changes (append-only pool: R).  Keys the pooled reference
                                         heads and the dense kernel's plan */
     const float *ref_emb;            /* [R * h * w, C]   reference pool, resident, append-only */
     const float *ref_labels;         /* [R * h * w, n_obj] float 0 / 1 */
+    const float *match_emb;          /* [R * match_hw, C] the pool the dense and cluster matchings see when match_hw > 0 (aoc_atrous_subsample of every
+                                        pool frame; the label-prep arrays below then index ITS rows); NULL with match_hw = 0.  The pooled heads
+                                        (attention head, k = 1 proxies) always come from ref_emb / ref_labels (aocnet.py:297) */
     const float *prev_emb, *prev_labels, *cur_emb;     /* [h * w, C], [h * w, n_obj], [h * w, C] */
     const float *dis_bias;           /* [n_obj] */
     const uint32_t *right_bits, *wrong_bits;           /* aoc_label_prep(ref_labels) */

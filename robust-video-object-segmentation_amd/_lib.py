@@ -80,6 +80,7 @@ SIGNATURES = {
     "aoc_local_window_match_ex": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _vp]),
     "aoc_resize_bilinear_planes": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _i64, _i64, _i64, _vp]),
     "aoc_resize_nearest_bits": (_i, [_vp, _i, _i, _vp, _i, _i, _vp]),
+    "aoc_atrous_subsample": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "aoc_fg2bg_min": (_i, [_vp, _i, _i, _i64, _i64, _vp, _i64, _vp]),
     "aoc_resize_bilinear_planes_grouped": (_i, [_vp, _i, _i, _i, _vp, _i, _i, _i, _i, _i64, _i64, _i64, _i64, _vp]),
     "aoc_local_window_match_pair": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _vp]),

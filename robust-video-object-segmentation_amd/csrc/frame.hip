@@ -37,6 +37,9 @@ struct FrameWs {
     uint32_t *bits2;
     char *pool_ws;
     size_t pool_ws_bytes;
+    // the non-default modes (float16 matching, full-resolution local matching): full-resolution label bits and per-pixel proxy map
+    uint32_t *bits_full;
+    float *pmap;
     size_t total, init_bytes;
 };
 
@@ -55,7 +58,8 @@ inline FrameWs frame_carve(void *base, int h, int w, int C, int n_obj, int R_cap
     f.ref_pos = reinterpret_cast<float *>(take((size_t)n_obj * C * sizeof(float)));
     f.ref_neg = reinterpret_cast<float *>(take((size_t)n_obj * C * sizeof(float)));
     f.ref_sq = reinterpret_cast<float *>(take((size_t)n_obj * sizeof(float)));
-    f.dense_bytes = aoc_dense_match_split_workspace_bytes(hw, n_cap, n_obj);
+    // the split kernel's workspace (which contains the exact-fp32 take-over's) up to 16 objects, the exact-fp32 kernel's beyond
+    f.dense_bytes = std::max(n_obj <= 16 ? aoc_dense_match_split_workspace_bytes(hw, n_cap, n_obj) : (size_t)0, aoc_dense_match_workspace_bytes(hw, n_cap, n_obj));
     f.dense_ws = take(f.dense_bytes);
     f.prev_pos = reinterpret_cast<float *>(take((size_t)n_obj * C * sizeof(float)));
     f.prev_neg = reinterpret_cast<float *>(take((size_t)n_obj * C * sizeof(float)));
@@ -66,8 +70,10 @@ inline FrameWs frame_carve(void *base, int h, int w, int C, int n_obj, int R_cap
     f.q2 = reinterpret_cast<float *>(take(half));
     f.p2 = reinterpret_cast<float *>(take(half));
     f.pm2 = reinterpret_cast<float *>(take(half));
-    f.lf = reinterpret_cast<float *>(take((size_t)2 * n_obj * n_radii * H2 * W2 * sizeof(float)));
+    f.lf = reinterpret_cast<float *>(take((size_t)2 * n_obj * n_radii * hw * sizeof(float)));       // full resolution: MODEL_LOCAL_DOWNSAMPLE off
     f.bits2 = reinterpret_cast<uint32_t *>(take((size_t)H2 * W2 * sizeof(uint32_t)));
+    f.bits_full = reinterpret_cast<uint32_t *>(take((size_t)hw * sizeof(uint32_t)));
+    f.pmap = reinterpret_cast<float *>(take((size_t)hw * C * sizeof(float)));
     f.pool_ws_bytes = std::max(aoc_masked_mean_pool_workspace_bytes(R_cap, hw, n_obj, C), aoc_masked_mean_pool_workspace_bytes(1, hw, n_obj, C));
     f.pool_ws = take(f.pool_ws_bytes);
     f.total = off;
@@ -99,17 +105,17 @@ int aoc_frame_enqueue(const aoc_frame_desc *d, aoc_seq_state *state, void *works
     if (d->h < 1 || d->w < 1 || d->n_obj < 1 || d->R < 1 || d->R > d->R_capacity || d->n_radii < 1 || d->n_radii > 8 || d->n_levels < 1 ||
         d->n_levels > 8 || d->kmax < 1 || d->pool_key == 0)
         return AOC_ERR_INVALID_ARG;
-    // the configuration this call covers (everything else goes through the individual entry points): C = 100 split records, <= 16 objects,
-    // half-resolution local matching (MODEL_LOCAL_DOWNSAMPLE), fp32 matching
-    if (d->C != 100 || d->n_obj > 16 || aoc_split_record_bytes(d->C) == 0) return AOC_ERR_UNSUPPORTED;
+    // the widths this call covers (everything else goes through the individual entry points): C = 100 (split records), <= AOC_MAX_OBJECTS objects
+    if (d->C != 100 || d->n_obj > AOC_MAX_OBJECTS || aoc_split_record_bytes(d->C) == 0) return AOC_ERR_UNSUPPORTED;
     const int h = d->h, w = d->w, C = d->C, O = d->n_obj, R = d->R, nl = d->n_radii, L = d->n_levels, kmax = d->kmax;
-    const int64_t hw = (int64_t)h * w, n = hw * R;
+    const int64_t hw = (int64_t)h * w;
     const int n_set = frame_sets(d);
     const int n_ad = L * O * 2 * kmax;
     if (d->n_adaptive != n_ad) return AOC_ERR_INVALID_ARG;
     // everything a later stage would reject is rejected HERE, before the first launch and before the state record is touched: the cluster
     // levels (set sizes of the correlation launch), the window radii (aoc_local_window_match_pair: ascending, window inside the kernel's reach)
-    if (d->pool_prefix_frames < 0 || d->stream_cus < 0) return AOC_ERR_INVALID_ARG;
+    if (d->pool_prefix_frames < 0 || d->stream_cus < 0 || d->local_atrous_rate < 0 || d->match_hw < 0 || d->match_hw > hw) return AOC_ERR_INVALID_ARG;
+    if ((d->match_hw > 0) != (d->match_emb != nullptr)) return AOC_ERR_INVALID_ARG;
     for (int l = 0; l < L; ++l)
         if (d->levels[l] < 1 || d->levels[l] > kmax) return AOC_ERR_INVALID_ARG;
     for (int i = 0; i < nl; ++i)
@@ -122,6 +128,14 @@ int aoc_frame_enqueue(const aoc_frame_desc *d, aoc_seq_state *state, void *works
     const int H2 = h / 2 + 1, W2 = w / 2 + 1;
     const int n_ch = aoc_frame_channels(nl, L, d->matching_background);
     const int64_t obj_stride = (int64_t)n_ch * hw;
+    // the reference's switches; `fused` = the default configuration, which keeps the fused launches of round 4
+    const bool f16 = d->float16_matching != 0, down = d->local_downsample != 0;
+    const int lrate = d->local_atrous_rate > 1 ? d->local_atrous_rate : 1;
+    const bool split = !f16 && O <= 16;                                 // dense + correlation on the fp16-split matrix pipe with records
+    const bool fused_local = !f16 && down && lrate == 1;
+    // the pool the dense and cluster matchings see (the atrous-sub-sampled pool with TEST_GLOBAL_ATROUS_RATE > 1)
+    const float *mpool = d->match_hw > 0 ? d->match_emb : d->ref_emb;
+    const int64_t mhw = d->match_hw > 0 ? d->match_hw : hw, n = mhw * R;
     // channel layout, aocnet.py:355-358
     const int c2 = 2 * L;
     const int ch_global = 0, ch_cluster = 1, ch_proxy = 1 + c2, ch_local = 2 + c2, ch_local_proxy = 2 + c2 + nl, ch_prev = 2 + c2 + 2 * nl;
@@ -132,7 +146,7 @@ int aoc_frame_enqueue(const aoc_frame_desc *d, aoc_seq_state *state, void *works
     // the CU budget of this call's stream (a caller that runs it under a HIP CU mask), for the duration of the call on this thread
     struct CuScope {
         int before;
-        explicit CuScope(int n) : before(aoc_stream_cus_scope(n)) {}
+        explicit CuScope(int n_cus) : before(aoc_stream_cus_scope(n_cus)) {}
         ~CuScope() { aoc_stream_cus_scope(before); }
     } cu_scope(d->stream_cus > 0 ? d->stream_cus : 0);
 
@@ -152,44 +166,85 @@ int aoc_frame_enqueue(const aoc_frame_desc *d, aoc_seq_state *state, void *works
     }
     AOC_TRY(aoc_masked_mean_pool(d->prev_emb, d->prev_labels, 1, hw, C, O, 1, d->epsilon, f.prev_pos, f.prev_neg, nullptr, f.pool_ws, f.pool_ws_bytes, stream));
 
-    // ---- half-resolution operands of the local matchings + the per-set bias table + the k = 1 rows of this frame's proxy table
+    // ---- half-resolution operands of the local matchings + the per-set bias table + the k = 1 rows of this frame's proxy table (the side
+    // tables are needed in every mode; the half-resolution maps only by the fp32 down-sampled local matching)
     AOC_TRY(aoc_local_prep(d->cur_emb, d->prev_emb, d->prev_labels, f.prev_pos, h, w, C, O, f.q2, f.p2, f.pm2, f.bits2, H2, W2, d->dis_bias, 2 * L * O,
                            f.set_bias, f.ref_pos, d->proxy_table + (size_t)n_ad * C, O * C, f.ref_sq, d->proxy_sqnorm + n_ad, O, stream));
 
     // ---- split records: pool frames that joined since the last call, and the query (tile-major)
-    if (state->records_frames > R) state->records_frames = 0;             // the pool restarted: the caller should have reset the state
-    // records behind the unchanged prefix belong to frames whose content was replaced (a pool that is not append-only): converted again
-    if (state->records_frames > d->pool_prefix_frames) state->records_frames = d->pool_prefix_frames;
-    if (state->records_frames < R) {
-        const int64_t r0 = state->records_frames * hw;
-        AOC_TRY(aoc_split_rows(d->ref_emb + (size_t)r0 * C, n - r0, C, f.pool_rec + (size_t)r0 * aoc_split_record_bytes(C), f.pool_sq + r0, f.overflow, stream));
-        state->records_frames = R;
+    if (split) {
+        if (state->records_frames > R) state->records_frames = 0;             // the pool restarted: the caller should have reset the state
+        // records behind the unchanged prefix belong to frames whose content was replaced (a pool that is not append-only): converted again
+        if (state->records_frames > d->pool_prefix_frames) state->records_frames = d->pool_prefix_frames;
+        if (state->records_frames < R) {
+            const int64_t r0 = state->records_frames * mhw;
+            AOC_TRY(aoc_split_rows(mpool + (size_t)r0 * C, n - r0, C, f.pool_rec + (size_t)r0 * aoc_split_record_bytes(C), f.pool_sq + r0, f.overflow, stream));
+            state->records_frames = R;
+        }
+        AOC_TRY(aoc_split_rows_tiled(d->cur_emb, hw, C, f.q_rec, f.q_sq, f.overflow, stream));
     }
-    AOC_TRY(aoc_split_rows_tiled(d->cur_emb, hw, C, f.q_rec, f.q_sq, f.overflow, stream));
 
-    // ---- dense pixel-level matching -> channel 0 (the plan is kept across the frames of one pool state)
-    {
+    // ---- dense pixel-level matching -> channel 0
+    mark(0);
+    if (split) {
+        // (the plan is kept across the frames of one pool state)
         const int reuse = state->plan_key == d->pool_key && state->plan_rows == n;
-        mark(0);
-        AOC_TRY(aoc_dense_match_min_split_cached(d->cur_emb, f.q_rec, f.q_sq, 1, hw, C, d->ref_emb, f.pool_rec, f.overflow, n, d->right_bits, d->wrong_bits,
+        AOC_TRY(aoc_dense_match_min_split_cached(d->cur_emb, f.q_rec, f.q_sq, 1, hw, C, mpool, f.pool_rec, f.overflow, n, d->right_bits, d->wrong_bits,
                                                  d->fg_rows, d->obj_rows, d->counts, d->obj_offsets, d->dis_bias, O, d->feat + (size_t)ch_global * hw, 1,
                                                  obj_stride, 1, f.dense_ws, f.dense_bytes, reuse, stream));
-        mark(1);
         state->plan_key = d->pool_key;
         state->plan_rows = n;
+    } else if (f16) {
+        // the reference's `.half()` arithmetic (AEM:801-803), as matching.global_matching_for_eval(use_float16=True) runs it
+        AOC_TRY(aoc_dense_match_min_f16(d->cur_emb, hw, C, mpool, d->fg_rows, d->counts + O, n, d->wrong_bits, d->dis_bias, O, d->feat + (size_t)ch_global * hw, 1,
+                                        obj_stride, 1, f.dense_ws, f.dense_bytes, stream));
+    } else {
+        // more than 16 objects: the exact-fp32 kernel (slices of 16 objects), as ops.dense_match picks it
+        AOC_TRY(aoc_dense_match_min(d->cur_emb, hw, C, mpool, d->fg_rows, d->counts + O, n, d->wrong_bits, d->dis_bias, O, d->feat + (size_t)ch_global * hw, 1,
+                                    obj_stride, 1, f.dense_ws, f.dense_bytes, stream));
     }
+    mark(1);
 
     // ---- both local matchings and their up-samples into the two channel ranges
     mark(4);
-    AOC_TRY(aoc_local_window_match_pair(f.q2, f.p2, f.pm2, f.bits2, H2, W2, C, d->radii, nl, d->dis_bias, O, f.lf, f.lf + (size_t)O * nl * H2 * W2, 1, stream));
-    mark(5);
-    AOC_TRY(aoc_resize_bilinear_planes_grouped(f.lf, 2 * O * nl, H2, W2, d->feat + (size_t)ch_local * hw, h, w, nl, O, (int64_t)(ch_local_proxy - ch_local) * hw,
-                                               obj_stride, hw, 1, stream));
+    if (fused_local) {
+        AOC_TRY(aoc_local_window_match_pair(f.q2, f.p2, f.pm2, f.bits2, H2, W2, C, d->radii, nl, d->dis_bias, O, f.lf, f.lf + (size_t)O * nl * H2 * W2, 1, stream));
+        mark(5);
+        AOC_TRY(aoc_resize_bilinear_planes_grouped(f.lf, 2 * O * nl, H2, W2, d->feat + (size_t)ch_local * hw, h, w, nl, O, (int64_t)(ch_local_proxy - ch_local) * hw,
+                                                   obj_stride, hw, 1, stream));
+    } else {
+        // matching.local_matching / local_matching_proxy step by step (AEM:968-1060): label bits, the per-pixel proxy map (aocnet.py:325), the
+        // down-samples in the mode's arithmetic (float16: F.interpolate on a float16 tensor), the windows with the atrous rate
+        const float *qm = d->cur_emb, *pa = d->prev_emb, *pb = f.pmap;
+        const uint32_t *bits = f.bits_full;
+        int Hm = h, Wm = w;
+        AOC_TRY(aoc_label_bits(d->prev_labels, hw, O, f.bits_full, nullptr, stream));
+        if (down) {
+            Hm = H2; Wm = W2;
+            bits = f.bits2;
+            if (f16) {
+                AOC_TRY(aoc_label_mix(d->prev_labels, f.prev_pos, hw, O, C, f.pmap, stream));
+                AOC_TRY(aoc_resize_bilinear_hwc_ex(d->cur_emb, h, w, C, f.q2, H2, W2, 1, stream));
+                AOC_TRY(aoc_resize_bilinear_hwc_ex(d->prev_emb, h, w, C, f.p2, H2, W2, 1, stream));
+                AOC_TRY(aoc_resize_bilinear_hwc_ex(f.pmap, h, w, C, f.pm2, H2, W2, 1, stream));
+                AOC_TRY(aoc_resize_nearest_bits(f.bits_full, h, w, f.bits2, H2, W2, stream));
+            }                                   // fp32: aoc_local_prep above left the same q2 / p2 / pm2 / bits2 the separate calls give
+            qm = f.q2; pa = f.p2; pb = f.pm2;
+        } else {
+            AOC_TRY(aoc_label_mix(d->prev_labels, f.prev_pos, hw, O, C, f.pmap, stream));
+        }
+        float *lf_b = f.lf + (size_t)O * nl * Hm * Wm;
+        AOC_TRY(aoc_local_window_match_ex(qm, pa, bits, Hm, Wm, C, d->radii, nl, d->dis_bias, O, f.lf, 1, lrate, f16 ? 1 : 0, stream));
+        AOC_TRY(aoc_local_window_match_ex(qm, pb, bits, Hm, Wm, C, d->radii, nl, d->dis_bias, O, lf_b, 1, lrate, f16 ? 1 : 0, stream));
+        mark(5);
+        AOC_TRY(aoc_resize_bilinear_planes_grouped(f.lf, 2 * O * nl, Hm, Wm, d->feat + (size_t)ch_local * hw, h, w, nl, O, (int64_t)(ch_local_proxy - ch_local) * hw,
+                                                   obj_stride, hw, 1, stream));
+    }
 
-    // ---- one correlation launch: cluster sets (2 per object and level) + the k = 1 set of every object
+    // ---- correlation: cluster sets (2 per object and level) + the k = 1 set of every object
     {
-        int32_t sb[2 * 8 * 16 + 16], ss[2 * 8 * 16 + 16];
-        int64_t so[2 * 8 * 16 + 16];
+        int32_t sb[2 * 8 * AOC_MAX_OBJECTS + AOC_MAX_OBJECTS], ss[2 * 8 * AOC_MAX_OBJECTS + AOC_MAX_OBJECTS];
+        int64_t so[2 * 8 * AOC_MAX_OBJECTS + AOC_MAX_OBJECTS];
         int s = 0;
         for (int l = 0; l < L; ++l)
             for (int o = 0; o < O; ++o)
@@ -204,16 +259,35 @@ int aoc_frame_enqueue(const aoc_frame_desc *d, aoc_seq_state *state, void *works
             so[s] = (int64_t)o * obj_stride + (int64_t)ch_proxy * hw;
         }
         if (d->proxies_ready && hipStreamWaitEvent(st, static_cast<hipEvent_t>(d->proxies_ready), 0) != hipSuccess) return AOC_ERR_LAUNCH;
-        aoc_corr_frame_rec fr;
-        fr.query = d->cur_emb;
-        fr.query_rec = f.q_rec;
-        fr.query_sqnorm = f.q_sq;
-        fr.proxies = d->proxy_table;
-        fr.proxy_sqnorm = d->proxy_sqnorm;
-        fr.set_bias = f.set_bias;
-        fr.out = d->feat;
         mark(2);
-        AOC_TRY(aoc_proxy_corr_min_records(&fr, 1, hw, C, n_ad + O, n_set, sb, ss, so, 1, f.corr_ws, aoc_proxy_corr_min_batched_workspace_bytes(), stream));
+        if (f16) {
+            // use_float16: scipy's kmeans2 rejects float16 data, the reference's bare `except` turns every cluster distance into 5e4, i.e. the
+            // feature 1.0: the 2 L cluster channels of every object are that constant; the k = 1 proxies run the `.half()` arithmetic
+            for (int o = 0; o < O; ++o)
+                if (hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(d->feat + (size_t)o * obj_stride + (size_t)ch_cluster * hw), 0x3f800000, (size_t)c2 * hw, st) !=
+                    hipSuccess)
+                    return AOC_ERR_LAUNCH;
+            AOC_TRY(aoc_proxy_corr_min_f16(d->cur_emb, hw, C, d->proxy_table, nullptr, n_ad + O, O, sb + 2 * L * O, ss + 2 * L * O, so + 2 * L * O,
+                                           f.set_bias + 2 * L * O, d->feat, 1, 1, stream));
+        } else if (split) {
+            aoc_corr_frame_rec fr;
+            fr.query = d->cur_emb;
+            fr.query_rec = f.q_rec;
+            fr.query_sqnorm = f.q_sq;
+            fr.proxies = d->proxy_table;
+            fr.proxy_sqnorm = d->proxy_sqnorm;
+            fr.set_bias = f.set_bias;
+            fr.out = d->feat;
+            AOC_TRY(aoc_proxy_corr_min_records(&fr, 1, hw, C, n_ad + O, n_set, sb, ss, so, 1, f.corr_ws, aoc_proxy_corr_min_batched_workspace_bytes(), stream));
+        } else {
+            aoc_corr_frame fr;
+            fr.query = d->cur_emb;
+            fr.proxies = d->proxy_table;
+            fr.proxy_sqnorm = d->proxy_sqnorm;
+            fr.set_bias = f.set_bias;
+            fr.out = d->feat;
+            AOC_TRY(aoc_proxy_corr_min_batched(&fr, 1, hw, C, n_ad + O, n_set, sb, ss, so, 1, AOC_CORR_SPLIT, f.corr_ws, aoc_proxy_corr_min_batched_workspace_bytes(), stream));
+        }
         mark(3);
     }
 

@@ -621,6 +621,25 @@ __global__ __launch_bounds__(256) void resize_bilinear_planes_kernel(const float
     out[(po / outer_count) * group_stride + (po % outer_count) * outer_stride + (p % inner_count) * plane_stride + ((int64_t)Y * W + X) * pixel_stride] = hy0 * (wx0 * v00 + wx1 * v01) + hy1 * (wx0 * v10 + wx1 * v11);
 }
 
+// out[y', x', :] = in[rate * y', rate * x', :]  (AEM:533-579: the atrous grid of the reference pool; X floats per pixel, X % 4 == 0 takes 16-byte moves)
+__global__ __launch_bounds__(256) void atrous_subsample_kernel(const float *__restrict__ in, int w, int X, int rate, float *__restrict__ out, int H, int W) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if ((X & 3) == 0) {
+        const int x4 = X >> 2;
+        if (idx >= (int64_t)H * W * x4) return;
+        const int c = (int)(idx % x4);
+        const int64_t pix = idx / x4;
+        const int xo = (int)(pix % W), yo = (int)(pix / W);
+        reinterpret_cast<float4 *>(out)[idx] = reinterpret_cast<const float4 *>(in)[((size_t)yo * rate * w + (size_t)xo * rate) * x4 + c];
+    } else {
+        if (idx >= (int64_t)H * W * X) return;
+        const int c = (int)(idx % X);
+        const int64_t pix = idx / X;
+        const int xo = (int)(pix % W), yo = (int)(pix / W);
+        out[idx] = in[((size_t)yo * rate * w + (size_t)xo * rate) * X + c];
+    }
+}
+
 __global__ __launch_bounds__(256) void local_prep_kernel(const float *__restrict__ cur, const float *__restrict__ prev, const float *__restrict__ lab,
                                                           const float *__restrict__ rows, int h, int w, int C, int n_obj, float *__restrict__ q2,
                                                           float *__restrict__ p2, float *__restrict__ pm2, uint32_t *__restrict__ bits2, int H, int W,
@@ -841,6 +860,16 @@ int aoc_local_prep(const float *cur_emb, const float *prev_emb, const float *pre
                        prev_pos, h, w, C, n_obj, q2, p2, pm2, bits2, H2, W2, align_corners_scale(h, H2), align_corners_scale(w, W2),
                        (float)h / (float)H2, (float)w / (float)W2, obj_bias, n_pair_sets, set_bias_out, copy_src_a, copy_dst_a, n_copy_a, copy_src_b,
                        copy_dst_b, n_copy_b);
+    AOC_RETURN_IF_LAUNCH_FAILED();
+    return AOC_OK;
+}
+
+int aoc_atrous_subsample(const float *in, int h, int w, int X, int rate, float *out, aoc_stream_t stream) {
+    if (!in || !out || h < 1 || w < 1 || X < 1 || rate < 1) return AOC_ERR_INVALID_ARG;
+    if (((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15) && (X & 3) == 0) return AOC_ERR_INVALID_ARG;
+    const int H = (h + rate - 1) / rate, W = (w + rate - 1) / rate;
+    const int64_t total = (int64_t)H * W * ((X & 3) == 0 ? X >> 2 : X);
+    hipLaunchKernelGGL(atrous_subsample_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, aoc_hip_stream(stream), in, w, X, rate, out, H, W);
     AOC_RETURN_IF_LAUNCH_FAILED();
     return AOC_OK;
 }

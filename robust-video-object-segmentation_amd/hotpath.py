@@ -32,6 +32,8 @@ class MatchingConfig:
     MODEL_EPSILON: float = 1e-5                                  # :75
     MODEL_MATCHING_BACKGROUND: bool = True                       # :76
     MODEL_FLOAT16_MATCHING: bool = False                         # :78
+    TEST_GLOBAL_ATROUS_RATE: int = 1                             # :125 (tools/eval_net_mm_rpa.py --global_atrous_rate)
+    TEST_LOCAL_ATROUS_RATE: int = 1                              # :126
     MEM_EVERY: int = 5                                           # :17
     CLUSTER_NUM: int = DEFAULT_CLUSTER_NUM                       # AEM:232
     CLUSTER_LEVELS: Optional[List[int]] = None                   # multi-level proxies (BASELINE.json configs[2]: [8, 16, 32]); None = [CLUSTER_NUM]
@@ -143,6 +145,25 @@ def launch_cluster_proxies_batch(cfg, ref_emb, ref_labels, init_rows_list, side_
     return outs
 
 
+def prepare_without_clustering(cfg, ref_emb, ref_labels):
+    """cfg.MODEL_FLOAT16_MATCHING: the reference's cluster channels are the constant 1 (scipy rejects float16 data), so a frame needs no k-means
+    chain -- only the label prep of the pool the matchings see and a proxy table for its k = 1 rows.  Returns the ClusterProxiesAhead that
+    FrameRunner / proto_mask_features(cluster_ahead=...) take."""
+    R, h, w, C = ref_emb.shape
+    O = ref_labels.shape[-1]
+    levels = cfg.cluster_levels
+    n_ad = len(levels) * O * 2 * max(levels)
+    out = ClusterProxiesAhead()
+    out.R, out.cluster_sets, out.aux = R, None, None
+    out.prep = ops.label_prep(ref_labels.reshape(-1, O))
+    out.prep_event = torch.cuda.Event()
+    out.prep_event.record()
+    out.table = torch.zeros(n_ad + O, C, dtype=torch.float32, device=ref_emb.device)
+    out.sqn = torch.full((n_ad + O,), float("inf"), dtype=torch.float32, device=ref_emb.device)
+    out.done_event = out.prep_event
+    return out
+
+
 def launch_cluster_proxies(cfg, ref_emb, ref_labels, init_rows_dev, side_stream=None, wait_event=None, prep=None):
     """launch_cluster_proxies_batch for one frame."""
     return launch_cluster_proxies_batch(cfg, ref_emb, ref_labels, [init_rows_dev], side_stream, wait_event, prep)[0]
@@ -246,7 +267,7 @@ def launch_correlations(pending, stream=None, precision="split"):
 
 def proto_mask_features(cfg, ref_emb, ref_labels, prev_emb, prev_labels, cur_emb, dis_bias, init_rows=None,
                         cluster_state=None, side_stream=None, dense_state=None, dense_precision=None, cluster_ahead=None,
-                        dense_stream=None, defer_correlation=False, rng=None):
+                        dense_stream=None, defer_correlation=False, rng=None, match_pool=None):
     """All matching branches of one frame -> (features [O, 24, h, w], attention_head [O, 4C], aux).
 
     ref_emb     [R, h, w, C]  reference pool (channel-last)          ref_labels [R, h, w, O] float one-hot
@@ -274,6 +295,11 @@ def proto_mask_features(cfg, ref_emb, ref_labels, prev_emb, prev_labels, cur_emb
                  batches the frames of several sequences into one launch (the cluster / k = 1 proxy channels of `feat` are complete
                  only after the event that call returns).
     With several cluster levels (cfg.CLUSTER_LEVELS) the cluster channels are (centroid, centroid_avg) per level, in level order.
+    The reference's evaluation switches (round 5): cfg.MODEL_FLOAT16_MATCHING (the `.half()` arithmetic of the dense, k = 1 proxy and local
+    matchings; cluster channels = the constant 1 the reference degrades to), cfg.MODEL_LOCAL_DOWNSAMPLE, cfg.TEST_LOCAL_ATROUS_RATE, and
+    cfg.TEST_GLOBAL_ATROUS_RATE through ``match_pool`` = (embeddings [R, h', w', C], labels [R, h', w', O]) of the pool on the atrous grid
+    (ops.atrous_subsample of every pool frame, AEM:533-579): the dense and cluster matchings (and a cluster_ahead) see THAT pool, the pooled
+    heads the full one.
     """
     R, h, w, C = ref_emb.shape
     O = ref_labels.shape[-1]
@@ -286,8 +312,11 @@ def proto_mask_features(cfg, ref_emb, ref_labels, prev_emb, prev_labels, cur_emb
     feat = torch.empty(O, n_ch, h, w, dtype=torch.float32, device=dev)
     base = feat.view(-1)
     obj_stride = n_ch * hw
-    pool = ref_emb.reshape(R * hw, C)
-    labels_flat = ref_labels.reshape(R * hw, O)
+    f16 = bool(cfg.MODEL_FLOAT16_MATCHING)
+    lrate = max(1, int(cfg.TEST_LOCAL_ATROUS_RATE))
+    m_emb, m_lab = match_pool if match_pool is not None else (ref_emb, ref_labels)
+    pool = m_emb.reshape(-1, C)                                 # what the dense and cluster matchings see
+    labels_flat = m_lab.reshape(-1, O)
     query_flat = cur_emb.reshape(hw, C)
     levels = cfg.cluster_levels
     L, kmax = len(levels), max(levels)
@@ -299,7 +328,7 @@ def proto_mask_features(cfg, ref_emb, ref_labels, prev_emb, prev_labels, cur_emb
     main = torch.cuda.current_stream()
     if cluster_ahead is None and cluster_state is not None:
         # host-sync-free variant: the chain is enqueued here (on side_stream when given) and joined in front of the correlation launch
-        cluster_ahead = launch_cluster_proxies(cfg, ref_emb, ref_labels, cluster_state["init_rows"], side_stream)
+        cluster_ahead = launch_cluster_proxies(cfg, m_emb, m_lab, cluster_state["init_rows"], side_stream)
     if cluster_ahead is not None:
         assert cluster_ahead.R == R, "cluster_ahead was launched for another pool size"
         main.wait_event(cluster_ahead.prep_event)
@@ -309,7 +338,8 @@ def proto_mask_features(cfg, ref_emb, ref_labels, prev_emb, prev_labels, cur_emb
     else:
         table = torch.empty(n_ad + O, C, dtype=torch.float32, device=dev)
         sqn = torch.empty(n_ad + O, dtype=torch.float32, device=dev)
-        cp = cluster_proxies(pool, labels_flat, levels if cfg.CLUSTER_LEVELS else levels[0], init_rows, rng)
+        # (float16 matching: no clustering at all -- scipy rejects float16 data and the reference's cluster channels are the constant 1)
+        cp = cluster_proxies(pool, labels_flat, levels if cfg.CLUSTER_LEVELS else levels[0], init_rows, rng) if not f16 else None
         prep = cp["prep"] if cp is not None else ops.label_prep(labels_flat)
         if cp is not None:
             table[:n_ad].copy_(cp["proxies"].reshape(-1, C))
@@ -332,11 +362,14 @@ def proto_mask_features(cfg, ref_emb, ref_labels, prev_emb, prev_labels, cur_emb
 
     # ---- dense pixel-level matching, AEM:688-817 -> channel 0
     pool_split = None
+    if f16:
+        dense_precision = "f16"                              # AEM:801-803 on float16 tensors
     if dense_state is not None and (dense_precision or ops.DENSE_PRECISION) == "split" and ops.split_record_bytes(C):
         pool_split = dense_state.get("pool_split")
         done = dense_state.get("frames", 0)
-        if pool_split is None or pool_split.records.shape[0] < R * hw:
-            cap = max(R, dense_state.get("capacity_frames", R)) * hw
+        mhw = pool.shape[0] // R
+        if pool_split is None or pool_split.records.shape[0] < R * mhw:
+            cap = max(R, dense_state.get("capacity_frames", R)) * mhw
             pool_split = ops.SplitRows()
             pool_split.records = torch.empty(cap, ops.split_record_bytes(C), dtype=torch.uint8, device=dev)
             pool_split.sqnorm = torch.empty(cap, dtype=torch.float32, device=dev)
@@ -344,7 +377,7 @@ def proto_mask_features(cfg, ref_emb, ref_labels, prev_emb, prev_labels, cur_emb
             pool_split.n = cap
             done = 0
         if done < R:
-            ops.split_rows(pool[done * hw:R * hw], out=pool_split, row0=done * hw)
+            ops.split_rows(pool[done * mhw:R * mhw], out=pool_split, row0=done * mhw)
         # records of pool frames [0, max(done, R)) are valid; a caller that restarts the pool (new sequence) resets "frames" to 0
         dense_state["pool_split"], dense_state["frames"] = pool_split, max(done, R)
     # the query's split records, ONCE per frame and tile-major: the dense kernel and the correlation kernel both stream them in their MFMA
@@ -372,7 +405,7 @@ def proto_mask_features(cfg, ref_emb, ref_labels, prev_emb, prev_labels, cur_emb
     # ---- local matching against the previous frame and against its per-pixel proxy map (aocnet.py:255,325-337)
     radii = list(cfg.MODEL_MULTI_LOCAL_DISTANCE)
     prev_flat_labels = prev_labels.reshape(hw, O)
-    if cfg.MODEL_LOCAL_DOWNSAMPLE:
+    if cfg.MODEL_LOCAL_DOWNSAMPLE and not f16 and lrate == 1:
         # one launch for the three bilinear down-samples, the (never materialised) proxy map and the label bits; one for both matchings;
         # one for both up-samples into their channel ranges
         H2, W2 = int(h / 2) + 1, int(w / 2) + 1
@@ -382,11 +415,19 @@ def proto_mask_features(cfg, ref_emb, ref_labels, prev_emb, prev_labels, cur_emb
         ops.resize_bilinear_planes_grouped(lf.view(2 * O * nl, H2, W2), h, w, base[ch["local"] * hw:], nl, O, (ch["local_proxy"] - ch["local"]) * hw,
                                            obj_stride, hw, 1)
     else:
+        # matching.local_matching / local_matching_proxy step by step (AEM:968-1060): full resolution (MODEL_LOCAL_DOWNSAMPLE off), the float16
+        # arithmetic (down-samples of float16 tensors), the atrous window stride
         right_prev, _ = ops.label_bits(prev_flat_labels, want_wrong=False)
         proxy_map = ops.label_mix(prev_flat_labels, prev_pos).view(h, w, C)                # aocnet.py:325
+        Hm, Wm, qm = h, w, cur_emb
+        if cfg.MODEL_LOCAL_DOWNSAMPLE:
+            Hm, Wm = int(h / 2) + 1, int(w / 2) + 1
+            qm = ops.resize_bilinear_hwc(cur_emb, Hm, Wm, float16=f16)
+            right_prev = ops.resize_nearest_bits(right_prev, h, w, Hm, Wm)
         for key, prev_map in (("local", prev_emb), ("local_proxy", proxy_map)):
-            lf = ops.local_window_match(cur_emb, prev_map, right_prev, radii, bias, O, True)        # [O, nl, h, w]
-            ops.resize_bilinear_planes(lf.view(O * nl, h, w), h, w, base[ch[key] * hw:], hw, 1, inner_count=nl, out_outer_stride=obj_stride)
+            pm = ops.resize_bilinear_hwc(prev_map, Hm, Wm, float16=f16) if cfg.MODEL_LOCAL_DOWNSAMPLE else prev_map
+            lf = ops.local_window_match(qm, pm, right_prev, radii, bias, O, True, atrous_rate=lrate, float16=f16)        # [O, nl, Hm, Wm]
+            ops.resize_bilinear_planes(lf.view(O * nl, Hm, Wm), h, w, base[ch[key] * hw:], hw, 1, inner_count=nl, out_outer_stride=obj_stride)
 
     # ---- one correlation launch: cluster (2 sets / object / level) + k = 1 proxy (1 set / object), AEM:316-319 + matching.py:2653
     set_begin, set_size, set_off, set_obj = [], [], [], []
@@ -427,7 +468,13 @@ def proto_mask_features(cfg, ref_emb, ref_labels, prev_emb, prev_labels, cur_emb
     for src, dst in k1_copies:                        # (no local-prep launch took them along)
         dst.copy_(src)
     pending = None
-    if defer_correlation:
+    if f16:
+        # cluster channels: the constant 1 (every cluster distance is the reference's 5e4 padding); k = 1 proxies in the `.half()` arithmetic
+        n_cl = 2 * L
+        feat[:, ch["cluster"]:ch["cluster"] + n_cl].fill_(1.0)
+        ops.proxy_corr_min(query_flat, table, None, [n_ad + o for o in range(O)], [1] * O, [o * obj_stride + ch["proxy"] * hw for o in range(O)], bias, feat, 1,
+                           True, float16=True)
+    elif defer_correlation:
         pending = PendingCorrelation()
         pending.query, pending.table, pending.sqn, pending.set_bias, pending.feat = query_flat, table, sqn, set_bias, feat
         pending.query_split = query_split
@@ -464,7 +511,8 @@ class FrameRunner:
             raise NotImplementedError("aoc_frame_enqueue does not cover this configuration: use proto_mask_features")
         self.cfg = cfg
         self.call = ops.FrameCall(h, w, C, n_obj, capacity_frames, cfg.MODEL_MULTI_LOCAL_DISTANCE, cfg.cluster_levels, cfg.MODEL_MATCHING_BACKGROUND,
-                                  cfg.MODEL_EPSILON, device)
+                                  cfg.MODEL_EPSILON, device, float16_matching=cfg.MODEL_FLOAT16_MATCHING, local_downsample=cfg.MODEL_LOCAL_DOWNSAMPLE,
+                                  local_atrous_rate=cfg.TEST_LOCAL_ATROUS_RATE, global_atrous_rate=cfg.TEST_GLOBAL_ATROUS_RATE)
 
     @staticmethod
     def supported(cfg, C, n_obj):
@@ -472,6 +520,11 @@ class FrameRunner:
 
     def reset(self):
         self.call.reset()
+
+    def match_pool(self, ref_emb, ref_labels, pool_prefix_frames=None):
+        """The pool the dense and cluster matchings see: (ref_emb, ref_labels) themselves, or with cfg.TEST_GLOBAL_ATROUS_RATE > 1 their atrous
+        sub-samples (AEM:533-579) -- launch_cluster_proxies[_batch] is given THIS pool, the frame call the full one."""
+        return self.call.match_pool(ref_emb, ref_labels, pool_prefix_frames)
 
     def pool_changed(self, valid_frames):
         """The pool's content beyond its first `valid_frames` frames was replaced (a benchmark that revisits pool states): their split records are
@@ -484,6 +537,7 @@ class FrameRunner:
         pool_prefix_frames: see ops.FrameCall.__call__ (None = append-only pool)."""
         a = cluster_ahead
         assert a is not None and a.cluster_sets is None and a.R == ref_emb.shape[0], "FrameRunner takes the ClusterProxiesAhead of this frame's pool"
+        # (with cfg.TEST_GLOBAL_ATROUS_RATE > 1 the ClusterProxiesAhead -- label prep and k-means chain -- is the one of match_pool(ref_emb, ref_labels))
         O = ref_labels.shape[-1]
         bias = _bias_vec(dis_bias, O, cur_emb.device)
         main = torch.cuda.current_stream()
@@ -558,8 +612,11 @@ class CalibrationGates(nn.Module):
         when the activation buffers or the weights' storage change."""
         # the descriptors hold raw pointers: of the activations AND of the module weights -- both are part of the key (module.to(), .float(),
         # load_state_dict(assign=True) or a re-assigned parameter give the weights new storage; an in-place update keeps it and needs no rebuild)
-        key = (tuple((x.data_ptr(), tuple(x.shape)) for x in activations) + (attention_head.shape[1],) +
-               tuple((p.data_ptr(), p.dtype) for p in self.parameters()))
+        if not hasattr(self, "_param_list"):
+            self._param_list = list(self.parameters())      # the module tree is fixed after __init__: walked once, not per frame
+        if len(self._param_list) and self._param_list[0] is not next(self.parameters()):
+            self._param_list = list(self.parameters())      # parameters were re-assigned (load_state_dict(assign=True), module.to() on some builds)
+        key = (tuple((x.data_ptr(), tuple(x.shape)) for x in activations) + (attention_head.shape[1],) + tuple(p.data_ptr() for p in self._param_list))
         if not hasattr(self, "_batches"):
             self._batches = {}
         cached = self._batches.get(slot)                 # one set of output buffers per caller slot (e.g. per sequence in flight)

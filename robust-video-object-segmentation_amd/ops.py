@@ -473,6 +473,17 @@ def resize_bilinear_planes(x, H, W, out, out_plane_stride, out_pixel_stride, inn
     return out
 
 
+def atrous_subsample(x, rate):
+    """aoc_atrous_subsample: [h, w, X] -> [ceil(h / rate), ceil(w / rate), X] = x[::rate, ::rate] (AEM:533-579, the atrous grid of the reference pool)."""
+    x = _f32c(x)
+    _need_gpu(x)
+    h, w, X = x.shape
+    rate = int(rate)
+    out = torch.empty((h + rate - 1) // rate, (w + rate - 1) // rate, X, dtype=torch.float32, device=x.device)
+    _lib.check(_lib.lib().aoc_atrous_subsample(_p(x), h, w, X, rate, _p(out), _stream()), "aoc_atrous_subsample")
+    return out
+
+
 def resize_nearest_bits(bits, h, w, H, W):
     _need_gpu(bits)
     out = torch.empty(H * W, dtype=torch.int32, device=bits.device)
@@ -572,8 +583,9 @@ class _FrameDesc(ctypes.Structure):
                 ("n_levels", ctypes.c_int32), ("levels", ctypes.c_int32 * 8),
                 ("kmax", ctypes.c_int32), ("matching_background", ctypes.c_int32), ("n_adaptive", ctypes.c_int32), ("epsilon", ctypes.c_float),
                 ("pool_prefix_frames", ctypes.c_int32), ("stream_cus", ctypes.c_int32),
+                ("float16_matching", ctypes.c_int32), ("local_downsample", ctypes.c_int32), ("local_atrous_rate", ctypes.c_int32), ("match_hw", ctypes.c_int32),
                 ("pool_key", ctypes.c_int64),
-                ("ref_emb", ctypes.c_void_p), ("ref_labels", ctypes.c_void_p), ("prev_emb", ctypes.c_void_p), ("prev_labels", ctypes.c_void_p),
+                ("ref_emb", ctypes.c_void_p), ("ref_labels", ctypes.c_void_p), ("match_emb", ctypes.c_void_p), ("prev_emb", ctypes.c_void_p), ("prev_labels", ctypes.c_void_p),
                 ("cur_emb", ctypes.c_void_p), ("dis_bias", ctypes.c_void_p),
                 ("right_bits", ctypes.c_void_p), ("wrong_bits", ctypes.c_void_p), ("fg_rows", ctypes.c_void_p), ("obj_rows", ctypes.c_void_p),
                 ("counts", ctypes.c_void_p), ("obj_offsets", ctypes.c_void_p),
@@ -638,9 +650,12 @@ class FrameCall:
 
     @staticmethod
     def supported(C, n_obj, local_downsample, float16_matching, n_radii, n_levels):
-        return C == 100 and n_obj <= 16 and bool(local_downsample) and not float16_matching and n_radii <= 8 and n_levels <= 8 and DENSE_PRECISION == "split"
+        """Round 5: every switch of the reference's evaluation CLI / config is covered (float16 matching, local matching with or without the
+        down-sample, the atrous rates, up to 30 objects); what remains outside is another embedding width and the developer's exact-fp32 mode."""
+        return C == 100 and n_obj <= MAX_OBJECTS and n_radii <= 8 and n_levels <= 8 and DENSE_PRECISION == "split"
 
-    def __init__(self, h, w, C, n_obj, capacity_frames, radii, levels, matching_background, epsilon, device):
+    def __init__(self, h, w, C, n_obj, capacity_frames, radii, levels, matching_background, epsilon, device, float16_matching=False, local_downsample=True,
+                 local_atrous_rate=1, global_atrous_rate=1):
         L = _lib.lib()
         self.h, self.w, self.C, self.n_obj, self.cap = int(h), int(w), int(C), int(n_obj), int(capacity_frames)
         self.n_ch = int(L.aoc_frame_channels(len(radii), len(levels), int(bool(matching_background))))
@@ -659,11 +674,34 @@ class FrameCall:
         d.matching_background = int(bool(matching_background))
         d.n_adaptive = len(levels) * self.n_obj * 2 * max(levels)
         d.epsilon = float(epsilon)
+        d.float16_matching, d.local_downsample, d.local_atrous_rate = int(bool(float16_matching)), int(bool(local_downsample)), int(local_atrous_rate)
+        # TEST_GLOBAL_ATROUS_RATE > 1: the dense and cluster matchings see every pool frame on the atrous grid (AEM:533-579); the sub-sampled pool is
+        # kept here, one aoc_atrous_subsample per frame that joins (append-only), and handed over as match_emb
+        self.grate = int(global_atrous_rate)
+        self.match_hw = ((self.h + self.grate - 1) // self.grate) * ((self.w + self.grate - 1) // self.grate) if self.grate > 1 else 0
+        self.match_emb = torch.empty(self.cap, self.match_hw, self.C, dtype=torch.float32, device=device) if self.grate > 1 else None
+        self.match_frames = 0
         self.device = device
 
     def reset(self):
         """A new sequence starts in this workspace (eval_manager_mm.py:376-382)."""
         ctypes.memset(ctypes.byref(self.state), 0, ctypes.sizeof(self.state))
+        self.match_frames = 0
+
+    def match_pool(self, ref_emb, ref_labels, pool_prefix_frames=None):
+        """TEST_GLOBAL_ATROUS_RATE > 1: (embeddings [R, h', w', C], labels [R, h', w', O]) of the pool on the atrous grid -- what the label prep and the
+        k-means chain of the frame have to be computed from.  The embeddings are kept per sequence (only frames that joined are sub-sampled);
+        rate 1: the arguments themselves."""
+        if self.grate <= 1:
+            return ref_emb, ref_labels
+        R = ref_emb.shape[0]
+        done = min(self.match_frames, R if pool_prefix_frames is None else int(pool_prefix_frames))
+        hh, ww = (self.h + self.grate - 1) // self.grate, (self.w + self.grate - 1) // self.grate
+        for r in range(done, R):
+            _lib.check(_lib.lib().aoc_atrous_subsample(_p(ref_emb[r]), self.h, self.w, self.C, self.grate, _p(self.match_emb[r]), _stream()), "aoc_atrous_subsample")
+        self.match_frames = R
+        labs = torch.stack([atrous_subsample(ref_labels[r], self.grate) for r in range(R)])
+        return self.match_emb[:R].view(R, hh, ww, self.C), labs
 
     def __call__(self, ref_emb, ref_labels, prev_emb, prev_labels, cur_emb, dis_bias, prep, table, sqn, prep_event=None, done_event=None, pool_key=None,
                  probes=None, pool_prefix_frames=None, stream_cus=0):
@@ -680,7 +718,13 @@ class FrameCall:
         R = ref_emb.shape[0]
         d = self.desc
         assert R <= self.cap and tuple(cur_emb.shape) == (self.h, self.w, self.C) and ref_labels.shape[-1] == self.n_obj and dis_bias.numel() == self.n_obj
-        assert table.shape[0] == d.n_adaptive + self.n_obj and prep.n == R * self.h * self.w
+        assert table.shape[0] == d.n_adaptive + self.n_obj and prep.n == R * (self.match_hw if self.grate > 1 else self.h * self.w), \
+            "prep = the label prep of the pool the matchings see (match_pool(...) with a global atrous rate)"
+        if self.grate > 1:
+            assert self.match_frames >= R, "call match_pool(ref_emb, ref_labels) first: it keeps the sub-sampled pool the matchings read"
+            d.match_hw, d.match_emb = self.match_hw, self.match_emb.data_ptr()
+        else:
+            d.match_hw, d.match_emb = 0, None
         feat = torch.empty(self.n_obj, self.n_ch, self.h, self.w, dtype=torch.float32, device=self.device)
         head = torch.empty(self.n_obj, 4 * self.C, dtype=torch.float32, device=self.device)
         d.R = R

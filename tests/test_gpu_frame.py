@@ -49,7 +49,7 @@ def test_frame_call_equals_python_orchestration(aoc, cfg_name, levels, backgroun
         counts = [int(ref_lab[..., o].sum().item()) for o in range(O)]
         init = _init_rows_dev(syn, 100 + t, counts, mc.cluster_levels, O)
         ahead = hot.launch_cluster_proxies(mc, ref_emb, ref_lab, init, side)
-        feat_c, head_c = runner(ref_emb, ref_lab, emb[t - 1], lab[t - 1], emb[t], bias, ahead)
+        feat_c, head_c = runner(ref_emb, ref_lab, emb[t - 1], lab[t - 1], emb[t], bias, ahead, pool_key=len(pool_ids))
         feat_c, head_c = feat_c.clone(), head_c.clone()
         feat_p, head_p, _ = hot.proto_mask_features(mc, ref_emb, ref_lab, emb[t - 1], lab[t - 1], emb[t], bias, cluster_ahead=ahead, dense_state=dense_state)
         torch.cuda.synchronize()
@@ -64,7 +64,7 @@ def test_frame_call_equals_python_orchestration(aoc, cfg_name, levels, backgroun
     ref_emb, ref_lab = emb[[2]].contiguous(), lab[[2]].contiguous()
     counts = [int(ref_lab[..., o].sum().item()) for o in range(O)]
     ahead = hot.launch_cluster_proxies(mc, ref_emb, ref_lab, _init_rows_dev(syn, 7, counts, mc.cluster_levels, O), side)
-    feat_c, head_c = runner(ref_emb, ref_lab, emb[2], lab[2], emb[3], bias, ahead)
+    feat_c, head_c = runner(ref_emb, ref_lab, emb[2], lab[2], emb[3], bias, ahead, pool_key=1)
     feat_p, head_p, _ = hot.proto_mask_features(mc, ref_emb, ref_lab, emb[2], lab[2], emb[3], bias, cluster_ahead=ahead)
     assert torch.equal(feat_c, feat_p) and torch.equal(head_c, head_p)
 
@@ -92,7 +92,7 @@ def test_frame_call_vs_reference_golden(aoc, golden):
         runner = hot.FrameRunner(mc, h, w, 100, n_obj, ref_emb.shape[0], ref_emb.device)
         b = torch.full((n_obj,), float(g["fg_bias"]))
         b[0] = float(g["bg_bias"])
-        feat, head = runner(ref_emb, ref_lab, dev(g["in_prev"]), prev_lab, dev(g["in_cur"]), b.cuda(), ahead)
+        feat, head = runner(ref_emb, ref_lab, dev(g["in_prev"]), prev_lab, dev(g["in_cur"]), b.cuda(), ahead, pool_key=ref_emb.shape[0])
         np.testing.assert_allclose(feat.cpu().numpy(), g["pre_to_cat"], rtol=0, atol=5e-6)
         np.testing.assert_allclose(head.cpu().numpy(), g["attention_head"], rtol=1e-5, atol=1e-6)
 

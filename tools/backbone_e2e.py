@@ -128,7 +128,7 @@ def main():
 
         def hot():
             ahead = hotpath.launch_cluster_proxies(mc, ref_emb, ref_lab, init)
-            return runner(ref_emb, ref_lab, emb[tq - 1], lab[tq - 1], emb[tq], bias, ahead)
+            return runner(ref_emb, ref_lab, emb[tq - 1], lab[tq - 1], emb[tq], bias, ahead, pool_key=ref_emb.shape[0])
 
         for _ in range(3):
             hot()

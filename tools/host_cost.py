@@ -51,7 +51,7 @@ def main():
             return r
     with torch.no_grad():
         ahead = hotpath.launch_cluster_proxies(mc, ref_emb, ref_lab, init, side)
-        feat, head = runner(ref_emb, ref_lab, emb[tq - 1], lab[tq - 1], emb[tq], bias, ahead)
+        feat, head = runner(ref_emb, ref_lab, emb[tq - 1], lab[tq - 1], emb[tq], bias, ahead, pool_key=ref_emb.shape[0])
         gates.forward_batched(acts, head)
         torch.cuda.synchronize()
         L.aoc_frame_enqueue = Timed()
@@ -59,7 +59,7 @@ def main():
         n = args.calls
         for i in range(n):
             t0 = time.perf_counter()
-            feat, head = runner(ref_emb, ref_lab, emb[tq - 1], lab[tq - 1], emb[tq], bias, ahead)
+            feat, head = runner(ref_emb, ref_lab, emb[tq - 1], lab[tq - 1], emb[tq], bias, ahead, pool_key=ref_emb.shape[0])
             t1 = time.perf_counter()
             gates.forward_batched(acts, head)
             t2 = time.perf_counter()
