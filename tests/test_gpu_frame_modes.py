@@ -118,3 +118,66 @@ def test_frame_call_modes(aoc, name):
         np.testing.assert_allclose(head_c.cpu().numpy(), head.cpu().numpy(), rtol=1e-5, atol=1e-6)
         if t == 2 or t == 4:
             pool_ids.append(t)
+
+
+def _dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).float().cuda()
+
+
+def _frame_for_golden(aoc, g, mode, kind, golden_loader):
+    """One aoc_frame_enqueue call on a golden's inputs (the inputs the golden does not hold -- a previous frame for the global goldens, a pool for
+    the local ones -- are seeded fillers: they only reach other channels).  Returns (features [O, n_ch, h, w], channel slices, config)."""
+    hot, ops, syn = aoc.hotpath, aoc.ops, aoc.synthetic
+    rng = np.random.RandomState(5)
+    if kind == "local":
+        cur, prev, prev_lab = _dev(g["in_query"]), _dev(g["in_prev"]), _dev(g["lab_onehot"])
+        h, w, O = prev_lab.shape
+        ref_emb, ref_lab = prev[None].contiguous(), prev_lab[None].contiguous()
+        mld = [int(v) for v in g["mld"]]
+    else:
+        cur, ref_emb, ref_lab = _dev(g["in_query"]), _dev(g["in_ref"]), _dev(g["lab_onehot"])
+        _, h, w, O = ref_lab.shape
+        prev, prev_lab = ref_emb[-1].contiguous(), ref_lab[-1].contiguous()
+        mld = [2, 4, 6, 8, 10, 12]
+    mc = hot.MatchingConfig(MODEL_MULTI_LOCAL_DISTANCE=mld, MODEL_FLOAT16_MATCHING=mode.get("f16", False), MODEL_LOCAL_DOWNSAMPLE=mode.get("down", True),
+                            TEST_LOCAL_ATROUS_RATE=mode.get("lrate", 1), TEST_GLOBAL_ATROUS_RATE=mode.get("grate", 1))
+    bias = _dev(g["in_bias"])
+    runner = hot.FrameRunner(mc, h, w, 100, O, capacity_frames=ref_emb.shape[0], device=cur.device)
+    m_emb, m_lab = runner.match_pool(ref_emb, ref_lab)
+    if mc.MODEL_FLOAT16_MATCHING:
+        ahead = hot.prepare_without_clustering(mc, m_emb, m_lab)
+    else:
+        counts = [int(m_lab[..., o].sum().item()) for o in range(O)]
+        seed = int(g["seed"]) if "seed" in g else 0
+        rows, _ = ops.kmeans_init_rows_draw(np.random.RandomState(seed), counts, mc.cluster_levels, 1, max(mc.cluster_levels))
+        ahead = hot.launch_cluster_proxies(mc, m_emb, m_lab, torch.from_numpy(rows[0]).cuda())
+    feat, _ = runner(ref_emb, ref_lab, prev, prev_lab, cur, bias, ahead, pool_key=1)
+    torch.cuda.synchronize()
+    return feat, hot.channel_slices(mc), mc
+
+
+@pytest.mark.parametrize("name,mode,kind", [
+    ("dense_atrous2", dict(grate=2), "dense"), ("dense_atrous3_even", dict(grate=3), "dense"), ("cluster_atrous2", dict(grate=2), "cluster"),
+    ("local_atrous2_down_O3", dict(lrate=2), "local"), ("local_atrous3_nodown_O3", dict(lrate=3, down=False), "local"),
+    ("dense_fp16_R2_O3", dict(f16=True), "dense"), ("local_fp16_down_O3", dict(f16=True), "local"), ("local_atrous2_fp16_down_O3", dict(f16=True, lrate=2), "local")])
+def test_reference_goldens_through_the_frame_call(aoc, golden, name, mode, kind):
+    """The reference's OWN outputs for the atrous / float16 / full-resolution modes (tests/golden/make_golden_r2*.py ran the reference's functions
+    with those arguments) against the matching channels of ONE aoc_frame_enqueue call on the same inputs."""
+    g = golden(name)
+    if "atrous_rate" in g:
+        assert int(g["atrous_rate"]) == mode.get("grate", mode.get("lrate", 1))
+    feat, ch, mc = _frame_for_golden(aoc, g, mode, kind, golden)
+    want = torch.from_numpy(g["out"])[0].permute(2, 3, 0, 1).numpy()                # [1, h, w, O, F] -> [O, F, h, w]
+    if kind == "dense":
+        got = feat[:, ch["global_fg"]:ch["global_fg"] + 1]
+    elif kind == "cluster":
+        got = feat[:, ch["cluster"]:ch["cluster"] + 2]
+    else:
+        got = feat[:, ch["local"]:ch["local"] + len(mc.MODEL_MULTI_LOCAL_DISTANCE)]
+    got = got.cpu().numpy()
+    assert got.shape == want.shape
+    if mode.get("f16"):
+        diff = np.abs(got - want)                                                   # the float16-mode tolerance of tests/test_gpu_round2.py::_f16_close
+        assert diff.max() <= 4e-3 and np.mean(diff <= 2e-6) >= 0.999, (diff.max(), np.mean(diff <= 2e-6))
+    else:
+        np.testing.assert_allclose(got, want, rtol=0, atol=5e-6)
