@@ -248,6 +248,18 @@ int aoc_proxy_corr_min_records(const aoc_corr_frame_rec *frames_host, int n_fram
                                const int32_t *set_begin_host, const int32_t *set_size_host,
                                const int64_t *set_out_offset_host, int transform,
                                void *workspace, size_t workspace_bytes, aoc_stream_t stream);
+/* The same call as ONE launch whatever the number of proxy tiles (round 5).  A workgroup's LDS image holds 5 proxy tiles of 32 rows; a frame
+ * with more (multi-level proxies: cfg3 has 22 tiles, cfg4 37) is cut into passes, and aoc_proxy_corr_min_records launches them one after
+ * another -- ~30-40 us each for ~2 us of MFMA work (launch, image staging, one stream over the query records).  Here the passes are a grid
+ * dimension: they run side by side and take the time of one.  Their tile tables live in the workspace
+ * (aoc_proxy_corr_min_records_cached_workspace_bytes) and are rewritten only when *tables_key -- a caller-owned HOST word, 0 = nothing
+ * cached, one per workspace -- does not match the call's set structure (a sequence writes them once).  tables_key = NULL: the plain call.
+ * Results are identical to aoc_proxy_corr_min_records (every workgroup runs the same code on the same pass). */
+size_t aoc_proxy_corr_min_records_cached_workspace_bytes(void);
+int aoc_proxy_corr_min_records_cached(const aoc_corr_frame_rec *frames_host, int n_frames, int64_t m, int C, int n_proxy, int n_set,
+                                      const int32_t *set_begin_host, const int32_t *set_size_host,
+                                      const int64_t *set_out_offset_host, int transform,
+                                      void *workspace, size_t workspace_bytes, int64_t *tables_key, aoc_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Dense pixel-level matching: AEM:178-227 + 61-89 without materialising [m, O, n]:
@@ -643,6 +655,7 @@ typedef struct aoc_frame_desc {
 /* Host-side record of what the workspace holds; caller-owned, zero-initialised when a sequence starts (the library keeps no state). */
 typedef struct aoc_seq_state {
     int64_t initialised, records_frames, ref_pool_key, plan_key, plan_rows;
+    int64_t corr_tables_key;         /* the correlation passes' tile tables the workspace holds (aoc_proxy_corr_min_records_cached) */
 } aoc_seq_state;
 int aoc_frame_channels(int n_radii, int n_levels, int matching_background);
 size_t aoc_frame_workspace_bytes(int h, int w, int C, int n_obj, int R_capacity, int n_radii, int n_levels);

@@ -52,6 +52,8 @@ SIGNATURES = {
     "aoc_proxy_corr_min_batched_workspace_bytes": (_sz, []),
     "aoc_proxy_corr_min_batched": (_i, [_vp, _i, _i64, _i, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _sz, _vp]),
     "aoc_proxy_corr_min_records": (_i, [_vp, _i, _i64, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
+    "aoc_proxy_corr_min_records_cached_workspace_bytes": (_sz, []),
+    "aoc_proxy_corr_min_records_cached": (_i, [_vp, _i, _i64, _i, _i, _i, _vp, _vp, _vp, _i, _vp, _sz, _vp, _vp]),
     "aoc_dense_match_workspace_bytes": (_sz, [_i64, _i64, _i]),
     "aoc_dense_match_min": (_i, [_vp, _i64, _i, _vp, _vp, _vp, _i64, _vp, _vp, _i, _vp, _i64, _i64, _i, _vp, _sz, _vp]),
     "aoc_dense_match_min_f16": (_i, [_vp, _i64, _i, _vp, _vp, _vp, _i64, _vp, _vp, _i, _vp, _i64, _i64, _i, _vp, _sz, _vp]),

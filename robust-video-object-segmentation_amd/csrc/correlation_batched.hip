@@ -25,6 +25,8 @@
 
 #include <atomic>
 
+#include <cstring>
+
 #include "aoc_common.h"
 #include "correlation_shared.h"
 
@@ -579,10 +581,10 @@ struct AocCorrRecFrames {
 constexpr int CR_NW = 8;
 constexpr int CR_TILE_CHUNKS = 2 * CB_SEG_STEPS * 64;                         // 16-byte chunks of one 32-pixel tile: [plane][k-step][lane]
 
+// `tiles`: the pass's tile table -- the kernel-argument copy (one pass per launch) or its copy in device memory (all passes in one launch)
 template <int NW, int NT, bool COL0>
-__global__ __launch_bounds__(NW * 64, 4) void proxy_corr_records_kernel(AocCorrRecFrames frames, int64_t m, AocCorrTiles tiles, int transform,
-                                                                         int32_t *__restrict__ gate, int dbg, int call_seq) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+__device__ __forceinline__ void cr_body(uint32_t *lds, const AocCorrRecFrames &frames, int64_t m, const AocCorrTiles &tiles, int transform,
+                                        int32_t *__restrict__ gate, int dbg, int call_seq) {
     AocCorrTiles &ltiles = *reinterpret_cast<AocCorrTiles *>(lds);
     for (int i = threadIdx.x; i < (int)(sizeof(AocCorrTiles) / 4); i += NW * 64)
         reinterpret_cast<uint32_t *>(&ltiles)[i] = reinterpret_cast<const uint32_t *>(&tiles)[i];
@@ -670,6 +672,44 @@ __global__ __launch_bounds__(NW * 64, 4) void proxy_corr_records_kernel(AocCorrR
     if (bad && dbg == 0) atomicExch(gate, call_seq);
 }
 
+template <int NW, int NT, bool COL0>
+__global__ __launch_bounds__(NW * 64, 4) void proxy_corr_records_kernel(AocCorrRecFrames frames, int64_t m, AocCorrTiles tiles, int transform,
+                                                                         int32_t *__restrict__ gate, int dbg, int call_seq) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    cr_body<NW, NT, COL0>(lds, frames, m, tiles, transform, gate, dbg, call_seq);
+}
+
+// Round 5: ALL passes of a frame (a pass = up to AOC_CORR_MAX_TILES proxy tiles, what one workgroup's LDS image holds) in ONE launch:
+// blockIdx.y = pass, its tile table read from device memory (`passes`, written once per set structure by cb_table_write_kernel).  A pass of
+// its own launch costs ~30-40 us at cfg3 / cfg4 sizes although its MFMAs take ~2 us -- launch, staging of the proxy image (dependent loads
+// and LDS phases) and one stream over the query records; the passes are independent, so side by side they take the time of ONE (cfg4: eight
+// launches of 38 us -> one).  Every workgroup runs the specialisation of its pass (uniform switch): same code, same results as pass by pass.
+template <int NW>
+__global__ __launch_bounds__(NW * 64, 4) void proxy_corr_records_multi_kernel(AocCorrRecFrames frames, int64_t m, const AocCorrTiles *__restrict__ passes,
+                                                                               int transform, int32_t *__restrict__ gate, int dbg, int call_seq) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+    const AocCorrTiles &tiles = passes[blockIdx.y];
+    const int key = tiles.n * 2 + (tiles.t[0].kind == 1 ? 1 : 0);
+    switch (key) {
+        case 2: cr_body<NW, 1, false>(lds, frames, m, tiles, transform, gate, dbg, call_seq); break;
+        case 3: cr_body<NW, 1, true>(lds, frames, m, tiles, transform, gate, dbg, call_seq); break;
+        case 4: cr_body<NW, 2, false>(lds, frames, m, tiles, transform, gate, dbg, call_seq); break;
+        case 5: cr_body<NW, 2, true>(lds, frames, m, tiles, transform, gate, dbg, call_seq); break;
+        case 6: cr_body<NW, 3, false>(lds, frames, m, tiles, transform, gate, dbg, call_seq); break;
+        case 7: cr_body<NW, 3, true>(lds, frames, m, tiles, transform, gate, dbg, call_seq); break;
+        case 8: cr_body<NW, 4, false>(lds, frames, m, tiles, transform, gate, dbg, call_seq); break;
+        case 9: cr_body<NW, 4, true>(lds, frames, m, tiles, transform, gate, dbg, call_seq); break;
+        case 10: cr_body<NW, 5, false>(lds, frames, m, tiles, transform, gate, dbg, call_seq); break;
+        case 11: cr_body<NW, 5, true>(lds, frames, m, tiles, transform, gate, dbg, call_seq); break;
+        default: break;
+    }
+}
+// one pass's tile table from the kernel arguments into the workspace (once per set structure: a sequence keeps it across its frames)
+__global__ __launch_bounds__(256) void cb_table_write_kernel(AocCorrTiles t, AocCorrTiles *__restrict__ dst) {
+    for (int i = threadIdx.x; i < (int)(sizeof(AocCorrTiles) / 4); i += 256)
+        reinterpret_cast<uint32_t *>(dst)[i] = reinterpret_cast<const uint32_t *>(&t)[i];
+}
+
 inline int cb_n_cus() {
     const int set = aoc_stream_cus();                                         // CUs the launching stream may use (aoc_set_stream_cus: HIP CU mask)
     if (set > 0) return set;
@@ -685,12 +725,20 @@ inline int cb_n_cus() {
 }
 
 constexpr size_t CB_WS_BYTES = 256;
+constexpr int CB_MAX_PASSES = 16;                                              // pass tables a workspace keeps for the one-launch form
+static_assert(sizeof(AocCorrTiles) % 8 == 0, "the pass tables are an array in the workspace");
+constexpr size_t CB_WS_CACHED_BYTES = (CB_WS_BYTES + (size_t)CB_MAX_PASSES * sizeof(AocCorrTiles) + 255) / 256 * 256;
+inline AocCorrTiles *cb_pass_table(void *workspace, int i) {                  // an ARRAY: the kernel indexes it with the pass
+    return reinterpret_cast<AocCorrTiles *>(static_cast<char *>(workspace) + CB_WS_BYTES) + i;
+}
 
 // rec_host != NULL: the frames' queries as tile-major split records (proxy_corr_records_kernel); frames_host always carries the fp32 rows
 // (the exact-fp32 take-over reads them)
+// tables_key != NULL (records form, one chunk of frames, workspace of CB_WS_CACHED_BYTES): ALL passes in one launch, their tile tables kept in
+// the workspace and rewritten only when *tables_key (caller-owned host word; 0 = nothing cached) does not match this call's tables
 int cb_run(const aoc_corr_frame *frames_host, const AocCorrRecFrame *rec_host, int n_frames, int64_t m, int C, int n_proxy, int n_set,
            const int32_t *set_begin_host, const int32_t *set_size_host, const int64_t *set_out_offset_host,
-           int transform, int precision, void *workspace, size_t workspace_bytes, aoc_stream_t stream) {
+           int transform, int precision, void *workspace, size_t workspace_bytes, aoc_stream_t stream, int64_t *tables_key = nullptr) {
     if (!frames_host || !set_begin_host || !set_size_host || !set_out_offset_host) return AOC_ERR_INVALID_ARG;
     if (n_frames < 1 || m < 1 || n_set < 1 || n_proxy < 0 || C < 4) return AOC_ERR_INVALID_ARG;
     if (m > (int64_t)80000000) return AOC_ERR_UNSUPPORTED;                    // 32-bit chunk indices inside the kernels (m * 25 < 2^31)
@@ -747,8 +795,21 @@ int cb_run(const aoc_corr_frame *frames_host, const AocCorrRecFrame *rec_host, i
         }
         AocCorrTiles tab;
         auto reset = [&]() { tab.n = 0; tab.n_out = 0; };
+        const bool multi = rec_host && tables_key && n_frames <= AOC_CORR_MAX_FRAMES && workspace_bytes >= CB_WS_CACHED_BYTES;
+        AocCorrTiles *passes_host = multi ? static_cast<AocCorrTiles *>(malloc(sizeof(AocCorrTiles) * CB_MAX_PASSES)) : nullptr;
+        int n_pass = 0;
+        bool multi_ok = passes_host != nullptr;
+        struct FreeGuard { void *p; ~FreeGuard() { free(p); } } free_guard{passes_host};
         auto flush = [&]() -> int {
             if (tab.n == 0) return AOC_OK;
+            if (multi_ok) {
+                // one-launch form: the pass is only recorded here; everything is launched after the packing loop
+                if (n_pass == CB_MAX_PASSES) return AOC_ERR_UNSUPPORTED;
+                memcpy(static_cast<void *>(&passes_host[n_pass]), &tab, sizeof(tab));
+                ++n_pass;
+                reset();
+                return AOC_OK;
+            }
             const size_t lds = (size_t)tab.n * tile_bytes + lds_fixed;
             int64_t grid = T * fr.n;
             if (rec_host) {
@@ -890,6 +951,40 @@ int cb_run(const aoc_corr_frame *frames_host, const AocCorrRecFrame *rec_host, i
         }
         int rc = flush();
         if (rc) return rc;
+        if (multi_ok && n_pass > 0) {
+            // the tables are a function of the set structure alone: a sequence writes them once (key = a hash of their bytes)
+            uint64_t key = 0xcbf29ce484222325ull ^ (uint64_t)n_pass;
+            for (int i = 0; i < n_pass; ++i) {
+                // every byte is initialised: tiles are value-initialised, the per-output arrays and the unused tiles are zeroed below
+                AocCorrTiles &t = passes_host[i];
+                for (int k = t.n; k < AOC_CORR_TABLE_TILES; ++k) t.t[k] = AocCorrTile{};
+                for (int k = t.n_out; k < AOC_CORR_MAX_OUT; ++k) { t.oc_offset[k] = 0; t.oc_bias[k] = 0; t.oc_row0[k] = 0; t.oc_rows[k] = 0; }
+                const uint64_t *w = reinterpret_cast<const uint64_t *>(&t);
+                for (size_t k = 0; k < sizeof(AocCorrTiles) / 8; ++k) key = (key ^ w[k]) * 0x100000001b3ull + (key >> 29);
+            }
+            key |= 1ull;
+            if ((uint64_t)*tables_key != key) {
+                for (int i = 0; i < n_pass; ++i)
+                    hipLaunchKernelGGL(cb_table_write_kernel, dim3(1), dim3(256), 0, st, passes_host[i], cb_pass_table(workspace, i));
+                *tables_key = (int64_t)key;
+            }
+            int nt_max = 0;
+            for (int i = 0; i < n_pass; ++i) nt_max = passes_host[i].n > nt_max ? passes_host[i].n : nt_max;
+            const size_t lds = (size_t)nt_max * tile_bytes + lds_fixed;
+            int64_t bpp = (2 * (int64_t)n_cu) / n_pass;                       // the passes' workgroups are resident together: two per CU in all
+            if (bpp < 1) bpp = 1;
+            if (bpp > T * fr.n) bpp = T * fr.n;
+            AocCorrRecFrames rf;
+            rf.n = fr.n;
+            for (int f = 0; f < fr.n; ++f) rf.f[f] = rec_host[f0 + f];
+            static const bool lds_ok = hipFuncSetAttribute(reinterpret_cast<const void *>(proxy_corr_records_multi_kernel<CR_NW>),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) == hipSuccess;
+            if (!lds_ok) return AOC_ERR_LAUNCH;
+            static const int dbg_m = AOC_DEV_ENV_INT("AOC_CORR_DEBUG", 0);
+            hipLaunchKernelGGL((proxy_corr_records_multi_kernel<CR_NW>), dim3((unsigned)bpp, (unsigned)n_pass), dim3(CR_NW * 64), lds, st, rf, m,
+                               cb_pass_table(workspace, 0), transform, gate, dbg_m, call_seq);
+            if (hipGetLastError() != hipSuccess) return AOC_ERR_LAUNCH;
+        }
     }
     // exact-fp32 kernel: runs only when a precondition of the split arithmetic failed somewhere in the launch
     return aoc_corr_fp32_batched(frames_host, n_frames, m, C, n_proxy, n_set, set_begin_host, set_size_host, set_out_offset_host, 1, transform,
@@ -912,9 +1007,18 @@ int aoc_proxy_corr_min_batched(const aoc_corr_frame *frames_host, int n_frames, 
 int aoc_proxy_corr_min_records(const aoc_corr_frame_rec *frames_host, int n_frames, int64_t m, int C, int n_proxy, int n_set,
                                const int32_t *set_begin_host, const int32_t *set_size_host, const int64_t *set_out_offset_host,
                                int transform, void *workspace, size_t workspace_bytes, aoc_stream_t stream) {
+    return aoc_proxy_corr_min_records_cached(frames_host, n_frames, m, C, n_proxy, n_set, set_begin_host, set_size_host, set_out_offset_host, transform,
+                                             workspace, workspace_bytes, nullptr, stream);
+}
+
+size_t aoc_proxy_corr_min_records_cached_workspace_bytes(void) { return CB_WS_CACHED_BYTES; }
+
+int aoc_proxy_corr_min_records_cached(const aoc_corr_frame_rec *frames_host, int n_frames, int64_t m, int C, int n_proxy, int n_set,
+                                      const int32_t *set_begin_host, const int32_t *set_size_host, const int64_t *set_out_offset_host,
+                                      int transform, void *workspace, size_t workspace_bytes, int64_t *tables_key, aoc_stream_t stream) {
     if (!frames_host || n_frames < 1 || n_frames > 4096) return AOC_ERR_INVALID_ARG;
     if (C != 100) return AOC_ERR_UNSUPPORTED;                                 // the records of dense_split.hip at the kernel's channel count
-    if (!workspace || workspace_bytes < CB_WS_BYTES) return AOC_ERR_WORKSPACE;
+    if (!workspace || workspace_bytes < (tables_key ? CB_WS_CACHED_BYTES : CB_WS_BYTES)) return AOC_ERR_WORKSPACE;
     aoc_corr_frame *plain = static_cast<aoc_corr_frame *>(malloc(sizeof(aoc_corr_frame) * (size_t)n_frames));
     AocCorrRecFrame *rec = static_cast<AocCorrRecFrame *>(malloc(sizeof(AocCorrRecFrame) * (size_t)n_frames));
     int rc = (plain && rec) ? AOC_OK : AOC_ERR_LAUNCH;
@@ -927,7 +1031,7 @@ int aoc_proxy_corr_min_records(const aoc_corr_frame_rec *frames_host, int n_fram
     }
     if (rc == AOC_OK)
         rc = cb_run(plain, rec, n_frames, m, C, n_proxy, n_set, set_begin_host, set_size_host, set_out_offset_host, transform, AOC_CORR_SPLIT,
-                    workspace, workspace_bytes, stream);
+                    workspace, workspace_bytes, stream, tables_key);
     free(plain);
     free(rec);
     return rc;

@@ -51,7 +51,7 @@ inline FrameWs frame_carve(void *base, int h, int w, int C, int n_obj, int R_cap
     const int64_t hw = (int64_t)h * w, n_cap = hw * R_cap;
     const int H2 = h / 2 + 1, W2 = w / 2 + 1;
     f.overflow = reinterpret_cast<int32_t *>(take(256));
-    f.corr_ws = take(aoc_proxy_corr_min_batched_workspace_bytes());
+    f.corr_ws = take(aoc_proxy_corr_min_records_cached_workspace_bytes());
     f.init_bytes = off;                                     // [0, init_bytes) is zeroed when a sequence starts
     f.pool_rec = take((size_t)n_cap * aoc_split_record_bytes(C));
     f.pool_sq = reinterpret_cast<float *>(take((size_t)n_cap * sizeof(float)));
@@ -156,6 +156,7 @@ int aoc_frame_enqueue(const aoc_frame_desc *d, aoc_seq_state *state, void *works
         state->records_frames = 0;
         state->ref_pool_key = 0;
         state->plan_key = 0;
+        state->corr_tables_key = 0;
     }
     if (d->prep_ready && hipStreamWaitEvent(st, static_cast<hipEvent_t>(d->prep_ready), 0) != hipSuccess) return AOC_ERR_LAUNCH;
 
@@ -278,7 +279,9 @@ int aoc_frame_enqueue(const aoc_frame_desc *d, aoc_seq_state *state, void *works
             fr.proxy_sqnorm = d->proxy_sqnorm;
             fr.set_bias = f.set_bias;
             fr.out = d->feat;
-            AOC_TRY(aoc_proxy_corr_min_records(&fr, 1, hw, C, n_ad + O, n_set, sb, ss, so, 1, f.corr_ws, aoc_proxy_corr_min_batched_workspace_bytes(), stream));
+            // one launch whatever the number of proxy tiles; the passes' tile tables are written into the workspace once per sequence
+            AOC_TRY(aoc_proxy_corr_min_records_cached(&fr, 1, hw, C, n_ad + O, n_set, sb, ss, so, 1, f.corr_ws, aoc_proxy_corr_min_records_cached_workspace_bytes(),
+                                                      &state->corr_tables_key, stream));
         } else {
             aoc_corr_frame fr;
             fr.query = d->cur_emb;

@@ -278,10 +278,19 @@ def proxy_corr_min_batched(frames, set_begin, set_size, set_out_offset, transfor
     return [f[4] for f in frames]
 
 
-def proxy_corr_min_records(frames, set_begin, set_size, set_out_offset, transform=True, prepare_only=False):
+class CorrTableCache:
+    """Workspace + host key of aoc_proxy_corr_min_records_cached: the tile tables of a frame's correlation passes stay in the workspace, so
+    every call is ONE launch whatever the number of proxy tiles.  One per stream / sequence (the calls that share it are stream-ordered)."""
+
+    def __init__(self, device):
+        self.ws = torch.zeros(int(_lib.lib().aoc_proxy_corr_min_records_cached_workspace_bytes()), dtype=torch.uint8, device=device)
+        self.key = ctypes.c_int64(0)
+
+
+def proxy_corr_min_records(frames, set_begin, set_size, set_out_offset, transform=True, prepare_only=False, cache=None):
     """aoc_proxy_corr_min_records: proxy_corr_min_batched with every frame's query handed over as the tile-major split records the dense
     kernel consumes for the same frame.  frames: sequence of (query_flat [m, C], query_split (SplitRows, tiled), proxies, proxy_sqnorm or
-    None, set_bias or None, out)."""
+    None, set_bias or None, out).  cache: a CorrTableCache -> aoc_proxy_corr_min_records_cached (all passes in one launch; same results)."""
     q0, p0 = frames[0][0], frames[0][2]
     m, C = q0.shape
     n_proxy = p0.shape[0]
@@ -309,6 +318,11 @@ def proxy_corr_min_records(frames, set_begin, set_size, set_out_offset, transfor
     outs = [f[5] for f in frames]
 
     def launch():
+        if cache is not None:
+            _lib.check(_lib.lib().aoc_proxy_corr_min_records_cached(ctypes.cast(arr, vp), n_frames, m, C, n_proxy, n_set, sb.ctypes.data_as(vp),
+                                                                    ss.ctypes.data_as(vp), so.ctypes.data_as(vp), int(bool(transform)), _p(cache.ws),
+                                                                    cache.ws.numel(), ctypes.byref(cache.key), _stream()), "aoc_proxy_corr_min_records_cached")
+            return outs
         ws = _corr_workspace(dev)
         _lib.check(fn(ctypes.cast(arr, vp), n_frames, m, C, n_proxy, n_set, sb.ctypes.data_as(vp), ss.ctypes.data_as(vp), so.ctypes.data_as(vp),
                       int(bool(transform)), _p(ws), ws.numel(), _stream()), "aoc_proxy_corr_min_records")
@@ -641,7 +655,7 @@ class GateBatch:
 class _SeqState(ctypes.Structure):
     """aoc_seq_state of include/aoc_hip.h."""
     _fields_ = [("initialised", ctypes.c_int64), ("records_frames", ctypes.c_int64), ("ref_pool_key", ctypes.c_int64), ("plan_key", ctypes.c_int64),
-                ("plan_rows", ctypes.c_int64)]
+                ("plan_rows", ctypes.c_int64), ("corr_tables_key", ctypes.c_int64)]
 
 
 class FrameCall:

@@ -157,3 +157,47 @@ def test_tiled_records_are_the_row_major_records_reordered(aoc):
     # row-major chunk (plane p, k-step s, half h) of row r = bytes [(p * 14 + s * 2 + h) * 16, +16)
     want = rows.view(T, 32, 2, 7, 2, 16).permute(0, 2, 3, 4, 1, 5).contiguous().view(T * 32, 448)
     assert torch.equal(b.records, want)
+
+
+@pytest.mark.parametrize("levels,n_obj,kmax", [([8, 16, 32], 6, 32), ([64], 9, 64), ([16], 4, 16), ([8, 16, 32], 2, 32)])
+def test_all_passes_in_one_launch_equal_pass_by_pass(levels, n_obj, kmax):
+    """aoc_proxy_corr_min_records_cached (round 5: the passes of a frame with more than 5 proxy tiles as a grid dimension, tile tables kept in the
+    workspace) against aoc_proxy_corr_min_records (one launch per pass): every workgroup runs the same code on the same pass -> EQUAL, on the
+    first call (tables written), on a second call with other data (tables reused) and after the set structure changes (tables rewritten)."""
+    import aoc_amd
+    ops = aoc_amd.ops
+    torch.manual_seed(3)
+    h, w, C = 37, 53, 100
+    m = h * w
+    L = len(levels)
+    n_ad = L * n_obj * 2 * kmax
+    sb, ss, so = [], [], []
+    n_ch = 2 * L + 1
+    for l, k in enumerate(levels):
+        for o in range(n_obj):
+            for f in range(2):
+                sb.append(((l * n_obj + o) * 2 + f) * kmax)
+                ss.append(k)
+                so.append((o * n_ch + 2 * l + f) * m)
+    for o in range(n_obj):
+        sb.append(n_ad + o)
+        ss.append(1)
+        so.append((o * n_ch + 2 * L) * m)
+    cache = ops.CorrTableCache(torch.device("cuda"))
+    for trial in range(3):
+        q = (torch.rand(m, C, device="cuda") * 0.3).contiguous()
+        table = (torch.rand(n_ad + n_obj, C, device="cuda") * 0.3).contiguous()
+        sqn = table.pow(2).sum(1)
+        sqn[torch.rand_like(sqn) < 0.1] = float("inf")               # absent proxies
+        bias = torch.randn(len(sb), device="cuda") * 0.2
+        qs = ops.split_rows(q, tiled=True)
+        sets = (sb, ss, so) if trial < 2 else (sb[:-1], ss[:-1], so[:-1])       # third trial: another set structure -> tables rewritten
+        b = bias[:len(sets[0])].contiguous()
+        out_a = torch.zeros(n_obj, n_ch, m, device="cuda")
+        out_b = torch.zeros_like(out_a)
+        ops.proxy_corr_min_records([(q, qs, table, sqn, b, out_a)], *sets, True)
+        key_before = cache.key.value
+        ops.proxy_corr_min_records([(q, qs, table, sqn, b, out_b)], *sets, True, cache=cache)
+        torch.cuda.synchronize()
+        assert torch.equal(out_a, out_b), f"trial {trial}: one launch != pass by pass ({float((out_a - out_b).abs().max())})"
+        assert cache.key.value != 0 and (trial != 1 or cache.key.value == key_before) and (trial != 2 or cache.key.value != key_before)
