@@ -1151,17 +1151,24 @@ def main():
         km_roof = None
         if km and "gbs" in km:
             km_roof = dict(kernel="aoc_kmeans_segmented_rep (20 Lloyd iterations of the 2 or 3 frames that share a chain: replica-fused assignment, block scan + "
-                                  "scatter, literal heads (LDS-DMA) + chunk sums, fold, stitch: five launches per iteration)", bound="hbm",
+                                  "scatter, literal heads (LDS-DMA) + the tail chunks' integer folds in the binades the previous iteration recorded, stitch: "
+                                  "FOUR launches per iteration from the second one on)", bound="hbm",
                            achieved=km["gbs"], peak=PEAK_HBM_GBS, unit="GB/s", frac=round(km["gbs"] / PEAK_HBM_GBS, 4),
                            avg_launch_ms=km["avg_ms"], algorithmic_bytes_per_launch=km["avg_bytes"],
-                           note="a dependent chain of ~105 launches whose ordered float32 sums are latency-bound by construction; the in-run "
-                                "figure spans the time the chain shares the GPU with the other streams",
-                           traffic_offline=dict(file="profiles/r04_pmc_kmeans_R6_F3.txt", commit="e1871d4", source="constants copied from the committed file, not measured in this run",
-                                                workload="three frames per chain, R = 6 pool frames (61.9 MB of pool rows), per Lloyd iteration",
-                                                fetch_bytes_per_iteration=336.0e6, rows_bytes=61.9e6, reads_per_frame_and_iteration=round(336.0 / 3 / 61.9, 2),
-                                                note="FETCH_SIZE x 2 (gfx950 counts 128-byte requests as 64) summed over the five kernels of an iteration: "
-                                                     "1.81 passes over the rows per frame and iteration (assignment 0.34: one pass for three replicas; "
-                                                     "heads + chunk sums 1.02; fold 0.36; stitch 0.06; scan + scatter 0.03); round 3: 1.98, round 2: 2.84"))
+                           note="a dependent chain of ~85 launches whose ordered float32 sums are latency-bound by construction; the in-run "
+                                "figure spans the time the chain shares the GPU with the other streams")
+            if args.config == "cfg2":
+                km_roof["traffic_offline"] = dict(file="profiles/r05_pmc_kmeans_R6_F3.txt", source="constants copied from the committed file, not measured in this run",
+                                                  workload="three frames per chain, R = 6 pool frames (61.9 MB of pool rows), per Lloyd iteration",
+                                                  fetch_bytes_per_iteration=274.0e6, rows_bytes=61.9e6, reads_per_frame_and_iteration=round(274.0 / 3 / 61.9, 2),
+                                                  note="FETCH_SIZE x 2 (gfx950 counts 128-byte requests as 64) summed over the four kernels of an iteration: "
+                                                       "1.48 passes over the rows per frame and iteration (assignment 0.34: one pass for three replicas; "
+                                                       "heads + folds 1.05; stitch 0.06; scan + scatter 0.03); round 4: 1.81, round 3: 1.98")
+                km_roof["alone_offline"] = dict(file="profiles/r05_kmeans_chain_events.txt", source="constants copied from the committed file (tools/bench_kmeans_ev.py: "
+                                                "hipEvent pairs around every chain on an idle GPU, 50 chains each), not measured in this run",
+                                                chain_ms=dict(R1_F1=0.688, R6_F1=2.313, R6_F3=3.119, R12_F1=2.961, R12_F3=5.129),
+                                                frac_R6_F3=round(3 * 20 * 61.9e6 / 3.119e-3 / 1e9 / PEAK_HBM_GBS, 4),
+                                                note="frac_R6_F3 = 3 frames x 20 iterations x one pass over the 61.9 MB of rows / the chain's duration / 8 TB/s")
 
         def hbm_roof(name, kernel, note):
             kk = kernels.get(name)
@@ -1178,14 +1185,14 @@ def main():
         calib_pmc = dict(file="profiles/r04_pmc_gates_cfg2.txt", commit="e1871d4", source="constants copied from the committed file, not measured in this run")
         gates_alone = dict(file="profiles/r04_gates_standalone.txt", commit="e1871d4", source="constants copied from the committed file (tools/bench_gates.py on an idle GPU), "
                                                                                                 "not measured in this run")
-        if film_roof is not None:
+        if film_roof is not None and args.config == "cfg2":
             film_roof["traffic_offline"] = dict(calib_pmc, shape=[4, 256, 121, 213], algorithmic_bytes=211.1e6, fetch_bytes=111.8e6, write_bytes=105.2e6, ratio=1.03,
                                                 note="the kernel alone: FETCH_SIZE x 2 + WRITE_SIZE against one read + one write of the planes")
             film_roof["alone_offline"] = dict(gates_alone, shape=[4, 256, 121, 213], avg_launch_ms=0.0402, achieved=5252.0, frac=0.656,
                                               all_14_gates_ms=0.3708, all_14_gates_frac=0.597,
                                               note="film_scale_ahead_kernel: the plane slice is requested before the gain's dot product; round 3's kernel: 0.048 ms = 0.55 "
                                                    "at this shape, 0.485 ms over the 14 gates")
-        if cond_roof is not None:
+        if cond_roof is not None and args.config == "cfg2":
             cond_roof["traffic_offline"] = dict(calib_pmc, shape=[4, 256, 121, 213], algorithmic_bytes=105.6e6, fetch_bytes=104.8e6 + 107.3e6 + 4.2e6,
                                                 write_bytes=3.9e6, ratio=2.1,
                                                 note="the op alone: the scores pass and the masked pooling read z once each (104.8 + 107.3 MB), the score "
@@ -1193,6 +1200,11 @@ def main():
             cond_roof["alone_offline"] = dict(gates_alone, shape=[4, 256, 121, 213], avg_launch_ms=0.060, achieved=1760.0, frac=0.22, moved_frac=0.44,
                                               note="five launches (round 3: seven + a memset, 0.066 ms); frac prices ONE read of z, moved_frac the two reads the "
                                                    "exact k-th-largest selection forces")
+            cond_roof["second_read_offline"] = dict(file="profiles/r05_cond_second_read.txt", source="constants copied from the committed file (tools/bench_cond_warm.py "
+                                                    "under rocprofv3 --kernel-trace), not measured in this run", shape=[4, 256, 121, 213],
+                                                    first_read_cold_us=22.4, second_read_product_us=24.4, reread_warm_us=[18.8, 20.3],
+                                                    note="the product's second read of z streams at 4.3 TB/s; data streamed twice just before at 5.2-5.6 TB/s: on-die "
+                                                         "residency is worth 16-20 % of a pass, and one sample at a time (5 launches each) is 2.4-3x slower")
         corr_name = next((k for k in ("proxy_corr_min_records", "proxy_corr_min_batched") if k in kernels), "proxy_corr_min")
         corr = kernels.get(corr_name)
         corr_roof = None
