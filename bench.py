@@ -981,6 +981,8 @@ def main():
         for wl in workloads:
             wl.count_r = True
         timer.want_segments = args.segments
+        if args.segments:
+            args.probe_every = 1                  # consecutive frames of a stream: "to_next_frame" is then the gap to the very next frame
         timer.probe_every = args.probe_every
         for i, wl in enumerate(workloads):
             wl.probe_phase = i * max(1, args.probe_every // 2)
@@ -1006,6 +1008,7 @@ def main():
         # continues) with the queues drained in front of each -- the wall time of run_steps(1) is then the CPU time of the step's enqueue calls,
         # while `enqueue` above also contains the time the host sits in the runtime waiting for room in full queues (it runs ~3 ms ahead)
         cpu_enqueue = []
+        timer.want_segments = False               # (the drained steps below are not part of any reported bracket)
         for _ in range(8):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
