@@ -294,6 +294,36 @@ def test_frame_call_validates_everything_before_it_touches_the_state():
     assert call(desc(), nbytes=1024) == WORKSPACE     # a complete descriptor: the next check is the workspace size
 
 
+def test_round5_entry_points_reject_bad_arguments_without_a_gpu():
+    """aoc_atrous_subsample and aoc_proxy_corr_min_records_cached validate before any launch."""
+    import ctypes
+    L = aoc_amd._lib.lib()
+    vp = ctypes.c_void_p
+    buf = (ctypes.c_float * 64)()
+    p = ctypes.cast(buf, vp)
+    INVALID, WORKSPACE, UNSUPPORTED = -1, -2, -4
+    assert L.aoc_atrous_subsample(None, 4, 4, 4, 2, p, None) == INVALID
+    assert L.aoc_atrous_subsample(p, 4, 4, 4, 0, p, None) == INVALID              # rate >= 1
+    assert L.aoc_atrous_subsample(p, 0, 4, 4, 2, p, None) == INVALID
+    need = L.aoc_proxy_corr_min_records_cached_workspace_bytes()
+    assert need > L.aoc_proxy_corr_min_batched_workspace_bytes() >= 256 and need % 256 == 0
+
+    class Frame(ctypes.Structure):
+        _fields_ = [(n, vp) for n in ("query", "query_rec", "query_sqnorm", "proxies", "proxy_sqnorm", "set_bias", "out")]
+    fr = (Frame * 1)(Frame(*([ctypes.addressof(buf)] * 4), None, None, ctypes.addressof(buf)))
+    fp = ctypes.cast(fr, vp)
+    i32 = (ctypes.c_int32 * 4)()
+    i64 = (ctypes.c_int64 * 4)()
+    ip, lp = ctypes.cast(i32, vp), ctypes.cast(i64, vp)
+    key = ctypes.c_int64(0)
+    small = (ctypes.c_char * 256)()
+    # with a key the workspace has to hold the pass tables; without one the 256-byte flag workspace is enough to get past the size check
+    assert L.aoc_proxy_corr_min_records_cached(fp, 1, 64, 100, 4, 1, ip, ip, lp, 1, ctypes.cast(small, vp), 256, ctypes.byref(key), None) == WORKSPACE
+    assert L.aoc_proxy_corr_min_records_cached(fp, 1, 64, 96, 4, 1, ip, ip, lp, 1, ctypes.cast(small, vp), 256, ctypes.byref(key), None) == UNSUPPORTED
+    assert L.aoc_proxy_corr_min_records_cached(fp, 0, 64, 100, 4, 1, ip, ip, lp, 1, ctypes.cast(small, vp), 256, None, None) == INVALID
+    assert key.value == 0
+
+
 def test_mirrors_refuse_to_run_under_autograd():
     """the drop-in names include the reference's training-time ones; they build no autograd graph, so they must raise
     (instead of silently training nothing) when a gradient is wanted."""
