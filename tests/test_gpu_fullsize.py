@@ -238,3 +238,29 @@ def test_kmeans_bit_exact_with_the_single_pass_tail():
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.join(here, "test_gpu_fullsize.py"), os.path.join(here, "test_gpu_parity.py"),
                         "-k", "kmeans and not single_pass and not persistent"], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_kmeans_bit_exact_on_a_segment_beyond_the_inline_prediction_limit(aoc):
+    """ONE object of 460 000 rows (cfg4's background at a dozen pool frames): more than 409 600 rows per segment, so iteration 0 takes the
+    separate binade-prediction launch; iterations 1..19 fold their ~860 tail chunks in the binades the previous iteration recorded (round 5).
+    Labels, counts and the code book equal the oracle (== scipy) bit for bit."""
+    from oracle import kmeans as okm
+    rng = np.random.RandomState(77)
+    n, C, K = 460_000, 100, 16
+    x = (np.maximum(rng.randn(n, C), 0.0) * 0.3).astype(np.float32)
+    x[:, 5] = 0.0                                                   # a feature that is identically zero: sums stay 0 (the literal fallback)
+    lab = np.zeros((n, 2), np.float32)
+    lab[:, 0] = 1.0
+    lab[-50:, 0], lab[-50:, 1] = 0.0, 1.0                           # a second, tiny object
+    init = np.zeros((2, K), np.int32)
+    init[0] = rng.permutation(n - 50)[:K]
+    init[1] = rng.permutation(50)[:K]
+    pool, labels = torch.from_numpy(x).cuda(), torch.from_numpy(lab).cuda()
+    prep = aoc.ops.label_prep(labels)
+    seg_k = aoc.ops.kmeans_plan(prep.counts, 2, K)
+    cen, got_lab, got_cnt = aoc.ops.kmeans_segmented(pool, prep.obj_rows, prep.obj_offsets, seg_k, torch.from_numpy(init).cuda(), K, 20, rows_capacity=prep.obj_rows.numel())
+    offs = prep.obj_offsets.cpu().numpy()
+    for o, rows in enumerate((np.arange(n - 50), np.arange(n - 50, n))):
+        cb, l, cnt = okm.kmeans2_matrix(x[rows], x[rows][init[o]], 20)
+        assert np.array_equal(got_lab.cpu().numpy()[offs[o]:offs[o + 1]], l), f"object {o}: labels"
+        assert np.array_equal(got_cnt.cpu().numpy()[o], cnt) and np.array_equal(cen.cpu().numpy()[o], cb), f"object {o}: code book"
