@@ -612,11 +612,12 @@ class CalibrationGates(nn.Module):
         when the activation buffers or the weights' storage change."""
         # the descriptors hold raw pointers: of the activations AND of the module weights -- both are part of the key (module.to(), .float(),
         # load_state_dict(assign=True) or a re-assigned parameter give the weights new storage; an in-place update keeps it and needs no rebuild)
-        if not hasattr(self, "_param_list"):
-            self._param_list = list(self.parameters())      # the module tree is fixed after __init__: walked once, not per frame
-        if len(self._param_list) and self._param_list[0] is not next(self.parameters()):
-            self._param_list = list(self.parameters())      # parameters were re-assigned (load_state_dict(assign=True), module.to() on some builds)
-        key = (tuple((x.data_ptr(), tuple(x.shape)) for x in activations) + (attention_head.shape[1],) + tuple(p.data_ptr() for p in self._param_list))
+        if not hasattr(self, "_param_slots"):
+            # the module TREE is fixed after __init__ (walked once, not per frame); the Parameter objects in its slots are not: a re-assigned
+            # parameter or load_state_dict(assign=True) puts a new object -- new storage -- into the slot, so the slots are read every call
+            self._param_slots = [(m._parameters, n) for m in self.modules() for n in m._parameters]
+        key = (tuple((x.data_ptr(), tuple(x.shape)) for x in activations) + (attention_head.shape[1],) +
+               tuple(d[n].data_ptr() for d, n in self._param_slots if d[n] is not None))
         if not hasattr(self, "_batches"):
             self._batches = {}
         cached = self._batches.get(slot)                 # one set of output buffers per caller slot (e.g. per sequence in flight)

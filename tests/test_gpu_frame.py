@@ -119,3 +119,33 @@ def test_gates_one_call_equals_the_modules(aoc):
     want2 = gates(acts, head * 0.5)
     for a, b in zip(got2, want2):
         assert torch.equal(a, b)
+
+
+def test_gates_batch_follows_the_weights_storage(aoc):
+    """the cached descriptors of forward_batched hold raw pointers of the module weights.  New weight STORAGE (load_state_dict(assign=True), a
+    re-assigned parameter, module.to()) must rebuild them; an in-place update (the same storage) must simply be seen."""
+    hot = aoc.hotpath
+    torch.manual_seed(6)
+    gates = hot.CalibrationGates(hot.MatchingConfig()).cuda()
+    O, h, w = 2, 17, 23
+    g = torch.Generator().manual_seed(10)
+    acts = [torch.randn(O, c, hh, ww, generator=g).cuda() for (_, c, hh, ww, _) in gates.plan(h, w)]
+    head = torch.randn(O, 400, generator=g).cuda()
+    first = [t.clone() for t in gates.forward_batched(acts, head)]
+    # in place: same storage, new values
+    with torch.no_grad():
+        gates.IA1.IA.weight.mul_(0.5)
+    for a, b in zip(gates.forward_batched(acts, head), gates(acts, head)):
+        assert torch.equal(a, b)
+    # new storage for every parameter
+    sd = {k: (v.clone() * 1.25) for k, v in gates.state_dict().items()}
+    gates.load_state_dict(sd, assign=True)
+    got = [t.clone() for t in gates.forward_batched(acts, head)]
+    want = gates(acts, head)
+    for a, b in zip(got, want):
+        assert torch.equal(a, b), "the batch still reads the old weight storage"
+    assert not torch.equal(got[0], first[0])
+    # one re-assigned parameter
+    gates.IA11.IA.bias = torch.nn.Parameter(torch.full_like(gates.IA11.IA.bias, 0.3))
+    for a, b in zip(gates.forward_batched(acts, head), gates(acts, head)):
+        assert torch.equal(a, b)
