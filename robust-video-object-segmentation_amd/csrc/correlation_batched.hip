@@ -26,6 +26,7 @@
 #include <atomic>
 
 #include <cstring>
+#include <functional>
 
 #include "aoc_common.h"
 #include "correlation_shared.h"
@@ -800,11 +801,49 @@ int cb_run(const aoc_corr_frame *frames_host, const AocCorrRecFrame *rec_host, i
         int n_pass = 0;
         bool multi_ok = passes_host != nullptr;
         struct FreeGuard { void *p; ~FreeGuard() { free(p); } } free_guard{passes_host};
+        std::function<int()> launch_multi = [&]() -> int {
+            if (!multi_ok || n_pass == 0) return AOC_OK;
+            // the tables are a function of the set structure alone: a sequence writes them once (key = a hash of their bytes)
+            uint64_t key = 0xcbf29ce484222325ull ^ (uint64_t)n_pass;
+            for (int i = 0; i < n_pass; ++i) {
+                // every byte is initialised: tiles are value-initialised, the per-output arrays and the unused tiles are zeroed below
+                AocCorrTiles &t = passes_host[i];
+                for (int k = t.n; k < AOC_CORR_TABLE_TILES; ++k) t.t[k] = AocCorrTile{};
+                for (int k = t.n_out; k < AOC_CORR_MAX_OUT; ++k) { t.oc_offset[k] = 0; t.oc_bias[k] = 0; t.oc_row0[k] = 0; t.oc_rows[k] = 0; }
+                const uint64_t *w = reinterpret_cast<const uint64_t *>(&t);
+                for (size_t k = 0; k < sizeof(AocCorrTiles) / 8; ++k) key = (key ^ w[k]) * 0x100000001b3ull + (key >> 29);
+            }
+            key |= 1ull;
+            if ((uint64_t)*tables_key != key) {
+                for (int i = 0; i < n_pass; ++i)
+                    hipLaunchKernelGGL(cb_table_write_kernel, dim3(1), dim3(256), 0, st, passes_host[i], cb_pass_table(workspace, i));
+                *tables_key = (int64_t)key;
+            }
+            int nt_max = 0;
+            for (int i = 0; i < n_pass; ++i) nt_max = passes_host[i].n > nt_max ? passes_host[i].n : nt_max;
+            const size_t lds = (size_t)nt_max * tile_bytes + lds_fixed;
+            int64_t bpp = (2 * (int64_t)n_cu) / n_pass;                       // the passes' workgroups are resident together: two per CU in all
+            if (bpp < 1) bpp = 1;
+            if (bpp > T * fr.n) bpp = T * fr.n;
+            AocCorrRecFrames rf;
+            rf.n = fr.n;
+            for (int f = 0; f < fr.n; ++f) rf.f[f] = rec_host[f0 + f];
+            static const bool lds_ok = hipFuncSetAttribute(reinterpret_cast<const void *>(proxy_corr_records_multi_kernel<CR_NW>),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) == hipSuccess;
+            if (!lds_ok) return AOC_ERR_LAUNCH;
+            static const int dbg_m = AOC_DEV_ENV_INT("AOC_CORR_DEBUG", 0);
+            hipLaunchKernelGGL((proxy_corr_records_multi_kernel<CR_NW>), dim3((unsigned)bpp, (unsigned)n_pass), dim3(CR_NW * 64), lds, st, rf, m,
+                               cb_pass_table(workspace, 0), transform, gate, dbg_m, call_seq);
+            if (hipGetLastError() != hipSuccess) return AOC_ERR_LAUNCH;
+            n_pass = 0;
+            return AOC_OK;
+        };
         auto flush = [&]() -> int {
             if (tab.n == 0) return AOC_OK;
             if (multi_ok) {
-                // one-launch form: the pass is only recorded here; everything is launched after the packing loop
-                if (n_pass == CB_MAX_PASSES) return AOC_ERR_UNSUPPORTED;
+                // one-launch form: the pass is only recorded here; everything is launched after the packing loop (or when the table is full:
+                // more than CB_MAX_PASSES passes go out as several launches, whose tables then replace each other in the workspace)
+                if (n_pass == CB_MAX_PASSES) { const int rcm = launch_multi(); if (rcm) return rcm; }
                 memcpy(static_cast<void *>(&passes_host[n_pass]), &tab, sizeof(tab));
                 ++n_pass;
                 reset();
@@ -951,40 +990,7 @@ int cb_run(const aoc_corr_frame *frames_host, const AocCorrRecFrame *rec_host, i
         }
         int rc = flush();
         if (rc) return rc;
-        if (multi_ok && n_pass > 0) {
-            // the tables are a function of the set structure alone: a sequence writes them once (key = a hash of their bytes)
-            uint64_t key = 0xcbf29ce484222325ull ^ (uint64_t)n_pass;
-            for (int i = 0; i < n_pass; ++i) {
-                // every byte is initialised: tiles are value-initialised, the per-output arrays and the unused tiles are zeroed below
-                AocCorrTiles &t = passes_host[i];
-                for (int k = t.n; k < AOC_CORR_TABLE_TILES; ++k) t.t[k] = AocCorrTile{};
-                for (int k = t.n_out; k < AOC_CORR_MAX_OUT; ++k) { t.oc_offset[k] = 0; t.oc_bias[k] = 0; t.oc_row0[k] = 0; t.oc_rows[k] = 0; }
-                const uint64_t *w = reinterpret_cast<const uint64_t *>(&t);
-                for (size_t k = 0; k < sizeof(AocCorrTiles) / 8; ++k) key = (key ^ w[k]) * 0x100000001b3ull + (key >> 29);
-            }
-            key |= 1ull;
-            if ((uint64_t)*tables_key != key) {
-                for (int i = 0; i < n_pass; ++i)
-                    hipLaunchKernelGGL(cb_table_write_kernel, dim3(1), dim3(256), 0, st, passes_host[i], cb_pass_table(workspace, i));
-                *tables_key = (int64_t)key;
-            }
-            int nt_max = 0;
-            for (int i = 0; i < n_pass; ++i) nt_max = passes_host[i].n > nt_max ? passes_host[i].n : nt_max;
-            const size_t lds = (size_t)nt_max * tile_bytes + lds_fixed;
-            int64_t bpp = (2 * (int64_t)n_cu) / n_pass;                       // the passes' workgroups are resident together: two per CU in all
-            if (bpp < 1) bpp = 1;
-            if (bpp > T * fr.n) bpp = T * fr.n;
-            AocCorrRecFrames rf;
-            rf.n = fr.n;
-            for (int f = 0; f < fr.n; ++f) rf.f[f] = rec_host[f0 + f];
-            static const bool lds_ok = hipFuncSetAttribute(reinterpret_cast<const void *>(proxy_corr_records_multi_kernel<CR_NW>),
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) == hipSuccess;
-            if (!lds_ok) return AOC_ERR_LAUNCH;
-            static const int dbg_m = AOC_DEV_ENV_INT("AOC_CORR_DEBUG", 0);
-            hipLaunchKernelGGL((proxy_corr_records_multi_kernel<CR_NW>), dim3((unsigned)bpp, (unsigned)n_pass), dim3(CR_NW * 64), lds, st, rf, m,
-                               cb_pass_table(workspace, 0), transform, gate, dbg_m, call_seq);
-            if (hipGetLastError() != hipSuccess) return AOC_ERR_LAUNCH;
-        }
+        { const int rcm = launch_multi(); if (rcm) return rcm; }
     }
     // exact-fp32 kernel: runs only when a precondition of the split arithmetic failed somewhere in the launch
     return aoc_corr_fp32_batched(frames_host, n_frames, m, C, n_proxy, n_set, set_begin_host, set_size_host, set_out_offset_host, 1, transform,

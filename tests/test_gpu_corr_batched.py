@@ -159,7 +159,7 @@ def test_tiled_records_are_the_row_major_records_reordered(aoc):
     assert torch.equal(b.records, want)
 
 
-@pytest.mark.parametrize("levels,n_obj,kmax", [([8, 16, 32], 6, 32), ([64], 9, 64), ([16], 4, 16), ([8, 16, 32], 2, 32)])
+@pytest.mark.parametrize("levels,n_obj,kmax", [([8, 16, 32], 6, 32), ([64], 9, 64), ([16], 4, 16), ([8, 16, 32], 2, 32), ([64], 24, 64)])   # the last: 97 tiles = more passes than the table holds
 def test_all_passes_in_one_launch_equal_pass_by_pass(levels, n_obj, kmax):
     """aoc_proxy_corr_min_records_cached (round 5: the passes of a frame with more than 5 proxy tiles as a grid dimension, tile tables kept in the
     workspace) against aoc_proxy_corr_min_records (one launch per pass): every workgroup runs the same code on the same pass -> EQUAL, on the
@@ -200,4 +200,6 @@ def test_all_passes_in_one_launch_equal_pass_by_pass(levels, n_obj, kmax):
         ops.proxy_corr_min_records([(q, qs, table, sqn, b, out_b)], *sets, True, cache=cache)
         torch.cuda.synchronize()
         assert torch.equal(out_a, out_b), f"trial {trial}: one launch != pass by pass ({float((out_a - out_b).abs().max())})"
-        assert cache.key.value != 0 and (trial != 1 or cache.key.value == key_before) and (trial != 2 or cache.key.value != key_before)
+        assert cache.key.value != 0
+        if n_obj < 24:            # (beyond 16 passes the tables go out in two launches and the key is the last one's)
+            assert (trial != 1 or cache.key.value == key_before) and (trial != 2 or cache.key.value != key_before)
