@@ -661,6 +661,31 @@ int aoc_frame_channels(int n_radii, int n_levels, int matching_background);
 size_t aoc_frame_workspace_bytes(int h, int w, int C, int n_obj, int R_capacity, int n_radii, int n_levels);
 int aoc_frame_enqueue(const aoc_frame_desc *desc, aoc_seq_state *state, void *workspace, size_t workspace_bytes, aoc_stream_t stream);
 
+/* The adaptive proxies of the frames that see ONE pool state as ONE call (round 5): what hotpath.launch_cluster_proxies_batch issued as
+ * three C calls plus a dozen tensor allocations and 2 F table copies -- aoc_kmeans_replicate_levels, aoc_kmeans_segmented_rep (20 Lloyd
+ * iterations, AEM:252-279), aoc_build_proxies (AEM:280-282) and the scatter of every frame's proxies into ITS proxy table -- out of one
+ * caller-owned workspace, enqueued on `stream` (the caller's side stream) without host synchronisation.  Bit-identical to the three calls.
+ * With aoc_frame_enqueue and aoc_gates_enqueue a frame of the orchestrated path is three C calls (one per stream it touches). */
+typedef struct aoc_chain_desc {
+    int32_t C, n_obj, n_frames;      /* embedding width, objects incl. background, frames F that see this pool state (<= 8) */
+    int32_t n_levels, levels[8];     /* cluster_num per level (AEM:232) */
+    int32_t kmax, iters;             /* max(levels); Lloyd iterations (20: scipy's kmeans2 default the reference uses) */
+    int32_t reserved0;
+    int64_t pool_rows;               /* rows of the pool the matchings see (R * h * w, or R * match_hw on the atrous grid) */
+    int64_t rows_capacity;           /* entries of obj_rows (aoc_label_prep: pool_rows * n_obj) */
+    const float *pool;               /* [pool_rows, C] */
+    const int32_t *fg_rows, *obj_rows, *obj_offsets;    /* aoc_label_prep of that pool's labels */
+    const int32_t *init_rows;        /* [n_frames * n_levels * n_obj, kmax] segment-local initial rows, (frame, level, object)-major */
+    float *tables[8];                /* per frame: its proxy table [n_levels * n_obj * 2 * kmax + n_obj, C]; the adaptive rows are written */
+    float *sqnorms[8];               /* per frame: [n_levels * n_obj * 2 * kmax + n_obj] */
+} aoc_chain_desc;
+size_t aoc_cluster_chain_workspace_bytes(const aoc_chain_desc *desc);
+/* byte offsets (into the workspace) of what the chain leaves there, for callers that want to look at it: [0] centroids [S, kmax, C] float,
+ * [1] labels [n_frames * n_levels * rows_capacity] int32, [2] cluster counts [S, kmax] int32, [3] proxies [S, 2, kmax, C] float,
+ * [4] proxy squared norms [S, 2, kmax] float, [5] seg_k [S] int32, [6] seg_offsets [S + 1] int32;  S = n_frames * n_levels * n_obj */
+int aoc_cluster_chain_layout(const aoc_chain_desc *desc, int64_t *offsets7);
+int aoc_cluster_chain_enqueue(const aoc_chain_desc *desc, void *workspace, size_t workspace_bytes, aoc_stream_t stream);
+
 /* The modulation gates of CalibrationDecoding.forward (decoding_module.py:96-149, 162-210) as ONE call: a list of gate descriptors, every
  * gate issuing exactly the launches of its module mirror (outputs bit-identical to attention.IA_gate / conditioning_layer.conditioning_block).
  *   kind 0  IA_gate (ATT:7-17):                       y = x * (1 + tanh(head W^T + b)),                     W [channels, head_dim]

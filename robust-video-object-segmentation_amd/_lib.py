@@ -74,6 +74,9 @@ SIGNATURES = {
     "aoc_frame_channels": (_i, [_i, _i, _i]),
     "aoc_frame_workspace_bytes": (_sz, [_i, _i, _i, _i, _i, _i, _i]),
     "aoc_frame_enqueue": (_i, [_vp, _vp, _vp, _sz, _vp]),
+    "aoc_cluster_chain_workspace_bytes": (_sz, [_vp]),
+    "aoc_cluster_chain_layout": (_i, [_vp, _vp]),
+    "aoc_cluster_chain_enqueue": (_i, [_vp, _vp, _sz, _vp]),
     "aoc_gates_workspace_bytes": (_sz, [_vp, _i, _i, _i]),
     "aoc_gates_enqueue": (_i, [_vp, _i, _vp, _i, _i, _vp, _sz, _vp]),
     "aoc_local_window_match": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp]),

@@ -302,6 +302,101 @@ int aoc_frame_enqueue(const aoc_frame_desc *d, aoc_seq_state *state, void *works
 }
 
 // ------------------------------------------------------------------------------------------
+// The k-means chain of the frames that see one pool state as ONE call (see include/aoc_hip.h): the three entry points the Python orchestrator
+// called one by one, out of one workspace, plus one launch that scatters every frame's proxies into its own proxy table.
+namespace {
+struct ChainWs {
+    int32_t *rows_f, *off_f, *k_f, *labels, *ccounts;
+    float *centroids, *proxies, *psq;
+    char *km_ws, *bp_ws;
+    size_t km_bytes, bp_bytes, total;
+    int64_t off[7];
+};
+inline ChainWs chain_carve(void *base, const aoc_chain_desc *d) {
+    ChainWs w;
+    char *p = static_cast<char *>(base);
+    size_t off = 0;
+    auto take = [&](size_t bytes, int64_t *where) { char *r = p ? p + off : nullptr; if (where) *where = (int64_t)off; off += aoc_align_up(bytes, 256); return r; };
+    const int FL = d->n_frames * d->n_levels, S = FL * d->n_obj;
+    const int64_t cap = (int64_t)FL * d->rows_capacity;
+    w.centroids = reinterpret_cast<float *>(take((size_t)S * d->kmax * d->C * sizeof(float), &w.off[0]));
+    w.labels = reinterpret_cast<int32_t *>(take((size_t)cap * sizeof(int32_t), &w.off[1]));
+    w.ccounts = reinterpret_cast<int32_t *>(take((size_t)S * d->kmax * sizeof(int32_t), &w.off[2]));
+    w.proxies = reinterpret_cast<float *>(take((size_t)S * 2 * d->kmax * d->C * sizeof(float), &w.off[3]));
+    w.psq = reinterpret_cast<float *>(take((size_t)S * 2 * d->kmax * sizeof(float), &w.off[4]));
+    w.k_f = reinterpret_cast<int32_t *>(take((size_t)S * sizeof(int32_t), &w.off[5]));
+    w.off_f = reinterpret_cast<int32_t *>(take((size_t)(S + 1) * sizeof(int32_t), &w.off[6]));
+    w.rows_f = FL > 1 ? reinterpret_cast<int32_t *>(take((size_t)cap * sizeof(int32_t), nullptr)) : nullptr;      // one replica: the label prep's own list
+    w.km_bytes = aoc_kmeans_workspace_bytes(cap, S, d->kmax, d->C);
+    w.km_ws = take(w.km_bytes, nullptr);
+    w.bp_bytes = aoc_build_proxies_workspace_bytes(cap, S, d->kmax);
+    w.bp_ws = take(w.bp_bytes, nullptr);
+    w.total = off;
+    return w;
+}
+inline bool chain_desc_ok(const aoc_chain_desc *d) {
+    if (!d || d->C < 1 || d->n_obj < 1 || d->n_frames < 1 || d->n_frames > 8 || d->n_levels < 1 || d->n_levels > 8 || d->kmax < 1 || d->iters < 1) return false;
+    if (d->pool_rows < 1 || d->rows_capacity < 1 || (int64_t)d->n_frames * d->n_levels * d->rows_capacity >= (1ll << 31)) return false;
+    for (int l = 0; l < d->n_levels; ++l)
+        if (d->levels[l] < 1 || d->levels[l] > d->kmax) return false;
+    return true;
+}
+struct ChainTables {
+    float *table[8], *sqn[8];
+};
+// tables[f][row, :] = proxies[f * rows_per_frame + row, :], sqnorms[f][row] = psq[...]   (rows_per_frame = levels * objects * 2 * kmax)
+__global__ __launch_bounds__(256) void chain_scatter_kernel(const float *__restrict__ proxies, const float *__restrict__ psq, ChainTables t, int n_frames,
+                                                             int rows_per_frame, int C4) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t per = (int64_t)rows_per_frame * C4;
+    if (idx >= per * n_frames) return;
+    const int f = (int)(idx / per);
+    const int64_t rem = idx - (int64_t)f * per;
+    reinterpret_cast<float4 *>(t.table[f])[rem] = reinterpret_cast<const float4 *>(proxies)[idx];
+    if (rem < rows_per_frame) t.sqn[f][rem] = psq[(int64_t)f * rows_per_frame + rem];
+}
+}  // namespace
+
+size_t aoc_cluster_chain_workspace_bytes(const aoc_chain_desc *d) { return chain_desc_ok(d) ? chain_carve(nullptr, d).total : 0; }
+
+int aoc_cluster_chain_layout(const aoc_chain_desc *d, int64_t *offsets7) {
+    if (!chain_desc_ok(d) || !offsets7) return AOC_ERR_INVALID_ARG;
+    const ChainWs w = chain_carve(nullptr, d);
+    for (int i = 0; i < 7; ++i) offsets7[i] = w.off[i];
+    return AOC_OK;
+}
+
+int aoc_cluster_chain_enqueue(const aoc_chain_desc *d, void *workspace, size_t workspace_bytes, aoc_stream_t stream) {
+    if (!chain_desc_ok(d) || !workspace) return AOC_ERR_INVALID_ARG;
+    if (!d->pool || !d->fg_rows || !d->obj_rows || !d->obj_offsets || !d->init_rows) return AOC_ERR_INVALID_ARG;
+    if (d->C > AOC_MAX_CHANNELS || d->kmax > AOC_MAX_CLUSTERS || d->n_obj > AOC_MAX_OBJECTS || (d->C & 3)) return AOC_ERR_UNSUPPORTED;
+    for (int f = 0; f < d->n_frames; ++f)
+        if (!d->tables[f] || !d->sqnorms[f] || (reinterpret_cast<uintptr_t>(d->tables[f]) & 15)) return AOC_ERR_INVALID_ARG;
+    if (workspace_bytes < aoc_cluster_chain_workspace_bytes(d)) return AOC_ERR_WORKSPACE;
+    const ChainWs w = chain_carve(workspace, d);
+    const int FL = d->n_frames * d->n_levels, S = FL * d->n_obj;
+    const int64_t cap = (int64_t)FL * d->rows_capacity;
+    int rc;
+    // the replicated segment lists with the sticky K of every (frame, level) (AEM:268) -- one replica: offsets and K only, the rows stay where they are
+    int32_t *rows_f = FL > 1 ? w.rows_f : const_cast<int32_t *>(d->obj_rows);
+    rc = aoc_kmeans_replicate_levels(d->obj_rows, d->obj_offsets, d->n_obj, FL, d->levels, d->n_levels, d->rows_capacity, rows_f, w.off_f, w.k_f, stream);
+    if (rc != AOC_OK) return rc;
+    rc = aoc_kmeans_segmented_rep(d->pool, d->pool_rows, d->C, rows_f, w.off_f, w.k_f, d->init_rows, S, FL, d->kmax, d->iters, cap, w.centroids, w.labels, w.ccounts,
+                                  w.km_ws, w.km_bytes, stream);
+    if (rc != AOC_OK) return rc;
+    rc = aoc_build_proxies(d->pool, d->pool_rows, d->C, d->fg_rows, w.off_f, w.k_f, w.labels, w.centroids, S, d->kmax, cap, w.proxies, w.psq, w.bp_ws, w.bp_bytes, stream);
+    if (rc != AOC_OK) return rc;
+    ChainTables t;
+    for (int f = 0; f < 8; ++f) { t.table[f] = f < d->n_frames ? d->tables[f] : nullptr; t.sqn[f] = f < d->n_frames ? d->sqnorms[f] : nullptr; }
+    const int rows_per_frame = d->n_levels * d->n_obj * 2 * d->kmax;
+    const int64_t total = (int64_t)rows_per_frame * (d->C / 4) * d->n_frames;
+    hipLaunchKernelGGL(chain_scatter_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, aoc_hip_stream(stream), w.proxies, w.psq, t, d->n_frames,
+                       rows_per_frame, d->C / 4);
+    AOC_RETURN_IF_LAUNCH_FAILED();
+    return AOC_OK;
+}
+
+// ------------------------------------------------------------------------------------------
 // The modulation gates of CalibrationDecoding.forward (decoding_module.py:96-149, 162-210) as ONE call: the reference applies them inside a
 // single forward call; here a list of gate descriptors is walked and each gate issues exactly the launches of its module mirror
 // (attention.IA_gate / hotpath's extended-head gate / conditioning_layer.conditioning_block), so the outputs are bit-identical to the modules'.

@@ -121,11 +121,10 @@ def launch_cluster_proxies_batch(cfg, ref_emb, ref_labels, init_rows_list, side_
                 t.record_stream(side)
         prep_event = torch.cuda.Event()
         prep_event.record(side)
-        cap = prep.obj_rows.numel()
-        rows_f, off_f, k_f = ops.kmeans_replicate_levels(prep.obj_rows, prep.obj_offsets, O, F * L, levels, rows_capacity=cap)
         init = init_rows_list[0] if F == 1 else torch.cat([r.reshape(L * O, kmax) for r in init_rows_list], dim=0)
-        cen, lab, _ = ops.kmeans_segmented(pool, rows_f, off_f, k_f, init.reshape(F * L * O, kmax), kmax, KMEANS_ITERS, rows_capacity=F * L * cap, n_rep=F * L)
-        proxies, psq = ops.build_proxies(pool, prep.fg_rows, off_f, k_f, lab, cen)          # [F*L*O, 2, kmax, C]
+        # ONE C call (aoc_cluster_chain_enqueue): replicated lists with the sticky K, 20 Lloyd iterations, proxy construction, and every frame's
+        # proxies scattered into its own table -- what used to be three C calls, a dozen allocations and 2 F table copies (same results)
+        ch = ops.cluster_chain(pool, prep, levels, init.reshape(F * L * O, kmax), tables, sqns, KMEANS_ITERS)
         for f in range(F):
             out = ClusterProxiesAhead()
             out.R = R
@@ -133,10 +132,8 @@ def launch_cluster_proxies_batch(cfg, ref_emb, ref_labels, init_rows_list, side_
             out.prep, out.prep_event = prep, prep_event
             out.table, out.sqn = tables[f], sqns[f]
             sl = slice(f * L * O, (f + 1) * L * O)
-            out.table[:n_ad].copy_(proxies[sl].reshape(-1, C))
-            out.sqn[:n_ad].copy_(psq[sl].reshape(-1))
-            out.aux = dict(prep=prep, centroids=cen[sl], proxies=proxies[sl], proxy_sqnorm=psq[sl], seg_k=k_f[sl], seg_offsets=off_f,
-                           labels=lab if F == 1 else None)
+            out.aux = dict(prep=prep, centroids=ch["centroids"][sl], proxies=ch["proxies"][sl], proxy_sqnorm=ch["proxy_sqnorm"][sl], seg_k=ch["seg_k"][sl],
+                           seg_offsets=ch["seg_offsets"], labels=ch["labels"] if F == 1 else None, chain=ch)
             outs.append(out)
         done = torch.cuda.Event()
         done.record(side)

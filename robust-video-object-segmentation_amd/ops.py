@@ -607,6 +607,51 @@ class _FrameDesc(ctypes.Structure):
                 ("feat", ctypes.c_void_p), ("head", ctypes.c_void_p), ("probe", ctypes.c_void_p * 6)]
 
 
+class _ChainDesc(ctypes.Structure):
+    """aoc_chain_desc of include/aoc_hip.h."""
+    _fields_ = [("C", ctypes.c_int32), ("n_obj", ctypes.c_int32), ("n_frames", ctypes.c_int32), ("n_levels", ctypes.c_int32), ("levels", ctypes.c_int32 * 8),
+                ("kmax", ctypes.c_int32), ("iters", ctypes.c_int32), ("reserved0", ctypes.c_int32),
+                ("pool_rows", ctypes.c_int64), ("rows_capacity", ctypes.c_int64),
+                ("pool", ctypes.c_void_p), ("fg_rows", ctypes.c_void_p), ("obj_rows", ctypes.c_void_p), ("obj_offsets", ctypes.c_void_p),
+                ("init_rows", ctypes.c_void_p), ("tables", ctypes.c_void_p * 8), ("sqnorms", ctypes.c_void_p * 8)]
+
+
+def cluster_chain(pool, prep, levels, init_rows, tables, sqnorms, iters=20):
+    """aoc_cluster_chain_enqueue: the k-means chain of len(tables) frames that see one pool state -- replicated lists with sticky K, 20 Lloyd
+    iterations, proxy construction, every frame's proxies scattered into ITS table -- as ONE C call out of one workspace (on the current stream,
+    no host synchronisation).  pool [rows, C]; prep = LabelPrep of the pool's labels; init_rows int32 [F * L * O, kmax]; tables[f] [L*O*2*kmax + O, C],
+    sqnorms[f] [L*O*2*kmax + O].  Returns a dict of views into the workspace (centroids, labels, cluster_counts, proxies, proxy_sqnorm, seg_k,
+    seg_offsets), valid until the workspace is reused."""
+    pool = _f32c(pool)
+    _need_gpu(pool, init_rows, *tables, *sqnorms)
+    F, L, O, C = len(tables), len(levels), prep.n_obj, pool.shape[1]
+    kmax = int(max(levels))
+    init_rows = init_rows.to(torch.int32).contiguous()
+    assert 1 <= F <= 8 and init_rows.numel() == F * L * O * kmax
+    d = _ChainDesc()
+    d.C, d.n_obj, d.n_frames, d.n_levels, d.kmax, d.iters = C, O, F, L, kmax, int(iters)
+    for i, k in enumerate(levels):
+        d.levels[i] = int(k)
+    d.pool_rows, d.rows_capacity = pool.shape[0], prep.obj_rows.numel()
+    d.pool, d.fg_rows, d.obj_rows, d.obj_offsets, d.init_rows = pool.data_ptr(), prep.fg_rows.data_ptr(), prep.obj_rows.data_ptr(), prep.obj_offsets.data_ptr(), init_rows.data_ptr()
+    for f in range(F):
+        assert tables[f].is_contiguous() and tables[f].dtype == torch.float32 and tables[f].shape[0] >= L * O * 2 * kmax
+        d.tables[f], d.sqnorms[f] = tables[f].data_ptr(), sqnorms[f].data_ptr()
+    lib = _lib.lib()
+    ws = _ws(lib.aoc_cluster_chain_workspace_bytes(ctypes.byref(d)), pool.device)
+    _lib.check(lib.aoc_cluster_chain_enqueue(ctypes.byref(d), _p(ws), ws.numel(), _stream()), "aoc_cluster_chain_enqueue")
+    off = (ctypes.c_int64 * 7)()
+    _lib.check(lib.aoc_cluster_chain_layout(ctypes.byref(d), off), "aoc_cluster_chain_layout")
+    S, cap = F * L * O, F * L * prep.obj_rows.numel()
+
+    def view(i, n, dtype, shape):
+        return ws[off[i]:off[i] + n * 4].view(dtype).view(shape)
+    return dict(workspace=ws, keep=(pool, init_rows), centroids=view(0, S * kmax * C, torch.float32, (S, kmax, C)), labels=view(1, cap, torch.int32, (cap,)),
+                cluster_counts=view(2, S * kmax, torch.int32, (S, kmax)), proxies=view(3, S * 2 * kmax * C, torch.float32, (S, 2, kmax, C)),
+                proxy_sqnorm=view(4, S * 2 * kmax, torch.float32, (S, 2, kmax)), seg_k=view(5, S, torch.int32, (S,)),
+                seg_offsets=view(6, S + 1, torch.int32, (S + 1,)))
+
+
 class _GateDesc(ctypes.Structure):
     """aoc_gate_desc of include/aoc_hip.h."""
     _fields_ = [("kind", ctypes.c_int32), ("channels", ctypes.c_int32), ("k_rank", ctypes.c_int32), ("reserved", ctypes.c_int32), ("hw", ctypes.c_int64),

@@ -149,3 +149,35 @@ def test_gates_batch_follows_the_weights_storage(aoc):
     gates.IA11.IA.bias = torch.nn.Parameter(torch.full_like(gates.IA11.IA.bias, 0.3))
     for a, b in zip(gates.forward_batched(acts, head), gates(acts, head)):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("levels,F", [(None, 1), (None, 3), ([8, 16, 32], 2)])
+def test_cluster_chain_one_call_equals_the_three_calls(aoc, levels, F):
+    """aoc_cluster_chain_enqueue (round 5) against aoc_kmeans_replicate_levels + aoc_kmeans_segmented_rep + aoc_build_proxies + the table copies."""
+    syn, hot, ops = aoc.synthetic, aoc.hotpath, aoc.ops
+    cfg = syn.CONFIGS["tiny"]
+    clip = syn.make_clip(cfg, 4, frames=3)
+    O, C = cfg.n_obj, cfg.c
+    mc = hot.MatchingConfig(CLUSTER_LEVELS=levels)
+    lv, kmax = mc.cluster_levels, max(mc.cluster_levels)
+    L = len(lv)
+    emb = torch.from_numpy(clip["emb"][:2].copy()).cuda()
+    lab = torch.from_numpy(np.stack([syn.one_hot(l, O) for l in clip["lab"][:2]])).cuda()
+    pool = emb.reshape(-1, C)
+    prep = ops.label_prep(lab.reshape(-1, O))
+    counts = [int(lab[..., o].sum().item()) for o in range(O)]
+    inits = [_init_rows_dev(syn, 40 + f, counts, lv, O) for f in range(F)]
+    outs = hot.launch_cluster_proxies_batch(mc, emb, lab, inits)
+    cap = prep.obj_rows.numel()
+    rows_f, off_f, k_f = ops.kmeans_replicate_levels(prep.obj_rows, prep.obj_offsets, O, F * L, lv, rows_capacity=cap)
+    init = torch.cat([r.reshape(L * O, kmax) for r in inits], dim=0)
+    cen, labels, cnt = ops.kmeans_segmented(pool, rows_f, off_f, k_f, init, kmax, 20, rows_capacity=F * L * cap, n_rep=F * L)
+    proxies, psq = ops.build_proxies(pool, prep.fg_rows, off_f, k_f, labels, cen)
+    torch.cuda.synchronize()
+    n_ad = L * O * 2 * kmax
+    for f, out in enumerate(outs):
+        sl = slice(f * L * O, (f + 1) * L * O)
+        assert torch.equal(out.table[:n_ad], proxies[sl].reshape(-1, C)) and torch.equal(out.sqn[:n_ad], psq[sl].reshape(-1))
+        assert torch.equal(out.aux["centroids"], cen[sl]) and torch.equal(out.aux["seg_k"], k_f[sl])
+    ch = outs[0].aux["chain"]
+    assert torch.equal(ch["labels"][:int(off_f[-1])], labels[:int(off_f[-1])]) and torch.equal(ch["cluster_counts"], cnt) and torch.equal(ch["seg_offsets"], off_f)

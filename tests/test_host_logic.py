@@ -294,6 +294,32 @@ def test_frame_call_validates_everything_before_it_touches_the_state():
     assert call(desc(), nbytes=1024) == WORKSPACE     # a complete descriptor: the next check is the workspace size
 
 
+def test_chain_desc_matches_the_header(tmp_path):
+    """aoc_chain_desc as ctypes lays it out (ops._ChainDesc) against the C compiler's view of include/aoc_hip.h; validation without a GPU."""
+    import ctypes
+    src = tmp_path / "cz.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "%s"\nint main(void){printf("%%zu %%zu %%zu %%zu %%zu\\n", sizeof(aoc_chain_desc), '
+                   'offsetof(aoc_chain_desc, pool_rows), offsetof(aoc_chain_desc, pool), offsetof(aoc_chain_desc, init_rows), offsetof(aoc_chain_desc, sqnorms));return 0;}\n'
+                   % os.path.join(ROOT, "include", "aoc_hip.h"))
+    exe = tmp_path / "cz"
+    subprocess.run(["gcc", "-o", str(exe), str(src)], check=True)
+    got = [int(v) for v in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.split()]
+    D = aoc_amd.ops._ChainDesc
+    assert got == [ctypes.sizeof(D), D.pool_rows.offset, D.pool.offset, D.init_rows.offset, D.sqnorms.offset]
+    L = aoc_amd._lib.lib()
+    d = D()
+    assert L.aoc_cluster_chain_workspace_bytes(ctypes.byref(d)) == 0                 # an empty descriptor
+    d.C, d.n_obj, d.n_frames, d.n_levels, d.kmax, d.iters, d.pool_rows, d.rows_capacity = 100, 3, 2, 2, 16, 20, 960, 2880
+    d.levels[0], d.levels[1] = 8, 16
+    need = L.aoc_cluster_chain_workspace_bytes(ctypes.byref(d))
+    off = (ctypes.c_int64 * 7)()
+    assert need > 0 and L.aoc_cluster_chain_layout(ctypes.byref(d), off) == 0 and list(off) == sorted(off) and off[0] == 0 and off[6] < need
+    buf = (ctypes.c_float * 16)()
+    assert L.aoc_cluster_chain_enqueue(ctypes.byref(d), ctypes.cast(buf, ctypes.c_void_p), need, None) == -1          # null pool / lists
+    d.levels[1] = 17
+    assert L.aoc_cluster_chain_workspace_bytes(ctypes.byref(d)) == 0                 # a level above kmax
+
+
 def test_round5_entry_points_reject_bad_arguments_without_a_gpu():
     """aoc_atrous_subsample and aoc_proxy_corr_min_records_cached validate before any launch."""
     import ctypes
