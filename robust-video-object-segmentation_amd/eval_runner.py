@@ -321,7 +321,7 @@ def run_sequence(spec: SequenceSpec, backend, device, metric=None, max_frames: O
                 sum_f=after["sum_f"] - before["sum_f"], iou_count=after["objects"] - before["objects"])
 
 
-def run_interleaved(specs_data, device, lanes, backend_factory=None, dense_precision=None):
+def run_interleaved(specs_data, device, lanes, backend_factory=None, dense_precision=None, stagger=1):
     """A rank's share with ``lanes`` sequences in flight: every lane owns a HIP stream, a backend (per-sequence state) and a metric
     accumulator, takes the next sequence off the rank's list when it finishes one, and the lanes' frames are enqueued round-robin from
     this one host thread.  The reference-API path reads the O + 1 row counts back once per frame (scipy's initial rows are drawn on the
@@ -336,9 +336,16 @@ def run_interleaved(specs_data, device, lanes, backend_factory=None, dense_preci
     frames = objects = 0
     keep = []                                       # the sequences' tensors stay alive until the last lane has drained
     torch.cuda.synchronize(device)
+    n_pass = 0
     while True:
         busy = False
+        n_pass += 1
         for l in range(n_lanes):
+            if n_pass <= l * stagger and todo:
+                # lane l takes its first sequence l * stagger passes after lane 0: sequences with the same MEM_EVERY would otherwise reach their
+                # pool changes (row-count read-back, host draws, a k-means chain nothing else of the lane overlaps) on the same pass
+                busy = True
+                continue
             with torch.cuda.stream(streams[l]):
                 if running[l] is None and todo:
                     spec, data = todo.pop(0)
@@ -358,11 +365,12 @@ def run_interleaved(specs_data, device, lanes, backend_factory=None, dense_preci
                 iou_count=sum(t["objects"] for t in tot))
 
 
-def eval_sharded(specs: Sequence[SequenceSpec], rank: int, world: int, device, backend=None, metric=None, max_frames=None, barrier=None, lanes=1):
+def eval_sharded(specs: Sequence[SequenceSpec], rank: int, world: int, device, backend=None, metric=None, max_frames=None, barrier=None, lanes=1, stagger=1):
     """Partition ``specs`` over ``world`` ranks (LPT on frames x objects), make this rank's sequences resident on the device, then (after
     ``barrier()`` when given) run them and all-reduce the accumulators.  Returns the job totals plus the load-balance figures (max / mean
     rank time) and ``loop_seconds_max`` = the slowest rank's time for its share, inputs resident; identical on every rank.
-    lanes > 1 (GPU only): that many of the rank's sequences are in flight at a time (run_interleaved); a rank's time is then its loop time."""
+    lanes > 1 (GPU only): that many of the rank's sequences are in flight at a time (run_interleaved, lane l starting l * stagger frames after
+    lane 0); a rank's time is then its loop time."""
     parts = sharding.lpt_partition([s.cost for s in specs], world)
     mine = parts[rank]
     interleave = lanes > 1 and device.type == "cuda" and backend is None and metric is None
@@ -375,7 +383,7 @@ def eval_sharded(specs: Sequence[SequenceSpec], rank: int, world: int, device, b
     t0 = time.perf_counter()
     if interleave:
         order = sorted(mine, key=lambda i: -specs[i].cost)           # longest first: the lanes finish together
-        r = run_interleaved([(specs[i], data.pop(i)) for i in order], device, lanes)
+        r = run_interleaved([(specs[i], data.pop(i)) for i in order], device, lanes, stagger=stagger)
         for k in r:
             local[k] += r[k]
         local["gpu_seconds"] = time.perf_counter() - t0

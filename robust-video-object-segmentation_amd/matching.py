@@ -14,7 +14,6 @@ reference (cited per function); every computation runs in csrc/libaoc_hip.so.  `
 """
 import numpy as np
 import torch
-import torch.nn.functional as F
 
 from . import ops
 
@@ -35,42 +34,32 @@ def _bias_vec(dis_bias, obj_nums, device):
 
 
 def _flatten_pool(all_ref_emb, all_ref_labels, h, w, atrous_rate, atrous_obj_pixel_num):
-    """AEM:507-579 / 715-787: concatenate the reference frames (+ optional atrous subsampling).
-    Pure view / concat plumbing; unlike the reference it never writes into the caller's labels."""
-    embedding_dim = all_ref_emb[0].size(2)
-    obj_nums = all_ref_labels[0].size(2)
+    """The reference pool as rows (AEM:507-579 / 715-787): every reference frame's pixels, one after the other.
+    atrous_rate > 1, atrous_obj_pixel_num <= 0: only the pixels of the rate-strided grid are rows of the pool -- a device gather
+        (aoc_atrous_subsample) of embeddings and labels;
+    atrous_rate > 1, atrous_obj_pixel_num > 0: all pixels stay rows, but an object with more than atrous_obj_pixel_num * rate^2
+        pixels in a frame keeps its label on the strided grid only.
+    Never writes into the caller's labels (the reference does)."""
+    C, O = all_ref_emb[0].size(2), all_ref_labels[0].size(2)
+    rate = int(atrous_rate)
     embs, labs = [], []
-    if atrous_obj_pixel_num > 0:
-        sel = None
-        if atrous_rate > 1:
-            h_pad = (atrous_rate - h % atrous_rate) % atrous_rate
-            w_pad = (atrous_rate - w % atrous_rate) % atrous_rate
-            sel = torch.zeros(h + h_pad, w + w_pad, device=all_ref_emb[0].device)
-            sel = sel.view((h + h_pad) // atrous_rate, atrous_rate, (w + w_pad) // atrous_rate, atrous_rate)
-            sel[:, 0, :, 0] = 1.
-            sel = sel.reshape(h + h_pad, w + w_pad, 1)[:h, :w]
-        for e, l in zip(all_ref_emb, all_ref_labels):
-            if atrous_rate > 1:
-                l = l.clone()
-                big = l.sum(dim=(0, 1)) > (atrous_obj_pixel_num * atrous_rate ** 2)
-                l[:, :, big] = l[:, :, big] * sel
-            embs.append(e.reshape(-1, embedding_dim))
-            labs.append(l.reshape(-1, obj_nums))
-    else:
-        for e, l in zip(all_ref_emb, all_ref_labels):
-            if atrous_rate > 1:
-                h_pad = (atrous_rate - h % atrous_rate) % atrous_rate
-                w_pad = (atrous_rate - w % atrous_rate) % atrous_rate
-                if h_pad > 0 or w_pad > 0:
-                    e = F.pad(e, (0, 0, 0, w_pad, 0, h_pad))
-                    l = F.pad(l, (0, 0, 0, w_pad, 0, h_pad))
-                e = e.reshape((h + h_pad) // atrous_rate, atrous_rate, (w + w_pad) // atrous_rate, atrous_rate, -1)[:, 0, :, 0, :]
-                l = l.reshape((h + h_pad) // atrous_rate, atrous_rate, (w + w_pad) // atrous_rate, atrous_rate, -1)[:, 0, :, 0, :]
-            embs.append(e.reshape(-1, embedding_dim))
-            labs.append(l.reshape(-1, obj_nums))
+    off_grid = None
+    for e, l in zip(all_ref_emb, all_ref_labels):
+        e, l = e.float(), l.float()
+        if rate > 1 and atrous_obj_pixel_num > 0:
+            if off_grid is None:
+                dev = e.device
+                on = (torch.arange(h, device=dev) % rate == 0)[:, None] & (torch.arange(w, device=dev) % rate == 0)[None, :]
+                off_grid = (~on)[:, :, None]
+            large = l.sum(dim=(0, 1)) > atrous_obj_pixel_num * rate * rate
+            l = l.masked_fill(off_grid & large[None, None, :], 0.0)
+        elif rate > 1:
+            e, l = ops.atrous_subsample(e, rate), ops.atrous_subsample(l, rate)
+        embs.append(e.reshape(-1, C))
+        labs.append(l.reshape(-1, O))
     pool = embs[0] if len(embs) == 1 else torch.cat(embs, 0)
     labels = labs[0] if len(labs) == 1 else torch.cat(labs, 0)
-    return pool.float().contiguous(), labels.float().contiguous()
+    return pool.contiguous(), labels.contiguous()
 
 
 def _emit(feature_planes, h, w, n_planes_per_obj, obj_nums, ori_size):
