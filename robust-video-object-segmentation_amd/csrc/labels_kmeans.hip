@@ -2045,8 +2045,9 @@ __device__ __forceinline__ float ks_chunk_exact(float s, const KsChunkT<NF> &ch,
     return s;
 }
 
+constexpr int KS_SCAN_WAVES = 4;      // waves (feature slices) per workgroup of the stitch
 template <int MODE, int NF>
-__global__ __launch_bounds__(64) void km_sum_scan_kernel(const float *__restrict__ pool, uint32_t pool_bytes, int C,
+__global__ __launch_bounds__(KS_SCAN_WAVES * 64) void km_sum_scan_kernel(const float *__restrict__ pool, uint32_t pool_bytes, int C,
                                                           const int32_t *__restrict__ seg_off, const int32_t *__restrict__ seg_k,
                                                           const int32_t *__restrict__ counts, const int32_t *__restrict__ cbase,
                                                           const uint32_t *__restrict__ moff, int kmax, float *__restrict__ dst,
@@ -2054,24 +2055,29 @@ __global__ __launch_bounds__(64) void km_sum_scan_kernel(const float *__restrict
                                                           const int32_t *__restrict__ cinc0, const int32_t *__restrict__ cinc1,
                                                           int start_chunk, const float *__restrict__ head_state, int n_seg_grid, int xcd_aware,
                                                           KsPred pred) {
-    // 1-D grid, XCD-aware: the C / NF waves of ONE cluster each read 4 NF bytes of the same member rows (the chunks whose summaries do
-    // not apply); with ids that differ by 8 they run on one XCD and fetch every 64-byte sector once instead of once per XCD.  Blocks of 8
-    // clusters x n_q waves; the last block may hold fewer clusters.
+    // 1-D grid of workgroups of KS_SCAN_WAVES independent waves (no barrier, no LDS: a workgroup is only the unit of dispatch -- most clusters
+    // have no tail and their waves leave at once, and a launch of C x kmax x n_seg ONE-wave workgroups is bound by the dispatcher: 172 800 of them
+    // at cfg3, F = 3, took 37 us with nothing to do).  The waves of a workgroup take neighbouring feature slices of ONE cluster.  XCD-aware: the
+    // C / NF waves of a cluster each read 4 NF bytes of the same member rows (the chunks whose summaries do not apply); workgroups whose ids
+    // differ by 8 run on one XCD and fetch every 64-byte sector once instead of once per XCD.  Blocks of 8 clusters x n_qg workgroups; the last
+    // block may hold fewer clusters.
     int s, j, q;
     {
-        const int n_q = C / NF, n_cl = kmax * n_seg_grid;
-        const int b = blockIdx.x, blk = b / (8 * n_q), rem = b - blk * (8 * n_q);
+        const int n_q = C / NF, n_qg = (n_q + KS_SCAN_WAVES - 1) / KS_SCAN_WAVES, n_cl = kmax * n_seg_grid;
+        const int b = blockIdx.x, blk = b / (8 * n_qg), rem = b - blk * (8 * n_qg);
         const int pc = min(8, n_cl - blk * 8);
-        q = rem / pc;
-        int c = blk * 8 + rem - q * pc;
-        if (!xcd_aware) { q = b % n_q; c = b / n_q; }
+        int qg = rem / pc;
+        int c = blk * 8 + rem - qg * pc;
+        if (!xcd_aware) { qg = b % n_qg; c = b / n_qg; }
+        q = qg * KS_SCAN_WAVES + (int)(threadIdx.x >> 6);
+        if (q >= n_q) return;
         j = c % kmax;
         s = c / kmax;
     }
     if (j >= seg_k[s]) return;
     const int cnt = counts[s * kmax + j];
     if (start_chunk > 0 && cnt <= start_chunk * KS_CHUNK) return;       // finished by km_ordered_sum_kernel
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     float *out = (MODE == 0) ? dst + ((size_t)s * kmax + j) * C + NF * q : dst + (((size_t)s * 2 + 1) * kmax + j) * C + NF * q;
     if (cnt == 0) {
         if (MODE == 1 && lane < NF) out[lane] = 0.0f;
@@ -2849,7 +2855,7 @@ inline void ks_launch_sums(hipStream_t st, const float *pool, uint32_t pool_byte
             hipLaunchKernelGGL(km_chunk_fold_kernel, dim3((unsigned)ws.nch_cap * n_fold_groups), dim3(256), 0, st, pool, C, seg_offsets, counts, ws.cbase, ws.moff,
                                kmax, ws.owner_cluster, ws.owner_local, ws.cexp, ws.cinc0, ws.cinc1, start, (const float *)nullptr, ws.cchunk, ws.head, ws.nch_cap,
                                n_fold_groups, km_xcd_aware(), pred);
-        hipLaunchKernelGGL((km_sum_scan_kernel<MODE, 1>), dim3((unsigned)C * kmax * n_seg), dim3(64), 0, st, pool, pool_bytes, C, seg_offsets, seg_k, counts, ws.cbase,
+        hipLaunchKernelGGL((km_sum_scan_kernel<MODE, 1>), dim3((unsigned)((C + KS_SCAN_WAVES - 1) / KS_SCAN_WAVES) * kmax * n_seg), dim3(KS_SCAN_WAVES * 64), 0, st, pool, pool_bytes, C, seg_offsets, seg_k, counts, ws.cbase,
                            ws.moff, kmax, dst, ws.cchunk, ws.cexp, ws.cinc0, ws.cinc1, start, ws.head, n_seg, km_xcd_aware(), pred);
         return;
     }
@@ -2915,7 +2921,7 @@ inline void ks_launch_sums(hipStream_t st, const float *pool, uint32_t pool_byte
     }
 #endif
     static const int nf = AOC_DEV_ENV_INT("AOC_KS_NF", 1);       // features per stitch wave (developer switch)
-#define AOC_KSS(NF) hipLaunchKernelGGL((km_sum_scan_kernel<MODE, NF>), dim3((unsigned)(C / NF) * kmax * n_seg), dim3(64), 0, st, pool, pool_bytes, C, seg_offsets, seg_k, \
+#define AOC_KSS(NF) hipLaunchKernelGGL((km_sum_scan_kernel<MODE, NF>), dim3((unsigned)((C / NF + KS_SCAN_WAVES - 1) / KS_SCAN_WAVES) * kmax * n_seg), dim3(KS_SCAN_WAVES * 64), 0, st, pool, pool_bytes, C, seg_offsets, seg_k, \
                                        counts, ws.cbase, ws.moff, kmax, dst, ws.cchunk, ws.cexp, ws.cinc0, ws.cinc1, start, ws.head, n_seg, km_xcd_aware(), pred)
 #ifdef AOC_DEV
     if (nf == 4) AOC_KSS(4); else if (nf == 2) AOC_KSS(2); else AOC_KSS(1);
