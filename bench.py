@@ -932,6 +932,10 @@ def main():
         n = pool.shape[0]
         return dict(flops=2.0 * iters * n * kmax * C, bytes=float(iters) * n * C * 4 * 2 + n * 4)
 
+    def meta_chain(pool, prep, levels, init_rows, tables, sqnorms, iters=20):
+        n = pool.shape[0]
+        return dict(flops=2.0 * iters * n * max(levels) * C, bytes=float(iters) * n * C * 4 * 2 + n * 4)
+
     def meta_film(x, *a, **k):
         return dict(flops=float(x.numel()), bytes=2.0 * x.numel() * 4)          # 2 O c h w s
 
@@ -940,7 +944,7 @@ def main():
 
     # HIP-event pairs only around the ops the roofline objects need (an event pair costs ~25 us of host time, and the host
     # enqueues ~60 ops per frame); every kernel's duration is in the rocprofv3 summary under profiles/
-    timer = OpTimer(["dense_match_min", "dense_match_min_split", "proxy_corr_min", "proxy_corr_min_batched", "proxy_corr_min_records", "kmeans_segmented",
+    timer = OpTimer(["dense_match_min", "dense_match_min_split", "proxy_corr_min", "proxy_corr_min_batched", "proxy_corr_min_records", "kmeans_segmented", "cluster_chain",
                      "local_window_match",
                      "film_scale", "cond_gate_pool"])
     def frame_meta(kind, m, n):
@@ -953,7 +957,7 @@ def main():
         wl.timer = timer
     timer.serialize_dense = bool(args.dense_order) and not args.no_dense_order
     timer.install(dict(dense_match_min=meta_dense, dense_match_min_split=meta_dense_split, proxy_corr_min=meta_proxy,
-                       proxy_corr_min_batched=meta_proxy_batched, proxy_corr_min_records=meta_proxy_records, kmeans_segmented=meta_kmeans, film_scale=meta_film, cond_gate_pool=meta_cond))
+                       proxy_corr_min_batched=meta_proxy_batched, proxy_corr_min_records=meta_proxy_records, kmeans_segmented=meta_kmeans, cluster_chain=meta_chain, film_scale=meta_film, cond_gate_pool=meta_cond))
     corr_stream = torch.cuda.Stream(device=dev) if batch_corr else None
 
     def run_steps(n):
@@ -1084,7 +1088,9 @@ def main():
         np.random.seed(1234 + rank)
         with torch.no_grad():
             eval_runner.eval_sharded(specs[:1], 0, 1, dev, max_frames=3)          # warm-up of this path's allocations
-            tot = eval_runner.eval_sharded(specs, rank, world, dev, barrier=barrier, lanes=max(1, args.eval_lanes))
+            first = eval_runner.eval_sharded(specs, rank, world, dev, barrier=barrier, lanes=max(1, args.eval_lanes))
+            barrier()
+            tot = eval_runner.eval_sharded(specs, rank, world, dev, barrier=barrier, lanes=max(1, args.eval_lanes))       # the same set once more
             barrier()
         secs = float(tot["loop_seconds_max"])
         # like for like with `value`: the same closed loop over DAVIS-17-like sequences only (121x213 maps, K = 16, 1-3 objects: the cfg2 shape; the
@@ -1102,6 +1108,9 @@ def main():
                           "cfg2-shaped part of the set, second of two passes over the same sequences (first_pass_value = the first): compare with `value` (orchestrated matching + calibration gates, 4 objects incl. background)")
         strong = dict(metric="frames/sec, sequence-sharded evaluation of a fixed set (strong scaling)", value=round(tot["frames"] / secs, 3), unit="frames/s",
                       n_gpus=world, sequences=int(tot["sequences"]), frames=int(tot["frames"]), objects=int(tot["objects"]),
+                      first_pass_value=round(first["frames"] / float(first["loop_seconds_max"]), 3),
+                      passes="two passes over the same set in one process, `value` = the second (first_pass_value = the first, which also pays the process's "
+                             "one-time costs)",
                       loop_seconds_max=round(secs, 4), rank_seconds_mean=round(float(tot["rank_seconds_mean"]), 4),
                       imbalance=round(float(tot["imbalance"]), 4), planned_imbalance=round(float(tot["planned_imbalance"]), 4),
                       mean_j=tot["mean_j"], mean_f=tot["mean_f"], lanes_per_rank=max(1, args.eval_lanes), closed_loop_davis17_like=davis,
@@ -1167,10 +1176,11 @@ def main():
                     cus = n_cu - args.cu_reserve
                     roofline["cus_available_to_kernel"] = cus
                     roofline["pipe_frac_of_available_cus"] = round(executed / (PEAK_F16_MFMA_TFLOPS * cus / n_cu), 4)
-        km = kernels.get("kmeans_segmented")
+        km = kernels.get("cluster_chain") or kernels.get("kmeans_segmented")
         km_roof = None
         if km and "gbs" in km:
-            km_roof = dict(kernel="aoc_kmeans_segmented_rep (20 Lloyd iterations of the 2 or 3 frames that share a chain: replica-fused assignment, block scan + "
+            km_roof = dict(kernel="aoc_cluster_chain_enqueue (replicated lists, then aoc_kmeans_segmented_rep = 20 Lloyd iterations of the 1 to 3 frames that share a chain, "
+                                  "then the proxy construction and the table scatter -- ~0.15 ms of the call: replica-fused assignment, block scan + "
                                   "scatter, literal heads (LDS-DMA) + the tail chunks' integer folds in the binades the previous iteration recorded, stitch: "
                                   "FOUR launches per iteration from the second one on)", bound="hbm",
                            achieved=km["gbs"], peak=PEAK_HBM_GBS, unit="GB/s", frac=round(km["gbs"] / PEAK_HBM_GBS, 4),
@@ -1183,11 +1193,13 @@ def main():
                                                   fetch_bytes_per_iteration=274.0e6, rows_bytes=61.9e6, reads_per_frame_and_iteration=round(274.0 / 3 / 61.9, 2),
                                                   note="FETCH_SIZE x 2 (gfx950 counts 128-byte requests as 64) summed over the four kernels of an iteration: "
                                                        "1.48 passes over the rows per frame and iteration (assignment 0.34: one pass for three replicas; "
-                                                       "heads + folds 1.05; stitch 0.06; scan + scatter 0.03); round 4: 1.81, round 3: 1.98")
+                                                       "heads + folds 1.05; stitch 0.06; scan + scatter 0.03); round 4: 1.81, round 3: 1.98.  The x 2 is calibrated "
+                                                       "for these kernels' gathered 400 / 112 / 80-byte pieces (profiles/r05_fetch_size_calibration.txt: the counter is "
+                                                       "half the bytes of the distinct 128-byte lines touched in every pattern)")
                 km_roof["alone_offline"] = dict(file="profiles/r05_kmeans_chain_events.txt", source="constants copied from the committed file (tools/bench_kmeans_ev.py: "
                                                 "hipEvent pairs around every chain on an idle GPU, 50 chains each), not measured in this run",
-                                                chain_ms=dict(R1_F1=0.688, R6_F1=2.313, R6_F3=3.119, R12_F1=2.961, R12_F3=5.129),
-                                                frac_R6_F3=round(3 * 20 * 61.9e6 / 3.119e-3 / 1e9 / PEAK_HBM_GBS, 4),
+                                                chain_ms=dict(R1_F1=0.682, R6_F1=2.280, R6_F3=3.113, R12_F1=2.870, R12_F3=5.029),
+                                                frac_R6_F3=round(3 * 20 * 61.9e6 / 3.113e-3 / 1e9 / PEAK_HBM_GBS, 4),
                                                 note="frac_R6_F3 = 3 frames x 20 iterations x one pass over the 61.9 MB of rows / the chain's duration / 8 TB/s")
 
         def hbm_roof(name, kernel, note):

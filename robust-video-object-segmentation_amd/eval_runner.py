@@ -64,13 +64,25 @@ def make_sequence_set(kind="cfg5", scale=1.0, seed=0) -> List[SequenceSpec]:
     return out
 
 
+_STREAMS = {}
+
+
+def _cached_stream(device, kind, lane, priority=0):
+    """The lanes' HIP streams are created once per process and device: torch's caching allocator keeps freed blocks per stream, so a caller that
+    runs eval_sharded repeatedly on fresh streams would never get a cached block back (measured: + 10.7 GB reserved per call)."""
+    key = (torch.device(device).index or 0, kind, int(lane))
+    if key not in _STREAMS:
+        _STREAMS[key] = torch.cuda.Stream(device, priority=priority)
+    return _STREAMS[key]
+
+
 class HotPathBackend:
     """One frame on the MI355X: matching (libaoc_hip.so) -> DynamicPreHead -> stand-in read-out -> soft-max.  The conv decoder is out of
     scope; its stand-in ranks the objects by their matching evidence (logit = -12 x the mean of the dense-matching and the widest
     local-window proto-mask channels, i.e. nearest-neighbour label propagation) plus a small seeded linear read-out of the pre-head output,
     which is computed because the real decoder consumes it.  Seeded, so every rank decodes identically."""
 
-    def __init__(self, device, dense_precision=None, ahead=True):
+    def __init__(self, device, dense_precision=None, ahead=True, lane=0):
         from . import hotpath
         self.hot = hotpath
         self.device = device
@@ -82,6 +94,7 @@ class HotPathBackend:
         import os
         self.chain_plan = [int(x) for x in os.environ.get("AOC_EVAL_CHAIN_PLAN", "1").split(",") if x.strip()] or [1]   # developer switch
         self.side = None
+        self.lane = int(lane)                  # which of the rank's lanes this backend serves (its side stream is kept per lane)
         self._worker, self._pending = None, None
 
     def _head(self, n_ch):
@@ -127,7 +140,7 @@ class HotPathBackend:
             self._runners[key] = self.runner                 # most recently used last
             self.runner.reset()
         if self.ahead and self.side is None:
-            self.side = torch.cuda.Stream(self.device, priority=-1)
+            self.side = _cached_stream(self.device, "side", self.lane, priority=-1)
 
     def first_frame(self, emb, gt_label):
         self.policy.start(emb, gt_label)
@@ -329,14 +342,19 @@ def run_interleaved(specs_data, device, lanes, backend_factory=None, dense_preci
     specs_data: list of (spec, (embeddings, ground truth)).  Returns the summed accumulators (sharding.METRIC_FIELDS without gpu_seconds)."""
     todo = list(specs_data)
     n_lanes = max(1, min(lanes, len(todo)))
-    streams = [torch.cuda.Stream(device) for _ in range(n_lanes)]
-    backends = [backend_factory() if backend_factory else HotPathBackend(device, dense_precision) for _ in range(n_lanes)]
+    streams = [_cached_stream(device, "lane", l) for l in range(n_lanes)]
+    backends = [backend_factory() if backend_factory else HotPathBackend(device, dense_precision, lane=l) for l in range(n_lanes)]
     metrics = [_default_metric(device) for _ in range(n_lanes)]
     running = [None] * n_lanes
     frames = objects = 0
     keep = []                                       # the sequences' tensors stay alive until the last lane has drained
     torch.cuda.synchronize(device)
     n_pass = 0
+    import collections
+    import os
+    depth, depth_total = int(os.environ.get("AOC_EVAL_DEPTH", "0")), int(os.environ.get("AOC_EVAL_DEPTH_TOTAL", "0"))     # developer switches
+    done_l = [collections.deque() for _ in range(n_lanes)]
+    done_all = collections.deque()
     while True:
         busy = False
         n_pass += 1
@@ -355,8 +373,19 @@ def run_interleaved(specs_data, device, lanes, backend_factory=None, dense_preci
                     running[l] = sequence_steps(spec, backends[l], metrics[l], data)
                 if running[l] is not None:
                     busy = True
+                    if depth > 0 and len(done_l[l]) >= depth:
+                        done_l[l].popleft().synchronize()
+                    if depth_total > 0 and len(done_all) >= depth_total:
+                        done_all.popleft().synchronize()
                     if next(running[l], None) is None:
                         running[l] = None
+                    if depth > 0 or depth_total > 0:
+                        e = torch.cuda.Event()
+                        e.record()
+                        if depth > 0:
+                            done_l[l].append(e)
+                        if depth_total > 0:
+                            done_all.append(e)
         if not busy:
             break
     torch.cuda.synchronize(device)
