@@ -350,11 +350,6 @@ def run_interleaved(specs_data, device, lanes, backend_factory=None, dense_preci
     keep = []                                       # the sequences' tensors stay alive until the last lane has drained
     torch.cuda.synchronize(device)
     n_pass = 0
-    import collections
-    import os
-    depth, depth_total = int(os.environ.get("AOC_EVAL_DEPTH", "0")), int(os.environ.get("AOC_EVAL_DEPTH_TOTAL", "0"))     # developer switches
-    done_l = [collections.deque() for _ in range(n_lanes)]
-    done_all = collections.deque()
     while True:
         busy = False
         n_pass += 1
@@ -373,19 +368,8 @@ def run_interleaved(specs_data, device, lanes, backend_factory=None, dense_preci
                     running[l] = sequence_steps(spec, backends[l], metrics[l], data)
                 if running[l] is not None:
                     busy = True
-                    if depth > 0 and len(done_l[l]) >= depth:
-                        done_l[l].popleft().synchronize()
-                    if depth_total > 0 and len(done_all) >= depth_total:
-                        done_all.popleft().synchronize()
                     if next(running[l], None) is None:
                         running[l] = None
-                    if depth > 0 or depth_total > 0:
-                        e = torch.cuda.Event()
-                        e.record()
-                        if depth > 0:
-                            done_l[l].append(e)
-                        if depth_total > 0:
-                            done_all.append(e)
         if not busy:
             break
     torch.cuda.synchronize(device)
