@@ -557,3 +557,13 @@ def test_reference_model_files_import_against_the_mirrors(tmp_path):
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-B", str(script), _REF_ROOT, repo], capture_output=True, text=True, timeout=300, cwd=str(tmp_path))
     assert r.returncode == 0 and "INTEGRATION_OK" in r.stdout, r.stdout + r.stderr
+
+
+def test_package_import_asks_for_enough_hardware_queues_unless_the_caller_chose():
+    """The evaluation runner keeps 8 streams busy (4 lanes + their chain streams): the package asks the HIP runtime for 16 hardware queues on
+    import (profiles/r05_closed_loop_hw_queues.txt) and leaves a caller's own setting alone."""
+    code = "import os, sys; sys.path.insert(0, %r); import aoc_amd; print(os.environ['GPU_MAX_HW_QUEUES'])" % ROOT
+    env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+    assert subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout.strip() == "16"
+    env["GPU_MAX_HW_QUEUES"] = "6"
+    assert subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout.strip() == "6"
