@@ -89,6 +89,9 @@ def launch_cluster_proxies_batch(cfg, ref_emb, ref_labels, init_rows_list, side_
                     reads the row counts back from it): it is reused instead of being computed a second time on the side stream
     Returns one ClusterProxiesAhead per frame, to pass to proto_mask_features(cluster_ahead=...)."""
     F = len(init_rows_list)
+    if F > ops.CHAIN_MAX_FRAMES:              # aoc_chain_desc names at most 8 frames: more (MEM_EVERY > 9) go out as several chains over the same label prep
+        first = launch_cluster_proxies_batch(cfg, ref_emb, ref_labels, init_rows_list[:ops.CHAIN_MAX_FRAMES], side_stream, wait_event, prep)
+        return first + launch_cluster_proxies_batch(cfg, ref_emb, ref_labels, init_rows_list[ops.CHAIN_MAX_FRAMES:], side_stream, wait_event, first[0].prep)
     R, h, w, C = ref_emb.shape
     O = ref_labels.shape[-1]
     hw = h * w

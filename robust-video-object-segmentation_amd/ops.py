@@ -616,6 +616,9 @@ class _ChainDesc(ctypes.Structure):
                 ("init_rows", ctypes.c_void_p), ("tables", ctypes.c_void_p * 8), ("sqnorms", ctypes.c_void_p * 8)]
 
 
+CHAIN_MAX_FRAMES = 8      # frames one aoc_chain_desc names (tables[8] / sqnorms[8])
+
+
 def cluster_chain(pool, prep, levels, init_rows, tables, sqnorms, iters=20):
     """aoc_cluster_chain_enqueue: the k-means chain of len(tables) frames that see one pool state -- replicated lists with sticky K, 20 Lloyd
     iterations, proxy construction, every frame's proxies scattered into ITS table -- as ONE C call out of one workspace (on the current stream,
@@ -627,7 +630,8 @@ def cluster_chain(pool, prep, levels, init_rows, tables, sqnorms, iters=20):
     F, L, O, C = len(tables), len(levels), prep.n_obj, pool.shape[1]
     kmax = int(max(levels))
     init_rows = init_rows.to(torch.int32).contiguous()
-    assert 1 <= F <= 8 and init_rows.numel() == F * L * O * kmax
+    if not (1 <= F <= CHAIN_MAX_FRAMES and 1 <= L <= 8 and len(sqnorms) == F and init_rows.numel() == F * L * O * kmax):
+        raise _lib.AocHipError("cluster_chain: 1..8 frames, 1..8 levels, one squared-norm array per table, init_rows [F * L * O, kmax]")
     d = _ChainDesc()
     d.C, d.n_obj, d.n_frames, d.n_levels, d.kmax, d.iters = C, O, F, L, kmax, int(iters)
     for i, k in enumerate(levels):

@@ -181,3 +181,23 @@ def test_cluster_chain_one_call_equals_the_three_calls(aoc, levels, F):
         assert torch.equal(out.aux["centroids"], cen[sl]) and torch.equal(out.aux["seg_k"], k_f[sl])
     ch = outs[0].aux["chain"]
     assert torch.equal(ch["labels"][:int(off_f[-1])], labels[:int(off_f[-1])]) and torch.equal(ch["cluster_counts"], cnt) and torch.equal(ch["seg_offsets"], off_f)
+
+
+def test_cluster_chain_of_more_frames_than_one_descriptor_names(aoc):
+    """Ten frames that see one pool state (MEM_EVERY > 9): the batch goes out as two chains over one label prep; every frame's table equals its own chain's."""
+    syn, hot = aoc.synthetic, aoc.hotpath
+    cfg = syn.CONFIGS["tiny"]
+    clip = syn.make_clip(cfg, 9, frames=2)
+    O = cfg.n_obj
+    mc = hot.MatchingConfig()
+    emb = torch.from_numpy(clip["emb"][:1].copy()).cuda()
+    lab = torch.from_numpy(np.stack([syn.one_hot(l, O) for l in clip["lab"][:1]])).cuda()
+    counts = [int(lab[..., o].sum().item()) for o in range(O)]
+    inits = [_init_rows_dev(syn, 300 + f, counts, mc.cluster_levels, O) for f in range(10)]
+    outs = hot.launch_cluster_proxies_batch(mc, emb, lab, inits)
+    assert len(outs) == 10 and outs[9].prep is outs[0].prep
+    for f in (0, 7, 8, 9):
+        one = hot.launch_cluster_proxies(mc, emb, lab, inits[f])
+        torch.cuda.synchronize()
+        n_ad = len(mc.cluster_levels) * O * 2 * max(mc.cluster_levels)
+        assert torch.equal(outs[f].table[:n_ad], one.table[:n_ad]) and torch.equal(outs[f].sqn[:n_ad], one.sqn[:n_ad])
