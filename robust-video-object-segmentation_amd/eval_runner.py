@@ -65,6 +65,7 @@ def make_sequence_set(kind="cfg5", scale=1.0, seed=0) -> List[SequenceSpec]:
 
 
 _STREAMS = {}
+SIDE_STREAM_PRIORITY = -1        # the k-means chains' streams (a frame waits for its chain; -1 = high)
 
 
 def _cached_stream(device, kind, lane, priority=0):
@@ -140,7 +141,7 @@ class HotPathBackend:
             self._runners[key] = self.runner                 # most recently used last
             self.runner.reset()
         if self.ahead and self.side is None:
-            self.side = _cached_stream(self.device, "side", self.lane, priority=-1)
+            self.side = _cached_stream(self.device, "side", self.lane, priority=SIDE_STREAM_PRIORITY)
 
     def first_frame(self, emb, gt_label):
         self.policy.start(emb, gt_label)
