@@ -677,7 +677,7 @@ __global__ __launch_bounds__(256) void km_rownorm_kernel(const float *__restrict
 // D: lane holds row j = lane & 15 and clusters (lane >> 4) * 4 + r: the argmin is 4 in-lane compares and two
 // cross-group exchanges, ties to the lowest index like scipy's strict <.
 template <int TMAX, int KT>
-__global__ __launch_bounds__(256, 2) void km_assign_mfma_kernel(const float *__restrict__ pool, int C, const int32_t *__restrict__ rows,
+__global__ __launch_bounds__(256, KT == 1 ? 3 : 2) void km_assign_mfma_kernel(const float *__restrict__ pool, int C, const int32_t *__restrict__ rows,
                                                               const int32_t *__restrict__ seg_off, const int32_t *__restrict__ seg_k, int n_seg,
                                                               const float *__restrict__ centroids, int kmax, int32_t *__restrict__ labels,
                                                               uint16_t *__restrict__ rank16, int32_t *__restrict__ hist, int nb_max,
@@ -897,7 +897,7 @@ __global__ __launch_bounds__(256, 2) void km_assign_mfma_kernel(const float *__r
 // is exactly that of km_assign_mfma_kernel; what changes is the traffic: with F frames x L levels in a chain the single-replica kernel
 // streams the pool rows F * L times per Lloyd iteration.
 template <int TMAX, int KT>
-__global__ __launch_bounds__(256, 2) void km_assign_mfma_rep_kernel(const float *__restrict__ pool, int C, const int32_t *__restrict__ rows,
+__global__ __launch_bounds__(256, KT == 1 ? 3 : 2) void km_assign_mfma_rep_kernel(const float *__restrict__ pool, int C, const int32_t *__restrict__ rows,
                                                                   const int32_t *__restrict__ seg_off, const int32_t *__restrict__ seg_k, int n_base,
                                                                   int n_rep, int n_grp, const float *__restrict__ centroids, int kmax,
                                                                   int32_t *__restrict__ labels, uint16_t *__restrict__ rank16,
@@ -931,7 +931,7 @@ __global__ __launch_bounds__(256, 2) void km_assign_mfma_rep_kernel(const float 
         }
     }
 
-    constexpr int SEG_LDS = 128;
+    constexpr int SEG_LDS = 32;        // (static LDS small enough for three workgroups of three code books per CU, KT = 1)
     __shared__ int32_t lseg_off[SEG_LDS + 1], lseg_nb[SEG_LDS];
     const bool seg_in_lds = n_base <= SEG_LDS;
     // a base segment is walked if ANY replica clusters it (the cluster counts may differ per replica; a replica with K = 0 is skipped below)
@@ -3050,6 +3050,8 @@ int aoc_kmeans_segmented_rep(const float *pool, int64_t pool_rows, int C, const 
         const int first = (it == 0);
         if (use_mfma) {
             const int kt = (kmax + 15) / 16;
+            // K <= 16: the kernels are built for three workgroups per CU (168 registers, <= 53 KB of LDS): 768 resident workgroups instead of 512
+            const int64_t gcap = kt == 1 ? (int64_t)km_assign_grid_cap() * 3 / 2 : km_assign_grid_cap();
             bool rep_done = false;
             // replicated segment lists: the rows of a block are staged once for a group of replicas (km_assign_mfma_rep_kernel) as long as
             // at least two code books fit next to the row images in half a CU's LDS
@@ -3064,7 +3066,7 @@ int aoc_kmeans_segmented_rep(const float *pool, int64_t pool_rows, int C, const 
                     const int n_base = n_seg / n_rep;
                     const size_t rlds = fixed + (size_t)n_grp * per;
                     const int64_t base_rows = std::min<int64_t>(rows_capacity / n_rep, seg_bound * n_base);
-                    const unsigned rgrid = (unsigned)std::min<int64_t>((base_rows / 256 + n_base) * n_groups, km_assign_grid_cap());
+                    const unsigned rgrid = (unsigned)std::min<int64_t>((base_rows / 256 + n_base) * n_groups, gcap);
 #define AOC_KAR(KT)                                                                                                                                        \
     do {                                                                                                                                                   \
         static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(km_assign_mfma_rep_kernel<25, KT>),                                     \
@@ -3080,7 +3082,7 @@ int aoc_kmeans_segmented_rep(const float *pool, int64_t pool_rows, int C, const 
             }
             if (!rep_done) {
             const size_t alds = ((size_t)kt * 16 * 116 + kt * 16 + (size_t)4 * 16 * 116) * sizeof(float) + (size_t)4 * kmax * sizeof(int32_t);
-            const unsigned pgrid = (unsigned)std::min<int64_t>(std::min<int64_t>(rows_capacity, seg_bound * n_seg) / 256 + n_seg, km_assign_grid_cap());    // persistent workgroups, several 256-row items each: the code book staging is paid once per workgroup
+            const unsigned pgrid = (unsigned)std::min<int64_t>(std::min<int64_t>(rows_capacity, seg_bound * n_seg) / 256 + n_seg, gcap);    // persistent workgroups, several 256-row items each: the code book staging is paid once per workgroup
 #define AOC_KA(KT) hipLaunchKernelGGL((km_assign_mfma_kernel<25, KT>), dim3(pgrid), dim3(256), alds, st, pool, C, rows, seg_offsets, seg_k, n_seg, centroids, \
                                       kmax, labels, ws.rank16, ws.hist, ws.nb_max, rownorm)
             if (kt == 1) AOC_KA(1); else if (kt == 2) AOC_KA(2); else if (kt == 3) AOC_KA(3); else AOC_KA(4);
