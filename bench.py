@@ -1198,8 +1198,8 @@ def main():
                                                        "half the bytes of the distinct 128-byte lines touched in every pattern)")
                 km_roof["alone_offline"] = dict(file="profiles/r05_kmeans_chain_events.txt", source="constants copied from the committed file (tools/bench_kmeans_ev.py: "
                                                 "hipEvent pairs around every chain on an idle GPU, 50 chains each), not measured in this run",
-                                                chain_ms=dict(R1_F1=0.682, R6_F1=2.280, R6_F3=3.113, R12_F1=2.870, R12_F3=5.029),
-                                                frac_R6_F3=round(3 * 20 * 61.9e6 / 3.113e-3 / 1e9 / PEAK_HBM_GBS, 4),
+                                                chain_ms=dict(R1_F1=0.695, R6_F1=2.217, R6_F3=2.889, R12_F1=2.817, R12_F3=4.871),
+                                                frac_R6_F3=round(3 * 20 * 61.9e6 / 2.889e-3 / 1e9 / PEAK_HBM_GBS, 4),
                                                 note="frac_R6_F3 = 3 frames x 20 iterations x one pass over the 61.9 MB of rows / the chain's duration / 8 TB/s")
 
         def hbm_roof(name, kernel, note):
