@@ -676,6 +676,9 @@ __global__ __launch_bounds__(256) void km_rownorm_kernel(const float *__restrict
 // tiles in a private, double-buffered, k-permuted LDS image (lane (j, kq) reads x[j][4t + kq] with ds_read_b128).
 // D: lane holds row j = lane & 15 and clusters (lane >> 4) * 4 + r: the argmin is 4 in-lane compares and two
 // cross-group exchanges, ties to the lowest index like scipy's strict <.
+#ifndef AOC_KA_TPF4
+#define AOC_KA_TPF4 1
+#endif
 template <int TMAX, int KT>
 __global__ __launch_bounds__(256, KT == 1 ? 3 : 2) void km_assign_mfma_kernel(const float *__restrict__ pool, int C, const int32_t *__restrict__ rows,
                                                               const int32_t *__restrict__ seg_off, const int32_t *__restrict__ seg_k, int n_seg,
@@ -742,7 +745,7 @@ __global__ __launch_bounds__(256, KT == 1 ? 3 : 2) void km_assign_mfma_kernel(co
         }
         if (s >= n_seg) break;
         // ---- this item's rows: all loads of TPF tiles are issued before anything waits (ids -> pieces in registers)
-        constexpr int TPF = 2;                             // tiles in flight per wave
+        constexpr int TPF = KT >= 4 ? AOC_KA_TPF4 : 2;       // tiles in flight per wave (K > 48: one -- the second set of staging registers spilled 36 VGPRs)
         const int ibeg = seg_in_lds ? lseg_off[s] : seg_off[s], ilen = (seg_in_lds ? lseg_off[s + 1] : seg_off[s + 1]) - ibeg;
         const int wave_row0 = bx * 256 + wave * 64;
         float4 pv[TPF][PIECES];
