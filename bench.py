@@ -755,7 +755,7 @@ def main():
                          "frame (measured slower with 2 sequences in flight: the shared launch makes the streams wait for each other every step)")
     ap.add_argument("--dense-order", action="store_true",
                     help="order the in-flight sequences' dense kernels explicitly (one after the other: the kernel's live timing then excludes "
-                         "the time it shares the chip with the other sequence's dense kernel -- 0.24 instead of 0.22 of the fp16 peak -- at 2 % "
+                         "the time it shares the chip with the other sequence's dense kernel -- 0.24 instead of 0.22 of the fp16 peak -- at 2 %% "
                          "fewer frames/s: 325 against 332)")
     ap.add_argument("--no-dense-order", action="store_true", help="(default since round 3; kept for old command lines)")
     ap.add_argument("--no-stagger", dest="stagger", action="store_false",

@@ -567,3 +567,9 @@ def test_package_import_asks_for_enough_hardware_queues_unless_the_caller_chose(
     assert subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout.strip() == "16"
     env["GPU_MAX_HW_QUEUES"] = "6"
     assert subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, check=True).stdout.strip() == "6"
+
+
+def test_bench_help_prints():
+    """argparse expands '%' in help strings: an unescaped one made `python bench.py --help` raise."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True)
+    assert r.returncode == 0 and "--gpus" in r.stdout and "--steps" in r.stdout and "--warmup" in r.stdout
