@@ -573,3 +573,22 @@ def test_bench_help_prints():
     """argparse expands '%' in help strings: an unescaped one made `python bench.py --help` raise."""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True)
     assert r.returncode == 0 and "--gpus" in r.stdout and "--steps" in r.stdout and "--warmup" in r.stdout
+
+
+def test_every_profile_a_document_cites_is_committed():
+    """The current-state documents point at files under profiles/ for every figure: each such path has to exist (round-4 verdict: docs follow the files)."""
+    import re
+    missing = []
+    for doc in ("DESIGN.md", "STATUS.md", "README.md", "INTEGRATION.md", "HISTORY.md", "tools/README.md"):
+        text = open(os.path.join(ROOT, doc)).read()
+        for m in re.finditer(r"(profiles/[A-Za-z0-9_./\-]+)", text):
+            path = m.group(1).rstrip(".,;:)")
+            if "*" in path or path.endswith(("_", "/")):
+                continue                                    # a family of files (r05_pmc_*), or the directory
+            if not os.path.exists(os.path.join(ROOT, path)):
+                missing.append((doc, path))
+    text = open(os.path.join(ROOT, "profiles", "README.md")).read()
+    for m in re.finditer(r"`(r0\d_[A-Za-z0-9_.\-]+)`", text):
+        if "*" not in m.group(1) and not os.path.exists(os.path.join(ROOT, "profiles", m.group(1))):
+            missing.append(("profiles/README.md", m.group(1)))
+    assert not missing, missing
