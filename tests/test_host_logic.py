@@ -2,6 +2,7 @@
 Python mirrors keep the reference's signatures, operators refuse CPU tensors (no fallback), the
 synthetic generator is deterministic, and the N > 1 sharding path works over gloo (world_size 2)."""
 import inspect
+import json
 import os
 import re
 import subprocess
@@ -592,3 +593,14 @@ def test_every_profile_a_document_cites_is_committed():
         if "*" not in m.group(1) and not os.path.exists(os.path.join(ROOT, "profiles", m.group(1))):
             missing.append(("profiles/README.md", m.group(1)))
     assert not missing, missing
+
+
+def test_headline_figures_in_the_documents_are_the_committed_line():
+    """STATUS.md / README.md quote the driver-style line of the final code: the figures they print are the ones in profiles/r05_bench_line.json."""
+    line = json.loads([l for l in open(os.path.join(ROOT, "profiles", "r05_bench_line.json")) if l.startswith("{")][-1])
+    status, readme = open(os.path.join(ROOT, "STATUS.md")).read(), open(os.path.join(ROOT, "README.md")).read()
+    assert "%.1f frames/s" % line["value"] in status and "%.1f frames/s" % line["value"] in readme
+    for name, cfg in line["other_configs"].items():
+        assert "%s %.1f" % (name, cfg["value"]) in status, name
+    closed = line["strong_scaling"]
+    assert "%.1f (65 sequences)" % closed["value"] in status and "%.1f on the cfg2-shaped part" % closed["closed_loop_davis17_like"]["value"] in status
