@@ -12,7 +12,15 @@ import os as _os
 # lane's frame then waits behind another lane's chain (measured: closed loop 356 frames/s at 4 queues, 377 at 8, 380-385 at 16;
 # profiles/r05_closed_loop_hw_queues.txt).  The runtime reads the variable when it initialises (the first HIP call of the process), so it is
 # set here, on import, unless the caller has set it; the C-ABI library itself reads no environment.
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+if "GPU_MAX_HW_QUEUES" not in _os.environ:
+    import sys as _sys
+    _torch = _sys.modules.get("torch")
+    if _torch is not None and _torch.cuda.is_initialized():
+        # too late: the runtime has read the variable already.  Entry points (bench.py, tools/) import this package before their first torch.cuda call.
+        import warnings as _warnings
+        _warnings.warn("aoc_amd imported after the HIP runtime was initialised with GPU_MAX_HW_QUEUES unset: streams share the default 4 hardware queues "
+                       "(closed loop ~6 % slower); export GPU_MAX_HW_QUEUES=16 or import aoc_amd before the first torch.cuda call", RuntimeWarning)
+    _os.environ["GPU_MAX_HW_QUEUES"] = "16"
 
 from . import synthetic  # noqa: F401,E402
 from . import _lib  # noqa: F401,E402

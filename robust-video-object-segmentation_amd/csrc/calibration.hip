@@ -459,111 +459,12 @@ __global__ __launch_bounds__(256) void film_scale_ahead_kernel(const float *__re
 }
 
 // ------------------------------------------------------------------------------------------ conditioning layer
-// scores[n,p] = sum_c w[c] z[n,c,p] + b      (CL:27, the 1x1 conv C -> 1)
-__global__ __launch_bounds__(256) void cond_scores_kernel(const float *__restrict__ z, int C, int64_t hw, const float *__restrict__ phi_w,
-                                                           const float *__restrict__ phi_b, float *__restrict__ scores) {
-    const int n = blockIdx.y;
-    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= hw) return;
-    const float *zp = z + (size_t)n * C * hw + p;
-    float s = 0.0f;
-    int c = 0;
-    for (; c + 8 <= C; c += 8) {          // 8 independent loads in flight per thread
-        float v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = zp[(size_t)(c + u) * hw];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) s += phi_w[c + u] * v[u];
-    }
-    for (; c < C; ++c) s += phi_w[c] * zp[(size_t)c * hw];
-    scores[(size_t)n * hw + p] = s + phi_b[0];
-}
-
 __device__ __forceinline__ uint32_t float_order_key(float f) {
     const uint32_t b = __float_as_uint(f);
     return (b & 0x80000000u) ? ~b : (b | 0x80000000u);    // larger float <=> larger key
 }
 __device__ __forceinline__ float key_to_float(uint32_t k) {
     return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
-}
-
-// threshold[n] = k-th largest score of sample n  (CL:33 topk(...)[..., -1]); exact radix select.
-__global__ __launch_bounds__(1024) void cond_kth_largest_kernel(const float *__restrict__ scores, int64_t hw, int k_rank,
-                                                                 float *__restrict__ threshold) {
-    __shared__ uint32_t hist[256];
-    __shared__ uint32_t sel_prefix, sel_k;
-    const int n = blockIdx.x;
-    const float *s = scores + (size_t)n * hw;
-    if (threadIdx.x == 0) { sel_prefix = 0; sel_k = (uint32_t)k_rank; }
-    uint32_t mask = 0;
-    for (int shift = 24; shift >= 0; shift -= 8) {
-        if (threadIdx.x < 256) hist[threadIdx.x] = 0;
-        __syncthreads();
-        const uint32_t prefix = sel_prefix;
-        // scores of one map share their sign/exponent byte, so a plain LDS atomic per element serialises 64 ways; the
-        // lanes of a wave that hit the same bin are counted with a ballot first (two rounds take care of the hot bins),
-        // whatever is left is spread over many bins and goes through ordinary atomics
-        const int lane = threadIdx.x & 63;
-        for (int64_t i0 = 0; i0 < hw; i0 += blockDim.x) {
-            const int64_t i = i0 + threadIdx.x;
-            uint32_t key = 0;
-            bool act = false;
-            if (i < hw) {
-                key = float_order_key(s[i]);
-                act = (key & mask) == prefix;
-            }
-            const uint32_t bin = (key >> shift) & 255u;
-#pragma unroll
-            for (int round = 0; round < 2; ++round) {
-                const unsigned long long m = __ballot(act);
-                if (m == 0ull) break;
-                const int leader = __builtin_ctzll(m);
-                const uint32_t lb = __shfl(bin, leader);
-                const unsigned long long same = __ballot(act && bin == lb);
-                if (lane == leader) atomicAdd(&hist[lb], (uint32_t)__popcll(same));
-                act = act && bin != lb;
-            }
-            if (act) atomicAdd(&hist[bin], 1u);
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            uint32_t need = sel_k, acc = 0;
-            int b = 255;
-            for (; b > 0; --b) {
-                if (acc + hist[b] >= need) break;
-                acc += hist[b];
-            }
-            sel_k = need - acc;
-            sel_prefix = prefix | ((uint32_t)b << shift);
-        }
-        mask |= 0xffu << shift;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) threshold[n] = key_to_float(sel_prefix);
-}
-
-// gap[n,c] = (1/HW) * sum_p z[n,c,p] * (scores[n,p] > threshold[n])    (CL:36-43); one block per plane
-__global__ __launch_bounds__(256) void cond_masked_gap_kernel(const float *__restrict__ z, int C, int64_t hw, const float *__restrict__ scores,
-                                                               const float *__restrict__ threshold, float *__restrict__ gap) {
-    __shared__ float wsum[4];
-    const int c = blockIdx.x, n = blockIdx.y;
-    const float thr = threshold[n];
-    const float *zp = z + ((size_t)n * C + c) * hw;
-    const float *sp = scores + (size_t)n * hw;
-    float acc = 0.0f;
-    int64_t p = threadIdx.x;
-    for (; p + 3 * (int64_t)blockDim.x < hw; p += 4 * (int64_t)blockDim.x) {
-        float zv[4], sv[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) { zv[u] = zp[p + u * blockDim.x]; sv[u] = sp[p + u * blockDim.x]; }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) acc += (sv[u] > thr) ? zv[u] : 0.0f;
-    }
-    for (; p < hw; p += blockDim.x) acc += (sp[p] > thr) ? zp[p] : 0.0f;
-    acc = aoc_wave_sum(acc);
-    if (aoc_lane() == 0) wsum[threadIdx.x >> 6] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) gap[(size_t)n * C + c] = (wsum[0] + wsum[1] + wsum[2] + wsum[3]) / (float)hw;
 }
 
 // ---- fused conditioning-layer streams (round 2) --------------------------------------------------------------------------

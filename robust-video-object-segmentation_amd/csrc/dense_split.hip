@@ -128,8 +128,14 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float *__restrict
         // k-steps 6, 0, 1 / 6, 0, 1, 2): Cauchy-Schwarz turns the two sides' values into an upper bound of the rest of the hi x hi product.
         // Every consumer multiplies them by zero on one side except that kernel (the query side's other slot is masked there; the proxy image of
         // the correlation kernel has zeros in slots 103..111)
+        // Development build only (the checkpoint is not in the product): release records keep zeros there, so no product of two records depends on them
+#ifdef AOC_DEV
         hi[SP_REST_SLOT % 16] = (_Float16)(sqrtf(hr3) * 1.002f + 1e-6f);
         hi[SP_REST_SLOT % 16 + 1] = (_Float16)(sqrtf(hr4) * 1.002f + 1e-6f);
+#else
+        (void)hr3;
+        (void)hr4;
+#endif
     }
     if (bad && live) atomicOr(overflow, 1);
     union { _Float16 h[32]; uint4 q[4]; } u;
@@ -294,8 +300,16 @@ __global__ __launch_bounds__(NW * 64, 1) void dense_prune_kernel(const uint4 *__
                                                                      const uint4 *__restrict__ prec, const int32_t *__restrict__ tile_rows,
                                                                      const int32_t *__restrict__ tile_obj, const int32_t *__restrict__ n_tiles_ptr,
                                                                      const int32_t *__restrict__ gate, const uint32_t *__restrict__ pmax_bits,
-                                                                     int n_obj, uint32_t *__restrict__ gbest, int dbg, int q_tiled) {
+                                                                     int n_obj, uint32_t *__restrict__ gbest, int dbg_arg, int q_tiled) {
     if (*gate) return;
+    // developer bits (timing experiments that give WRONG results on purpose) exist in the development build only: in the release library `dbg` is
+    // the constant 0 and every test on it folds away
+#ifdef AOC_DEV
+    const int dbg = dbg_arg;
+#else
+    constexpr int dbg = 0;
+    (void)dbg_arg;
+#endif
     extern __shared__ __attribute__((aligned(16))) uint4 lds4[];
     static_assert(SP_NB == 4 && SP_NQ == 2 && (NW == 8 || NW == 4), "the step structure below is written for 4 tiles x 2 query tiles x 8 (or 4) waves");
     static_assert(CKPT == 0 || CKPT == 3 || CKPT == 4, "checkpoint after 3 or 4 k-steps (rest norms in slots 104 / 105), or none");
@@ -369,7 +383,7 @@ __global__ __launch_bounds__(NW * 64, 1) void dense_prune_kernel(const uint4 *__
         const float qn = valid[iq] ? sqrtf(q2[row]) : 0.0f;
         const float ql = valid[iq] ? __shfl(ql_own, col) : 0.0f;
         // (with a checkpoint the partial sums also carry the bound's term, at most 2^20 |q| max|r|: 16 |q| max|r| covers the roundings at that size)
-        eps[iq] = (1026.0f * (qn * plmax + ql * pmax) + 8.0f * pmax * pmax + 16.0f * qn * pmax + 8.0f) * ((dbg & 64) ? 0.4f : 1.0f);
+        eps[iq] = (1026.0f * (qn * plmax + ql * pmax) + 8.0f * pmax * pmax + (CKPT != 0 ? 16.0f * qn * pmax : 0.0f) + 8.0f) * ((dbg & 64) ? 0.4f : 1.0f);
     }
 
     // ---- DMA plan of this wave: transfer k of a chunk fills the LDS slots [64 (7 wave + k), +64); slot j holds row j / 28, position j % 28.

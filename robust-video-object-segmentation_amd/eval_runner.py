@@ -71,7 +71,9 @@ SIDE_STREAM_PRIORITY = -1        # the k-means chains' streams (a frame waits fo
 def _cached_stream(device, kind, lane, priority=0):
     """The lanes' HIP streams are created once per process and device: torch's caching allocator keeps freed blocks per stream, so a caller that
     runs eval_sharded repeatedly on fresh streams would never get a cached block back (measured: + 10.7 GB reserved per call)."""
-    key = (torch.device(device).index or 0, kind, int(lane))
+    dev = torch.device(device)
+    index = dev.index if dev.index is not None else torch.cuda.current_device()      # an index-less "cuda" means the CURRENT device, not device 0
+    key = (index, kind, int(lane))
     if key not in _STREAMS:
         _STREAMS[key] = torch.cuda.Stream(device, priority=priority)
     return _STREAMS[key]
@@ -344,7 +346,12 @@ def run_interleaved(specs_data, device, lanes, backend_factory=None, dense_preci
     todo = list(specs_data)
     n_lanes = max(1, min(lanes, len(todo)))
     streams = [_cached_stream(device, "lane", l) for l in range(n_lanes)]
-    backends = [backend_factory() if backend_factory else HotPathBackend(device, dense_precision, lane=l) for l in range(n_lanes)]
+    backends = []
+    for l in range(n_lanes):
+        b = backend_factory() if backend_factory else HotPathBackend(device, dense_precision, lane=l)
+        if backend_factory and hasattr(b, "lane"):
+            b.lane = l                  # a factory does not know its lane: without this every backend would share lane 0's cached side stream
+        backends.append(b)
     metrics = [_default_metric(device) for _ in range(n_lanes)]
     running = [None] * n_lanes
     frames = objects = 0

@@ -34,9 +34,10 @@ def _reduce_device(device):
 
 
 def allreduce_metrics(local: dict, device=None) -> dict:
-    """Sum the metric accumulators over all ranks (no-op without an initialised process group)."""
+    """Sum the metric accumulators over all ranks (no-op without an initialised process group; with one, the collective runs even for a
+    single rank -- that is how a one-GPU box exercises RCCL)."""
     vec = torch.tensor([float(local.get(k, 0.0)) for k in METRIC_FIELDS], dtype=torch.float64, device=_reduce_device(device))
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized():
         dist.all_reduce(vec, op=dist.ReduceOp.SUM)
     return dict(zip(METRIC_FIELDS, vec.tolist()))
 
@@ -44,7 +45,7 @@ def allreduce_metrics(local: dict, device=None) -> dict:
 def allreduce_max(value: float, device=None) -> float:
     """Maximum of a scalar over the ranks (the slowest rank's time: load imbalance)."""
     t = torch.tensor([float(value)], dtype=torch.float64, device=_reduce_device(device))
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 

@@ -179,7 +179,67 @@ def test_bench_two_ranks_on_one_gpu_over_gloo():
     assert len(lines) == 1, "exactly one JSON line, from rank 0"
     line = lines[0]
     assert line["n_gpus"] == 2 and line["steps"] == 4 and line["scaling"] == "weak"
-    assert line["value"] > 0 and abs(line["value"] - 2 * line["config"]["frames_per_step"] * 1e3 / line["ms_per_step"]) < 0.05 * line["value"]
+    assert line["value"] > 0 and abs(line["value"] - 2 * line["config"]["sequences_per_gpu"] * 1e3 / line["ms_per_step"]) < 0.05 * line["value"]
+    assert line["ranks_seen"] == 2 and line["frames_per_rank"] == [4 * line["config"]["sequences_per_gpu"]] * 2 and line["imbalance"] >= 1.0
+    assert len(r.stdout.splitlines()[-1]) < 4096 and line["cpu_baseline"] is None and os.path.exists(os.path.join(root, line["details_file"]))
+
+
+def _run_py(code, env=None, timeout=900):
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    return subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **(env or {})), capture_output=True, text=True, timeout=timeout, cwd=root)
+
+
+def test_metric_allreduce_through_rccl_with_one_rank():
+    """The only collectives of the sequence-sharded evaluation (one all-reduce(SUM) of the metric accumulators + one all-reduce(MAX) of the
+    rank seconds, eval_manager_mm.py:172 is the shard point) through RCCL itself -- backend "nccl", device tensors -- with the one rank a one-GPU box
+    can host, then the whole sharded runner on top of it: RCCL plumbing (device_id binding, float64 reductions, barrier, teardown) has run before the
+    first multi-GPU node does."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    code = r'''
+import os, socket, sys
+sys.path.insert(0, os.getcwd())
+import torch, torch.distributed as dist
+import aoc_amd
+from aoc_amd import sharding, eval_runner
+s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+assert dist.get_backend() == "nccl" and dist.get_world_size() == 1
+m = sharding.allreduce_metrics(dict(frames=7, objects=21, gpu_seconds=0.5, sum_iou=3.25, iou_count=4, sum_f=1.5), device=dev)
+assert m == dict(frames=7.0, objects=21.0, gpu_seconds=0.5, sum_iou=3.25, iou_count=4.0, sum_f=1.5), m
+assert sharding.allreduce_max(2.75, device=dev) == 2.75
+specs = eval_runner.make_sequence_set("davis17", scale=0.07, seed=0)
+def barrier():
+    torch.cuda.synchronize(); dist.barrier()
+with torch.no_grad():
+    tot = eval_runner.eval_sharded(specs, 0, 1, dev, barrier=barrier, lanes=2, max_frames=6)
+assert tot["ranks"] == 1 and tot["frames"] > 0 and 0.0 <= tot["mean_j"] <= 1.0, tot
+dist.barrier(); dist.destroy_process_group()
+print("RCCL_OK", tot["frames"], tot["mean_j"])
+'''
+    r = _run_py(code, env=dict(HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert r.returncode == 0 and "RCCL_OK" in r.stdout, r.stdout[-1500:] + r.stderr[-2500:]
+
+
+def test_bench_line_with_the_process_group_on_rccl():
+    """bench.py's multi-rank code path (process-group set-up with device_id, barriers, the region-count agreement, max-over-ranks timing, the metric and
+    per-rank all-reduces, rank-0 report, teardown) with backend "nccl" = RCCL, forced on for the single rank of a one-GPU box (AOC_DIST_FORCE=1)."""
+    import json, os, subprocess, sys
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, AOC_DIST_FORCE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("AOC_DIST_BACKEND", None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--exact-steps", "0", "--no-extras",
+                        "--details-file", "gpurun_out/bench_details_rccl1.json"], env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-2500:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["ranks_seen"] == 1 and line["frames_per_rank"] == [4 * line["config"]["sequences_per_gpu"]] and line["imbalance"] == 1.0
+    assert line["value"] > 0 and line["roofline"]["bound"] == "mfma" and line["roofline_correlation"]["bound"] == "hbm"
 
 
 @pytest.mark.gpu

@@ -604,3 +604,67 @@ def test_headline_figures_in_the_documents_are_the_committed_line():
         assert "%s %.1f" % (name, cfg["value"]) in status, name
     closed = line["strong_scaling"]
     assert "%.1f (65 sequences)" % closed["value"] in status and "%.1f on the cfg2-shaped part" % closed["closed_loop_davis17_like"]["value"] in status
+
+
+def _canned_full_record():
+    """A full bench record shaped like bench.py's, with numbers made up and every free-text field as long as round 5's."""
+    prose = "x" * 900
+    roof = dict(kernel="dense_prune_kernel (aoc_dense_match_min_split), " + prose, bound="mfma", achieved=652.123, peak=2500.0, unit="TFLOP/s", frac=0.2608,
+                traffic=400123456.0, traffic_source=prose, avg_launch_ms=1.3229, algorithmic_flops_per_launch=8.56e11, executed_tflops=870.1, pipe_frac=0.348,
+                note=prose, op_avg_ms=1.598)
+    corr = dict(kernel="proxy_corr_records_kernel (" + prose + ")", bound="hbm", achieved=573.1, peak=8000.0, unit="GB/s", frac=0.0716, traffic=None,
+                avg_launch_ms=0.0202, frames_per_launch=1, in_run_frac=0.0079, best_frac=0.4225, best_frames_per_launch=16,
+                isolated=[dict(frames_per_launch=b, note=prose) for b in (1, 4, 16, 32)])
+    hbm = dict(kernel="k (" + prose + ")", bound="hbm", achieved=213.07, peak=8000.0, unit="GB/s", frac=0.0266, traffic=None, avg_launch_ms=6.81, note=prose, offline={"a": prose})
+    return {"metric": "frames/sec, AOC-Net matching + calibration hot path (480p, 3 objects)", "value": 422.321, "unit": "frames/s", "n_gpus": 8, "steps": 20, "warmup": 5,
+            "ms_per_step": 4.7357, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "dtype_detail": prose,
+            "timed_regions": 11, "region_ms": [94.7] * 15, "ranks_seen": 8, "frames_per_rank": [40] * 8, "imbalance": 1.0123,
+            "config": {"workload": "cfg2: 121x213 stride-4 maps (480p), O=4 (3 objects + background), K=16 proxies, C=100, 60-frame clips, MEM_EVERY=5 (pool R=1..12), "
+                                   "20 Lloyd iterations, local windows 2..12, 10 IA gates + 4 conditioning blocks", "R_mean": 6.4, "R_timed": {"histogram": {str(r): 10 for r in range(1, 13)}},
+                       "sequences_per_gpu": 2, "proxy_mode": "reference", "proxy_mode_detail": prose, "frame_call": prose, "dense_precision": prose},
+            "host_enqueue_ms_per_step": 4.1, "host_enqueue_cpu_ms_per_step": 0.95, "probe_sampling": prose,
+            "exact_fp32_dense_run": dict(value=109.6, note=prose), "exact_fp32_value": 109.6, "cfg3_value": 239.917, "cfg4_value": 202.7, "closed_loop_value": 364.4,
+            "roofline": roof, "roofline_correlation": corr, "roofline_kmeans_chain": hbm, "roofline_film_scale": dict(hbm), "roofline_cond_gate_pool": dict(hbm),
+            "strong_scaling": dict(note=prose, workload=prose), "other_configs": {"cfg3": dict(workload=prose), "cfg4": dict(workload=prose)},
+            "image_level_end_to_end": dict(note=prose),
+            "cpu_baseline": dict(value=0.04185, unit="frames/s", cores=32, kind="port", runs=5, sample="median of 5 runs after 1 warm-up: " + prose, detail=prose,
+                                 frame_seconds=[23.9] * 5),
+            "parity": dict(max_abs_feature_diff=1.43e-6, per_branch={k: 1e-6 for k in ("dense", "cluster", "proxy", "local", "local_proxy")}, surrogate_mask_mean_iou=1.0),
+            "kernels": {f"op{i}": dict(calls=100, avg_ms=1.0, note=prose) for i in range(12)}, "skipped": ["cfg4:budget"], "phases_s": {"a": 1.0}, "wall_s": 93.2}
+
+
+def test_bench_line_is_compact():
+    """Round 5's headline went unmeasured because the ONE line bench.py prints had grown to 23 KB and the driver (which keeps an 8 KB tail of stdout) could
+    not parse it.  The printed line is a pure function of the full record: whatever prose the record carries, the line stays one line under 4 KB, parses,
+    and holds every key the contract and the verdict ask for; everything else lives in the details file the line points at."""
+    import bench
+    full = _canned_full_record()
+    assert len(json.dumps(full)) > 20000                   # the canned record is as verbose as round 5's line
+    line = bench.compact_line(full, "gpurun_out/bench_details.json")
+    text = json.dumps(line)
+    assert len(text) < 4096 and "\n" not in text, len(text)
+    back = json.loads(text)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+              "roofline", "cpu_baseline", "parity", "exact_fp32_value", "cfg3_value", "cfg4_value", "details_file", "ranks_seen", "imbalance", "schema"):
+        assert k in back, k
+    assert back["config"]["workload"].startswith("cfg2") and "model" not in back["config"]
+    for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in back["roofline"], k
+    assert back["roofline"]["bound"] == "mfma" and back["roofline_correlation"]["bound"] == "hbm" and back["roofline_correlation"]["traffic"] is None
+    assert abs(back["roofline"]["frac"] - back["roofline"]["achieved"] / back["roofline"]["peak"]) < 1e-3
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in back["cpu_baseline"], k
+    assert back["parity"]["max_abs_feature_diff"] == 1.43e-6
+    # a record whose optional objects are absent (N > 1: no CPU baseline, no other configs) still makes a valid line
+    for k in ("cpu_baseline", "parity", "exact_fp32_value", "cfg3_value", "cfg4_value", "roofline_film_scale", "skipped"):
+        full[k] = None
+    back = json.loads(json.dumps(bench.compact_line(full, "d.json")))
+    assert back["cpu_baseline"] is None and back["value"] == 422.321 and "cfg3_value" not in back
+
+
+def test_bench_reads_pmc_traffic_from_the_committed_file():
+    """`roofline.traffic` is read from the committed rocprofv3 --pmc summary at bench time (FETCH x 2 + WRITE, KB -> bytes), not copied into bench.py."""
+    import bench
+    t = bench.pmc_traffic_bytes("profiles/r04_pmc_dense_R6.txt")
+    assert t is not None and abs(t - (2 * 1.8296e5 + 34155) * 1024) < 1.0
+    assert bench.pmc_traffic_bytes("profiles/does_not_exist.txt") is None
