@@ -705,6 +705,29 @@ def compact_line(full, details_file):
     return line
 
 
+def _drain_stdout():
+    sys.stdout.flush()
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except OSError:
+        pass
+
+
+def finish(report, use_dist):
+    """The JSON line has to be the LAST line of the job's stdout (that is what the driver parses), and RCCL announces itself there ("Librccl path : ...")
+    through a buffered C stream that is otherwise flushed at exit, after the report.  So: every rank drains its C-level stdout, the group is torn down,
+    the ranks drain again, and only then does rank 0 print (after a short pause with several ranks: their output reaches the launcher through pipes)."""
+    _drain_stdout()
+    if use_dist:
+        torch.distributed.barrier()                        # the other ranks wait for rank 0 before tearing down
+        torch.distributed.destroy_process_group()
+        _drain_stdout()
+    if report is not None:
+        if use_dist and int(os.environ.get("WORLD_SIZE", "1")) > 1:
+            time.sleep(0.5)
+        print(report, flush=True)
+
+
 def free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -939,12 +962,9 @@ def main():
                     "eval": {k: tot[k] for k in ("sequences", "ranks", "frames", "objects", "mean_j", "mean_f", "rank_seconds_max", "rank_seconds_mean",
                                                  "imbalance", "planned_imbalance")},
                     "roofline": None, "cpu_baseline": None, "ranks_seen": int(tot["ranks"]), "imbalance": round(float(tot["imbalance"]), 4), "schema": SCHEMA}
-            text = json.dumps(line)
-            assert len(text) < COMPACT_LIMIT, len(text)
-            print(text, flush=True)
-        if use_dist:
-            torch.distributed.barrier()
-            torch.distributed.destroy_process_group()
+            report = json.dumps(line)
+            assert len(report) < COMPACT_LIMIT, len(report)
+        finish(report if rank == 0 else None, use_dist)
         return
 
     cfg = syn.CONFIGS[args.config]
@@ -1476,10 +1496,8 @@ def main():
                 json.dump(full, f, indent=1)
         except OSError as e:                               # a read-only tree must not cost the line
             details_path = f"(not written: {e.__class__.__name__})"
-        print(json.dumps(compact_line(full, details_path)), flush=True)
-    if use_dist:
-        torch.distributed.barrier()                        # the other ranks wait for rank 0's report before tearing down
-        torch.distributed.destroy_process_group()
+        report = json.dumps(compact_line(full, details_path))
+    finish(report if rank == 0 else None, use_dist)
 
 
 if __name__ == "__main__":

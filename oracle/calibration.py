@@ -11,12 +11,15 @@ weights to the HIP path.
 PARITY STATUS
 * ``ia_gate``, ``attention_head_for_eval_p_m``, ``conditioning_layer`` (4-D input): pinned by
   golden vectors generated from the reference (tests/golden/make_golden.py).
-* ``conditioning_block``: **parity unpinned**.  CLB:66-86 cannot execute as shipped
-  (``CL_1``/``mlp_layer`` without ``self.``; ``CL_2``/``CL_3`` receive 2-D tensors that Conv2d
-  rejects; with [N,D,1,1] inputs ``k = int(beta*1*1) = 0`` and CLB:36 raises IndexError).
-  The repairs applied here (documented in DESIGN.md) are: ``self.`` prefixes; a 2-D input v is
-  treated as the H=W=1 limit of Eq.7 with the gate identically 1, i.e. ``CL(v) = mlp(v)``;
-  ``CL_3`` is sized by ``proxy_dim``.
+* ``conditioning_block``: CLB:66-86 cannot execute as shipped (``CL_1``/``mlp_layer`` without
+  ``self.``; ``CL_2``/``CL_3`` receive 2-D tensors that Conv2d rejects; with [N,D,1,1] inputs
+  ``k = int(beta*1*1) = 0`` and CLB:36 raises IndexError).  Since round 6 the reference's OWN forward
+  is run unmodified with the four missing names injected as module globals
+  (tests/golden/make_golden_r6.py: ``CL_1`` = the reference layer, ``mlp_layer`` = its MLP,
+  ``CL_2``/``CL_3`` = the repair below) and its output pins CLB:68-69, CLB:72 and CLB:81-84
+  (tests/golden/conditioning_block_injected_*.npz).  **Still unpinned** -- nothing in the reference
+  can execute it: the repair of the vector branch, a 2-D input v treated as the H=W=1 limit of
+  Eq.7 with the gate identically 1, i.e. ``CL(v) = mlp(v)``; ``CL_3`` is sized by ``proxy_dim``.
 """
 import torch
 

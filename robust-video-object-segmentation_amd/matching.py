@@ -33,6 +33,18 @@ def _bias_vec(dis_bias, obj_nums, device):
     return torch.full((obj_nums,), float(dis_bias), dtype=torch.float32, device=device)
 
 
+def _off_grid(h, w, rate, device):
+    """[h, w, 1] bool: pixels that are NOT on the rate-strided grid (rows and columns 0, rate, 2 rate, ...)."""
+    on = (torch.arange(h, device=device) % rate == 0)[:, None] & (torch.arange(w, device=device) % rate == 0)[None, :]
+    return (~on)[:, :, None]
+
+
+def _keep_big_objects_on_grid(labels, off_grid, rate, obj_pixel_num):
+    """An object with more than obj_pixel_num * rate^2 labelled pixels in the frame loses its label off the strided grid (AEM:531-541 / 437-446)."""
+    large = labels.sum(dim=(0, 1)) > obj_pixel_num * rate * rate
+    return labels.masked_fill(off_grid & large[None, None, :], 0.0)
+
+
 def _flatten_pool(all_ref_emb, all_ref_labels, h, w, atrous_rate, atrous_obj_pixel_num):
     """The reference pool as rows (AEM:507-579 / 715-787): every reference frame's pixels, one after the other.
     atrous_rate > 1, atrous_obj_pixel_num <= 0: only the pixels of the rate-strided grid are rows of the pool -- a device gather
@@ -48,11 +60,8 @@ def _flatten_pool(all_ref_emb, all_ref_labels, h, w, atrous_rate, atrous_obj_pix
         e, l = e.float(), l.float()
         if rate > 1 and atrous_obj_pixel_num > 0:
             if off_grid is None:
-                dev = e.device
-                on = (torch.arange(h, device=dev) % rate == 0)[:, None] & (torch.arange(w, device=dev) % rate == 0)[None, :]
-                off_grid = (~on)[:, :, None]
-            large = l.sum(dim=(0, 1)) > atrous_obj_pixel_num * rate * rate
-            l = l.masked_fill(off_grid & large[None, None, :], 0.0)
+                off_grid = _off_grid(h, w, rate, e.device)
+            l = _keep_big_objects_on_grid(l, off_grid, rate, atrous_obj_pixel_num)
         elif rate > 1:
             e, l = ops.atrous_subsample(e, rate), ops.atrous_subsample(l, rate)
         embs.append(e.reshape(-1, C))
@@ -174,19 +183,12 @@ def global_matching_for_eval_cluster(all_reference_embeddings, query_embeddings,
 
 
 def _train_twin_labels(reference_labels, h, w, atrous_rate, atrous_obj_pixel_num):
-    """AEM:437-446 (== 368-377, 648-657): the training twins mask the labels of every "big" object with the atrous grid
-    whenever atrous_rate > 1.  Works on a clone (the reference writes into the caller's tensor)."""
+    """AEM:437-446 (== 368-377, 648-657): with atrous_rate > 1 the training twins keep the label of every "big" object (more than
+    atrous_obj_pixel_num * rate^2 pixels -- every labelled object when that parameter is 0) on the rate-strided grid only.  Same mask as the
+    evaluation pool's (_keep_big_objects_on_grid); returns a new tensor (the reference writes into the caller's)."""
     if atrous_rate <= 1:
         return reference_labels
-    h_pad = (atrous_rate - h % atrous_rate) % atrous_rate
-    w_pad = (atrous_rate - w % atrous_rate) % atrous_rate
-    sel = torch.zeros((h + h_pad) // atrous_rate, atrous_rate, (w + w_pad) // atrous_rate, atrous_rate, device=reference_labels.device)
-    sel[:, 0, :, 0] = 1.
-    sel = sel.reshape(h + h_pad, w + w_pad, 1)[:h, :w]
-    labels = reference_labels.clone()
-    big = labels.sum(dim=(0, 1)) > (atrous_obj_pixel_num * atrous_rate ** 2)
-    labels[:, :, big] = labels[:, :, big] * sel
-    return labels
+    return _keep_big_objects_on_grid(reference_labels.float(), _off_grid(h, w, int(atrous_rate), reference_labels.device), atrous_rate, atrous_obj_pixel_num)
 
 
 def global_matching_cluster(reference_embeddings, query_embeddings, reference_labels,

@@ -46,3 +46,16 @@ def check_eval_loop(g, policy, to_dev=lambda t: t):
         if t > 0:
             assert np.array_equal(prev_mask.reshape(H, W), g[f"f{t}_prev_mask"]), f"frame {t}: previous mask"
             assert np.array_equal(saved.reshape(H, W), g["saved_labels"][t - 1]), f"frame {t}: saved label map"
+
+
+BLOCK_CASES = ["conditioning_block_injected_small", "conditioning_block_injected_wide", "conditioning_block_injected_one_object"]
+
+
+def block_weights(g):
+    """The oracle's weight dict from a round-6 conditioning_block golden (tests/golden/make_golden_r6.py stores the reference module's state_dict)."""
+    sd = {k[2:].replace("__", "."): T(g[k]) for k in list(g.keys()) if k.startswith("w_")}
+    return {"CL_1.phi_w": sd["CL_1.phi_layer.weight"].reshape(-1), "CL_1.phi_b": sd["CL_1.phi_layer.bias"],
+            "CL_1.mlp_w": sd["CL_1.mlp_layer.weight"], "CL_1.mlp_b": sd["CL_1.mlp_layer.bias"],
+            "CL_2.mlp_w": sd["CL_2.mlp_layer.weight"], "CL_2.mlp_b": sd["CL_2.mlp_layer.bias"],
+            "CL_3.mlp_w": sd["CL_3.mlp_layer.weight"], "CL_3.mlp_b": sd["CL_3.mlp_layer.bias"],
+            "mlp_w": sd["mlp_layer.weight"], "mlp_b": sd["mlp_layer.bias"]}, sd

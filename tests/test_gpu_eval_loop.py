@@ -172,7 +172,8 @@ def test_bench_two_ranks_on_one_gpu_over_gloo():
         pytest.skip("needs an MI355X")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, AOC_DIST_BACKEND="gloo")
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--exact-steps", "0"],
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--exact-steps", "0", "--no-extras",
+                        "--details-file", "gpurun_out/bench_details_gloo2.json"],
                        env=env, capture_output=True, text=True, timeout=900, cwd=root)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
     lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith("{")]
@@ -237,7 +238,7 @@ def test_bench_line_with_the_process_group_on_rccl():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "4", "--warmup", "1", "--no-cpu-baseline", "--exact-steps", "0", "--no-extras",
                         "--details-file", "gpurun_out/bench_details_rccl1.json"], env=env, capture_output=True, text=True, timeout=900, cwd=root)
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-2500:]
-    line = json.loads(r.stdout.strip().splitlines()[-1])
+    line = json.loads(r.stdout.strip().splitlines()[-1])            # the report is the LAST line of stdout, after whatever RCCL prints about itself
     assert line["n_gpus"] == 1 and line["ranks_seen"] == 1 and line["frames_per_rank"] == [4 * line["config"]["sequences_per_gpu"]] and line["imbalance"] == 1.0
     assert line["value"] > 0 and line["roofline"]["bound"] == "mfma" and line["roofline_correlation"]["bound"] == "hbm"
 

@@ -254,6 +254,24 @@ def test_conditioning_layer_golden(aoc, golden):
     np.testing.assert_allclose(out.cpu().numpy(), g["out"], rtol=1e-5, atol=2e-6)
 
 
+@pytest.mark.parametrize("case", ["conditioning_block_injected_small", "conditioning_block_injected_wide", "conditioning_block_injected_one_object"])
+def test_conditioning_block_vs_reference_forward(aoc, golden, case):
+    """a13 against the reference's OWN forward (CLB:66-86 executed unmodified with its missing globals injected; tests/golden/make_golden_r6.py):
+    the mirror is loaded with the reference module's state_dict -- same parameter names -- and must reproduce the recorded output."""
+    import golden_cases
+    g = golden(case)
+    _, sd = golden_cases.block_weights(g)
+    n, c, h, w = g["in_x"].shape
+    blk = aoc.conditioning_layer.conditioning_block(c, g["in_head"].shape[1], float(g["beta"]))
+    blk.load_state_dict(sd, strict=True)
+    blk = blk.cuda()
+    with torch.no_grad():
+        got = blk(dev(g["in_x"].astype(np.float32)), dev(g["in_head"].astype(np.float32)))
+        c1 = blk.CL_1(dev(g["in_x"].astype(np.float32)))
+    np.testing.assert_allclose(c1.cpu().numpy(), g["cl1"], rtol=1e-5, atol=2e-6)
+    np.testing.assert_allclose(got.cpu().numpy(), g["out"], rtol=1e-5, atol=5e-6)
+
+
 def test_conditioning_block_vs_oracle(aoc):
     from oracle import calibration as ocal
     torch.manual_seed(0)

@@ -4,6 +4,7 @@ import numpy as np
 import pytest
 import torch
 
+import golden_cases  # tests/golden_cases.py
 from oracle import calibration as ocal
 from oracle import matching as om
 
@@ -169,6 +170,20 @@ def test_conditioning_block_repair_is_consistent():
     a = 1 + torch.tanh(torch.cat([c1, delta @ w["CL_2.mlp_w"].t() + w["CL_2.mlp_b"],
                                   head @ w["CL_3.mlp_w"].t() + w["CL_3.mlp_b"]], 1) @ w["mlp_w"].t() + w["mlp_b"])
     np.testing.assert_allclose(y.numpy(), (a[:, :, None, None] * x).numpy(), rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("case", golden_cases.BLOCK_CASES)
+def test_conditioning_block_against_the_reference_forward(golden, case):
+    """a13, round 6: the reference's OWN conditioning_block.forward (CLB:66-86), executed unmodified with CL_1 / CL_2 / CL_3 / mlp_layer injected as
+    module globals (CL_1 = the reference layer, CL_2 / CL_3 = the documented vector repair; tests/golden/make_golden_r6.py).  Pins CLB:68-69, CLB:72
+    through the real layer and CLB:81-84; what stays pinned by the restatement alone is the repair v -> mlp(v) itself."""
+    g = golden(case)
+    w, _ = golden_cases.block_weights(g)
+    x, head = T(g["in_x"].astype(np.float32)), T(g["in_head"].astype(np.float32))
+    c1 = ocal.conditioning_layer(x, w["CL_1.phi_w"], w["CL_1.phi_b"], w["CL_1.mlp_w"], w["CL_1.mlp_b"], float(g["beta"]))
+    np.testing.assert_allclose(c1.numpy(), g["cl1"], rtol=1e-5, atol=1e-6)
+    y = ocal.conditioning_block(x, head, w, float(g["beta"]))
+    np.testing.assert_allclose(y.numpy(), g["out"], rtol=1e-5, atol=2e-6)
 
 
 def test_shannon_entropy_matches_reference_output(golden):
