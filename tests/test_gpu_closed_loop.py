@@ -28,12 +28,16 @@ def _iou(a, b, n_obj):
     return float(np.mean(vals))
 
 
-def test_closed_loop_masks_within_iou_budget(aoc):
+@pytest.mark.parametrize("cfg_name,T", [("tiny", 7), ("cfg2", 4)])
+def test_closed_loop_masks_within_iou_budget(aoc, cfg_name, T):
+    """tiny: 7 frames, three pool changes.  cfg2 (round 6): BASELINE.json configs[1]'s full size -- 121x213 maps, 3 objects + background, K = 16 -- for
+    3 frames with a pool change in between (R = 1, 1, 2), every frame against the oracle's whole frame (about 20 s of CPU), and the per-frame k-means
+    assignments of the pool compared BIT FOR BIT with the oracle's (== scipy's) while the two loops' pools agree."""
     from oracle import eval_loop as oe
     from oracle import hotpath as ohot
+    from oracle import kmeans as okm
     syn, hot = aoc.synthetic, aoc.hotpath
-    cfg = syn.CONFIGS["tiny"]
-    T = 7
+    cfg = syn.CONFIGS[cfg_name]
     clip = syn.make_clip(cfg, 11, frames=T)
     n_obj, h, w, C = cfg.n_obj, cfg.h, cfg.w, cfg.c
     H, W = h * 4, w * 4
@@ -71,6 +75,7 @@ def test_closed_loop_masks_within_iou_budget(aoc):
     gpu.start(emb[0].cuda(), gt0.cuda())
     cpu.start(emb[0], gt0.long())
     ious = []
+    checked_pools = 0
     with torch.no_grad():
         for t in range(1, T):
             # the same initial rows on both sides, drawn from the CPU pool's row counts (as scipy would from numpy's RandomState)
@@ -85,8 +90,25 @@ def test_closed_loop_masks_within_iou_budget(aoc):
                                                  init_rows=rows)
             if same_pool:
                 np.testing.assert_allclose(feat_g.cpu().numpy(), feat_c.numpy(), rtol=0, atol=5e-6)
+                # bit-exact argmin cluster assignments (north_star) on this frame's pool, at this size, with this frame's initial rows
+                cp = aoc.matching.cluster_proxies(g_ref_emb.reshape(-1, C), g_ref_lab.reshape(-1, n_obj), 16, rows)
+                offs = cp["prep"].obj_offsets.cpu().numpy()
+                got_lab, got_cen = cp["labels"].cpu().numpy(), cp["centroids"].cpu().numpy()
+                pool_rows, flat_lab = torch.stack(cpu.ref_embeddings).reshape(-1, C).numpy(), c_ref_lab.reshape(-1, n_obj)
+                ids = torch.where(flat_lab.sum(1) > 0, flat_lab.argmax(1), torch.full((flat_lab.shape[0],), -1)).numpy()   # uncertain pixels (125) belong to nobody
+                kk = 16
+                for o in range(n_obj):
+                    kk = min(kk, counts[o])
+                    if kk == 0:
+                        continue
+                    x = pool_rows[ids == o]
+                    cb, l, _ = okm.kmeans2_matrix(x, x[rows[o]], 20)
+                    assert np.array_equal(got_lab[offs[o]:offs[o + 1]], l), f"frame {t}, object {o}: k-means labels"
+                    assert np.array_equal(got_cen[o][:kk], cb), f"frame {t}, object {o}: code book"
+                checked_pools += 1
             lab_g, _, _ = gpu.update(emb[t].cuda(), decode_gpu(feat_g))
             lab_c, _, _ = cpu.update(emb[t], decode_cpu(feat_c))
             ious.append(_iou(lab_g.cpu().numpy(), lab_c.numpy(), n_obj))
     assert min(ious) >= 1.0 - 1e-3, ious
+    assert checked_pools >= 1                                  # the loops' pools agreed at least on the first frame
     assert len(gpu.ref_embeddings) == len(cpu.ref_embeddings) == 1 + (T - 1) // 2
