@@ -34,8 +34,7 @@ constexpr float SP_SCALE = 1024.0f;            // 2^10
 constexpr float SP_QCONST = 32768.0f;          // query-side value of the norm slots: 2^15 * (-16 |r|^2) = -2^19 |r|^2
 constexpr float SP_UNSCALE = -1.0f / 524288.0f;   // d - |q|^2 = -2^-19 * acc
 constexpr int SP_TILE = 32;                    // reference pixels per MFMA tile
-constexpr int SP_NB = 4;                       // tiles per staged chunk
-constexpr int SP_NW = 8;                       // waves per block
+constexpr int SP_NB = 4;                       // tiles per staged chunk (the product; dense_prune_kernel<4, 0, 2> stages two)
 constexpr int SP_NQ = 2;                       // 32-pixel query tiles per wave (stationary B operands in registers)
 
 static_assert(SP_NORM_SLOT + 4 <= SP_K && SP_NORM_SLOT / 16 == SP_KS - 1 && (SP_NORM_SLOT % 16) + 4 <= 8, "norm slots live in the low half of the last k-step");
@@ -260,12 +259,12 @@ __device__ __forceinline__ void glds4(const void *gsrc, uint32_t lds_dst) {
 }
 
 constexpr int SP_NBUF = 2;                                        // chunk buffers in LDS
-constexpr int SP_CHUNK_BYTES = SP_NB * SP_TILE * SP_REC * 16;     // 57344: four tiles x 32 rows x 448 B, rows unpadded
-constexpr int SP_RING_BYTES = SP_NBUF * SP_CHUNK_BYTES;
-constexpr int SP_IDS_OFF = SP_RING_BYTES;                         // 2 slots x 128 row ids
-constexpr int SP_OBJ_OFF = SP_IDS_OFF + 2 * 512;                  // 4 slots x 64 tile objects (4 used)
-constexpr int SP_BND_OFF = SP_OBJ_OFF + 4 * 256;                  // per (wave, query tile): 64 published bounds
-constexpr int SP_LDS_BYTES = SP_BND_OFF + SP_NW * SP_NQ * 256;      // (for the widest workgroup)
+// LDS layout of a workgroup of NW waves that stages NB tiles per chunk
+__host__ __device__ constexpr int sp_chunk_bytes(int nb) { return nb * SP_TILE * SP_REC * 16; }     // NB = 4: 57344 (four tiles x 32 rows x 448 B, rows unpadded)
+__host__ __device__ constexpr int sp_ids_off(int nb) { return SP_NBUF * sp_chunk_bytes(nb); }       // 2 slots x (up to) 128 row ids
+__host__ __device__ constexpr int sp_obj_off(int nb) { return sp_ids_off(nb) + 2 * 512; }           // 4 slots x 64 tile objects (NB used)
+__host__ __device__ constexpr int sp_bnd_off(int nb) { return sp_obj_off(nb) + 4 * 256; }           // per (wave, query tile): 64 published bounds
+__host__ __device__ constexpr int sp_lds_bytes(int nw, int nb) { return sp_bnd_off(nb) + nw * SP_NQ * 256; }
 constexpr int SP_TILE_SLACK = 2;                                  // the plan always holds an empty tile after the last one
 
 // Coarse-then-rescore.  Block = 8 waves x 2 query tiles (512 query pixels; both planes of their records are the stationary B
@@ -295,8 +294,8 @@ constexpr int SP_TILE_SLACK = 2;                                  // the plan al
 // MFMA whose A fragment is zero except for the negated norm slot, then continues as before.  The bound is rigorous (the products of the fp16
 // values are exact, the norms are rounded up, the accumulations' roundings are inside eps), so the set of discarded pairs can never contain
 // the maximum: same results as CKPT = 0, deterministic as before (a pair's value does not depend on what else was evaluated).
-template <int NW, int CKPT>
-__global__ __launch_bounds__(NW * 64, 1) void dense_prune_kernel(const uint4 *__restrict__ qrec, const float *__restrict__ q2, int64_t m,
+template <int NW, int CKPT, int NB = SP_NB>
+__global__ __launch_bounds__(NW * 64, NB == 2 ? 2 : 1) void dense_prune_kernel(const uint4 *__restrict__ qrec, const float *__restrict__ q2, int64_t m,
                                                                      const uint4 *__restrict__ prec, const int32_t *__restrict__ tile_rows,
                                                                      const int32_t *__restrict__ tile_obj, const int32_t *__restrict__ n_tiles_ptr,
                                                                      const int32_t *__restrict__ gate, const uint32_t *__restrict__ pmax_bits,
@@ -311,7 +310,9 @@ __global__ __launch_bounds__(NW * 64, 1) void dense_prune_kernel(const uint4 *__
     (void)dbg_arg;
 #endif
     extern __shared__ __attribute__((aligned(16))) uint4 lds4[];
-    static_assert(SP_NB == 4 && SP_NQ == 2 && (NW == 8 || NW == 4), "the step structure below is written for 4 tiles x 2 query tiles x 8 (or 4) waves");
+    static_assert(SP_NQ == 2 && ((NB == 4 && (NW == 8 || NW == 4)) || (NB == 2 && NW == 4)),
+                  "the step structure below is written for 4 tiles x 2 query tiles x 8 (or 4) waves, or 2 tiles x 2 query tiles x 4 waves (two workgroups per CU)");
+    constexpr int SP_CHUNK_BYTES = sp_chunk_bytes(NB), SP_IDS_OFF = sp_ids_off(NB), SP_OBJ_OFF = sp_obj_off(NB), SP_BND_OFF = sp_bnd_off(NB);
     static_assert(CKPT == 0 || CKPT == 3 || CKPT == 4, "checkpoint after 3 or 4 k-steps (rest norms in slots 104 / 105), or none");
     constexpr int SP_DMA_PER_WAVE = SP_CHUNK_BYTES / 1024 / NW;      // 7 (14) wave-wide 1 KiB transfers per wave and chunk
     constexpr int W_ID0 = NW / 2, W_ID1 = NW - 1, W_OBJ = 1;         // the waves that also fetch the row ids / the tiles' objects
@@ -335,7 +336,7 @@ __global__ __launch_bounds__(NW * 64, 1) void dense_prune_kernel(const uint4 *__
     const int ns = gridDim.y;
     if (by >= n_tiles) return;
     const int n_mine = (n_tiles - by + ns - 1) / ns;
-    const int n_chunks = (n_mine + SP_NB - 1) / SP_NB;
+    const int n_chunks = (n_mine + NB - 1) / NB;
 
     const int lane = aoc_lane(), wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int col = lane & 31, h = lane >> 5;
@@ -398,13 +399,13 @@ __global__ __launch_bounds__(NW * 64, 1) void dense_prune_kernel(const uint4 *__
     const char *prec_bytes = reinterpret_cast<const char *>(prec);
     auto dma_meta = [&](int chunk) {            // row ids (two waves, two tiles each) and tile objects (one wave) of a chunk -> their rings
         // tile i of the split is tile by + i ns of the plan; past the end everything reads the (always present) empty tile n_tiles
-        const int i0 = chunk * SP_NB;
-        if (wave == W_ID0 || wave == W_ID1) {
+        const int i0 = chunk * NB;
+        if (wave == W_ID0 || (NB == 4 && wave == W_ID1)) {
             const int i = i0 + (wave == W_ID1 ? 2 : 0) + (lane >> 5);
             const int t = min(by + i * ns, n_tiles);
             glds4(tile_rows + (size_t)t * SP_TILE + (lane & 31), lds_base + SP_IDS_OFF + (chunk & 1) * 512 + (wave == W_ID1 ? 256 : 0));
         }
-        if (wave == W_OBJ) glds4(tile_obj + min(by + (i0 + (lane & 3)) * ns, n_tiles), lds_base + SP_OBJ_OFF + (chunk & 3) * 256);
+        if (wave == W_OBJ) glds4(tile_obj + min(by + (i0 + (lane & (NB - 1))) * ns, n_tiles), lds_base + SP_OBJ_OFF + (chunk & 3) * 256);
     };
     auto dma_rows = [&](int chunk) {            // the chunk's records -> buffer chunk % 2 (its ids must have landed and been published)
         const int32_t *ids = reinterpret_cast<const int32_t *>(lds_bytes + SP_IDS_OFF + (chunk & 1) * 512);
@@ -428,6 +429,12 @@ __global__ __launch_bounds__(NW * 64, 1) void dense_prune_kernel(const uint4 *__
     }
     int cur = -1;
     unsigned n_rescored = 0, n_any = 0, n_seen = 0, n_dead = 0;
+    // development build, dbg 4096: core-clock stamps (s_memtime) around the pieces of a tile / a step, summed per wave.  dbg 8192 selects the second
+    // triple.  [0] a tile's 14 coarse MFMAs (issue), [1] decision, [2] rescoring | [3] between tiles (object switch, loop), [4] step head (DMA
+    // issue), [5] step tail (vmcnt(0), bound read-back, barrier)
+    unsigned long long cyc[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long t_prev = 0;
+    auto stamp = [&]() -> unsigned long long { return (dbg & 4096) ? __builtin_amdgcn_s_memtime() : 0ull; };
     // what the other workgroups have published for the current object: one 4-byte transfer per query tile into this wave's own LDS
     // words, read back one step later (device-scope load: the values come from L2, not from this CU's vector cache)
     auto dma_bound = [&]() {
@@ -473,6 +480,7 @@ __global__ __launch_bounds__(NW * 64, 1) void dense_prune_kernel(const uint4 *__
     for (int s = 0; s < n_chunks; ++s) {
         // (a) prefetches for the next step: published bounds of the current object, meta of chunk s + 2, rows of chunk s + 1 (whose ids
         // the barrier that ended step s - 1 published)
+        const unsigned long long t_s0 = stamp();
         const int4 objs = *reinterpret_cast<const int4 *>(lds_bytes + SP_OBJ_OFF + (s & 3) * 256);
         const int bound_obj = (dbg & 32) ? -3 : cur;
         if (!(dbg & 32)) dma_bound();
@@ -481,16 +489,20 @@ __global__ __launch_bounds__(NW * 64, 1) void dense_prune_kernel(const uint4 *__
 
         // (b) the four tiles of chunk s
         const char *chunk_base = lds_bytes + (s % SP_NBUF) * SP_CHUNK_BYTES;
-        const int n_here = min(SP_NB, n_mine - s * SP_NB);
+        const int n_here = min(NB, n_mine - s * NB);
         // the first two A fragments of a tile are requested while the previous tile's epilogue runs
         f16x8 pre0 = frag(chunk_base, 2 * ks_of(0)), pre1 = frag(chunk_base, 2 * ks_of(1));
         // the four tiles' objects in one scalar (objects are < 256): two SALU operations per tile instead of a chain of selects
         const uint32_t objs_packed = (uint32_t)__builtin_amdgcn_readfirstlane((objs.x & 0xff) | ((objs.y & 0xff) << 8) | ((objs.z & 0xff) << 16) | ((objs.w & 0xff) << 24));
+        t_prev = stamp();
+        cyc[4] += t_prev - t_s0;
 #pragma unroll 1
         for (int t = 0; t < n_here; ++t) {
             const char *tile_base = chunk_base + t * (SP_TILE * SP_REC * 16);
             const int o = (int)((objs_packed >> (8 * t)) & 0xffu);
             if (o != cur) switch_object(o);
+            const unsigned long long t_0 = stamp();
+            cyc[3] += t_0 - t_prev;
             // coarse pass: 7 k-steps x 2 query tiles, A fragments two k-steps ahead through a ring of three
             f32x16 acc[SP_NQ];
 #pragma unroll
@@ -504,7 +516,7 @@ __global__ __launch_bounds__(NW * 64, 1) void dense_prune_kernel(const uint4 *__
                 af[1] = pre1;
 #pragma unroll
                 for (int kk = 0; kk < SP_KS; ++kk) {
-                    if (kk + 2 < SP_KS) af[(kk + 2) % 3] = frag(tile_base, 2 * ks_of(kk + 2));
+                    if (kk + 2 < SP_KS && !(dbg & 512)) af[(kk + 2) % 3] = frag(tile_base, 2 * ks_of(kk + 2));   // dbg 512: stale fragments, no LDS reads
 #pragma unroll
                     for (int iq = 0; iq < SP_NQ; ++iq)
                         acc[iq] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[kk % 3], bh[iq][ks_of(kk)], acc[iq], 0, 0, 0);
@@ -561,17 +573,22 @@ __global__ __launch_bounds__(NW * 64, 1) void dense_prune_kernel(const uint4 *__
                     else phase2(std::false_type{}, std::true_type{});
                 }
             }
+            const unsigned long long t_1 = stamp();
+            cyc[0] += t_1 - t_0;
             // which query tiles may hold a new maximum (wave-uniform)
             bool want[SP_NQ];
 #pragma unroll
             for (int iq = 0; iq < SP_NQ; ++iq) {
                 want[iq] = false;
-                if (live[iq]) {
+                if (live[iq] && !(dbg & 256)) {                    // dbg 256: no decision (the accumulators are never read)
                     const float cm = max16(acc[iq]);
                     want[iq] = __builtin_amdgcn_ballot_w64(cm + eps[iq] >= __builtin_fmaxf(best[iq], shared[iq])) != 0ull;
                 }
             }
             n_seen += 1;
+            const unsigned long long t_2 = stamp();
+            cyc[1] += t_2 - t_1;
+            t_prev = t_2;
             if ((want[0] || want[1]) && !(dbg & 2)) {
                 n_any += 1;
 #pragma unroll
@@ -601,8 +618,11 @@ __global__ __launch_bounds__(NW * 64, 1) void dense_prune_kernel(const uint4 *__
                         }
                     }
                 }
+                t_prev = stamp();
+                cyc[2] += t_prev - t_2;
             }
         }
+        const unsigned long long t_s1 = stamp();
 
         // (c) this step's transfers have landed (they had four tiles of time).  The wave reads back its own bound words right away (its
         // own vmcnt(0) covers them) so that the lgkmcnt(0) below also retires those reads before the next step's transfer can overwrite
@@ -619,6 +639,7 @@ __global__ __launch_bounds__(NW * 64, 1) void dense_prune_kernel(const uint4 *__
             for (int iq = 0; iq < SP_NQ; ++iq)
                 if (valid[iq]) shared[iq] = __builtin_fmaxf(shared[iq], ord_dec(seen[iq]));
         }
+        cyc[5] += stamp() - t_s1;
     }
     if (lane == 0) {
         atomicAdd(&g_prune_stats[0], (unsigned long long)n_seen * SP_NQ);
@@ -626,6 +647,12 @@ __global__ __launch_bounds__(NW * 64, 1) void dense_prune_kernel(const uint4 *__
         atomicAdd(&g_prune_stats[2], (unsigned long long)n_any);
         atomicAdd(&g_prune_stats[3], (unsigned long long)n_seen);
         atomicAdd(&g_prune_stats[4], (unsigned long long)n_dead);
+        if (dbg & 4096) {
+            const int b = (dbg & 8192) ? 3 : 0;
+            atomicAdd(&g_prune_stats[5], cyc[b]);
+            atomicAdd(&g_prune_stats[6], cyc[b + 1]);
+            atomicAdd(&g_prune_stats[7], cyc[b + 2]);
+        }
     }
 }
 
@@ -678,15 +705,22 @@ inline int split_waves() {
     static const int nw = AOC_DEV_ENV_INT("AOC_DENSE_WAVES", 8) == 4 ? 4 : 8;
     return nw;
 }
+inline int split_tiles_per_chunk() {
+    // developer switch AOC_DENSE_NB=2 (with AOC_DENSE_WAVES=4): chunks of two tiles, 60 KB of LDS per workgroup -> TWO workgroups of four waves per
+    // CU, i.e. two waves per SIMD as in the product but from different workgroups: their barriers and their phases are independent
+    static const int nb = (AOC_DEV_ENV_INT("AOC_DENSE_NB", SP_NB) == 2 && split_waves() == 4) ? 2 : SP_NB;
+    return nb;
+}
 inline int split_nsplit(int64_t m) {
     const int64_t rpb = (int64_t)split_waves() * SP_NQ * 32;
     const int64_t row_blocks = (m + rpb - 1) / rpb;
+    const int wg_per_cu = split_tiles_per_chunk() == 2 ? 2 : 1;
     // at most two rounds of workgroups (developer switch AOC_DENSE_ROUNDS): fewer splits share their bounds sooner (in-run launch 1.43 /
     // 1.50 / 1.56 ms at 1 / 2 / 4 rounds), but with one round the other streams' kernels wait for a whole dense launch before a CU
     // comes free: bench 320 / 324 / 320 frames/s
     static const int max_rounds = AOC_DEV_ENV_INT("AOC_DENSE_ROUNDS", 2);
     // CUs the launching stream may use (256 unless the caller runs it under a HIP CU mask and says so)
-    const int n_cu = aoc_stream_cus() > 0 ? aoc_stream_cus() : 256;
+    const int n_cu = (aoc_stream_cus() > 0 ? aoc_stream_cus() : 256) * wg_per_cu;      // resident workgroups
     int best = 1;
     double best_eff = 0.0;
     for (int k = 1; k <= max_rounds; ++k) {
@@ -812,28 +846,30 @@ int aoc_dense_match_min_split_cached(const float *query, const void *query_rec, 
     const int nw = split_waves();
     const int64_t rpb = (int64_t)nw * SP_NQ * 32;
     const dim3 grid((unsigned)((m + rpb - 1) / rpb), ns);
-    const size_t lds = SP_LDS_BYTES;
+    const int nb = split_tiles_per_chunk();
+    const size_t lds = sp_lds_bytes(nw, nb);
     const AocDenseProbe probe = aoc_take_dense_probe();
     static const int dbg = AOC_DEV_ENV_INT("AOC_DENSE_DEBUG", 0);       // developer switch: timing experiments only
     const int ckpt = split_ckpt();
     int launched = 0;
-#define AOC_DENSE_LAUNCH(NW_, CK_)                                                                                                                          \
-    if (!launched && nw == NW_ && ckpt == CK_) {                                                                                                            \
-        static const bool lds_ok = hipFuncSetAttribute(reinterpret_cast<const void *>(dense_prune_kernel<NW_, CK_>),                                       \
+#define AOC_DENSE_LAUNCH(NW_, CK_, NB_)                                                                                                                     \
+    if (!launched && nw == NW_ && ckpt == CK_ && nb == NB_) {                                                                                               \
+        static const bool lds_ok = hipFuncSetAttribute(reinterpret_cast<const void *>(dense_prune_kernel<NW_, CK_, NB_>),                                  \
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;                                \
         if (!lds_ok) return AOC_ERR_LAUNCH;                                                                                                                 \
         if (probe.start) (void)hipEventRecord(probe.start, st);                                                                                             \
-        hipLaunchKernelGGL((dense_prune_kernel<NW_, CK_>), grid, dim3(NW_ * 64), lds, st, static_cast<const uint4 *>(query_rec), query_sqnorm, m,           \
+        hipLaunchKernelGGL((dense_prune_kernel<NW_, CK_, NB_>), grid, dim3(NW_ * 64), lds, st, static_cast<const uint4 *>(query_rec), query_sqnorm, m,           \
                            static_cast<const uint4 *>(pool_rec), w.tile_rows, w.tile_obj, w.n_tiles, w.gate, w.pmax, n_obj, w.gbest, dbg,                   \
                            query_rec_tiled ? 1 : 0);                                                                                                        \
         launched = 1;                                                                                                                                       \
     }
-    AOC_DENSE_LAUNCH(8, 0)
+    AOC_DENSE_LAUNCH(8, 0, 4)
 #ifdef AOC_DEV
-    AOC_DENSE_LAUNCH(8, 3)
-    AOC_DENSE_LAUNCH(8, 4)
-    AOC_DENSE_LAUNCH(4, 0)
-    AOC_DENSE_LAUNCH(4, 3)
+    AOC_DENSE_LAUNCH(8, 3, 4)
+    AOC_DENSE_LAUNCH(8, 4, 4)
+    AOC_DENSE_LAUNCH(4, 0, 4)
+    AOC_DENSE_LAUNCH(4, 3, 4)
+    AOC_DENSE_LAUNCH(4, 0, 2)
 #endif
 #undef AOC_DENSE_LAUNCH
     if (!launched) return AOC_ERR_UNSUPPORTED;

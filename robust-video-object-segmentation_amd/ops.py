@@ -406,7 +406,8 @@ def dense_prune_stats(reset=True):
     import ctypes
     v = (ctypes.c_uint64 * 8)()
     _lib.check(_lib.lib().aoc_dense_prune_stats_ex(v, 1 if reset else 0), "aoc_dense_prune_stats_ex")
-    return dict(tested=int(v[0]), rescored=int(v[1]), tiles_rescored=int(v[2]), tiles=int(v[3]), stopped=int(v[4]))
+    return dict(tested=int(v[0]), rescored=int(v[1]), tiles_rescored=int(v[2]), tiles=int(v[3]), stopped=int(v[4]),
+                dev_cycles=[int(v[5]), int(v[6]), int(v[7])])      # development build, AOC_DENSE_DEBUG 4096 / 8192: core-clock sums (tools/bench_dense.py)
 
 
 def dense_match_min_split(query_flat, query_split, pool, pool_split, prep, obj_bias, out, out_pixel_stride, out_obj_stride, transform=True):

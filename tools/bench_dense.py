@@ -1,5 +1,5 @@
 """Developer micro-benchmark: dense matching alone (fp32-exact vs split-fp16) at cfg2 size."""
-import sys, time
+import os, sys, time
 import numpy as np
 import torch
 sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
@@ -8,11 +8,12 @@ from aoc_amd import ops, synthetic as syn
 
 R = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 cfg = syn.CONFIGS[sys.argv[2] if len(sys.argv) > 2 else "cfg2"]
-import os
 STRIDE = int(os.environ.get("POOL_STRIDE", "1"))          # pool = frames 0, STRIDE, 2 STRIDE, ... (the bench's memory policy: 5)
 QOFF = int(os.environ.get("QUERY_OFFSET", "1"))           # query = last pool frame + QOFF
 clip = syn.make_clip(cfg, 0, frames=(R - 1) * STRIDE + QOFF + 1)
 emb = torch.from_numpy(clip["emb"]).cuda()
+if os.environ.get("DATA_SCALE"):                              # timing experiment: 0 = all-zero operands (no toggling in the matrix pipe), 0.001 = tiny values
+    emb = emb * float(os.environ["DATA_SCALE"])
 lab = torch.from_numpy(np.stack([syn.one_hot(l, cfg.n_obj) for l in clip["lab"]])).cuda()
 hw, C, O = cfg.h * cfg.w, cfg.c, cfg.n_obj
 pool = emb[0:(R - 1) * STRIDE + 1:STRIDE].reshape(-1, C).contiguous()
@@ -41,6 +42,10 @@ for mode in ("fp32", "split"):
     res = out.clone()
     if mode == "split":
         st = ops.dense_prune_stats()
+        if any(st["dev_cycles"]):
+            waves = 8 * ((hw + 511) // 512)
+            print("  dev_cycles per wave-tile (core clocks; tiles per wave summed over the %d timed + 3 warm-up calls): %s ; tiles %d" %
+                  (n, [round(c / max(st["tiles"], 1), 1) for c in st["dev_cycles"]], st["tiles"]), flush=True)
         print("  rescored %.3f of the (reference tile, query tile) pairs; %.3f of the reference tiles had a rescoring; %.3f of the pairs stopped at the checkpoint" %
               (st["rescored"] / max(st["tested"], 1), st["tiles_rescored"] / max(st["tiles"], 1), st["stopped"] / max(st["tested"], 1)), flush=True)
     if mode == "fp32":

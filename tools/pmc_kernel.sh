@@ -3,6 +3,10 @@
 # averages of every collected counter for the kernels whose name contains <pattern>.
 # Usage: tools/pmc_kernel.sh <pattern> "<counters>" <command...>
 pat=$1; ctrs=$2; shift 2
+export PYTHONPATH=${GRAFT_REPO_ROOT:-$PWD}:${PYTHONPATH:-}
+args=()
+for a in "$@"; do if [ -f "$a" ]; then a=$(realpath "$a"); fi; args+=("$a"); done      # relative script paths survive the cd below
+set -- "${args[@]}"
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/pmc_k
 rocprofv3 --kernel-trace --pmc $ctrs -d /tmp/pmc_k -o pmc --output-format csv -- "$@" > /tmp/pmc_k.log 2>&1
