@@ -28,7 +28,7 @@ if "local" in what:
     ops.local_window_match = fake_local
 if "corr" in what:
     ops.proxy_corr_min = lambda *a, **k: None
-    ops.proxy_corr_min_records = lambda *a, **k: None
+    ops.proxy_corr_min_records = lambda *a, **k: (lambda: None) if k.get("prepare_only") else None      # (bench.correlation_roofline asks for a prepared launch)
     ops.proxy_corr_min_batched = lambda *a, **k: None
 if "kmeans" in what:
     # keep the launch structure but run a single Lloyd iteration
