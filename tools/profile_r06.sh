@@ -2,22 +2,39 @@
 # Round-6 measurement artifacts (GPU box), final code: driver-style bench line (+ --steps 20, + segments), rocprofv3 kernel statistics of the cfg2 /
 # cfg3 / cfg4 bench and of the k-means chain alone, FETCH / WRITE counter passes of the chain (separate --pmc runs), hipEvent-timed chains, gates
 # alone, the sequence-sharded evaluation line, the step ablations.
-# Usage: tools/profile_r05.sh [part ...]   (parts: bench stats pmc chain gates eval ablate; default all; outputs under gpurun_out/r06f/)
+# Usage: tools/profile_r06.sh [part ...]   (parts: bench stats pmc pmcdense chain gates eval cfg5 ablate; default all; outputs under gpurun_out/r06f/)
 set -u
 out=$GRAFT_REPO_ROOT/gpurun_out/r06f
 mkdir -p "$out"
-parts="${*:-bench stats pmc chain gates eval ablate}"
+parts="${*:-bench stats pmc pmcdense chain gates eval cfg5 ablate}"
 has() { case " $parts " in *" $1 "*) return 0;; *) return 1;; esac; }
 cd $GRAFT_REPO_ROOT
 if has bench; then
-  python bench.py > "$out/bench_line.json" 2> "$out/bench_line.err"
-  python bench.py --steps 20 --no-extras --no-cpu-baseline > "$out/bench_line_steps20.json" 2> /dev/null
-  python bench.py --segments --no-extras --no-cpu-baseline --exact-steps 0 2> /dev/null | python -c "
-import json, sys
-for l in sys.stdin:
-    if l.startswith('{'):
-        d = json.loads(l); print(json.dumps(dict(value=d['value'], ms_per_step=d['ms_per_step'], host_enqueue_ms_per_step=d['host_enqueue_ms_per_step'], host_enqueue_wall_ms_per_step=d.get('host_enqueue_wall_ms_per_step'), frame_segments_ms=d['frame_segments_ms']), indent=1))" > "$out/bench_segments.json"
+  # the driver's command, then the same with every optional leg (closed loop, backbone, correlation sweep; no wall-time budget)
+  ( time python bench.py --gpus 1 --steps 20 --warmup 5 --details-file gpurun_out/r06f/bench_details_driver_style.json ) > "$out/bench_line_driver_style.json" 2> "$out/bench_line_driver_style.err"
+  python bench.py --details-file gpurun_out/r06f/bench_details.json > "$out/bench_line.json" 2> "$out/bench_line.err"
+  python bench.py --extras all --budget-s 0 --details-file gpurun_out/r06f/bench_details_all_legs.json > "$out/bench_line_all_legs.json" 2> /dev/null
+  python bench.py --segments --no-extras --no-cpu-baseline --exact-steps 0 --details-file gpurun_out/r06f/bench_details_segments.json > /dev/null 2>&1
   python tools/host_cost.py 2> /dev/null | grep "FrameRunner" > "$out/host_cost.txt"
+fi
+if has pmcdense; then
+  # the dense kernel alone at R = 6, bench pools: timing, then one rocprofv3 --pmc pass per counter group (separate runs), in the format bench.py parses
+  export POOL_STRIDE=5 QUERY_OFFSET=3
+  {
+    echo "# Dense kernel alone at R = 6 (cfg2, pool = every 5th frame as in the bench): tools/bench_dense.py 6 with POOL_STRIDE=5 QUERY_OFFSET=3, then one"
+    echo "# rocprofv3 --kernel-trace --pmc <counter(s)> pass per line group (tools/pmc_kernel.sh dense_prune ...; separate runs).  Per-dispatch averages;"
+    echo "# FETCH_SIZE / WRITE_SIZE in KB, on gfx950 FETCH_SIZE counts a 128-byte request as 64 bytes (x2 for bytes).  Round 6, final code."
+    python tools/bench_dense.py 6 2>/dev/null
+    for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES" "SQ_LDS_BANK_CONFLICT"; do
+      echo "--pmc $set"
+      tools/pmc_kernel.sh dense_prune "$set" python tools/bench_dense.py 6
+    done
+  } > "$out/pmc_dense_R6.txt" 2>&1
+  unset POOL_STRIDE QUERY_OFFSET
+fi
+if has cfg5; then
+  # BASELINE.json configs[4] on its own terms as far as one GPU goes: a quarter of the 30 + 507 sequence set, closed loop, one rank (RCCL forced on)
+  AOC_DIST_FORCE=1 python bench.py --eval-sharded --eval-scale 0.25 --no-cpu-baseline > "$out/eval_sharded_quarter_scale_rccl1.json" 2> "$out/eval_sharded_quarter_scale.err"
 fi
 if has chain; then
   rm -f "$out/kmeans_chain_events.txt"
