@@ -656,6 +656,279 @@ __global__ __launch_bounds__(NW * 64, NB == 2 ? 2 : 1) void dense_prune_kernel(c
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Round 6: the same algorithm with ONE wave per SIMD.  Workgroup = 4 waves x 4 query tiles (the same 512 query pixels, the same grid, the same LDS ring
+// and DMA plan geometry as dense_prune_kernel<8, 0>); a wave holds both planes of FOUR query tiles (224 registers of the 512 a lone wave may have) and
+// TWO accumulator sets, so that
+//   * every A fragment read from LDS feeds four MFMAs instead of two (half the LDS read traffic per product),
+//   * the A fragments of tile t + 1 are requested before tile t's 28 MFMAs are issued (a whole tile of cover for the LDS latency),
+//   * the decision of tile t - 1 (max over its 4 x 16 accumulators, bound test, ballot) sits in program order behind tile t's MFMAs and executes in their
+//     shadow -- with one wave per SIMD nothing else would hide it (profiles/r06_dense_experiments.txt, section 3: a wave of the 8 x 2 kernel spends ~2 000
+//     cycles per tile of which 448 are matrix-pipe time; tools/probe/mfma_probe3.hip prices this shape at 25 ns per MFMA and SIMD against 37.5).
+// The pipeline drains at the end of every step (the last tile's LDS buffer is the DMA target of the step after next) and in front of an object switch.
+// Same values as the 8 x 2 kernel (a pair's exact value does not depend on what else was evaluated; a bound that is one tile stale only rescoring more).
+#ifndef AOC_DENSE_Q4
+#define AOC_DENSE_Q4 0           /* compile-time default of the kernel choice; the kernel itself is only compiled with -DAOC_DEV or -DAOC_DENSE_Q4=1 */
+#endif
+#if defined(AOC_DEV) || AOC_DENSE_Q4
+constexpr int Q4_NW = 4, Q4_NQ = 4;
+#ifndef AOC_Q4_DBG
+#define AOC_Q4_DBG 0           /* timing experiments (tools/build_variant.sh ... "-DAOC_Q4_DBG=n"): 2 no rescoring, 4 no row DMA, 8 no step barrier -- WRONG results */
+#endif
+__host__ __device__ constexpr int q4_lds_bytes() { return sp_bnd_off(SP_NB) + Q4_NW * Q4_NQ * 256; }
+
+__global__ __launch_bounds__(Q4_NW * 64, 1) void dense_prune_q4_kernel(const uint4 *__restrict__ qrec, const float *__restrict__ q2, int64_t m,
+                                                                      const uint4 *__restrict__ prec, const int32_t *__restrict__ tile_rows,
+                                                                      const int32_t *__restrict__ tile_obj, const int32_t *__restrict__ n_tiles_ptr,
+                                                                      const int32_t *__restrict__ gate, const uint32_t *__restrict__ pmax_bits,
+                                                                      int n_obj, uint32_t *__restrict__ gbest, int q_tiled) {
+    if (*gate) return;
+    extern __shared__ __attribute__((aligned(16))) uint4 lds4[];
+    constexpr int NW = Q4_NW, NQ = Q4_NQ, NB = SP_NB;
+    constexpr int SP_CHUNK_BYTES = sp_chunk_bytes(NB), SP_IDS_OFF = sp_ids_off(NB), SP_OBJ_OFF = sp_obj_off(NB), SP_BND_OFF = sp_bnd_off(NB);
+    constexpr int DMA_PER_WAVE = SP_CHUNK_BYTES / 1024 / NW;          // 14 wave-wide 1 KiB transfers per wave and chunk
+    constexpr int W_ID0 = 2, W_ID1 = 3, W_OBJ = 1;
+    constexpr int TILE_BYTES = SP_TILE * SP_REC * 16;
+    const uint32_t lds_base = (uint32_t)reinterpret_cast<uintptr_t>(lds4);
+    const char *lds_bytes = reinterpret_cast<const char *>(lds4);
+
+    int bx, by;                                                       // XCD-aware block -> (query block, tile split) map, as in dense_prune_kernel
+    {
+        const int nb = gridDim.x * gridDim.y, lin = blockIdx.y * gridDim.x + blockIdx.x;
+        const int xcd = lin & 7, slot = lin >> 3, q = nb >> 3, r = nb & 7;
+        const int v = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+        by = v / gridDim.x;
+        bx = v - by * gridDim.x;
+    }
+    const int n_tiles = *n_tiles_ptr;
+    const int ns = gridDim.y;
+    if (by >= n_tiles) return;
+    const int n_mine = (n_tiles - by + ns - 1) / ns;
+    const int n_chunks = (n_mine + NB - 1) / NB;
+
+    const int lane = aoc_lane(), wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int col = lane & 31, h = lane >> 5;
+    const int64_t wave_row0 = (int64_t)bx * (NW * NQ * 32) + (int64_t)wave * (NQ * 32);
+
+    const float pmax = sqrtf(__uint_as_float(*pmax_bits)) * 1.001f;
+    const float plmax = __uint_as_float(*(pmax_bits - 2));
+    f16x8 bh[NQ][SP_KS], bl[NQ][SP_KS];
+    float eps[NQ];
+    bool valid[NQ];
+#pragma unroll
+    for (int iq = 0; iq < NQ; ++iq) {
+        const int64_t row = wave_row0 + iq * 32 + col;
+        valid[iq] = row < m;
+        const int64_t rr = valid[iq] ? row : 0;
+        const uint4 *r = q_tiled ? qrec + (size_t)(rr >> 5) * (2 * SP_KS * 64) + h * 32 + (rr & 31) : qrec + (size_t)rr * SP_REC + h;
+        const int ks_step = q_tiled ? 64 : 2, plane_step = q_tiled ? SP_KS * 64 : SP_HALF;
+#pragma unroll
+        for (int ks = 0; ks < SP_KS; ++ks) {
+            uint4 u = r[ks * ks_step], v = r[plane_step + ks * ks_step];
+            if (!valid[iq]) { u = make_uint4(0, 0, 0, 0); v = make_uint4(0, 0, 0, 0); }
+            bh[iq][ks] = __builtin_bit_cast(f16x8, u);
+            bl[iq][ks] = __builtin_bit_cast(f16x8, v);
+        }
+        const float ql_own = (float)bh[iq][SP_KS - 1][SP_NORM_SLOT % 16 + 3];
+        if (h == 0) {
+            bh[iq][SP_KS - 1][SP_NORM_SLOT % 16 + 3] = (_Float16)0.0f;
+            bh[iq][SP_KS - 1][SP_NORM_SLOT % 16] = (_Float16)SP_QCONST;
+            bh[iq][SP_KS - 1][SP_NORM_SLOT % 16 + 1] = (_Float16)SP_QCONST;
+            bh[iq][SP_KS - 1][SP_NORM_SLOT % 16 + 2] = (_Float16)SP_QCONST;
+        } else {
+            bh[iq][SP_KS - 1][0] = (_Float16)0.0f;                   // (the rest-norm slots of a development build's records)
+            bh[iq][SP_KS - 1][1] = (_Float16)0.0f;
+        }
+        const float qn = valid[iq] ? sqrtf(q2[row]) : 0.0f;
+        const float ql = valid[iq] ? __shfl(ql_own, col) : 0.0f;
+        eps[iq] = 1026.0f * (qn * plmax + ql * pmax) + 8.0f * pmax * pmax + 8.0f;
+    }
+
+    uint32_t dma_plan[DMA_PER_WAVE];
+#pragma unroll
+    for (int k = 0; k < DMA_PER_WAVE; ++k) {
+        const int j = (wave * DMA_PER_WAVE + k) * 64 + lane;
+        const int r = j / SP_REC, pos = j - r * SP_REC;
+        dma_plan[k] = ((uint32_t)r << 16) | (uint32_t)((pos ^ ((r >> 3) & 3)) * 16);
+    }
+    const char *prec_bytes = reinterpret_cast<const char *>(prec);
+    auto dma_meta = [&](int chunk) {
+        const int i0 = chunk * NB;
+        if (wave == W_ID0 || wave == W_ID1) {
+            const int i = i0 + (wave == W_ID1 ? 2 : 0) + (lane >> 5);
+            const int t = min(by + i * ns, n_tiles);
+            glds4(tile_rows + (size_t)t * SP_TILE + (lane & 31), lds_base + SP_IDS_OFF + (chunk & 1) * 512 + (wave == W_ID1 ? 256 : 0));
+        }
+        if (wave == W_OBJ) glds4(tile_obj + min(by + (i0 + (lane & 3)) * ns, n_tiles), lds_base + SP_OBJ_OFF + (chunk & 3) * 256);
+    };
+    auto dma_rows = [&](int chunk) {
+        const int32_t *ids = reinterpret_cast<const int32_t *>(lds_bytes + SP_IDS_OFF + (chunk & 1) * 512);
+        const uint32_t dst = lds_base + (uint32_t)(chunk % SP_NBUF) * SP_CHUNK_BYTES + (uint32_t)(wave * DMA_PER_WAVE) * 1024u;
+        int id[DMA_PER_WAVE];
+#pragma unroll
+        for (int k = 0; k < DMA_PER_WAVE; ++k) id[k] = ids[dma_plan[k] >> 16];
+#pragma unroll
+        for (int k = 0; k < DMA_PER_WAVE; ++k)
+            glds16(prec_bytes + (size_t)(uint32_t)max(id[k], 0) * (SP_REC * 16) + (dma_plan[k] & 0xffffu), dst + (uint32_t)k * 1024u);
+    };
+
+    float best[NQ], shared[NQ];
+    uint32_t grow[NQ];
+#pragma unroll
+    for (int iq = 0; iq < NQ; ++iq) {
+        grow[iq] = valid[iq] ? (uint32_t)(wave_row0 + iq * 32 + col) * (uint32_t)n_obj : 0u;
+        best[iq] = INFINITY;
+        shared[iq] = INFINITY;
+    }
+    int cur = -1;
+    unsigned n_rescored = 0, n_seen = 0;
+    auto dma_bound = [&]() {
+#pragma unroll
+        for (int iq = 0; iq < NQ; ++iq) {
+            unsigned keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off sc1\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(gbest + grow[iq] + max(cur, 0)), "s"(lds_base + SP_BND_OFF + (uint32_t)(wave * NQ + iq) * 256u) : "memory");
+        }
+    };
+    auto switch_object = [&](int o) {
+        cur = o;
+        uint32_t u[NQ];
+#pragma unroll
+        for (int iq = 0; iq < NQ; ++iq) u[iq] = load_relaxed(gbest + grow[iq] + cur);
+#pragma unroll
+        for (int iq = 0; iq < NQ; ++iq) {
+            best[iq] = valid[iq] ? -INFINITY : INFINITY;
+            shared[iq] = valid[iq] ? ord_dec(u[iq]) : INFINITY;
+        }
+    };
+
+    dma_meta(0);
+    dma_meta(1);
+    __builtin_amdgcn_s_waitcnt(0x0f70);
+    __builtin_amdgcn_s_barrier();
+    dma_rows(0);
+    __builtin_amdgcn_s_waitcnt(0x0f70);
+    __builtin_amdgcn_s_barrier();
+
+    const int xs = (col >> 3) & 3;
+    const uint32_t row_off = (uint32_t)col * (SP_REC * 16);
+    const uint32_t sw0 = row_off + (uint32_t)((h ^ xs) * 16), sw2 = row_off + (uint32_t)(((2 + h) ^ xs) * 16);
+    auto frag = [&](const char *tile_base, int e) -> f16x8 {
+        const uint32_t off = ((e & 2) ? sw2 : sw0) + (uint32_t)((e & ~3) * 16);
+        return __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4 *>(tile_base + off));
+    };
+    auto ks_of = [&](int kk) { return (kk + SP_KS - 1) % SP_KS; };
+    // BOTH planes of a reference tile travel to registers a tile ahead: a rescoring then needs no LDS round trip of its own (with one wave per SIMD nobody
+    // would hide it: profiles/r06_dense_experiments.txt, section 5) -- 14 reads per 28 coarse MFMAs, the LDS traffic per MFMA of the 8 x 2 kernel
+    auto load_frags = [&](f16x8 (&af)[SP_KS], f16x8 (&al)[SP_KS], const char *tile_base) {
+#pragma unroll
+        for (int kk = 0; kk < SP_KS; ++kk) af[kk] = frag(tile_base, 2 * ks_of(kk));
+#pragma unroll
+        for (int kk = 0; kk < SP_KS; ++kk) al[kk] = frag(tile_base, 2 * SP_KS + 2 * ks_of(kk));
+    };
+    // one chain of 7 dependent MFMAs: the hi x hi pass of the reference tile against query tile IQ
+    auto chain = [&](f32x16 &acc, const f16x8 (&af)[SP_KS], auto iq_c) {
+        constexpr int IQ = decltype(iq_c)::value;
+#pragma unroll
+        for (int kk = 0; kk < SP_KS; ++kk)
+            acc = kk == 0 ? __builtin_amdgcn_mfma_f32_32x32x16_f16(af[kk], bh[IQ][ks_of(kk)], f32x16{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, 0, 0, 0)
+                          : __builtin_amdgcn_mfma_f32_32x32x16_f16(af[kk], bh[IQ][ks_of(kk)], acc, 0, 0, 0);
+    };
+    // settle one (reference tile, query tile) pair: the bound test on its coarse values and, if it may hold a new maximum, the cross terms onto the same
+    // accumulator and the exact maximum.  Program-ordered BEHIND the next chain's MFMAs: the test executes in their shadow.
+    auto settle = [&](f32x16 &acc, auto iq_c, const f16x8 (&ah)[SP_KS], const f16x8 (&al)[SP_KS]) {
+        constexpr int IQ = decltype(iq_c)::value;
+        const float cm = max16(acc);
+        if (__builtin_amdgcn_ballot_w64(cm + eps[IQ] >= __builtin_fmaxf(best[IQ], shared[IQ])) == 0ull) return;
+        n_rescored += 1;
+        if (AOC_Q4_DBG & 2) return;                                  // (the count keeps the decision alive)
+#pragma unroll
+        for (int kk = 0; kk < SP_KS; ++kk) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[kk], bl[IQ][ks_of(kk)], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[kk], bh[IQ][ks_of(kk)], acc, 0, 0, 0);
+        }
+        const float ex = max16(acc);
+        if (ex > best[IQ]) {
+            best[IQ] = ex;
+            if (ex > shared[IQ]) atomicMax(gbest + grow[IQ] + cur, ord_enc(ex));
+        }
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    using I3 = std::integral_constant<int, 3>;
+
+    f16x8 afA[SP_KS], afB[SP_KS], alA[SP_KS], alB[SP_KS];
+    f32x16 accX, accY;                                               // the chains of the query tiles 0 / 2 and 1 / 3 (ping-pong)
+    for (int s = 0; s < n_chunks; ++s) {
+        const int4 objs = *reinterpret_cast<const int4 *>(lds_bytes + SP_OBJ_OFF + (s & 3) * 256);
+        const int bound_obj = cur;
+        dma_bound();
+        dma_meta(s + 2);
+        if (!(AOC_Q4_DBG & 4)) dma_rows(s + 1);
+
+        const char *chunk_base = lds_bytes + (s % SP_NBUF) * SP_CHUNK_BYTES;
+        const int n_here = min(NB, n_mine - s * NB);
+        const uint32_t objs_packed = (uint32_t)__builtin_amdgcn_readfirstlane((objs.x & 0xff) | ((objs.y & 0xff) << 8) | ((objs.z & 0xff) << 16) | ((objs.w & 0xff) << 24));
+        load_frags(afA, alA, chunk_base);
+        bool pending = false;                                        // accY still holds (previous tile, query tile 3), unsettled
+        // tiles 0 and 2 read their fragments from set A, tiles 1 and 3 from set B (fully unrolled: register arrays)
+#pragma unroll
+        for (int t = 0; t < NB; ++t) {
+            if (t < n_here) {
+                const char *tile_base = chunk_base + t * TILE_BYTES;
+                const int o = (int)((objs_packed >> (8 * t)) & 0xffu);
+                f16x8(&af_cur)[SP_KS] = (t & 1) ? afB : afA;
+                f16x8(&al_cur)[SP_KS] = (t & 1) ? alB : alA;
+                f16x8(&af_prev)[SP_KS] = (t & 1) ? afA : afB;         // (= the next tile's: requested only after the previous tile's last pair is settled)
+                f16x8(&al_prev)[SP_KS] = (t & 1) ? alA : alB;
+                if (pending) {
+                    if (o != cur) {                                  // an object switch: the previous tile is settled under ITS object first
+                        settle(accY, I3{}, af_prev, al_prev);
+                        pending = false;
+                    }
+                }
+                if (o != cur) switch_object(o);
+                chain(accX, af_cur, I0{});
+                if (pending) settle(accY, I3{}, af_prev, al_prev);
+                if (t + 1 < n_here) load_frags(af_prev, al_prev, tile_base + TILE_BYTES);      // the other set is free now: the next tile's fragments
+                chain(accY, af_cur, I1{});
+                settle(accX, I0{}, af_cur, al_cur);
+                chain(accX, af_cur, I2{});
+                settle(accY, I1{}, af_cur, al_cur);
+                chain(accY, af_cur, I3{});
+                settle(accX, I2{}, af_cur, al_cur);
+                n_seen += 1;
+                pending = true;
+            }
+        }
+        // drain: the last pair of the step (its LDS buffer is overwritten by the DMA of the step after next)
+        if (pending) {
+            if (n_here & 1) settle(accY, I3{}, afA, alA);
+            else settle(accY, I3{}, afB, alB);
+        }
+
+        __builtin_amdgcn_s_waitcnt(0x0f70);          // vmcnt(0)
+        uint32_t seen[NQ];
+#pragma unroll
+        for (int iq = 0; iq < NQ; ++iq)
+            seen[iq] = *reinterpret_cast<const volatile uint32_t *>(lds_bytes + SP_BND_OFF + (wave * NQ + iq) * 256 + lane * 4);
+        __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0)
+        if (!(AOC_Q4_DBG & 8)) __builtin_amdgcn_s_barrier();
+        if (bound_obj == cur && cur >= 0) {
+#pragma unroll
+            for (int iq = 0; iq < NQ; ++iq)
+                if (valid[iq]) shared[iq] = __builtin_fmaxf(shared[iq], ord_dec(seen[iq]));
+        }
+    }
+    if (lane == 0) {
+        atomicAdd(&g_prune_stats[0], (unsigned long long)n_seen * NQ);
+        atomicAdd(&g_prune_stats[1], (unsigned long long)n_rescored);
+        atomicAdd(&g_prune_stats[3], (unsigned long long)n_seen);
+    }
+}
+#endif  // AOC_DEV || AOC_DENSE_Q4
+
 // out[i,o] = f( min(own_o, 5e4 + min_{o' != o} own_o') ), own_o = |q_i|^2 - 2^-19 max-accumulator (+inf: no pixel of o)
 // (every word of gbest it reads is zeroed again: a caller that keeps the workspace across the frames of one pool state -- aoc_dense_match_min_split_cached
 // -- starts the next frame without a memset)
@@ -705,6 +978,14 @@ inline int split_waves() {
     static const int nw = AOC_DEV_ENV_INT("AOC_DENSE_WAVES", 8) == 4 ? 4 : 8;
     return nw;
 }
+#if defined(AOC_DEV) || AOC_DENSE_Q4
+inline bool split_q4() {
+    // dense_prune_q4_kernel instead of dense_prune_kernel<8, 0>: compile-time default AOC_DENSE_Q4, developer switch AOC_DENSE_Q4=0/1 (the workgroup
+    // covers the same 512 query pixels, so the grid and the split count are those of the eight-wave kernel: AOC_DENSE_WAVES must stay 8)
+    static const bool q4 = AOC_DEV_ENV_INT("AOC_DENSE_Q4", AOC_DENSE_Q4) != 0 && split_waves() == 8;
+    return q4;
+}
+#endif
 inline int split_tiles_per_chunk() {
     // developer switch AOC_DENSE_NB=2 (with AOC_DENSE_WAVES=4): chunks of two tiles, 60 KB of LDS per workgroup -> TWO workgroups of four waves per
     // CU, i.e. two waves per SIMD as in the product but from different workgroups: their barriers and their phases are independent
@@ -848,6 +1129,24 @@ int aoc_dense_match_min_split_cached(const float *query, const void *query_rec, 
     const dim3 grid((unsigned)((m + rpb - 1) / rpb), ns);
     const int nb = split_tiles_per_chunk();
     const size_t lds = sp_lds_bytes(nw, nb);
+#if defined(AOC_DEV) || AOC_DENSE_Q4
+    if (split_q4()) {
+        // one wave per SIMD, four query tiles per wave (dense_prune_q4_kernel): same grid, same plan, same gbest
+        static const bool q4_ok = hipFuncSetAttribute(reinterpret_cast<const void *>(dense_prune_q4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                      q4_lds_bytes()) == hipSuccess;
+        if (!q4_ok) return AOC_ERR_LAUNCH;
+        const AocDenseProbe probe4 = aoc_take_dense_probe();
+        if (probe4.start) (void)hipEventRecord(probe4.start, st);
+        hipLaunchKernelGGL(dense_prune_q4_kernel, grid, dim3(Q4_NW * 64), q4_lds_bytes(), st, static_cast<const uint4 *>(query_rec), query_sqnorm, m,
+                           static_cast<const uint4 *>(pool_rec), w.tile_rows, w.tile_obj, w.n_tiles, w.gate, w.pmax, n_obj, w.gbest, query_rec_tiled ? 1 : 0);
+        if (probe4.stop) (void)hipEventRecord(probe4.stop, st);
+        hipLaunchKernelGGL(dense_split_finalize_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, w.gbest, m, n_obj, counts, w.gate,
+                           query_sqnorm, obj_bias, out, out_pixel_stride, out_obj_stride, transform);
+        AOC_RETURN_IF_LAUNCH_FAILED();
+        return aoc_dense_match_min_gated(query, m, C, pool, fg_rows, counts + n_obj, n, wrong_bits, obj_bias, n_obj, out, out_pixel_stride,
+                                         out_obj_stride, transform, w.fp32_ws, w.fp32_bytes, w.gate, stream);
+    }
+#endif
     const AocDenseProbe probe = aoc_take_dense_probe();
     static const int dbg = AOC_DEV_ENV_INT("AOC_DENSE_DEBUG", 0);       // developer switch: timing experiments only
     const int ckpt = split_ckpt();
