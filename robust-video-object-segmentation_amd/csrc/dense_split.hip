@@ -243,6 +243,11 @@ __device__ __forceinline__ uint32_t load_relaxed(const uint32_t *p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+#ifdef AOC_DEV
+// development build, AOC_DENSE_DEBUG bit 32768: per workgroup [start, prologue done, first step done, end] on the 100 MHz wall clock + [tiles, rescored pairs]
+// of wave 0 (tools/dense_block_timeline.py reads the symbol through the HIP runtime)
+__device__ unsigned long long aoc_dev_block_times[4096 * 6];
+#endif
 __device__ unsigned long long g_prune_stats[8];    // (tile, query tile) pairs tested / rescored, tiles with any rescoring, tiles, pairs stopped at the checkpoint
 
 // LDS-DMA: 64 lanes x 16 bytes (or 4 bytes) from per-lane global addresses to the LDS bytes [lds_dst + 16 lane, +16).  Written in asm so
@@ -457,6 +462,11 @@ __global__ __launch_bounds__(NW * 64, NB == 2 ? 2 : 1) void dense_prune_kernel(c
         }
     };
 
+#ifdef AOC_DEV
+    const int blk_lin = blockIdx.y * gridDim.x + blockIdx.x;
+    const bool blk_rec = (dbg & 32768) && threadIdx.x == 0 && blk_lin < 4096;
+    if (blk_rec) aoc_dev_block_times[blk_lin * 6 + 0] = wall_clock64();
+#endif
     // ---- prologue: meta of chunks 0 and 1, rows of chunk 0 (drained: once per workgroup)
     dma_meta(0);
     dma_meta(1);
@@ -476,6 +486,9 @@ __global__ __launch_bounds__(NW * 64, NB == 2 ? 2 : 1) void dense_prune_kernel(c
         return __builtin_bit_cast(f16x8, *reinterpret_cast<const uint4 *>(tile_base + off));
     };
     auto ks_of = [&](int kk) { return (kk + SP_KS - 1) % SP_KS; };  // norm slots first: partial sums stay small
+#ifdef AOC_DEV
+    if (blk_rec) aoc_dev_block_times[blk_lin * 6 + 1] = wall_clock64();
+#endif
 
     for (int s = 0; s < n_chunks; ++s) {
         // (a) prefetches for the next step: published bounds of the current object, meta of chunk s + 2, rows of chunk s + 1 (whose ids
@@ -640,7 +653,17 @@ __global__ __launch_bounds__(NW * 64, NB == 2 ? 2 : 1) void dense_prune_kernel(c
                 if (valid[iq]) shared[iq] = __builtin_fmaxf(shared[iq], ord_dec(seen[iq]));
         }
         cyc[5] += stamp() - t_s1;
+#ifdef AOC_DEV
+        if (blk_rec && s == 0) aoc_dev_block_times[blk_lin * 6 + 2] = wall_clock64();
+#endif
     }
+#ifdef AOC_DEV
+    if (blk_rec) {
+        aoc_dev_block_times[blk_lin * 6 + 3] = wall_clock64();
+        aoc_dev_block_times[blk_lin * 6 + 4] = n_seen;
+        aoc_dev_block_times[blk_lin * 6 + 5] = n_rescored;
+    }
+#endif
     if (lane == 0) {
         atomicAdd(&g_prune_stats[0], (unsigned long long)n_seen * SP_NQ);
         atomicAdd(&g_prune_stats[1], (unsigned long long)n_rescored);
@@ -929,6 +952,49 @@ __global__ __launch_bounds__(Q4_NW * 64, 1) void dense_prune_q4_kernel(const uin
 }
 #endif  // AOC_DEV || AOC_DENSE_Q4
 
+// ------------------------------------------------------------------------------------------
+// Seeds of the shared bounds (round 6).  The pruning only bites once gbest[pixel][object] holds a good exact value, and until then almost every pair
+// is rescored (at R = 1 a quarter of all pairs; profiles/r06_dense_experiments.txt, section 6).  A video's best match of query pixel i is, more often than
+// not, the SAME pixel of the newest reference frame -- pool row n - m + i when the pool is whole frames of m rows.  This kernel evaluates that one pair per
+// query pixel in plain fp32 and publishes  seed = 2^20 (q.r - |r|^2 / 2) - margin  for the object the row is labelled with, BEFORE the matrix kernel
+// starts.  Whatever row that is, it is a real (pixel, kept row) pair of that object, and the margin keeps the seed at or below the value the matrix kernel
+// itself computes for that pair (|three-product value - true value| <= 2^-22 |qh||rh| + the roundings of ~340 fp32 accumulations: < 0.3 |q||r| + 32
+// accumulator units; margin = |q||r| + 64).  Hence  seed <= exact(seed pair) <= exact(best pair) <= coarse(best pair) + eps : the best pair is still
+// evaluated and the published maximum is the same number as without seeds -- the seeds only spare pairs that could never have held it.
+#ifndef AOC_DENSE_SEED
+#define AOC_DENSE_SEED 1
+#endif
+#ifndef AOC_DENSE_SEED_FRAMES
+#define AOC_DENSE_SEED_FRAMES 1
+#endif
+__global__ __launch_bounds__(256) void dense_seed_kernel(const float *__restrict__ query, const float *__restrict__ q2, int64_t m, int C,
+                                                          const float *__restrict__ pool, int64_t n, const uint32_t *__restrict__ right_bits, int n_obj,
+                                                          const int32_t *__restrict__ gate, uint32_t *__restrict__ gbest) {
+    if (*gate) return;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    const uint32_t mask = (n_obj >= 32) ? 0xffffffffu : ((1u << n_obj) - 1u);
+    const float4 *qr = reinterpret_cast<const float4 *>(query + (size_t)i * C);
+    const float qq = q2[i];
+    // the same pixel of the newest AOC_DENSE_SEED_FRAMES reference frames: where an object has moved over the pixel, the older frames seed another object
+    for (int f = 0; f < AOC_DENSE_SEED_FRAMES && (int64_t)(f + 1) * m <= n; ++f) {
+        const int64_t j = n - (int64_t)(f + 1) * m + i;
+        const uint32_t right = right_bits[j];
+        if (!(right & AOC_ROW_KEPT_BIT) || __popc(right & mask) != 1) continue;
+        const int o = __ffs((int)(right & mask)) - 1;
+        const float4 *rr = reinterpret_cast<const float4 *>(pool + (size_t)j * C);
+        float dot = 0.0f, r2 = 0.0f;
+        for (int t = 0; t < (C >> 2); ++t) {
+            const float4 a = qr[t], b = rr[t];
+            dot = dot + a.x * b.x; dot = dot + a.y * b.y; dot = dot + a.z * b.z; dot = dot + a.w * b.w;
+            r2 = r2 + b.x * b.x; r2 = r2 + b.y * b.y; r2 = r2 + b.z * b.z; r2 = r2 + b.w * b.w;
+        }
+        const float value = 1048576.0f * (dot - 0.5f * r2);
+        const float seed = value - (sqrtf(qq * r2) + 64.0f);
+        atomicMax(gbest + (size_t)i * n_obj + o, ord_enc(seed));
+    }
+}
+
 // out[i,o] = f( min(own_o, 5e4 + min_{o' != o} own_o') ), own_o = |q_i|^2 - 2^-19 max-accumulator (+inf: no pixel of o)
 // (every word of gbest it reads is zeroed again: a caller that keeps the workspace across the frames of one pool state -- aoc_dense_match_min_split_cached
 // -- starts the next frame without a memset)
@@ -1123,6 +1189,10 @@ int aoc_dense_match_min_split_cached(const float *query, const void *query_rec, 
                            right_bits, wrong_bits, overflow_flag, static_cast<const uint4 *>(pool_rec), w.tile_capacity, w.tile_rows, w.tile_obj,
                            w.n_tiles, w.gate, w.pmax);
     }
+    static const bool seeds = AOC_DEV_ENV_INT("AOC_DENSE_SEED", AOC_DENSE_SEED) != 0;     // developer switch (A / B)
+    if (seeds && n >= m)
+        hipLaunchKernelGGL(dense_seed_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, query, query_sqnorm, m, C, pool, n, right_bits, n_obj, w.gate,
+                           w.gbest);
     const int ns = split_nsplit(m);
     const int nw = split_waves();
     const int64_t rpb = (int64_t)nw * SP_NQ * 32;
@@ -1197,6 +1267,14 @@ int aoc_dense_prune_stats(uint64_t *out4, int reset) {
     for (int i = 0; i < 4 && rc == AOC_OK; ++i) out4[i] = v[i];
     return rc;
 }
+
+#ifdef AOC_DEV
+// development build only (not part of the C ABI of include/aoc_hip.h): the per-workgroup stamps of the last launches with AOC_DENSE_DEBUG bit 32768
+int aoc_dev_dense_block_times(uint64_t *out, int n_words) {
+    if (!out || n_words < 1 || n_words > 4096 * 6) return AOC_ERR_INVALID_ARG;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(aoc_dev_block_times), (size_t)n_words * sizeof(uint64_t)) == hipSuccess ? AOC_OK : AOC_ERR_LAUNCH;
+}
+#endif
 
 // out8[0..3] as aoc_dense_prune_stats; out8[4] = (reference tile, query tile) pairs that stopped at the checkpoint; out8[5..7] = 0.
 int aoc_dense_prune_stats_ex(uint64_t *out8, int reset) {

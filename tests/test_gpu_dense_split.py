@@ -324,3 +324,53 @@ def test_full_size_configs_against_exact_fp32(aoc, name, R):
     want = _dense(aoc, q, pool, lab, bias, "fp32")
     assert got.shape == (cfg.n_obj, cfg.h * cfg.w)
     assert float((got - want).abs().max()) < ATOL
+
+
+def test_bound_seeds_change_no_result():
+    """Round 6: dense_seed_kernel publishes, before the matrix kernel starts, one exact-minus-margin value per query pixel (the same pixel of the newest reference
+    frame).  The seeds may only spare work: the development build with AOC_DENSE_SEED=0 and =1 has to produce the same bits for every output -- growing pools,
+    a pool whose newest frame IS the query (the seed pair is the unique best, at distance 0), exact duplicates of the best row elsewhere in the pool, a moved
+    object (seeds for the wrong object), and a pool that is not whole frames (the seed rule then picks unrelated rows: still real pairs)."""
+    import hashlib, os, subprocess, sys
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import hashlib, sys
+import numpy as np, torch
+sys.path.insert(0, %r)
+import aoc_amd
+from aoc_amd import ops, synthetic as syn
+cfg = syn.ClipConfig("t", 45, 77, 4, 16, frames=10)
+clip = syn.make_clip(cfg, 5)
+emb = torch.from_numpy(clip["emb"]).cuda()
+lab = torch.from_numpy(np.stack([syn.one_hot(l, cfg.n_obj) for l in clip["lab"]])).cuda()
+hw, C, O = cfg.h * cfg.w, cfg.c, cfg.n_obj
+h = hashlib.sha256()
+def run(pool, labels, q):
+    prep = ops.label_prep(labels.contiguous())
+    out = torch.empty(O, q.shape[0], device="cuda")
+    ps = ops.split_rows(pool.contiguous())
+    qs = ops.split_rows(q.contiguous(), overflow=ps.overflow)
+    ops.dense_match_min_split(q.contiguous(), qs, pool.contiguous(), ps, prep, torch.zeros(O, device="cuda"), out, 1, q.shape[0], True)
+    torch.cuda.synchronize()
+    h.update(out.cpu().numpy().tobytes())
+for R in (1, 2, 4):                                             # growing pools, query three frames after the newest pool frame
+    run(emb[:R * 2:2].reshape(-1, C), lab[:R * 2:2].reshape(-1, O), emb[R * 2 + 1].reshape(-1, C))
+run(emb[[0, 3]].reshape(-1, C), lab[[0, 3]].reshape(-1, O), emb[3].reshape(-1, C))              # the newest pool frame is the query itself
+pool = emb[[0, 3]].reshape(-1, C).clone(); pool[100:140] = pool[hw + 100:hw + 140]                # duplicates of best rows in the older frame
+run(pool, lab[[0, 3]].reshape(-1, O), emb[3].reshape(-1, C))
+moved = torch.roll(lab[3], shifts=(7, 11), dims=(0, 1))                                           # labels moved: seeds land on other objects
+run(emb[[0, 3]].reshape(-1, C), torch.stack([lab[0], moved]).reshape(-1, O), emb[4].reshape(-1, C))
+run(emb[[0, 3]].reshape(-1, C)[: 2 * hw - 333], lab[[0, 3]].reshape(-1, O)[: 2 * hw - 333], emb[4].reshape(-1, C))   # not whole frames
+st = ops.dense_prune_stats()
+print("HASH", h.hexdigest(), st["rescored"], st["tested"])
+''' % root
+    res = {}
+    for seed in ("0", "1"):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, AOC_LIB_VARIANT="dev", AOC_DENSE_SEED=seed), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-2500:]
+        line = [l for l in r.stdout.splitlines() if l.startswith("HASH")][-1].split()
+        res[seed] = (line[1], int(line[2]), int(line[3]))
+    assert res["0"][0] == res["1"][0], "the seeds changed a result"
+    assert res["0"][2] == res["1"][2] and res["1"][1] < res["0"][1], res          # same pairs tested, fewer rescored
