@@ -6,7 +6,7 @@
 set -u
 out=$GRAFT_REPO_ROOT/gpurun_out/r06f
 mkdir -p "$out"
-parts="${*:-bench stats pmc pmcdense chain gates eval cfg5 ablate}"
+parts="${*:-bench stats pmc pmcdense chain gates eval timeline seedab cfg5 ablate}"
 has() { case " $parts " in *" $1 "*) return 0;; *) return 1;; esac; }
 cd $GRAFT_REPO_ROOT
 if has bench; then
@@ -31,6 +31,21 @@ if has pmcdense; then
     done
   } > "$out/pmc_dense_R6.txt" 2>&1
   unset POOL_STRIDE QUERY_OFFSET
+fi
+if has timeline; then
+  # per-workgroup wall-clock stamps of one dense launch (development build)
+  ( export POOL_STRIDE=5 QUERY_OFFSET=3 AOC_LIB_VARIANT=dev AOC_DENSE_DEBUG=32768; for R in 1 6; do python tools/dense_block_timeline.py $R; done; AOC_DENSE_ROUNDS=1 python tools/dense_block_timeline.py 1 ) 2>/dev/null > "$out/dense_block_timeline.txt"
+fi
+if has seedab; then
+  # bound seeds off / on in the bench (development build's switch), alternating runs
+  rm -f "$out/bench_seed_ab.txt"
+  for rep in 1 2 3; do for seed in 0 1; do for cfg in cfg2 cfg3 cfg4; do
+    AOC_LIB_VARIANT=dev AOC_DENSE_SEED=$seed python bench.py --config $cfg --no-extras --no-cpu-baseline --exact-steps 0 --details-file gpurun_out/r06f/bd_tmp.json 2>/dev/null | python -c "
+import json,sys
+for l in sys.stdin:
+    if l.startswith('{'):
+        d=json.loads(l); print('$cfg development build AOC_DENSE_SEED=$seed', d['value'], 'frames/s', d['roofline']['avg_launch_ms'], 'ms dense kernel in-run')" >> "$out/bench_seed_ab.txt"
+  done; done; done
 fi
 if has cfg5; then
   # BASELINE.json configs[4] on its own terms as far as one GPU goes: a quarter of the 30 + 507 sequence set, closed loop, one rank (RCCL forced on)
