@@ -1288,7 +1288,7 @@ def main():
                 # pairs that could hold a maximum (counted by the kernel over the timed regions)
                 rescored = prune["rescored"] / max(prune["tested"], 1)
                 executed = k["tflops"] * (1.0 + 2.0 * rescored) * 112.0 / C
-                traffic_file = "profiles/r04_pmc_dense_R6.txt"
+                traffic_file = "profiles/r06_pmc_dense_R6.txt"
                 roofline = dict(kernel="dense_prune_kernel (aoc_dense_match_min_split), an fp16-pipe kernel: algorithmic fp32 flops priced against the DENSE FP16 MFMA peak",
                                 bound="mfma", achieved=k["tflops"],
                                 peak=PEAK_F16_MFMA_TFLOPS, unit="TFLOP/s", frac=round(k["tflops"] / PEAK_F16_MFMA_TFLOPS, 4),
@@ -1314,7 +1314,7 @@ def main():
             km_roof = dict(kernel="aoc_cluster_chain_enqueue (20 Lloyd iterations of the 1 to 3 frames that share a chain + proxy construction)", bound="hbm",
                            achieved=km["gbs"], peak=PEAK_HBM_GBS, unit="GB/s", frac=round(km["gbs"] / PEAK_HBM_GBS, 4), traffic=None,
                            avg_launch_ms=km["avg_ms"], algorithmic_bytes_per_launch=km["avg_bytes"],
-                           offline={"traffic": "profiles/r05_pmc_kmeans_R6_F3.txt", "alone": "profiles/r05_kmeans_chain_events.txt"},
+                           offline={"traffic": "profiles/r06_pmc_kmeans_R6_F3.txt", "alone": "profiles/r06_kmeans_chain_events.txt"},
                            note="a dependent chain of ~85 launches whose ordered float32 sums are latency-bound by construction; the in-run "
                                 "figure spans the time the chain shares the GPU with the other streams")
 
@@ -1327,7 +1327,7 @@ def main():
 
         film_roof = hbm_roof("film_scale", "film_scale_ahead_kernel (aoc_film_scale: IA gates and the FiLM of the conditioning blocks)",
                              "in-run average over the 14 activation shapes of decoding_module.py:22-84; algorithmic bytes 2 O c h w 4 (SURVEY 8d)",
-                             {"traffic": "profiles/r04_pmc_gates_cfg2.txt", "alone": "profiles/r05_gates_standalone.txt"})
+                             {"traffic": "profiles/r04_pmc_gates_cfg2.txt", "alone": "profiles/r06_gates_standalone.txt"})
         cond_roof = hbm_roof("cond_gate_pool", "cond_scores_part / cond_scores_reduce / cond_select_tail / cond_masked_gap_fused (aoc_cond_gate_pool_ex)",
                              "in-run average over the 4 conditioning blocks; algorithmic bytes O C H W 4 = ONE read of z (SURVEY 8d); the op reads z twice "
                              "(scores, masked pooling) around the exact k-th-largest selection",

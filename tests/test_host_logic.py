@@ -596,14 +596,19 @@ def test_every_profile_a_document_cites_is_committed():
 
 
 def test_headline_figures_in_the_documents_are_the_committed_line():
-    """STATUS.md / README.md quote the driver-style line of the final code: the figures they print are the ones in profiles/r05_bench_line.json."""
-    line = json.loads([l for l in open(os.path.join(ROOT, "profiles", "r05_bench_line.json")) if l.startswith("{")][-1])
+    """STATUS.md / README.md quote the driver-style line of the final code: the figures they print are the ones in profiles/r06_bench_line_driver_style.json (and, for the
+    optional legs, r06_bench_line_all_legs.json); both committed lines are compact records with the keys the driver needs."""
+    line = json.loads([l for l in open(os.path.join(ROOT, "profiles", "r06_bench_line_driver_style.json")) if l.startswith("{")][-1])
+    legs = json.loads([l for l in open(os.path.join(ROOT, "profiles", "r06_bench_line_all_legs.json")) if l.startswith("{")][-1])
     status, readme = open(os.path.join(ROOT, "STATUS.md")).read(), open(os.path.join(ROOT, "README.md")).read()
-    assert "%.1f frames/s" % line["value"] in status and "%.1f frames/s" % line["value"] in readme
-    for name, cfg in line["other_configs"].items():
-        assert "%s %.1f" % (name, cfg["value"]) in status, name
-    closed = line["strong_scaling"]
-    assert "%.1f (65 sequences)" % closed["value"] in status and "%.1f on the cfg2-shaped part" % closed["closed_loop_davis17_like"]["value"] in status
+    for doc in (status, readme):
+        assert "%.1f frames/s" % line["value"] in doc
+        assert "cfg3 %.1f" % line["cfg3_value"] in doc and "cfg4 %.1f" % line["cfg4_value"] in doc
+        assert "%.1f" % legs["closed_loop_value"] in doc
+    for rec in (line, legs):
+        assert len(json.dumps(rec)) < 4096 and rec["schema"] == 6 and rec["roofline"]["bound"] == "mfma" and rec["roofline_correlation"]["bound"] == "hbm"
+        assert rec["cpu_baseline"]["kind"] == "port" and rec["cpu_baseline"]["runs"] == 5 and rec["config"]["workload"].startswith("cfg2")
+        assert os.path.exists(os.path.join(ROOT, "profiles", "r06_" + os.path.basename(rec["details_file"])))
 
 
 def _canned_full_record():
@@ -665,6 +670,10 @@ def test_bench_line_is_compact():
 def test_bench_reads_pmc_traffic_from_the_committed_file():
     """`roofline.traffic` is read from the committed rocprofv3 --pmc summary at bench time (FETCH x 2 + WRITE, KB -> bytes), not copied into bench.py."""
     import bench
-    t = bench.pmc_traffic_bytes("profiles/r04_pmc_dense_R6.txt")
-    assert t is not None and abs(t - (2 * 1.8296e5 + 34155) * 1024) < 1.0
+    import re
+    text = open(os.path.join(ROOT, "profiles", "r06_pmc_dense_R6.txt")).read()
+    fetch = float(re.search(r"^FETCH_SIZE .*avg=([0-9.e+]+)", text, re.M).group(1))
+    write = float(re.search(r"^WRITE_SIZE .*avg=([0-9.e+]+)", text, re.M).group(1))
+    t = bench.pmc_traffic_bytes("profiles/r06_pmc_dense_R6.txt")
+    assert t is not None and abs(t - (2 * fetch + write) * 1024) < 1.0 and 2.0e8 < t < 6.0e8
     assert bench.pmc_traffic_bytes("profiles/does_not_exist.txt") is None
