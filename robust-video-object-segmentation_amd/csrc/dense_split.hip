@@ -958,9 +958,14 @@ __global__ __launch_bounds__(Q4_NW * 64, 1) void dense_prune_q4_kernel(const uin
 // not, the SAME pixel of the newest reference frame -- pool row n - m + i when the pool is whole frames of m rows.  This kernel evaluates that one pair per
 // query pixel in plain fp32 and publishes  seed = 2^20 (q.r - |r|^2 / 2) - margin  for the object the row is labelled with, BEFORE the matrix kernel
 // starts.  Whatever row that is, it is a real (pixel, kept row) pair of that object, and the margin keeps the seed at or below the value the matrix kernel
-// itself computes for that pair (|three-product value - true value| <= 2^-22 |qh||rh| + the roundings of ~340 fp32 accumulations: < 0.3 |q||r| + 32
-// accumulator units; margin = |q||r| + 64).  Hence  seed <= exact(seed pair) <= exact(best pair) <= coarse(best pair) + eps : the best pair is still
-// evaluated and the published maximum is the same number as without seeds -- the seeds only spare pairs that could never have held it.
+// itself computes for that pair, in the WORST case of every rounding: with M = 2^20 (|q||r| + |r|^2 / 2) >= every partial sum on either side,
+//   the matrix kernel's 21 MFMAs round at most 21 x 16 times by half an ulp <= 2^-24 M each                          336 x 2^-24 M
+//   this kernel's two fp32 dot products of C <= 100 terms (sequential adds) and the final subtraction                  ~210 x 2^-24 M
+//   the ql.rl product the three-product value leaves out: <= 2^20 (2^-11 |q|)(2^-11 |r|)                              0.25 |q||r|
+// margin = 4e-5 M + |q||r| + 16 (4e-5 > 546 x 2^-24 = 3.3e-5; tests/test_host_logic.py::test_dense_seed_margin_covers_the_worst_case replays the
+// arithmetic in numpy).  Hence  seed <= exact(seed pair) <= exact(best pair) <= coarse(best pair) + eps : the best pair is still evaluated and the
+// published maximum is the same number as without seeds -- the seeds only spare pairs that could never have held it.  (~5e-4 in squared-distance units
+// on the bench's embeddings, below the kernel's own rescoring margin eps = 1.4e-3.)
 #ifndef AOC_DENSE_SEED
 #define AOC_DENSE_SEED 1
 #endif
@@ -990,7 +995,8 @@ __global__ __launch_bounds__(256) void dense_seed_kernel(const float *__restrict
             r2 = r2 + b.x * b.x; r2 = r2 + b.y * b.y; r2 = r2 + b.z * b.z; r2 = r2 + b.w * b.w;
         }
         const float value = 1048576.0f * (dot - 0.5f * r2);
-        const float seed = value - (sqrtf(qq * r2) + 64.0f);
+        const float qr_n = sqrtf(qq * r2);
+        const float seed = value - (4e-5f * (1048576.0f * (qr_n + 0.5f * r2)) + qr_n + 16.0f);
         atomicMax(gbest + (size_t)i * n_obj + o, ord_enc(seed));
     }
 }

@@ -677,3 +677,55 @@ def test_bench_reads_pmc_traffic_from_the_committed_file():
     t = bench.pmc_traffic_bytes("profiles/r06_pmc_dense_R6.txt")
     assert t is not None and abs(t - (2 * fetch + write) * 1024) < 1.0 and 2.0e8 < t < 6.0e8
     assert bench.pmc_traffic_bytes("profiles/does_not_exist.txt") is None
+
+
+def test_dense_seed_margin_covers_the_worst_case():
+    """dense_seed_kernel (csrc/dense_split.hip) publishes  seed = fp32[2^20 (q.r - |r|^2 / 2)] - margin  and relies on  seed <= the value the matrix kernel computes for
+    the same pair  -- whatever the roundings.  Replay in numpy: the matrix kernel's value is the EXACT sum of the fp16 split products qh.rh + qh.rl + ql.rh and the
+    three fp16 norm pieces (float64 holds every such product and sum exactly at these sizes) perturbed by at most 336 half-ulps of the largest partial sum; the seed
+    is computed in float32 with sequential adds as the kernel does.  Random rows, rows at the fp16-split range limits, anti-correlated and tiny rows."""
+    rng = np.random.RandomState(0)
+    f32, f64 = np.float32, np.float64
+
+    def split(x):                                           # x' = 2^10 x = hi + lo, both fp16 (dense_split.hip: split_rows_kernel)
+        v = (x.astype(f32) * f32(1024.0)).astype(f32)
+        hi = v.astype(np.float16)
+        lo = (v - hi.astype(f32)).astype(np.float16)
+        return hi.astype(f64), lo.astype(f64)
+
+    worst = 1e30
+    for case in range(400):
+        C = 100
+        scale = [0.3, 0.3, 1.0, 6.0, 0.01][case % 5]
+        q = (np.maximum(rng.randn(C), 0) * scale).astype(f32)
+        r = (np.maximum(rng.randn(C), 0) * scale).astype(f32) if case % 7 else q.copy()          # every 7th: the pair at distance 0
+        if case % 11 == 0:
+            r = (-q).astype(f32)                            # anti-correlated: large negative value
+        if float((r.astype(f64) ** 2).sum()) > 4000.0 or np.abs(q).max() * 1024 > 65000 or np.abs(r).max() * 1024 > 65000:
+            continue                                        # outside the split kernels' preconditions: the exact-fp32 kernels take over
+        qh, ql = split(q)
+        rh, rl = split(r)
+        r2_32 = f32(0.0)
+        for t in range(C):                                  # |r|^2 as split_rows_kernel sums it (sequential fp32)
+            r2_32 = f32(r2_32 + f32(r[t] * r[t]))
+        p = f32(-16.0) * r2_32                              # three fp16 pieces of -16 |r|^2, times the query side's 2^15
+        p1 = np.float16(p); p2 = np.float16(f32(p - f32(p1))); p3 = np.float16(f32(f32(p - f32(p1)) - f32(p2)))
+        norm_term = (f64(p1) + f64(p2) + f64(p3)) * 32768.0
+        exact3 = float((qh * rh).sum() + (qh * rl).sum() + (ql * rh).sum() + norm_term)          # what the 21 MFMAs add up, before their roundings
+        qn, rn = float(np.sqrt((q.astype(f64) ** 2).sum())), float(np.sqrt((r.astype(f64) ** 2).sum()))
+        M = 2.0 ** 20 * (qn * rn + 0.5 * rn * rn)
+        kernel_lowest = exact3 - 336 * 2.0 ** -24 * M       # the matrix kernel's value can be this low, not lower
+        # the seed, as dense_seed_kernel computes it
+        dot, r2 = f32(0.0), f32(0.0)
+        for t in range(C):
+            dot = f32(dot + f32(q[t] * r[t]))
+            r2 = f32(r2 + f32(r[t] * r[t]))
+        qq = f32(0.0)
+        for t in range(C):
+            qq = f32(qq + f32(q[t] * q[t]))
+        value = f32(f32(1048576.0) * f32(dot - f32(f32(0.5) * r2)))
+        qr_n = f32(np.sqrt(f32(qq * r2)))
+        seed = f32(value - f32(f32(f32(4e-5) * f32(f32(1048576.0) * f32(qr_n + f32(f32(0.5) * r2)))) + qr_n + f32(16.0)))
+        assert float(seed) <= kernel_lowest, (case, float(seed), kernel_lowest, exact3)
+        worst = min(worst, kernel_lowest - float(seed))
+    assert worst >= 0.0
