@@ -976,28 +976,40 @@ __global__ __launch_bounds__(256) void dense_seed_kernel(const float *__restrict
                                                           const float *__restrict__ pool, int64_t n, const uint32_t *__restrict__ right_bits, int n_obj,
                                                           const int32_t *__restrict__ gate, uint32_t *__restrict__ gbest) {
     if (*gate) return;
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= m) return;
+    // eight lanes per query pixel, a wave = eight consecutive pixels: their rows (and the candidate rows, consecutive as well) are read as whole 128-byte
+    // lines; partial sums meet over three shuffles.  (One thread per pixel walked its two 400-byte rows alone: 37 us per launch on the frame's critical path.)
+    const int sub = threadIdx.x & 7;
+    const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 3;
+    const bool live = i < m;
+    const int64_t ii = live ? i : m - 1;
     const uint32_t mask = (n_obj >= 32) ? 0xffffffffu : ((1u << n_obj) - 1u);
-    const float4 *qr = reinterpret_cast<const float4 *>(query + (size_t)i * C);
-    const float qq = q2[i];
+    const float4 *qr = reinterpret_cast<const float4 *>(query + (size_t)ii * C);
+    const float qq = q2[ii];
+    const int c4 = C >> 2;
     // the same pixel of the newest AOC_DENSE_SEED_FRAMES reference frames: where an object has moved over the pixel, the older frames seed another object
     for (int f = 0; f < AOC_DENSE_SEED_FRAMES && (int64_t)(f + 1) * m <= n; ++f) {
-        const int64_t j = n - (int64_t)(f + 1) * m + i;
+        const int64_t j = n - (int64_t)(f + 1) * m + ii;
         const uint32_t right = right_bits[j];
-        if (!(right & AOC_ROW_KEPT_BIT) || __popc(right & mask) != 1) continue;
-        const int o = __ffs((int)(right & mask)) - 1;
+        const bool ok = live && (right & AOC_ROW_KEPT_BIT) && __popc(right & mask) == 1;      // (uniform over the pixel's eight lanes)
         const float4 *rr = reinterpret_cast<const float4 *>(pool + (size_t)j * C);
         float dot = 0.0f, r2 = 0.0f;
-        for (int t = 0; t < (C >> 2); ++t) {
+        for (int t = sub; t < c4; t += 8) {
             const float4 a = qr[t], b = rr[t];
             dot = dot + a.x * b.x; dot = dot + a.y * b.y; dot = dot + a.z * b.z; dot = dot + a.w * b.w;
             r2 = r2 + b.x * b.x; r2 = r2 + b.y * b.y; r2 = r2 + b.z * b.z; r2 = r2 + b.w * b.w;
         }
-        const float value = 1048576.0f * (dot - 0.5f * r2);
-        const float qr_n = sqrtf(qq * r2);
-        const float seed = value - (4e-5f * (1048576.0f * (qr_n + 0.5f * r2)) + qr_n + 16.0f);
-        atomicMax(gbest + (size_t)i * n_obj + o, ord_enc(seed));
+#pragma unroll
+        for (int d = 1; d < 8; d <<= 1) {
+            dot = dot + __shfl_xor(dot, d);
+            r2 = r2 + __shfl_xor(r2, d);
+        }
+        if (ok && sub == 0) {
+            const int o = __ffs((int)(right & mask)) - 1;
+            const float value = 1048576.0f * (dot - 0.5f * r2);
+            const float qr_n = sqrtf(qq * r2);
+            const float seed = value - (4e-5f * (1048576.0f * (qr_n + 0.5f * r2)) + qr_n + 16.0f);
+            atomicMax(gbest + (size_t)ii * n_obj + o, ord_enc(seed));
+        }
     }
 }
 
@@ -1197,7 +1209,7 @@ int aoc_dense_match_min_split_cached(const float *query, const void *query_rec, 
     }
     static const bool seeds = AOC_DEV_ENV_INT("AOC_DENSE_SEED", AOC_DENSE_SEED) != 0;     // developer switch (A / B)
     if (seeds && n >= m)
-        hipLaunchKernelGGL(dense_seed_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, query, query_sqnorm, m, C, pool, n, right_bits, n_obj, w.gate,
+        hipLaunchKernelGGL(dense_seed_kernel, dim3((unsigned)((m * 8 + 255) / 256)), dim3(256), 0, st, query, query_sqnorm, m, C, pool, n, right_bits, n_obj, w.gate,
                            w.gbest);
     const int ns = split_nsplit(m);
     const int nw = split_waves();
