@@ -19,8 +19,11 @@ order, so that ANY number of steps sees small and large pools in proportion (the
 inside a group everything happens as in the sequential loop: the first frame's k-means chain can only start once the pool is final,
 the chains of the others are enqueued ahead.
 
-Prints ONE JSON line on rank 0 (contract in the task statement): whole-job frames/s, roofline objects measured with HIP events inside
-the run, and a CPU baseline (the oracle timed on the host cores, rank 0, N = 1 only).
+Prints ONE compact JSON line on rank 0 as the LAST line of stdout (contract in the task statement; compact_line(): held under 4 KB by a CPU test):
+whole-job frames/s, roofline objects measured with HIP events inside the run, and a CPU baseline (the oracle timed on the host cores, rank 0, N = 1
+only).  Everything else -- notes, per-op tables, sweeps, the other configs' records -- goes to --details-file (default gpurun_out/bench_details.json),
+whose path the line carries.  Optional legs (--extras: cfg3, cfg4, closed-loop, backbone, corr-sweep) are not started once --budget-s seconds of wall
+time have passed; the default run takes about a minute.
 """
 import argparse
 import os
