@@ -609,6 +609,7 @@ __global__ __launch_bounds__(NW * 64, NB == 2 ? 2 : 1) void dense_prune_kernel(c
                     if (want[iq]) {
                         // cross terms: acc += rh.ql + rl.qh (one chain of 14 MFMAs), then the exact maximum
                         n_rescored += 1;
+                        if ((dbg & 65536) && cur < 3) cyc[cur] += 1;      // dbg 65536: rescored pairs of the objects 0, 1, 2 (read back like the stamps)
                         f16x8 ah[3], al[3];
 #pragma unroll
                         for (int kk = 0; kk < 2; ++kk) {
@@ -670,7 +671,7 @@ __global__ __launch_bounds__(NW * 64, NB == 2 ? 2 : 1) void dense_prune_kernel(c
         atomicAdd(&g_prune_stats[2], (unsigned long long)n_any);
         atomicAdd(&g_prune_stats[3], (unsigned long long)n_seen);
         atomicAdd(&g_prune_stats[4], (unsigned long long)n_dead);
-        if (dbg & 4096) {
+        if (dbg & (4096 | 65536)) {
             const int b = (dbg & 8192) ? 3 : 0;
             atomicAdd(&g_prune_stats[5], cyc[b]);
             atomicAdd(&g_prune_stats[6], cyc[b + 1]);
