@@ -2935,6 +2935,16 @@ inline void ks_launch_sums(hipStream_t st, const float *pool, uint32_t pool_byte
 #undef AOC_KSS
 }
 
+#ifndef AOC_KM_REP64
+#define AOC_KM_REP64 0
+#endif
+// LDS a workgroup of the replica-fused assignment may use: half a CU's (two workgroups per CU; three at K <= 16) -- or, for K = 64 (four cluster tiles: two
+// 30 KB code books do not fit half a CU), a whole CU's with AOC_KM_REP64 (one workgroup of four waves per CU then stages the rows once for up to four code books)
+inline size_t km_rep_lds_budget(int kt) {
+    static const bool rep64 = AOC_DEV_ENV_INT("AOC_KM_REP64", AOC_KM_REP64) != 0;
+    return (kt == 4 && rep64) ? (size_t)150 * 1024 : (size_t)78 * 1024;
+}
+
 inline int km_assign_grid_cap() {
     static const int cap = AOC_DEV_ENV_INT("AOC_KM_ASSIGN_GRID", 512);      // developer switch (measured: 128 .. 512 within 3 %)
     return cap > 0 ? cap : 512;
@@ -3044,7 +3054,7 @@ int aoc_kmeans_segmented_rep(const float *pool, int64_t pool_rows, int C, const 
         // takes the matrix-pipe kernel as well
         const size_t per_r = ((size_t)((kmax + 15) / 16) * 16 * 116 + ((kmax + 15) / 16) * 16) * sizeof(float) + 256;
         const size_t fixed_r = (size_t)4 * 16 * 116 * sizeof(float) + (size_t)4 * kmax * sizeof(int32_t);
-        const bool rep_path = n_rep > 1 && (78 * 1024 - fixed_r) / per_r >= 2 && AOC_DEV_ENV_INT("AOC_KM_ASSIGN_REP", 1) != 0;
+        const bool rep_path = n_rep > 1 && (km_rep_lds_budget((kmax + 15) / 16) - fixed_r) / per_r >= 2 && AOC_DEV_ENV_INT("AOC_KM_ASSIGN_REP", 1) != 0;
         const int lim = rep_path ? n_seg / n_rep : n_seg;
         const int64_t bound = rep_path ? std::min<int64_t>(rows_capacity / n_rep + 1, rows_capacity) : rows_capacity;
         hipLaunchKernelGGL(km_rownorm_kernel, dim3((unsigned)((bound + 255) / 256)), dim3(256), 0, st, pool, C, rows, seg_offsets, lim, rownorm);
@@ -3061,7 +3071,7 @@ int aoc_kmeans_segmented_rep(const float *pool, int64_t pool_rows, int C, const 
             {
                 const size_t fixed = (size_t)4 * 16 * 116 * sizeof(float) + (size_t)4 * kmax * sizeof(int32_t);
                 const size_t per = ((size_t)kt * 16 * 116 + kt * 16) * sizeof(float) + 256;
-                const int fit = (int)std::min<size_t>(16, (78 * 1024 - fixed) / per);
+                const int fit = (int)std::min<size_t>(16, (km_rep_lds_budget(kt) - fixed) / per);
                 static const bool rep_off = AOC_DEV_ENV_INT("AOC_KM_ASSIGN_REP", 1) == 0;     // developer switch
                 if (n_rep > 1 && fit >= 2 && !rep_off) {
                     const int n_groups = (n_rep + fit - 1) / fit;
@@ -3073,7 +3083,7 @@ int aoc_kmeans_segmented_rep(const float *pool, int64_t pool_rows, int C, const 
 #define AOC_KAR(KT)                                                                                                                                        \
     do {                                                                                                                                                   \
         static const bool ok = hipFuncSetAttribute(reinterpret_cast<const void *>(km_assign_mfma_rep_kernel<25, KT>),                                     \
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) == hipSuccess;                                  \
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)km_rep_lds_budget(KT) + 2048) == hipSuccess;           \
         if (!ok) return AOC_ERR_LAUNCH;                                                                                                                    \
         hipLaunchKernelGGL((km_assign_mfma_rep_kernel<25, KT>), dim3(rgrid), dim3(256), rlds, st, pool, C, rows, seg_offsets, seg_k, n_base, n_rep, n_grp, \
                            centroids, kmax, labels, ws.rank16, ws.hist, ws.nb_max, rownorm);                                                               \
