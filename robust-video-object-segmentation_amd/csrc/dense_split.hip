@@ -609,7 +609,11 @@ __global__ __launch_bounds__(NW * 64, NB == 2 ? 2 : 1) void dense_prune_kernel(c
                     if (want[iq]) {
                         // cross terms: acc += rh.ql + rl.qh (one chain of 14 MFMAs), then the exact maximum
                         n_rescored += 1;
-                        if ((dbg & 65536) && cur < 3) cyc[cur] += 1;      // dbg 65536: rescored pairs of the objects 0, 1, 2 (read back like the stamps)
+                        if (dbg & 65536) {                                 // rescored pairs of the objects 0, 1, 2 (read back like the stamps).  STATIC indices:
+                            if (cur == 0) cyc[0] += 1;                     // `cyc[cur]` made hipcc index the register array dynamically and the kernel -- whose
+                            else if (cur == 1) cyc[1] += 1;                // DMA statements are hand-written asm around m0 -- returned wrong minima for nine
+                            else if (cur == 2) cyc[2] += 1;                // objects even with the bit off (caught by test_kmeans_bit_exact_with_the_single_pass_tail)
+                        }
                         f16x8 ah[3], al[3];
 #pragma unroll
                         for (int kk = 0; kk < 2; ++kk) {
